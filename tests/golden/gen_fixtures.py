@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+
+    PYTORCH_JIT=0 PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_fixtures.py
+
+Every array written is an input or an output of a reference function
+(``models.tadgan``, ``hyperspace.*``, ``train.*_iteration``,
+``utils.anomaly_detection_utils.*`` imported from /root/reference through
+tests/golden/refharness.py) -- data only, no reference source.  The versions that
+produced them are recorded in ``versions.json``.
+"""
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+os.environ.setdefault("PYTORCH_JIT", "0")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import refharness  # noqa: E402
+
+refharness.install()
+
+import geoopt.manifolds.stereographic.math as gmath  # noqa: E402  (the reference's vendored math_.py)
+import models.tadgan as ref_tadgan  # noqa: E402
+import train as ref_train  # noqa: E402
+from hyperspace.hyrnn_nets import mobius_linear as ref_mobius_linear  # noqa: E402
+from hyperspace.poincare_distance import poincare_distance as ref_pairdist  # noqa: E402
+import utils.anomaly_detection_utils as ref_adu  # noqa: E402
+
+torch.set_num_threads(1)
+K = torch.tensor(-1.0)
+F32 = np.float32
+
+
+def sd_np(prefix, module):
+    return {f"{prefix}.{k}": v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def build(S, L=20, seed=0):
+    torch.manual_seed(seed)
+    enc = ref_tadgan.Encoder(S, L)
+    dec = ref_tadgan.Decoder(S, L, True)
+    cx = ref_tadgan.CriticX(S, L)
+    cz = ref_tadgan.CriticZ(L)
+    dec_e = ref_tadgan.Decoder(S, L, False)
+    # Euclidean decoder shares every non-head tensor with the hyperbolic one (keeps the fixture small)
+    dec_e.load_state_dict({k: v for k, v in dec.state_dict().items() if not k.startswith("hyperbolic_linear")})
+    return enc, dec, dec_e, cx, cz
+
+
+def synth_windows(n, S, seed=0):
+    """SURVEY.md §8d config-1 stand-in: sine + noise + one square jump, clipped to [-1, 1], float64 (n,S,1)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n + S - 1)
+    series = np.sin(2 * np.pi * t / 288.0) + 0.05 * rng.standard_normal(len(t))
+    series[n // 2: n // 2 + 40] += 0.8
+    series = np.clip(series, -1, 1)
+    idx = np.arange(n)[:, None] + np.arange(S)[None, :]
+    return series[idx][:, :, None].astype(np.float64)
+
+
+# ------------------------------------------------------------------------------ weights + forward
+def gen_forward(S, B, tag):
+    enc, dec, dec_e, cx, cz = build(S)
+    for m in (enc, dec, dec_e, cx, cz):
+        m.eval()
+    out = {}
+    for p, m in (("enc", enc), ("dec", dec), ("cx", cx), ("cz", cz)):
+        out.update(sd_np(p, m))
+    rng = np.random.default_rng(100 + S)
+    x = synth_windows(B, S, seed=1) if S == 100 else rng.uniform(-1, 1, size=(B, S, 1))
+    z = rng.standard_normal((B, 20)).astype(F32)
+    xt, zt = torch.from_numpy(x), torch.from_numpy(z).view(1, B, 20)
+    with torch.no_grad():
+        hyper, eucl = dec(zt)
+        out.update(x=x, z=z,
+                   enc_x=enc(xt).numpy(), dec_hyper=hyper.numpy(), dec_eucl=eucl.numpy(),
+                   dec_e_out=dec_e(zt).numpy(),
+                   head_x=dec.hyperbolic_linear(xt.view(-1, S).float()).numpy(),
+                   cx_x=cx(xt).numpy(), cz_z=cz(zt).numpy())
+        # test_tadgan batch body (anomaly_detection.py:67-95): enc -> dec -> head(sample) -> cx(sample)
+        lat = enc(xt.float())
+        h2, e2 = dec(lat)
+        out.update(s0_hyper=h2.numpy(), s0_eucl=e2.numpy())
+    np.savez(os.path.join(HERE, f"fwd_{tag}.npz"), **out)
+    return enc, dec, dec_e, cx, cz
+
+
+# ------------------------------------------------------------------------------ hyperbolic ops
+def edge_rows(S, rng):
+    rows = [np.zeros(S), np.full(S, 1e-20 / np.sqrt(S))]
+    for nrm in (1e-8, 0.3, 0.9, 0.995, 0.9961, 0.999, 0.99999995, 1.5, 20.0):
+        v = rng.standard_normal(S)
+        rows.append(v / np.linalg.norm(v) * nrm)
+    return np.asarray(rows, dtype=F32)
+
+
+def gen_ops(S=100):
+    rng = np.random.default_rng(7)
+    out = {}
+    u = np.concatenate([rng.standard_normal((40, S)).astype(F32) * s for s in (0.01, 0.1, 1.0)] + [edge_rows(S, rng)])
+    ball = np.concatenate([
+        (rng.standard_normal((40, S)) * 0.05).astype(F32),
+        (lambda v: (v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0.5, 0.99, (40, 1))).astype(F32))(
+            rng.standard_normal((40, S))),
+        edge_rows(S, rng)[:9]])          # keep inside (or barely outside) the ball
+    bias = gmath.expmap0(torch.from_numpy(rng.standard_normal(S).astype(F32)) / 400, k=K).numpy()
+    bias_big = gmath.expmap0(torch.from_numpy(rng.standard_normal(S).astype(F32)) / 12, k=K).numpy()
+    y2 = np.concatenate([(rng.standard_normal((len(ball) - 9, S)) * 0.04).astype(F32), ball[:9][::-1]])
+
+    def fwd_bwd(name, fn, *inputs):
+        ts = [torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True) for a in inputs]
+        o = fn(*ts)
+        go = torch.from_numpy(np.random.default_rng(len(name)).standard_normal(tuple(o.shape)).astype(F32))
+        gs = torch.autograd.grad(o, ts, go, allow_unused=True)
+        out[f"{name}_out"] = o.detach().numpy()
+        out[f"{name}_gout"] = go.numpy()
+        for i, g in enumerate(gs):
+            out[f"{name}_gin{i}"] = g.numpy()
+
+    out.update(u=u, ball=ball, bias=bias, bias_big=bias_big, y2=y2)
+    fwd_bwd("expmap0", lambda a: gmath.expmap0(a, k=K), u)
+    fwd_bwd("logmap0", lambda a: gmath.logmap0(a, k=K), ball)
+    fwd_bwd("mobius_add", lambda a, b: gmath.mobius_add(a, b, k=K), ball, y2)
+    fwd_bwd("mobius_add_bias", lambda a, b: gmath.mobius_add(a, b.unsqueeze(0).expand_as(a), k=K), ball, bias_big)
+    fwd_bwd("project", lambda a: gmath.project(a, k=K), u)
+    W = (rng.standard_normal((S, S)) * 0.02).astype(F32)
+    out["W"] = W
+    fwd_bwd("mobius_linear", lambda a, w, b: ref_mobius_linear(a, w, b, hyperbolic_input=False, hyperbolic_bias=True,
+                                                                nonlin=None, k=-1.0), u[:120] * 0.5, W, bias_big)
+    fwd_bwd("mobius_linear_small", lambda a, w, b: ref_mobius_linear(a, w, b, hyperbolic_input=False,
+                                                                      hyperbolic_bias=True, nonlin=None, k=-1.0),
+            u[:120] * 0.5, W * 0.01, bias)
+
+    def rowdist(a, b):   # train.py:226-230
+        sqdist = torch.sum((a - b) ** 2, dim=-1)
+        return torch.acosh(1 + 2 * sqdist / ((1 - torch.sum(a ** 2, dim=-1)) * (1 - torch.sum(b ** 2, dim=-1))) + 1e-7)
+
+    inside = ball[:80]
+    fwd_bwd("rowdist", rowdist, inside, np.roll(inside, 3, axis=0) * 0.9)
+    fwd_bwd("rowdist_same", rowdist, inside, inside.copy())
+    pa = np.concatenate([inside[:30], inside[:2], np.zeros((2, S), F32)])
+    pb = np.concatenate([inside[40:70] * 0.8, inside[:3]])
+    fwd_bwd("pairdist", ref_pairdist, pa, pb)
+    np.savez(os.path.join(HERE, "ops.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ training iterations
+class _Feed:
+    """Replaces numpy.random.normal / torch.rand inside the reference's iteration functions with
+    recorded draws (host RNG)."""
+
+    def __init__(self, zs, alphas):
+        self.zs, self.alphas = list(zs), list(alphas)
+
+    def __enter__(self):
+        self._n, self._r = np.random.normal, torch.rand
+        np.random.normal = lambda size=None, **k: self.zs.pop(0).reshape(size)
+        torch.rand = lambda *shape, **k: self.alphas.pop(0).reshape(*shape)
+        return self
+
+    def __exit__(self, *a):
+        np.random.normal, torch.rand = self._n, self._r
+
+
+def grads_np(prefix, module):
+    return {f"g.{prefix}.{k}": (p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), F32))
+            for k, p in module.named_parameters()}
+
+
+def gen_iters(S, B, hyperbolic, tag, steps=6):
+    enc, dec, dec_e, cx, cz = build(S)
+    if not hyperbolic:
+        dec = dec_e
+    for m in (enc, dec, cx, cz):
+        m.eval()                     # dropout off: bit-parity with CPU generators is impossible (SURVEY §7 hard part 4)
+    params = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=20, lr=5e-4, hyperbolic=hyperbolic)
+    rng = np.random.default_rng(11)
+    data = synth_windows(B * steps, S, seed=3)
+    perm = rng.permutation(len(data))
+    samples = [torch.from_numpy(data[perm[i * B:(i + 1) * B]]) for i in range(steps)]
+    out = dict(samples=np.stack([s.numpy() for s in samples]))
+    for p, m in (("enc", enc), ("dec", dec), ("cx", cx), ("cz", cz)):
+        out.update({f"w0.{k}": v for k, v in sd_np(p, m).items()})
+
+    ocx = torch.optim.Adam(cx.parameters(), lr=params.lr, betas=(0.9, 0.999))
+    ocz = torch.optim.Adam(cz.parameters(), lr=params.lr, betas=(0.9, 0.999))
+    if hyperbolic:
+        import geoopt
+        odec = geoopt.optim.RiemannianAdam(list(dec.parameters()) + list(enc.parameters()), lr=params.lr,
+                                           weight_decay=1e-5, stabilize=10)      # oracle.radam stand-in (UNPINNED)
+    else:
+        odec = torch.optim.Adam(list(dec.parameters()) + list(enc.parameters()), lr=params.lr, betas=(0.9, 0.999))
+
+    z_cx = rng.standard_normal((steps, B, 20))
+    z_cz = rng.standard_normal((steps, B, 20))
+    z_dec = rng.standard_normal((steps, B, 20))
+    a_cx = rng.uniform(size=(steps, B, S)).astype(F32)
+    a_cz = rng.uniform(size=(steps, B, 20)).astype(F32)
+    out.update(z_cx=z_cx, z_cz=z_cz, z_dec=z_dec, a_cx=a_cx, a_cz=a_cz)
+
+    # critic phase (train.py:306-328): generator frozen
+    ref_train_set(enc, dec, False)
+    ref_train_set(cx, cz, True)
+    l_cx, l_cz = [], []
+    for i in range(steps):
+        with _Feed([z_cx[i]], [torch.from_numpy(a_cx[i])]):
+            l = ref_train.critic_x_iteration(samples[i], dec, cx, ocx, params)
+        l_cx.append(float(l))
+        if i == 0:
+            out["cx_loss_dtype"] = np.array(str(l.dtype))
+            out.update({k.replace("g.", "g1.cx_iter."): v for k, v in grads_np("cx", cx).items()})
+            out.update({f"w1.{k}": v for k, v in sd_np("cx", cx).items()})
+        with _Feed([z_cz[i]], [torch.from_numpy(a_cz[i])]):
+            l = ref_train.critic_z_iteration(samples[i], enc, cz, ocz, params)
+        l_cz.append(float(l))
+        if i == 0:
+            out.update({k.replace("g.", "g1.cz_iter."): v for k, v in grads_np("cz", cz).items()})
+            out.update({f"w1.{k}": v for k, v in sd_np("cz", cz).items()})
+    out.update(loss_cx=np.asarray(l_cx), loss_cz=np.asarray(l_cz))
+    out.update({f"wN.{k}": v for k, v in sd_np("cx", cx).items()})
+    out.update({f"wN.{k}": v for k, v in sd_np("cz", cz).items()})
+
+    # generator phase (train.py:333-352): critics frozen at their trained state
+    ref_train_set(enc, dec, True)
+    ref_train_set(cx, cz, False)
+    l_dec, l_hyp, l_mse = [], [], []
+    for i in range(steps):
+        with _Feed([z_dec[i]], []):
+            l, h, m = ref_train.decoder_iteration(samples[i], enc, dec, cx, cz, odec, params)
+        l_dec.append(float(l)); l_hyp.append(float(h)); l_mse.append(float(m))
+        if i == 0:
+            out.update({k.replace("g.", "g1.dec_iter."): v for k, v in grads_np("dec", dec).items()})
+            out.update({k.replace("g.", "g1.dec_iter."): v for k, v in grads_np("enc", enc).items()})
+            out.update({f"w1.{k}": v for k, v in sd_np("dec", dec).items()})
+            out.update({f"w1.{k}": v for k, v in sd_np("enc", enc).items()})
+    out.update(loss_dec=np.asarray(l_dec), loss_hyper=np.asarray(l_hyp), loss_mse=np.asarray(l_mse))
+    out.update({f"wN.{k}": v for k, v in sd_np("dec", dec).items()})
+    out.update({f"wN.{k}": v for k, v in sd_np("enc", enc).items()})
+    np.savez(os.path.join(HERE, f"iters_{tag}.npz"), **out)
+
+
+def ref_train_set(a, b, flag):
+    for m in (a, b):
+        for p in m.parameters():
+            p.requires_grad = flag
+
+
+# ------------------------------------------------------------------------------ scoring
+def gen_scoring(N=300, S=100):
+    rng = np.random.default_rng(5)
+    y = synth_windows(N, S, seed=9)
+    y_hat = (y[:, :, 0] + 0.05 * rng.standard_normal((N, S))).astype(F32)
+    y_hat[N // 3: N // 3 + 20] += 0.4
+    critic = rng.standard_normal(N).astype(F32)
+    out = dict(y=y, y_hat=y_hat, critic=critic)
+    w = int(N * 0.01)
+    err, pvs = ref_adu.reconstruction_errors(y, y_hat, 1, 10, w, True, "point")
+    out.update(point_err=np.asarray(err, dtype=np.float64), predictions_vs=np.asarray(pvs, dtype=np.float64))
+    err_raw, _ = ref_adu.reconstruction_errors(y, y_hat, 1, 10, w, False, "point")
+    out.update(point_err_raw=np.asarray(err_raw, dtype=np.float64))
+    from scipy import stats
+    out["point_z"] = np.clip(stats.zscore(err), a_min=0, a_max=None) + 1
+    cs = ref_adu.final_critic_scores(list(critic), y)
+    out["critic_scores"] = np.asarray(cs, dtype=np.float64)
+    out["critic_score_direct"] = ref_adu._compute_critic_score(critic, 7)
+    # hyperbolic branch of univariate_anomaly_detection (:54-86), minus I/O
+    ball_a = (0.3 * np.tanh(y_hat)).astype(F32)
+    ball_b = (0.3 * np.tanh(y[:, :, 0])).astype(F32)
+    ta, tb = torch.Tensor(ball_a).reshape(-1, S), torch.Tensor(ball_b).reshape(-1, S)
+    sqdist = torch.sum((tb - ta) ** 2, dim=1)
+    rec = torch.acosh(1 + 2 * sqdist / ((1 - torch.sum(tb ** 2, dim=-1)) * (1 - torch.sum(ta ** 2, dim=-1))) + 1e-7)
+    out.update(ball_recons=ball_a, ball_real=ball_b, hyper_rec=rec.numpy())
+    crit = np.asarray(cs)[: rec.shape[0]]
+    for comb in ("sum", "mult", "uncertainty", "critic", "critic_uncertainty", "sum_uncertainty", "rec",
+                 "rec_uncertainty"):
+        out[f"comb_{comb}"] = np.asarray(ref_adu.combine_scores(comb, crit, rec.numpy(), ball_a), dtype=np.float64)
+    # Euclidean branch (score_anomalies :407-576, path=None so nothing is pickled), point error
+    for comb in ("mult", "sum", "rec", "critic"):
+        fs, _, true, _ = ref_adu.score_anomalies(y, y_hat, critic, None, rec_error_type="point", comb=comb)
+        out[f"eucl_{comb}"] = np.asarray(fs, dtype=np.float64)
+    out["true_unrolled"] = np.asarray(true, dtype=np.float64).reshape(-1)
+    np.savez(os.path.join(HERE, "score.npz"), **out)
+
+
+if __name__ == "__main__":
+    import pandas
+    import scipy
+    gen_forward(100, 64, "S100_B64")
+    gen_forward(150, 256, "S150_B256")
+    gen_ops()
+    gen_iters(100, 64, True, "hyper_S100")
+    gen_iters(100, 64, False, "eucl_S100")
+    gen_scoring()
+    with open(os.path.join(HERE, "versions.json"), "w") as f:
+        json.dump(dict(torch=torch.__version__, numpy=np.__version__, scipy=scipy.__version__,
+                       pandas=pandas.__version__, python=sys.version.split()[0],
+                       reference="aleflabo/HypAD @ /root/reference (v1)",
+                       note="RiemannianAdam steps (iters_hyper: w1/wN of dec.* and enc.*) come from oracle.radam "
+                            "(geoopt 0.5.0 is not vendored): UNPINNED"), f, indent=1)
+    print("fixtures written to", HERE)

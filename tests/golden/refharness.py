@@ -1,0 +1,154 @@
+"""Import harness for the *reference* HypAD sources (this container only).
+
+TEST INFRASTRUCTURE.  Used solely by ``tests/golden/gen_fixtures.py`` to run the
+reference's own Python on CPU and record golden input/output vectors.  Nothing
+here travels to the GPU box in executable form: ``/root/reference`` does not
+exist there, and every test that runs on the GPU box reads only the committed
+``.npz`` fixtures.
+
+The reference needs three things this image lacks:
+
+* ``geoopt`` (0.5.0 in ``environment.yml:91``) -- its stereographic math module
+  is vendored at ``/root/reference/math_.py`` but imports five helpers from
+  ``geoopt.utils`` which are *not* vendored.  They are restated below from the
+  published geoopt definitions.  ``geoopt.optim.RiemannianAdam`` is not
+  vendored at all: the stand-in registered here is ``oracle.radam`` (parity
+  UNPINNED for that one class; see oracle/radam.py).
+* ``torchvision.transforms`` and ``pyts.metrics`` -- import-time only stubs.
+* a GPU -- ``.cuda()`` is patched to the identity.
+
+``PYTORCH_JIT=0`` must be set before torch is imported (torch 2.10 cannot
+script ``math_.py:1315``) and bytecode writing is disabled so that nothing is
+ever written under /root/reference.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def _geoopt_utils_module():
+    import torch
+
+    m = types.ModuleType("geoopt.utils")
+
+    def sign(x):
+        return torch.sign(x.sign() + 0.5)
+
+    def sabs(x, eps: float = 1e-15):
+        return x.abs().add_(eps)
+
+    def clamp_abs(x, eps: float = 1e-15):
+        s = sign(x)
+        return s * sabs(x, eps=eps)
+
+    def list_range(end: int):
+        return list(range(end))
+
+    def drop_dims(tensor, dims):
+        seen = 0
+        for d in dims:
+            tensor = tensor.squeeze(d - seen)
+            seen += 1
+        return tensor
+
+    m.sign, m.sabs, m.clamp_abs = sign, sabs, clamp_abs
+    m.list_range, m.drop_dims = list_range, drop_dims
+    return m
+
+
+def install(repo_root=None):
+    """Put the reference on sys.path behind the stubs.  Idempotent."""
+    if "geoopt" in sys.modules and getattr(sys.modules["geoopt"], "_hypad_stub", False):
+        return sys.modules["geoopt"]
+    if os.environ.get("PYTORCH_JIT", "1") != "0":
+        raise RuntimeError("set PYTORCH_JIT=0 before importing torch (math_.py cannot be scripted)")
+    sys.dont_write_bytecode = True
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError("reference tree not present; fixtures can only be generated in the build container")
+
+    import torch
+
+    repo_root = repo_root or os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if repo_root not in sys.path:
+        sys.path.insert(0, repo_root)
+
+    # ---- geoopt package skeleton -------------------------------------------------
+    geoopt = types.ModuleType("geoopt")
+    geoopt._hypad_stub = True
+    geoopt.__path__ = []
+    manifolds = types.ModuleType("geoopt.manifolds")
+    manifolds.__path__ = []
+    stereo = types.ModuleType("geoopt.manifolds.stereographic")
+    stereo.__path__ = []
+    utils = _geoopt_utils_module()
+    sys.modules.update({
+        "geoopt": geoopt,
+        "geoopt.utils": utils,
+        "geoopt.manifolds": manifolds,
+        "geoopt.manifolds.stereographic": stereo,
+    })
+    geoopt.utils, geoopt.manifolds, manifolds.stereographic = utils, manifolds, stereo
+
+    spec = importlib.util.spec_from_file_location(
+        "geoopt.manifolds.stereographic.math", os.path.join(REFERENCE_ROOT, "math_.py"))
+    gmath = importlib.util.module_from_spec(spec)
+    sys.modules["geoopt.manifolds.stereographic.math"] = gmath
+    spec.loader.exec_module(gmath)
+    stereo.math = gmath
+
+    class PoincareBall:
+        def __init__(self, c=1.0):
+            self.c = torch.as_tensor(c, dtype=torch.float32)
+            self.k = -self.c
+
+    class Sphere:
+        pass
+
+    class ManifoldParameter(torch.nn.Parameter):
+        def __new__(cls, data=None, manifold=None, requires_grad=True):
+            inst = torch.nn.Parameter.__new__(cls, data.data if isinstance(data, torch.nn.Parameter) else data,
+                                              requires_grad)
+            inst.manifold = manifold
+            return inst
+
+    geoopt.PoincareBall = PoincareBall
+    geoopt.ManifoldParameter = ManifoldParameter
+    geoopt.ManifoldTensor = ManifoldParameter
+    manifolds.Sphere = Sphere
+    manifolds.PoincareBall = PoincareBall
+
+    optim = types.ModuleType("geoopt.optim")
+    from oracle.radam import RiemannianAdam  # UNPINNED stand-in (not in the reference tree)
+    optim.RiemannianAdam = RiemannianAdam
+    geoopt.optim = optim
+    sys.modules["geoopt.optim"] = optim
+
+    # ---- import-time stubs --------------------------------------------------------
+    tv = types.ModuleType("torchvision")
+    tv.__path__ = []
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    pyts = types.ModuleType("pyts")
+    pyts.__path__ = []
+    pm = types.ModuleType("pyts.metrics")
+
+    def _dtw_unavailable(*a, **k):
+        raise RuntimeError("pyts is not installed; DTW parity is pinned by oracle/scoring.py only")
+
+    pm.dtw = _dtw_unavailable
+    pyts.metrics = pm
+    sys.modules.setdefault("pyts", pyts)
+    sys.modules.setdefault("pyts.metrics", pm)
+
+    # ---- no GPU here ----------------------------------------------------------------
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(1, REFERENCE_ROOT)
+    return geoopt
