@@ -1,0 +1,162 @@
+"""ctypes binding of libhypad_hip.so (the C ABI declared in include/hypad.h).
+
+The product path has no CPU fallback: importing this module without the built
+library raises, and every call checks its status code.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhypad_hip.so")
+
+
+class HypadError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HypadError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m hypad_amd.build). "
+            "hypad_amd has no CPU fallback.")
+    return ctypes.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+NET_ENCODER, NET_DECODER, NET_CRITIC_X, NET_CRITIC_Z = 0, 1, 2, 3
+ACT_NONE, ACT_TANH, ACT_LEAKY02 = 0, 1, 2
+COMB = {"sum": 0, "mult": 1, "uncertainty": 2, "critic": 3, "critic_uncertainty": 4, "sum_uncertainty": 5, "rec": 6,
+        "rec_uncertainty": 7, "eucl_mult": 8, "eucl_sum": 9}
+
+
+class Dropout(Structure):
+    _fields_ = [("train_mode", c_int), ("masks", c_void_p), ("seed", c_uint64), ("offset", c_uint64)]
+
+
+class Dims(Structure):
+    _fields_ = [("signal_shape", c_int), ("latent_dim", c_int), ("batch", c_int), ("hyperbolic", c_int), ("n_signals", c_int)]
+
+
+class Nets(Structure):
+    _fields_ = [("enc", c_void_p), ("dec", c_void_p), ("cx", c_void_p), ("cz", c_void_p)]
+
+
+class TrainState(Structure):
+    _fields_ = [("params", Nets), ("exp_avg", Nets), ("exp_avg_sq", Nets), ("counters", c_void_p),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("gen_weight_decay", c_float), ("gen_stabilize", c_int)]
+
+
+class IterIO(Structure):
+    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("row_index", c_void_p), ("z", c_void_p), ("alpha", c_void_p),
+                ("drop", Dropout), ("losses", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+class EpochIO(Structure):
+    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
+                ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+
+
+P = c_void_p
+_SIGS = {
+    "hypad_abi_version": (c_int, []),
+    "hypad_error_string": (c_char_p, [c_int]),
+    "hypad_limits": (None, [POINTER(c_int), POINTER(c_int)]),
+    "hypad_param_count": (c_int, [c_int, c_int, c_int, c_int]),
+    "hypad_param_tensors": (c_int, [c_int, c_int]),
+    "hypad_param_info": (c_int, [c_int, c_int, c_int, c_int, c_int, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "hypad_expmap0_fwd": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_expmap0_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_logmap0_fwd": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_logmap0_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_mobius_add_fwd": (c_int, [P, P, P, c_int64, c_int, c_int64, P]),
+    "hypad_mobius_add_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_int64, P]),
+    "hypad_project_fwd": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_project_bwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_mobius_head_fwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_mobius_head_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    "hypad_mobius_linear_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "hypad_mobius_linear_fwd": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_mobius_linear_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_size_t, c_int64, c_int, c_int, P]),
+    "hypad_poincare_rowdist_fwd": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_poincare_rowdist_bwd": (c_int, [P, P, P, P, P, c_int64, c_int, P]),
+    "hypad_hyper_loss_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_hyper_loss_bwd": (c_int, [P, P, c_float, P, P, c_int64, c_int, c_int, P]),
+    "hypad_poincare_pairdist_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "hypad_column_sum": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_linear_act_fwd": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    "hypad_linear_act_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    "hypad_lstm_bidir_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_lstm_bidir_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_encoder_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_decoder_fwd": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, POINTER(Dropout), P]),
+    "hypad_critic_x_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, POINTER(Dropout), P]),
+    "hypad_critic_z_fwd": (c_int, [P, P, P, c_int64, c_int, POINTER(Dropout), P]),
+    "hypad_score_forward": (c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
+    "hypad_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
+    "hypad_critic_x_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
+    "hypad_critic_z_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
+    "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
+    "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
+    "hypad_adam_step": (c_int, [P, P, P, P, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, P]),
+    "hypad_radam_step": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P]),
+    "hypad_unroll_median": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_unroll_true": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_point_error": (c_int, [P, P, P, c_int64, P]),
+    "hypad_area_error": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_dtw_error": (c_int, [P, P, P, c_int64, c_int, P]),
+    "hypad_rolling_mean": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_zscore_clip": (c_int, [P, P, c_int64, P, c_size_t, P]),
+    "hypad_row_norms": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_combine_scores": (c_int, [c_int, P, P, P, P, c_int64, P]),
+}
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = the library does not match include/hypad.h
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.hypad_error_string(int(rc))
+        raise HypadError(f"{what or 'hypad call'} failed: {msg.decode() if msg else rc} ({rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t, name="tensor", dtype=torch.float32):
+    if not t.is_cuda:
+        raise HypadError(f"{name} must live on the GPU (hypad_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise HypadError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HypadError(f"{name} must be contiguous")
+    return t
+
+
+def param_catalogue(net, S, L, hyperbolic):
+    """[(name, offset, shape)] and the padded float count of one network's arena."""
+    n = lib.hypad_param_tensors(net, int(hyperbolic))
+    if n < 0:
+        raise HypadError("bad network id")
+    out = []
+    name = ctypes.create_string_buffer(64)
+    off, rows, cols = c_int(), c_int(), c_int()
+    for i in range(n):
+        check(lib.hypad_param_info(net, S, L, int(hyperbolic), i, name, 64, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols)))
+        shape = (rows.value, cols.value) if cols.value > 0 else (rows.value,)
+        out.append((name.value.decode(), off.value, shape))
+    return out, lib.hypad_param_count(net, S, L, int(hyperbolic))

@@ -1,0 +1,118 @@
+// ABI book-keeping: version, error strings, limits and the parameter-arena catalogue the host side builds
+// its tensor views from (names/shapes = the reference's state_dict).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/hypad.h"
+#include "layout.h"
+
+using namespace hypad;
+
+namespace {
+
+struct TensorInfo {
+  char name[64];
+  int offset, rows, cols;
+};
+
+void add(std::vector<TensorInfo>& v, const char* name, int off, int rows, int cols) {
+  TensorInfo t;
+  std::snprintf(t.name, sizeof(t.name), "%s", name);
+  t.offset = off; t.rows = rows; t.cols = cols;
+  v.push_back(t);
+}
+void add_lstm(std::vector<TensorInfo>& v, const LstmDir& d, int layer, bool reverse, int H, int in) {
+  char n[64];
+  const char* sfx = reverse ? "_reverse" : "";
+  std::snprintf(n, sizeof(n), "lstm.weight_ih_l%d%s", layer, sfx); add(v, n, d.w_ih, 4 * H, in);
+  std::snprintf(n, sizeof(n), "lstm.weight_hh_l%d%s", layer, sfx); add(v, n, d.w_hh, 4 * H, H);
+  std::snprintf(n, sizeof(n), "lstm.bias_ih_l%d%s", layer, sfx); add(v, n, d.b_ih, 4 * H, 0);
+  std::snprintf(n, sizeof(n), "lstm.bias_hh_l%d%s", layer, sfx); add(v, n, d.b_hh, 4 * H, 0);
+}
+
+bool catalogue(int net, int S, int L, int hyperbolic, std::vector<TensorInfo>& v, int& total) {
+  if (S <= 0 || L <= 0) return false;
+  switch (net) {
+    case HYPAD_NET_ENCODER: {
+      EncLayout e = enc_layout(S, L);
+      add_lstm(v, e.dir[0], 0, false, ENC_H, S);
+      add_lstm(v, e.dir[1], 0, true, ENC_H, S);
+      add(v, "dense.weight", e.dense_w, L, 2 * ENC_H);
+      add(v, "dense.bias", e.dense_b, L, 0);
+      total = e.total;
+      return true;
+    }
+    case HYPAD_NET_DECODER: {
+      DecLayout d = dec_layout(S, L, hyperbolic);
+      add(v, "dense1.weight", d.d1_w, DEC_D1, L);
+      add(v, "dense1.bias", d.d1_b, DEC_D1, 0);
+      for (int layer = 0; layer < 2; ++layer)
+        for (int dir = 0; dir < 2; ++dir) add_lstm(v, d.l[layer][dir], layer, dir == 1, DEC_H, layer == 0 ? DEC_D1 : 2 * DEC_H);
+      add(v, "dense2.weight", d.d2_w, S, 2 * DEC_H);
+      add(v, "dense2.bias", d.d2_b, S, 0);
+      if (hyperbolic) {
+        add(v, "hyperbolic_linear.weight", d.head_w, S, S);
+        add(v, "hyperbolic_linear.bias", d.head_b, S, 0);
+      }
+      total = d.total;
+      return true;
+    }
+    case HYPAD_NET_CRITIC_X:
+    case HYPAD_NET_CRITIC_Z: {
+      CriticLayout c = net == HYPAD_NET_CRITIC_X ? cx_layout(S, L) : cz_layout(L);
+      for (int i = 0; i <= c.nh; ++i) {
+        char n[64];
+        std::snprintf(n, sizeof(n), "dense%d.weight", i + 1); add(v, n, c.w[i], i == c.nh ? 1 : L, i == 0 ? c.in_dim : L);
+        std::snprintf(n, sizeof(n), "dense%d.bias", i + 1); add(v, n, c.b[i], i == c.nh ? 1 : L, 0);
+      }
+      total = c.total;
+      return true;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hypad_abi_version(void) { return HYPAD_ABI_VERSION; }
+
+const char* hypad_error_string(int code) {
+  switch (code) {
+    case HYPAD_OK: return "ok";
+    case HYPAD_EINVAL: return "invalid argument";
+    case HYPAD_EWORKSPACE: return "workspace missing or too small";
+    case HYPAD_EUNSUPPORTED: return "shape outside the fused kernels' limits";
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown error";
+}
+
+void hypad_limits(int* max_signal_shape, int* max_latent) {
+  if (max_signal_shape) *max_signal_shape = MAX_S;
+  if (max_latent) *max_latent = MAX_L;
+}
+
+int hypad_param_count(int net, int S, int L, int hyperbolic) {
+  std::vector<TensorInfo> v; int total = 0;
+  return catalogue(net, S, L, hyperbolic, v, total) ? total : HYPAD_EINVAL;
+}
+int hypad_param_tensors(int net, int hyperbolic) {
+  std::vector<TensorInfo> v; int total = 0;
+  return catalogue(net, 100, 20, hyperbolic, v, total) ? (int)v.size() : HYPAD_EINVAL;
+}
+int hypad_param_info(int net, int S, int L, int hyperbolic, int index, char* name, int name_cap, int* offset, int* rows, int* cols) {
+  std::vector<TensorInfo> v; int total = 0;
+  if (!catalogue(net, S, L, hyperbolic, v, total) || index < 0 || index >= (int)v.size()) return HYPAD_EINVAL;
+  if (name && name_cap > 0) std::snprintf(name, (size_t)name_cap, "%s", v[index].name);
+  if (offset) *offset = v[index].offset;
+  if (rows) *rows = v[index].rows;
+  if (cols) *cols = v[index].cols;
+  return HYPAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Device helpers: 64-lane wave reductions, Philox4x32-10, activations, launch-error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hypad {
+
+constexpr int WAVE = 64;
+constexpr float MIN_NORM = 1e-15f;          // math_.py:1134,1269,349
+constexpr float TANH_CLAMP = 15.0f;         // math_.py:53
+constexpr float ARTANH_EPS = 1e-7f;         // math_.py:58
+constexpr float BALL_MAXNORM = 1.0f - 4e-3f;// math_.py:343-349 (fp32), k = -1
+constexpr float LEAK = 0.2f;                // models/tadgan.py:76,121
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+// sum over aligned groups of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float leaky_slope(float pre) { return pre > 0.0f ? 1.0f : LEAK; }
+
+// ---------------------------------------------------------------------------------------- Philox4x32-10
+struct Philox {
+  uint32_t key[2];
+  __device__ __forceinline__ Philox(uint64_t seed) { key[0] = (uint32_t)seed; key[1] = (uint32_t)(seed >> 32); }
+  __device__ __forceinline__ uint4 operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
+    uint32_t k0 = key[0], k1 = key[1];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+      uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+      uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+      c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+  }
+};
+__device__ __forceinline__ float u32_to_unit_open(uint32_t x) {   // (0, 1]
+  return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float u32_to_unit(uint32_t x) {        // [0, 1)
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ uint32_t pick(const uint4& r, int i) {
+  return i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w;
+}
+// Streams (c1): which random tensor of an iteration
+enum RngStream : uint32_t {
+  RS_Z = 1, RS_ALPHA = 2, RS_DROP_DEC0 = 3, RS_DROP_DEC1 = 4, RS_DROP_CRITIC = 16 /* + pass*8 + layer */
+};
+// uniform [0,1) for element `idx` of stream `stream` at tick `tick` of model `sig`
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t idx) {
+  Philox ph(seed);
+  uint4 r = ph(idx >> 2, stream, tick, sig);
+  return u32_to_unit(pick(r, idx & 3));
+}
+__device__ __forceinline__ float rng_normal(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t idx) {
+  Philox ph(seed);
+  uint4 r = ph(idx >> 1, stream, tick, sig);
+  float u1 = u32_to_unit_open((idx & 1) ? r.z : r.x), u2 = u32_to_unit((idx & 1) ? r.w : r.y);
+  return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+}
+// dropout keep-scale: 0 or 1/(1-p)
+__device__ __forceinline__ float rng_dropout(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t idx, float p) {
+  return rng_uniform(seed, tick, stream, sig, idx) >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+}  // namespace hypad
+
+#define HYPAD_CHECK_LAUNCH()                          \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)

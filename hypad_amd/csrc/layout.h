@@ -1,0 +1,95 @@
+// Parameter-arena layouts of the four TadGAN networks (host + device).
+// Tensor order, names and shapes follow the reference's state_dict (models/tadgan.py:11-21,31-56,71-89,
+// 110-121); every tensor starts at a multiple of 4 floats (16 B).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define HD __host__ __device__ __forceinline__
+#else
+#define HD inline
+#endif
+
+namespace hypad {
+
+constexpr int ENC_H = 50;      // Encoder LSTM hidden size      models/tadgan.py:17
+constexpr int DEC_H = 64;      // Decoder LSTM hidden size      models/tadgan.py:36
+constexpr int DEC_D1 = 50;     // Decoder dense1 out_features   models/tadgan.py:34
+constexpr int MAX_S = 256;     // fused kernels: signal_shape limit (LDS budget)
+constexpr int MAX_L = 32;      // latent / critic width limit
+
+HD int pad4(int n) { return (n + 3) & ~3; }
+
+struct LstmDir { int w_ih, w_hh, b_ih, b_hh; };
+
+struct EncLayout {
+  LstmDir dir[2];
+  int dense_w, dense_b, total;
+};
+HD EncLayout enc_layout(int S, int L) {
+  EncLayout e; int o = 0;
+  for (int d = 0; d < 2; ++d) {
+    e.dir[d].w_ih = o; o += pad4(4 * ENC_H * S);
+    e.dir[d].w_hh = o; o += pad4(4 * ENC_H * ENC_H);
+    e.dir[d].b_ih = o; o += pad4(4 * ENC_H);
+    e.dir[d].b_hh = o; o += pad4(4 * ENC_H);
+  }
+  e.dense_w = o; o += pad4(L * 2 * ENC_H);
+  e.dense_b = o; o += pad4(L);
+  e.total = o;
+  return e;
+}
+
+struct DecLayout {
+  int d1_w, d1_b;
+  LstmDir l[2][2];     // [layer][direction]
+  int d2_w, d2_b, head_w, head_b, total;
+};
+HD DecLayout dec_layout(int S, int L, int hyperbolic) {
+  DecLayout d; int o = 0;
+  d.d1_w = o; o += pad4(DEC_D1 * L);
+  d.d1_b = o; o += pad4(DEC_D1);
+  for (int layer = 0; layer < 2; ++layer) {
+    int in = layer == 0 ? DEC_D1 : 2 * DEC_H;
+    for (int dir = 0; dir < 2; ++dir) {
+      d.l[layer][dir].w_ih = o; o += pad4(4 * DEC_H * in);
+      d.l[layer][dir].w_hh = o; o += pad4(4 * DEC_H * DEC_H);
+      d.l[layer][dir].b_ih = o; o += pad4(4 * DEC_H);
+      d.l[layer][dir].b_hh = o; o += pad4(4 * DEC_H);
+    }
+  }
+  d.d2_w = o; o += pad4(S * 2 * DEC_H);
+  d.d2_b = o; o += pad4(S);
+  d.head_w = d.head_b = -1;
+  if (hyperbolic) {
+    d.head_w = o; o += pad4(S * S);
+    d.head_b = o; o += pad4(S);
+  }
+  d.total = o;
+  return d;
+}
+
+// Critics: nh hidden Linear(.,L)+LeakyReLU+Dropout blocks, then Linear(L,1).
+struct CriticLayout {
+  int nh;              // 4 (CriticX) or 2 (CriticZ)
+  int in_dim;          // S or L
+  int w[5], b[5];      // layer li: weight (L, in_dim | L) ... last (1, L)
+  float p_drop;
+  int total;
+};
+HD CriticLayout critic_layout(int in_dim, int L, int nh, float p_drop) {
+  CriticLayout c; c.nh = nh; c.in_dim = in_dim; c.p_drop = p_drop; int o = 0;
+  for (int i = 0; i <= nh; ++i) {
+    int k = i == 0 ? in_dim : L;
+    int n = i == nh ? 1 : L;
+    c.w[i] = o; o += pad4(n * k);
+    c.b[i] = o; o += pad4(n);
+  }
+  for (int i = nh + 1; i < 5; ++i) c.w[i] = c.b[i] = -1;
+  c.total = o;
+  return c;
+}
+HD CriticLayout cx_layout(int S, int L) { return critic_layout(S, L, 4, 0.25f); }   // models/tadgan.py:75
+HD CriticLayout cz_layout(int L) { return critic_layout(L, L, 2, 0.2f); }          // models/tadgan.py:120
+
+}  // namespace hypad

@@ -1,0 +1,282 @@
+// Tile-level building blocks of the TadGAN networks: a workgroup carries MT*16 rows through whole layers,
+// activations in LDS, weights streamed from the parameter arena.  Closed forms follow SURVEY.md A.2 and
+// oracle/manual.py (the CPU derivation sheet these functions transcribe).
+#pragma once
+#include "layout.h"
+#include "rowops.h"
+#include "tile_gemm.h"
+
+namespace hypad {
+
+constexpr int LP = 32;  // padded row stride for latent / critic-width tiles (L <= MAX_L = 32)
+
+// ---------------------------------------------------------------------------------------- dropout source
+struct DropSrc {
+  int mode;               // 0 none (eval), 1 injected masks, 2 device Philox
+  const float* ptr;       // injected: [(layer)][batch][ncols]
+  int batch;              // rows per layer block of the injected array
+  uint64_t seed;
+  uint32_t tick, stream, sig;
+  float p;
+  __device__ __forceinline__ float get(int layer, int grow, int c, int ncols) const {
+    if (mode == 0) return 1.f;
+    if (mode == 1) return ptr[((size_t)layer * batch + grow) * ncols + c];
+    return rng_dropout(seed, tick, stream + layer, sig, (uint32_t)(grow * ncols + c), p);
+  }
+};
+__device__ __forceinline__ DropSrc no_drop() { return DropSrc{0, nullptr, 0, 0, 0, 0, 0, 0.f}; }
+
+// ---------------------------------------------------------------------------------------- tile movement
+// global (row stride gld) -> LDS [rows][ld]; rows >= valid are zero-filled
+__device__ __forceinline__ void tile_load(float* __restrict__ dst, int ld, const float* __restrict__ src, int64_t gld,
+                                          int rows, int cols, int valid) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    int r = i / cols, c = i - r * cols;
+    dst[r * ld + c] = r < valid ? src[(int64_t)r * gld + c] : 0.f;
+  }
+}
+__device__ __forceinline__ void tile_load_rows(float* __restrict__ dst, int ld, const float* __restrict__ base, int64_t gld,
+                                               const int32_t* __restrict__ row_index, int row0, int rows, int cols, int valid) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    int r = i / cols, c = i - r * cols;
+    float v = 0.f;
+    if (r < valid) {
+      int64_t gr = row_index ? (int64_t)row_index[row0 + r] : (int64_t)(row0 + r);
+      v = base[gr * gld + c];
+    }
+    dst[r * ld + c] = v;
+  }
+}
+__device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t gld, const float* __restrict__ src, int ld,
+                                           int rows, int cols, int valid) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    int r = i / cols, c = i - r * cols;
+    if (r < valid) dst[(int64_t)r * gld + c] = src[r * ld + c];
+  }
+}
+// Multi-pass tiles: LDS row r belongs to pass r>>4; its global row is (r>>4)*ps + (r&15) (ps = rows between passes;
+// ps = 16 means plain contiguous rows).
+__device__ __forceinline__ int64_t prow(int r, int ps) { return (int64_t)(r >> 4) * ps + (r & 15); }
+__device__ __forceinline__ void tile_store_p(float* __restrict__ dst, int64_t gld, int ps, const float* __restrict__ src, int ld,
+                                             int rows, int cols, int valid) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    int r = i / cols, c = i - r * cols;
+    if (r < valid) dst[prow(r, ps) * gld + c] = src[r * ld + c];
+  }
+}
+__device__ __forceinline__ void tile_load_p(float* __restrict__ dst, int ld, const float* __restrict__ src, int64_t gld, int ps,
+                                            int rows, int cols, int valid) {
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    int r = i / cols, c = i - r * cols;
+    dst[r * ld + c] = r < valid ? src[prow(r, ps) * gld + c] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- LSTM layer, T = 1
+// Gate pre-activations for both directions into Gs[rows][ldg] as compact [dir][i|g|o] blocks of H columns.
+template <int MT>
+__device__ __forceinline__ void lstm_gates_tile(const float* As, int lda, int K, const float* P, const LstmDir& d0,
+                                                const LstmDir& d1, int H, float* Gs, int ldg) {
+  gemm_nt<MT>(As, lda, P + d0.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d0.b_ih, P + d0.b_hh, Gs, ldg, 0);
+  gemm_nt<MT>(As, lda, P + d1.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d1.b_ih, P + d1.b_hh, Gs, ldg, 3 * H);
+}
+// cell: c = sig(i)*tanh(g), h = sig(o)*tanh(c).  Hs[rows][ldh] <- [h_fwd | h_rev].
+// gates_save (global, may be null): row r at gates_save + r*8H, layout [dir][i,g,o,tanh c][H].
+__device__ __forceinline__ void lstm_cell_tile(const float* Gs, int ldg, int H, int rows, float* Hs, int ldh,
+                                               float* gates_save, int valid, int ps = 16) {
+  const int per = 2 * H;
+  for (int idx = threadIdx.x; idx < rows * per; idx += blockDim.x) {
+    int r = idx / per, c = idx - r * per;
+    int d = c / H, jj = c - d * H;
+    const float* g = Gs + r * ldg + d * 3 * H;
+    float gi = sigmoidf_(g[jj]), gg = tanhf(g[H + jj]), go = sigmoidf_(g[2 * H + jj]);
+    float tc = tanhf(gi * gg);
+    Hs[r * ldh + c] = go * tc;
+    if (gates_save && r < valid) {
+      float* s = gates_save + prow(r, ps) * 8 * H + d * 4 * H + jj;
+      s[0] = gi; s[H] = gg; s[2 * H] = go; s[3 * H] = tc;
+    }
+  }
+}
+// backward of the cell: dHs[rows][ldh] -> dGs[rows][ldg] compact [dir][di|dg|do] (oracle/manual.py lstm_dir_bwd)
+__device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, const float* gates_saved, int H, int rows,
+                                                   float* dGs, int ldg, int valid, int ps = 16) {
+  const int per = 2 * H;
+  for (int idx = threadIdx.x; idx < rows * per; idx += blockDim.x) {
+    int r = idx / per, c = idx - r * per;
+    int d = c / H, jj = c - d * H;
+    float di = 0.f, dg = 0.f, dov = 0.f;
+    if (r < valid) {
+      const float* s = gates_saved + prow(r, ps) * 8 * H + d * 4 * H + jj;
+      float gi = s[0], gg = s[H], go = s[2 * H], tc = s[3 * H];
+      float dh = dHs[r * ldh + c];
+      dov = dh * tc * go * (1.f - go);
+      float dc = dh * go * (1.f - tc * tc);
+      di = dc * gg * gi * (1.f - gi);
+      dg = dc * gi * (1.f - gg * gg);
+    }
+    float* o = dGs + r * ldg + d * 3 * H;
+    o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
+  }
+}
+// dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)
+template <int MT>
+__device__ __forceinline__ void lstm_bwd_data_tile(const float* dGs, int ldg, const float* P, const LstmDir& d0,
+                                                   const LstmDir& d1, int H, int K, float* dAs, int lda) {
+  gemm_nn<MT>(dGs, ldg, 0, P + d0.w_ih, K, 3 * H, lstm_gate_map(H), K, dAs, lda, false);
+  __syncthreads();
+  gemm_nn<MT>(dGs, ldg, 3 * H, P + d1.w_ih, K, 3 * H, lstm_gate_map(H), K, dAs, lda, true);
+}
+
+// ---------------------------------------------------------------------------------------- critics (one 16-row tile)
+// LDS scratch of a critic pass
+struct CriticLds {
+  float* act;    // [nh][16][LP]   act[li] = output of hidden layer li (post leaky + dropout)
+  float* dm;     // [nh][16][LP]   dm[li]  = leaky'(pre) * dropout scale
+  float* dl;     // [2][16][LP]    ping-pong deltas
+  float* out;    // [16]
+};
+constexpr int CRITIC_LDS_FLOATS = (4 + 4 + 2) * 16 * LP + 16;
+__device__ __forceinline__ CriticLds critic_lds(float* base) {
+  CriticLds c;
+  c.act = base; c.dm = base + 4 * 16 * LP; c.dl = c.dm + 4 * 16 * LP; c.out = c.dl + 2 * 16 * LP;
+  return c;
+}
+
+// forward.  Xs: LDS [16][ldx] input (in_dim columns).  grow0: global batch row of tile row 0 (dropout indexing).
+__device__ __forceinline__ void critic_fwd_tile(const float* Xs, int ldx, const float* P, const CriticLayout& cl, int L,
+                                                const CriticLds& s, const DropSrc& drop, int grow0) {
+  const float* in = Xs;
+  int ldin = ldx, kin = cl.in_dim;
+  for (int li = 0; li < cl.nh; ++li) {
+    float* a = s.act + li * 16 * LP;
+    float* d = s.dm + li * 16 * LP;
+    gemm_nt<1>(in, ldin, P + cl.w[li], kin, kin, L, identity_map(), P + cl.b[li], nullptr, a, LP, 0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
+      int r = i / L, c = i - r * L;
+      float pre = a[r * LP + c];
+      float dd = leaky_slope(pre) * drop.get(li, grow0 + r, c, L);
+      d[r * LP + c] = dd;
+      a[r * LP + c] = pre * dd;
+    }
+    __syncthreads();
+    in = a; ldin = LP; kin = L;
+  }
+  // last layer (1, L): one thread per row
+  if (threadIdx.x < 16) {
+    const float* w = P + cl.w[cl.nh];
+    float acc = P[cl.b[cl.nh]];
+    for (int c = 0; c < L; ++c) acc += in[threadIdx.x * LP + c] * w[c];
+    s.out[threadIdx.x] = acc;
+  }
+  __syncthreads();
+}
+
+// first-order backward chain for a per-row output gradient dout[r] (LDS [16]).
+// Calls sink(li, delta_ptr) with delta_li in LDS [16][LP] for li = nh-1 .. 0 (the caller stores what it needs;
+// delta of the last layer is dout itself).  Returns a pointer to delta_0.
+template <class Sink>
+__device__ __forceinline__ const float* critic_bwd_chain_tile(const float* dout, const float* P, const CriticLayout& cl,
+                                                              int L, const CriticLds& s, Sink sink) {
+  float* cur = s.dl;
+  float* nxt = s.dl + 16 * LP;
+  const float* wl = P + cl.w[cl.nh];
+  const float* d = s.dm + (cl.nh - 1) * 16 * LP;
+  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
+    int r = i / L, c = i - r * L;
+    cur[r * LP + c] = dout[r] * wl[c] * d[r * LP + c];
+  }
+  __syncthreads();
+  sink(cl.nh - 1, cur);
+  for (int li = cl.nh - 2; li >= 0; --li) {
+    gemm_nn<1>(cur, LP, 0, P + cl.w[li + 1], L, L, identity_map(), L, nxt, LP, false);
+    __syncthreads();
+    const float* dd = s.dm + li * 16 * LP;
+    for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
+      int r = i / L, c = i - r * L;
+      nxt[r * LP + c] *= dd[r * LP + c];
+    }
+    __syncthreads();
+    sink(li, nxt);
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  return cur;
+}
+
+// ---------------------------------------------------------------------------------------- encoder (one tile)
+// Xs [16][ldx] (S columns) -> z in Zs [16][LP].  bufG: LDS scratch >= 16*ldg floats (ldg >= 6*ENC_H),
+// bufH: LDS scratch [16][ldh >= 2*ENC_H].  Optionally saves gates / h for the backward.
+__device__ __forceinline__ void encoder_fwd_tile(const float* Xs, int ldx, int S, int L, const float* P, const EncLayout& el,
+                                                 float* bufG, int ldg, float* bufH, int ldh, float* Zs,
+                                                 float* gates_save, float* h_save, int valid) {
+  lstm_gates_tile<1>(Xs, ldx, S, P, el.dir[0], el.dir[1], ENC_H, bufG, ldg);
+  __syncthreads();
+  lstm_cell_tile(bufG, ldg, ENC_H, 16, bufH, ldh, gates_save, valid);
+  __syncthreads();
+  if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
+  gemm_nt<1>(bufH, ldh, P + el.dense_w, 2 * ENC_H, 2 * ENC_H, L, identity_map(), P + el.dense_b, nullptr, Zs, LP, 0);
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------- decoder (MT tiles)
+struct DecSave {           // global workspace rows for this tile (null = do not save); pass p at + p*ps rows
+  int ps;
+  float* a0;               // [rows][DEC_D1]
+  float* g0;               // [rows][8*DEC_H]
+  float* h0d;              // [rows][2*DEC_H]   (post dropout)
+  float* mask;             // [rows][2*DEC_H]   dropout keep-scale
+  float* g1;               // [rows][8*DEC_H]
+  float* h1;               // [rows][2*DEC_H]
+};
+// Zs [rows][LP] -> tanh output E in bufA [rows][ldS].  bufA/bufB: LDS, each >= rows * max(ldS, 6*DEC_H + 4).
+// drop: inter-layer dropout (p = 0.2, models/tadgan.py:37); grow(r) = batch row of tile row r for the mask.
+template <int MT, class RowFn>
+__device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, int S, const float* P, const DecLayout& dl,
+                                                       float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
+                                                       const DecSave& sv, int valid) {
+  constexpr int rows = MT * 16;
+  constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
+  // dense1
+  gemm_nt<MT>(Zs, LP, P + dl.d1_w, L, L, DEC_D1, identity_map(), P + dl.d1_b, nullptr, bufB, ldA0, 0);
+  __syncthreads();
+  if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
+  // layer 0
+  lstm_gates_tile<MT>(bufB, ldA0, DEC_D1, P, dl.l[0][0], dl.l[0][1], DEC_H, bufA, ldG);
+  __syncthreads();
+  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g0, valid, sv.ps);
+  __syncthreads();
+  if (drop.mode != 0) {
+    for (int i = threadIdx.x; i < rows * 2 * DEC_H; i += blockDim.x) {
+      int r = i / (2 * DEC_H), c = i - r * (2 * DEC_H);
+      float m = drop.get(0, grow(r), c, 2 * DEC_H);
+      bufB[r * ldH + c] *= m;
+      if (sv.mask && r < valid) sv.mask[prow(r, sv.ps) * 2 * DEC_H + c] = m;
+    }
+    __syncthreads();
+  }
+  if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
+  // layer 1
+  lstm_gates_tile<MT>(bufB, ldH, 2 * DEC_H, P, dl.l[1][0], dl.l[1][1], DEC_H, bufA, ldG);
+  __syncthreads();
+  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g1, valid, sv.ps);
+  __syncthreads();
+  if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
+  // dense2 + tanh
+  gemm_nt<MT>(bufB, ldH, P + dl.d2_w, 2 * DEC_H, 2 * DEC_H, S, identity_map(), P + dl.d2_b, nullptr, bufA, ldS, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {
+    int r = i / S, c = i - r * S;
+    bufA[r * ldS + c] = tanhf(bufA[r * ldS + c]);
+  }
+  __syncthreads();
+}
+
+// Moebius head on LDS rows: Us[rows][ld] (u = e W_h^T) -> in place r = project(mobius_add(expmap0(u), bias)).
+__device__ __forceinline__ void head_rows_tile(float* Us, int ld, int rows, int S, const float* bias_g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const RowVec b = row_load(bias_g, S, lane);
+  for (int r = wave; r < rows; r += nw) row_store(Us + r * ld, head_row(row_load(Us + r * ld, S, lane), b), S, lane);
+}
+
+}  // namespace hypad

@@ -1,0 +1,507 @@
+// Network forwards and the dense building blocks, as row-tile kernels:
+// one workgroup = 16 (or 32) window rows carried through every layer with activations in LDS.
+#include <hip/hip_runtime.h>
+
+#include "../../include/hypad.h"
+#include "nets.h"
+
+using namespace hypad;
+
+namespace {
+
+constexpr int THREADS = 256;
+
+__host__ __device__ inline int ld_of(int n) { return pad4(n) + 4; }
+
+hipError_t allow_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+__device__ __forceinline__ DropSrc make_drop(const hypad_dropout& d, int batch, uint32_t stream, float p) {
+  DropSrc s;
+  s.mode = d.train_mode ? (d.masks ? 1 : 2) : 0;
+  s.ptr = d.masks; s.batch = batch; s.seed = d.seed; s.tick = (uint32_t)d.offset; s.stream = stream; s.sig = 0; s.p = p;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------ generic linear
+__global__ __launch_bounds__(THREADS) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float* __restrict__ y,
+                                                              int64_t rows, int K, int N, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = ld_of(K), ldy = ld_of(N);
+  float* xs = smem;
+  float* ys = xs + 16 * ldx;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
+  __syncthreads();
+  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), b, nullptr, ys, ldy, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < valid * N; i += THREADS) {
+    int r = i / N, c = i - r * N;
+    float v = ys[r * ldy + c];
+    if (act == HYPAD_ACT_TANH) v = tanhf(v);
+    else if (act == HYPAD_ACT_LEAKY02) v = v > 0.f ? v : LEAK * v;
+    y[(r0 + r) * N + c] = v;
+  }
+}
+
+// grad_pre = grad_y * act'(y) -> scratch (rows, N) ; grad_x = grad_pre W
+__global__ __launch_bounds__(THREADS) void linear_bwd_data_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                                   const float* __restrict__ gy, float* __restrict__ gpre,
+                                                                   float* __restrict__ gx, int64_t rows, int K, int N, int act) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldd = ld_of(N), ldx = ld_of(K);
+  float* ds = smem;
+  float* xs = ds + 16 * ldd;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  for (int i = threadIdx.x; i < 16 * N; i += THREADS) {
+    int r = i / N, c = i - r * N;
+    float v = 0.f;
+    if (r < valid) {
+      v = gy[(r0 + r) * N + c];
+      float o = y ? y[(r0 + r) * N + c] : 0.f;
+      if (act == HYPAD_ACT_TANH) v *= 1.f - o * o;
+      else if (act == HYPAD_ACT_LEAKY02) v *= o > 0.f ? 1.f : LEAK;
+      if (gpre) gpre[(r0 + r) * N + c] = v;
+    }
+    ds[r * ldd + c] = v;
+  }
+  __syncthreads();
+  if (gx) {
+    gemm_nn<1>(ds, ldd, 0, w, K, N, identity_map(), K, xs, ldx, false);
+    __syncthreads();
+    tile_store(gx + r0 * K, K, xs, ldx, 16, K, valid);
+  }
+}
+
+// grad_w[n][k] = sum_r left[r][n] * right[r][k]; 16x16 tile per wave on MFMA; optional bias column sums.
+__global__ __launch_bounds__(THREADS) void outer_sum_kernel(const float* __restrict__ left, int ldl, const float* __restrict__ right,
+                                                             int ldr, float* __restrict__ gw, float* __restrict__ gb,
+                                                             int64_t rows, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int tk = (K + 15) >> 4, tn = (N + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile < tn * tk) {
+    const int n0 = (tile / tk) * 16, k0 = (tile % tk) * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t rr = 0; rr < rows; rr += 4) {
+      const int64_t r = rr + q;
+      const float a = (r < rows && n0 + j < N) ? left[r * ldl + n0 + j] : 0.f;
+      const float b = (r < rows && k0 + j < K) ? right[r * ldr + k0 + j] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n = n0 + 4 * q + r, k = k0 + j;
+      if (n < N && k < K) gw[(size_t)n * K + k] = acc[r];
+    }
+  }
+  if (gb) {
+    int n = blockIdx.x * THREADS + threadIdx.x;
+    if (n < N) {
+      float s = 0.f;
+      for (int64_t r = 0; r < rows; ++r) s += left[r * ldl + n];
+      gb[n] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ generic BiLSTM (T=1)
+__global__ __launch_bounds__(THREADS) void lstm_fwd_kernel(const float* __restrict__ x, const float* wf, const float* bif,
+                                                            const float* bhf, const float* wr, const float* bir,
+                                                            const float* bhr, float* __restrict__ out,
+                                                            float* __restrict__ gates_save, int64_t rows, int K, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = ld_of(K), ldg = ld_of(6 * H), ldh = ld_of(2 * H);
+  float* xs = smem;
+  float* gs = xs + 16 * ldx;
+  float* hs = gs + 16 * ldg;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
+  __syncthreads();
+  gemm_nt<1>(xs, ldx, wf, K, K, 3 * H, lstm_gate_map(H), bif, bhf, gs, ldg, 0);
+  gemm_nt<1>(xs, ldx, wr, K, K, 3 * H, lstm_gate_map(H), bir, bhr, gs, ldg, 3 * H);
+  __syncthreads();
+  lstm_cell_tile(gs, ldg, H, 16, hs, ldh, gates_save ? gates_save + r0 * 8 * H : nullptr, valid);
+  __syncthreads();
+  tile_store(out + r0 * 2 * H, 2 * H, hs, ldh, 16, 2 * H, valid);
+}
+
+__global__ __launch_bounds__(THREADS) void lstm_bwd_kernel(const float* wf, const float* wr, const float* __restrict__ gates_saved,
+                                                            const float* __restrict__ gout, float* __restrict__ ggates,
+                                                            float* __restrict__ gx, int64_t rows, int K, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = ld_of(K), ldg = ld_of(6 * H), ldh = ld_of(2 * H);
+  float* dhs = smem;
+  float* dgs = dhs + 16 * ldh;
+  float* xs = dgs + 16 * ldg;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(dhs, ldh, gout + r0 * 2 * H, 2 * H, 16, 2 * H, valid);
+  __syncthreads();
+  lstm_cell_bwd_tile(dhs, ldh, gates_saved + r0 * 8 * H, H, 16, dgs, ldg, valid);
+  __syncthreads();
+  if (ggates) {   // (rows, 2, 4H) in PyTorch gate order, f block zero
+    for (int i = threadIdx.x; i < valid * 8 * H; i += THREADS) {
+      int r = i / (8 * H), c = i - r * 8 * H;
+      int d = c / (4 * H), g = (c - d * 4 * H) / H, jj = c - d * 4 * H - g * H;
+      float v = 0.f;
+      if (g != 1) v = dgs[r * ldg + d * 3 * H + (g == 0 ? 0 : g - 1) * H + jj];
+      ggates[(r0 + r) * 8 * H + c] = v;
+    }
+  }
+  if (gx) {
+    gemm_nn<1>(dgs, ldg, 0, wf, K, 3 * H, lstm_gate_map(H), K, xs, ldx, false);
+    __syncthreads();
+    gemm_nn<1>(dgs, ldg, 3 * H, wr, K, 3 * H, lstm_gate_map(H), K, xs, ldx, true);
+    __syncthreads();
+    tile_store(gx + r0 * K, K, xs, ldx, 16, K, valid);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ networks
+struct NetLds {          // float offsets into dynamic LDS for the network kernels
+  int xs, zs, bufA, bufB, crit, total;
+  int ldS, bufFloats;
+};
+__host__ __device__ inline NetLds net_lds(int S, int MT) {
+  NetLds n;
+  n.ldS = pad4(S) + 4;
+  int rows = MT * 16;
+  int per_row = n.ldS > 6 * DEC_H + 4 ? n.ldS : 6 * DEC_H + 4;
+  n.bufFloats = rows * per_row;
+  int o = 0;
+  n.xs = o; o += 16 * n.ldS;
+  n.zs = o; o += rows * LP;
+  n.bufA = o; o += n.bufFloats;
+  n.bufB = o; o += n.bufFloats;
+  n.crit = o; o += CRITIC_LDS_FLOATS;
+  n.total = o;
+  return n;
+}
+
+__global__ __launch_bounds__(THREADS) void encoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ x,
+                                                               float* __restrict__ out, int64_t rows, int S, int L) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const NetLds nl = net_lds(S, 1);
+  const EncLayout el = enc_layout(S, L);
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(smem + nl.xs, nl.ldS, x + r0 * S, S, 16, S, valid);
+  __syncthreads();
+  encoder_fwd_tile(smem + nl.xs, nl.ldS, S, L, P, el, smem + nl.bufA, 6 * ENC_H + 4, smem + nl.bufB, 2 * ENC_H + 4,
+                   smem + nl.zs, nullptr, nullptr, valid);
+  tile_store(out + r0 * L, L, smem + nl.zs, LP, 16, L, valid);
+}
+
+template <int MT>
+__global__ __launch_bounds__(THREADS) void decoder_fwd_kernel(const float* __restrict__ P, const float* __restrict__ z,
+                                                               float* __restrict__ hyper, float* __restrict__ eucl,
+                                                               int64_t rows, int S, int L, int hyperbolic, hypad_dropout dp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = MT * 16;
+  const NetLds nl = net_lds(S, MT);
+  const DecLayout dl = dec_layout(S, L, hyperbolic);
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int valid = (int)min((int64_t)R, rows - r0);
+  float* zs = smem + nl.zs; float* bufA = smem + nl.bufA; float* bufB = smem + nl.bufB;
+  tile_load(zs, LP, z + r0 * L, L, R, L, valid);
+  __syncthreads();
+  DropSrc drop = make_drop(dp, (int)rows, RS_DROP_DEC0, 0.2f);
+  DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int base_row = (int)r0;
+  decoder_trunk_fwd_tile<MT>(zs, L, S, P, dl, bufA, bufB, nl.ldS, drop, [base_row](int r) { return base_row + r; }, none, valid);
+  if (eucl) tile_store(eucl + r0 * S, S, bufA, nl.ldS, R, S, valid);
+  if (hyperbolic && hyper) {
+    gemm_nt<MT>(bufA, nl.ldS, P + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0);
+    __syncthreads();
+    head_rows_tile(bufB, nl.ldS, R, S, P + dl.head_b);
+    __syncthreads();
+    tile_store(hyper + r0 * S, S, bufB, nl.ldS, R, S, valid);
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void critic_fwd_kernel(const float* __restrict__ P, const float* __restrict__ x,
+                                                              float* __restrict__ out, int64_t rows, int in_dim, int L,
+                                                              int nh, float p, hypad_dropout dp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = pad4(in_dim) + 4;
+  float* xs = smem;
+  CriticLds cs = critic_lds(smem + 16 * ldx);
+  const CriticLayout cl = critic_layout(in_dim, L, nh, p);
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(xs, ldx, x + r0 * in_dim, in_dim, 16, in_dim, valid);
+  __syncthreads();
+  DropSrc drop = make_drop(dp, (int)rows, RS_DROP_CRITIC, p);
+  critic_fwd_tile(xs, ldx, P, cl, L, cs, drop, (int)r0);
+  if (threadIdx.x < valid) out[r0 + threadIdx.x] = cs.out[threadIdx.x];
+}
+
+// mobius_linear forward: u = x W^T (saved) ; out = head(u)
+__global__ __launch_bounds__(THREADS) void mobius_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                                     float* __restrict__ u_save, int64_t rows, int K, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = ld_of(K), ldy = ld_of(N);
+  float* xs = smem;
+  float* ys = xs + 16 * ldx;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
+  __syncthreads();
+  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), nullptr, nullptr, ys, ldy, 0);
+  __syncthreads();
+  if (u_save) tile_store(u_save + r0 * N, N, ys, ldy, 16, N, valid);
+  __syncthreads();
+  head_rows_tile(ys, ldy, 16, N, bias);
+  __syncthreads();
+  tile_store(out + r0 * N, N, ys, ldy, 16, N, valid);
+}
+
+// fused scoring forward (anomaly_detection.py:67-113 + utils/anomaly_detection_utils.py:58-66)
+__global__ __launch_bounds__(THREADS) void score_forward_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
+                                                                 const float* __restrict__ PC, const float* __restrict__ x,
+                                                                 float* __restrict__ hyper, float* __restrict__ eucl,
+                                                                 float* __restrict__ hyper_real, float* __restrict__ critic,
+                                                                 float* __restrict__ rowdist, int64_t rows, int S, int L,
+                                                                 int hyperbolic) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const NetLds nl = net_lds(S, 2);      // bufA/bufB sized for 32 rows: decoder rows 0..15, head(x) rows 16..31
+  const EncLayout el = enc_layout(S, L);
+  const DecLayout dl = dec_layout(S, L, hyperbolic);
+  const CriticLayout cl = cx_layout(S, L);
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)min((int64_t)16, rows - r0);
+  float* xs = smem + nl.xs; float* zs = smem + nl.zs; float* bufA = smem + nl.bufA; float* bufB = smem + nl.bufB;
+  CriticLds cs = critic_lds(smem + nl.crit);
+  tile_load(xs, nl.ldS, x + r0 * S, S, 16, S, valid);
+  __syncthreads();
+  if (critic) {
+    critic_fwd_tile(xs, nl.ldS, PC, cl, L, cs, no_drop(), 0);
+    if (threadIdx.x < valid) critic[r0 + threadIdx.x] = cs.out[threadIdx.x];
+  }
+  encoder_fwd_tile(xs, nl.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid);
+  DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, nl.ldS, no_drop(), [](int r) { return r; }, none, valid);
+  if (eucl) tile_store(eucl + r0 * S, S, bufA, nl.ldS, 16, S, valid);
+  if (hyperbolic) {
+    // rows 16..31 of bufA <- x: one head GEMM serves decoder output and the real window
+    for (int i = threadIdx.x; i < 16 * nl.ldS; i += THREADS) bufA[16 * nl.ldS + i] = xs[i];
+    __syncthreads();
+    gemm_nt<2>(bufA, nl.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0);
+    __syncthreads();
+    head_rows_tile(bufB, nl.ldS, 32, S, PD + dl.head_b);
+    __syncthreads();
+    if (hyper) tile_store(hyper + r0 * S, S, bufB, nl.ldS, 16, S, valid);
+    if (hyper_real) tile_store(hyper_real + r0 * S, S, bufB + 16 * nl.ldS, nl.ldS, 16, S, valid);
+    if (rowdist) {
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int r = wave; r < valid; r += 4) {
+        // (pred = real window on the ball, true = reconstruction): anomaly_detection_utils.py:58-65
+        float d = rowdist_row(row_load(bufB + (16 + r) * nl.ldS, S, lane), row_load(bufB + r * nl.ldS, S, lane));
+        if (lane == 0) rowdist[r0 + r] = d;
+      }
+    }
+  }
+}
+
+inline int tiles16(int64_t rows) { return (int)((rows + 15) / 16); }
+
+}  // namespace
+
+extern "C" {
+
+int hypad_linear_act_fwd(const float* x, const float* w, const float* b, float* y, int64_t rows, int K, int N, int act,
+                         hypad_stream_t s) {
+  if (!x || !w || !y || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)16 * (ld_of(K) + ld_of(N)) * sizeof(float);
+  if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
+  hipError_t e = allow_lds((const void*)linear_fwd_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, x, w, b, y, rows, K, N, act);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+int hypad_linear_act_bwd(const float* x, const float* w, const float* y, const float* gy, float* gx, float* gw, float* gb,
+                         float* gpre, int64_t rows, int K, int N, int act, hypad_stream_t s) {
+  if (!w || !gy || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
+  if (act != HYPAD_ACT_NONE && !y) return HYPAD_EINVAL;
+  if ((gw || gb) && (!gpre || !x)) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)16 * (ld_of(K) + ld_of(N)) * sizeof(float);
+  if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
+  hipError_t e = allow_lds((const void*)linear_bwd_data_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, w, y, gy, gpre, gx,
+                     rows, K, N, act);
+  HYPAD_CHECK_LAUNCH();
+  if (gw || gb) {
+    int tiles = ((N + 15) / 16) * ((K + 15) / 16);
+    int blocks = (tiles + 3) / 4;
+    int bb = (N + THREADS - 1) / THREADS;
+    if (bb > blocks) blocks = bb;
+    if (!gw) return HYPAD_EINVAL;
+    hipLaunchKernelGGL(outer_sum_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)s, gpre, N, x, K, gw, gb, rows, N, K);
+    HYPAD_CHECK_LAUNCH();
+  }
+  return HYPAD_OK;
+}
+
+int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, const float* bhf, const float* wr,
+                         const float* bir, const float* bhr, float* out, float* gates_save, int64_t rows, int K, int H,
+                         hypad_stream_t s) {
+  if (!x || !wf || !bif || !bhf || !wr || !bir || !bhr || !out || rows < 0 || K <= 0 || H <= 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)16 * (ld_of(K) + ld_of(6 * H) + ld_of(2 * H)) * sizeof(float);
+  if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
+  hipError_t e = allow_lds((const void*)lstm_fwd_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr,
+                     out, gates_save, rows, K, H);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+int hypad_lstm_bidir_bwd(const float* wf, const float* wr, const float* gates_saved, const float* gout, float* ggates,
+                         float* gx, int64_t rows, int K, int H, hypad_stream_t s) {
+  if (!wf || !wr || !gates_saved || !gout || rows < 0 || K <= 0 || H <= 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)16 * (ld_of(K) + ld_of(6 * H) + ld_of(2 * H)) * sizeof(float);
+  if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
+  hipError_t e = allow_lds((const void*)lstm_bwd_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, wf, wr, gates_saved, gout,
+                     ggates, gx, rows, K, H);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+static int check_net(int S, int L) {
+  if (S <= 0 || L <= 0) return HYPAD_EINVAL;
+  if (S > MAX_S || L > MAX_L) return HYPAD_EUNSUPPORTED;
+  return HYPAD_OK;
+}
+
+int hypad_encoder_fwd(const float* P, const float* x, float* out, int64_t rows, int S, int L, hypad_stream_t s) {
+  int rc = check_net(S, L);
+  if (rc) return rc;
+  if (!P || !x || !out || rows < 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)net_lds(S, 1).total * sizeof(float);
+  hipError_t e = allow_lds((const void*)encoder_fwd_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, P, x, out, rows, S, L);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+int hypad_decoder_fwd(const float* P, const float* z, float* hyper, float* eucl, int64_t rows, int S, int L, int hyperbolic,
+                      const hypad_dropout* drop, hypad_stream_t s) {
+  int rc = check_net(S, L);
+  if (rc) return rc;
+  if (!P || !z || rows < 0 || (!hyper && !eucl)) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  hypad_dropout dp = drop ? *drop : hypad_dropout{0, nullptr, 0, 0};
+  if (rows >= 32 * 512) {
+    size_t lds = (size_t)net_lds(S, 2).total * sizeof(float);
+    hipError_t e = allow_lds((const void*)decoder_fwd_kernel<2>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(decoder_fwd_kernel<2>, dim3((int)((rows + 31) / 32)), dim3(THREADS), lds, (hipStream_t)s, P, z, hyper,
+                       eucl, rows, S, L, hyperbolic, dp);
+  } else {
+    size_t lds = (size_t)net_lds(S, 1).total * sizeof(float);
+    hipError_t e = allow_lds((const void*)decoder_fwd_kernel<1>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(decoder_fwd_kernel<1>, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, P, z, hyper, eucl,
+                       rows, S, L, hyperbolic, dp);
+  }
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+static int critic_fwd(const float* P, const float* x, float* out, int64_t rows, int in_dim, int L, int nh, float p,
+                      const hypad_dropout* drop, hypad_stream_t s) {
+  if (!P || !x || !out || rows < 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  hypad_dropout dp = drop ? *drop : hypad_dropout{0, nullptr, 0, 0};
+  size_t lds = (size_t)(16 * (pad4(in_dim) + 4) + CRITIC_LDS_FLOATS) * sizeof(float);
+  hipLaunchKernelGGL(critic_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, P, x, out, rows, in_dim, L,
+                     nh, p, dp);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_critic_x_fwd(const float* P, const float* x, float* out, int64_t rows, int S, int L, const hypad_dropout* drop,
+                       hypad_stream_t s) {
+  int rc = check_net(S, L);
+  if (rc) return rc;
+  return critic_fwd(P, x, out, rows, S, L, 4, 0.25f, drop, s);
+}
+int hypad_critic_z_fwd(const float* P, const float* z, float* out, int64_t rows, int L, const hypad_dropout* drop,
+                       hypad_stream_t s) {
+  int rc = check_net(1, L);
+  if (rc) return rc;
+  return critic_fwd(P, z, out, rows, L, L, 2, 0.2f, drop, s);
+}
+
+size_t hypad_mobius_linear_workspace_bytes(int64_t rows, int out_dim) {
+  return (size_t)rows * out_dim * 2 * sizeof(float);   // grad_u and per-row bias gradients
+}
+int hypad_mobius_linear_fwd(const float* x, const float* w, const float* bias, float* out, float* u_save, int64_t rows,
+                            int K, int N, hypad_stream_t s) {
+  if (!x || !w || !bias || !out || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
+  if (N > 64 * MAX_EPL) return HYPAD_EUNSUPPORTED;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)16 * (ld_of(K) + ld_of(N)) * sizeof(float);
+  if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
+  hipError_t e = allow_lds((const void*)mobius_linear_fwd_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(mobius_linear_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, x, w, bias, out,
+                     u_save, rows, K, N);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_mobius_linear_bwd(const float* x, const float* w, const float* bias, const float* u_saved, const float* go,
+                            float* gx, float* gw, float* gbias, void* workspace, size_t workspace_bytes, int64_t rows,
+                            int K, int N, hypad_stream_t s) {
+  if (!x || !w || !bias || !u_saved || !go || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < hypad_mobius_linear_workspace_bytes(rows, N)) return HYPAD_EWORKSPACE;
+  if (rows == 0) return HYPAD_OK;
+  float* gu = (float*)workspace;
+  float* gb_rows = gu + (size_t)rows * N;
+  int rc = hypad_mobius_head_bwd(u_saved, bias, go, gu, gb_rows, rows, N, s);
+  if (rc) return rc;
+  if (gbias) {
+    rc = hypad_column_sum(gb_rows, gbias, rows, N, s);
+    if (rc) return rc;
+  }
+  // grad_x = gu W ; grad_w = gu^T x
+  return hypad_linear_act_bwd(x, w, nullptr, gu, gx, gw, nullptr, gw ? gb_rows /*scratch for grad_pre*/ : nullptr, rows, K, N,
+                              HYPAD_ACT_NONE, s);
+}
+
+int hypad_score_forward(const float* enc, const float* dec, const float* cx, const float* x, float* hyper, float* eucl,
+                        float* hyper_real, float* critic, float* rowdist, int64_t rows, int S, int L, int hyperbolic,
+                        hypad_stream_t s) {
+  int rc = check_net(S, L);
+  if (rc) return rc;
+  if (!enc || !dec || !x || rows < 0 || (critic && !cx)) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  size_t lds = (size_t)net_lds(S, 2).total * sizeof(float);
+  hipError_t e = allow_lds((const void*)score_forward_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(score_forward_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, enc, dec, cx, x, hyper,
+                     eucl, hyper_real, critic, rowdist, rows, S, L, hyperbolic);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+// Window-scoring kernels: utils/anomaly_detection_utils.py on the GPU.
+// Post-processing arithmetic is fp64 because the reference computes it in NumPy/pandas fp64.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/hypad.h"
+#include "device_utils.h"
+
+using namespace hypad;
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int MAX_WINDOW = 256;
+
+inline int grid_for(int64_t n, int per_block) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- S1: anti-diagonal un-roll (:918-935).  One wave per output timestep: gather <= window values, rank them
+// by counting (ties broken by position), scatter into sorted order in LDS, read the order statistics.
+__device__ __forceinline__ float np_lerp(float a, float b, float t) {
+  // numpy.lib._function_base_impl._lerp, evaluated in the data's precision (float32) as NumPy does
+  float diff = b - a;
+  float r = a + diff * t;
+  if (t >= 0.5f) r = b - diff * (1.0f - t);
+  return r;
+}
+__global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
+                                                                 double* __restrict__ summary, int64_t n, int W) {
+  __shared__ float vals[THREADS / 64][MAX_WINDOW];
+  __shared__ float sorted[THREADS / 64][MAX_WINDOW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t T = n + W - 1;
+  float* v = vals[wave];
+  float* s = sorted[wave];
+  for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
+    const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
+    const int j1 = (int)(t + 1 < W ? t + 1 : W);
+    const int cnt = j1 - j0;
+    float mine[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int i = lane + 64 * e;
+      mine[e] = 0.f;
+      if (i < cnt) {
+        int j = j0 + i;
+        mine[e] = y_hat[(t - j) * W + j];
+        v[i] = mine[e];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave landed
+    int rank[4] = {0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      const float vk = v[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = lane + 64 * e;
+        rank[e] += (vk < mine[e]) || (vk == mine[e] && k < i);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (lane + 64 * e < cnt) s[rank[e]] = mine[e];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) {
+      const float lo = s[(cnt - 1) >> 1], hi = s[cnt >> 1];
+      median[t] = (cnt & 1) ? lo : (lo + hi) * 0.5f;     // np.median of float32 stays float32
+      if (summary) {
+        double* o = summary + t * 5;
+        o[0] = (double)s[0];
+        const double qs[3] = {0.25, 0.5, 0.75};
+        for (int qi = 0; qi < 3; ++qi) {
+          double pos = qs[qi] * (double)(cnt - 1);
+          int a = (int)floor(pos);
+          int b = a + 1 < cnt ? a + 1 : cnt - 1;
+          o[1 + qi] = (double)np_lerp(s[a], s[b], (float)(pos - (double)a));
+        }
+        o[4] = (double)s[cnt - 1];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void unroll_true_kernel(const double* __restrict__ y, double* __restrict__ out, int64_t n, int W) {
+  const int64_t T = n + W - 1;
+  for (int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x; t < T; t += (int64_t)gridDim.x * THREADS)
+    out[t] = t < n ? y[t * W] : y[(n - 1) * W + (t - n + 1)];
+}
+
+__global__ __launch_bounds__(THREADS) void point_error_kernel(const double* __restrict__ y, const float* __restrict__ yh,
+                                                               double* __restrict__ out, int64_t T) {
+  for (int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x; t < T; t += (int64_t)gridDim.x * THREADS)
+    out[t] = fabs(y[t] - (double)yh[t]);
+}
+
+// pandas centred window of size w at i: [i + off - w + 1, i + off], off = (w - 1) / 2, clipped to the array
+__device__ __forceinline__ void centred_window(int64_t i, int w, int64_t T, int64_t& lo, int64_t& hi) {
+  const int off = (w - 1) / 2;
+  lo = i + off - w + 1; hi = i + off;
+  if (lo < 0) lo = 0;
+  if (hi > T - 1) hi = T - 1;
+}
+
+__global__ __launch_bounds__(THREADS) void area_error_kernel(const double* __restrict__ y, const float* __restrict__ yh,
+                                                              double* __restrict__ out, int64_t T, int w) {
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS) {
+    int64_t lo, hi;
+    centred_window(i, w, T, lo, hi);
+    if (hi - lo + 1 < w / 2) { out[i] = NAN; continue; }
+    double a = 0.0, b = 0.0;
+    for (int64_t k = lo; k < hi; ++k) {
+      a += (y[k] + y[k + 1]) * 0.5;
+      b += ((double)yh[k] + (double)yh[k + 1]) * 0.5;
+    }
+    out[i] = fabs(a - b);
+  }
+}
+
+template <int LEN>
+__global__ __launch_bounds__(THREADS) void dtw_error_kernel(const double* __restrict__ y, const float* __restrict__ yh,
+                                                             double* __restrict__ out, int64_t T) {
+  constexpr int HALF = LEN / 2;
+  for (int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x; p < T; p += (int64_t)gridDim.x * THREADS) {
+    const int64_t i = p - HALF;                 // window start in padded coordinates
+    if (i < 0 || i >= T - LEN) { out[p] = 0.0; continue; }
+    double a[LEN], b[LEN], row[LEN];
+#pragma unroll
+    for (int k = 0; k < LEN; ++k) {
+      int64_t src = i + k - HALF;               // y_pad[i + k] = y[i + k - HALF]
+      bool ok = src >= 0 && src < T;
+      a[k] = ok ? y[src] : 0.0;
+      b[k] = ok ? (double)yh[src] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) { double d = a[0] - b[j]; acc += d * d; row[j] = acc; }
+#pragma unroll
+    for (int r = 1; r < LEN; ++r) {
+      double diag = row[0];
+      double d0 = a[r] - b[0];
+      row[0] = row[0] + d0 * d0;
+#pragma unroll
+      for (int j = 1; j < LEN; ++j) {
+        double up = row[j];
+        double d = a[r] - b[j];
+        double m = fmin(fmin(up, row[j - 1]), diag);
+        row[j] = d * d + m;
+        diag = up;
+      }
+    }
+    out[p] = sqrt(row[LEN - 1]);
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void rolling_mean_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t T, int w) {
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS) {
+    int64_t lo, hi;
+    centred_window(i, w, T, lo, hi);
+    int cnt = 0;
+    double s = 0.0;
+    for (int64_t k = lo; k <= hi; ++k) {
+      double v = in[k];
+      if (v == v) { s += v; ++cnt; }            // pandas skips NaN
+    }
+    out[i] = cnt >= w / 2 && cnt > 0 ? s / (double)cnt : NAN;
+  }
+}
+
+// stats[0] = mean, stats[1] = population std (scipy.stats.zscore, ddof = 0)
+__global__ __launch_bounds__(1024) void zscore_stats_kernel(const double* __restrict__ in, double* __restrict__ stats, int64_t T) {
+  __shared__ double part[16];
+  __shared__ double mean_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < T; i += 1024) s += in[i];
+  s = wave_sum(s);
+  if (lane == 0) part[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += part[k];
+    mean_s = t / (double)T;
+  }
+  __syncthreads();
+  const double mean = mean_s;
+  double q = 0.0;
+  for (int64_t i = threadIdx.x; i < T; i += 1024) { double d = in[i] - mean; q += d * d; }
+  q = wave_sum(q);
+  __syncthreads();
+  if (lane == 0) part[wave] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += part[k];
+    stats[0] = mean;
+    stats[1] = sqrt(t / (double)T);
+  }
+}
+__global__ __launch_bounds__(THREADS) void zscore_apply_kernel(const double* __restrict__ in, const double* __restrict__ stats,
+                                                                double* __restrict__ out, int64_t T) {
+  const double mean = stats[0], sd = stats[1];
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS) {
+    double z = (in[i] - mean) / sd;
+    out[i] = (z != z) ? z : fmax(z, 0.0) + 1.0;  // np.clip keeps NaN
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void row_norms_kernel(const float* __restrict__ x, double* __restrict__ out, int64_t rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * (THREADS / 64)) {
+    float s = 0.f;    // np.linalg.norm on float32 reduces in float32
+    for (int c = lane; c < dim; c += 64) { float v = x[r * dim + c]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = (double)sqrtf(s);
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void combine_kernel(int mode, const double* __restrict__ c, const double* __restrict__ r,
+                                                           const double* __restrict__ u, double* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+    double cv = c ? c[i] : 0.0, rv = r ? r[i] : 0.0, uv = u ? u[i] : 0.0, o;
+    switch (mode) {
+      case HYPAD_COMB_SUM: o = 0.2 * cv + 0.8 * rv; break;
+      case HYPAD_COMB_MULT: o = cv * rv; break;
+      case HYPAD_COMB_UNCERTAINTY: o = cv * rv * uv; break;
+      case HYPAD_COMB_CRITIC: o = cv; break;
+      case HYPAD_COMB_CRITIC_UNCERTAINTY: o = cv * uv; break;
+      case HYPAD_COMB_SUM_UNCERTAINTY: o = 0.5 * cv * uv + 0.5 * rv * uv; break;
+      case HYPAD_COMB_REC: o = rv; break;
+      case HYPAD_COMB_REC_UNCERTAINTY: o = rv * uv; break;
+      case HYPAD_COMB_EUCL_MULT: o = cv * rv; break;
+      default: o = 0.5 * (cv - 1.0) + 0.5 * (rv - 1.0); break;   // HYPAD_COMB_EUCL_SUM, lambda_rec = 0.5
+    }
+    out[i] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hypad_unroll_median(const float* y_hat, float* median, double* summary, int64_t n, int window, hypad_stream_t s) {
+  if (!y_hat || !median || n <= 0 || window <= 0) return HYPAD_EINVAL;
+  if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
+  const int64_t T = n + window - 1;
+  hipLaunchKernelGGL(unroll_median_kernel, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_unroll_true(const double* y, double* out, int64_t n, int window, hypad_stream_t s) {
+  if (!y || !out || n <= 0 || window <= 0) return HYPAD_EINVAL;
+  hipLaunchKernelGGL(unroll_true_kernel, dim3(grid_for(n + window - 1, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, out, n, window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_point_error(const double* y, const float* yh, double* out, int64_t t, hypad_stream_t s) {
+  if (!y || !yh || !out || t < 0) return HYPAD_EINVAL;
+  if (t == 0) return HYPAD_OK;
+  hipLaunchKernelGGL(point_error_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, yh, out, t);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_area_error(const double* y, const float* yh, double* out, int64_t t, int score_window, hypad_stream_t s) {
+  if (!y || !yh || !out || t < 0 || score_window < 2) return HYPAD_EINVAL;
+  if (t == 0) return HYPAD_OK;
+  hipLaunchKernelGGL(area_error_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, yh, out, t, score_window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_dtw_error(const double* y, const float* yh, double* out, int64_t t, int score_window, hypad_stream_t s) {
+  if (!y || !yh || !out || t < 0 || score_window < 2) return HYPAD_EINVAL;
+  if (t == 0) return HYPAD_OK;
+  const int len = (score_window / 2) * 2 + 1;
+  dim3 g(grid_for(t, THREADS)), b(THREADS);
+  switch (len) {
+    case 3: hipLaunchKernelGGL(dtw_error_kernel<3>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;
+    case 5: hipLaunchKernelGGL(dtw_error_kernel<5>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;
+    case 7: hipLaunchKernelGGL(dtw_error_kernel<7>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;
+    case 9: hipLaunchKernelGGL(dtw_error_kernel<9>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;
+    case 11: hipLaunchKernelGGL(dtw_error_kernel<11>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;   // reference default
+    case 21: hipLaunchKernelGGL(dtw_error_kernel<21>, g, b, 0, (hipStream_t)s, y, yh, out, t); break;
+    default: return HYPAD_EUNSUPPORTED;
+  }
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_rolling_mean(const double* in, double* out, int64_t t, int window, hypad_stream_t s) {
+  if (!in || !out || t < 0 || window < 1) return HYPAD_EINVAL;
+  if (t == 0) return HYPAD_OK;
+  hipLaunchKernelGGL(rolling_mean_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, out, t, window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  if (!in || !out || t <= 0) return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < 4 * sizeof(double)) return HYPAD_EWORKSPACE;
+  hipLaunchKernelGGL(zscore_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, in, (double*)workspace, t);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, (const double*)workspace, out, t);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_row_norms(const float* x, double* out, int64_t rows, int dim, hypad_stream_t s) {
+  if (!x || !out || rows < 0 || dim <= 0) return HYPAD_EINVAL;
+  if (rows == 0) return HYPAD_OK;
+  hipLaunchKernelGGL(row_norms_kernel, dim3(grid_for(rows, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, x, out, rows, dim);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_combine_scores(int mode, const double* c, const double* r, const double* u, double* out, int64_t n, hypad_stream_t s) {
+  if (!out || n < 0 || mode < 0 || mode > HYPAD_COMB_EUCL_SUM) return HYPAD_EINVAL;
+  if (n == 0) return HYPAD_OK;
+  hipLaunchKernelGGL(combine_kernel, dim3(grid_for(n, THREADS)), dim3(THREADS), 0, (hipStream_t)s, mode, c, r, u, out, n);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1023 @@
+// The three WGAN-GP minibatch steps of train.py (critic_x_iteration :18-104, critic_z_iteration :107-186,
+// decoder_iteration :189-249) with the optimizer step fused in.
+//
+// Launch structure per iteration (every kernel: grid = (work, n_signals), one model per blockIdx.y):
+//   critic_x / critic_z :  pass kernel  (row tiles: 3 critic passes, first GP backward, partial norms)
+//                          gp kernel    (row tiles: whole-batch norm -> second-order chain)
+//                          dw_adam      (16x16 weight tiles: dW = left^T right on MFMA, Adam in registers)
+//   decoder_iteration   :  gen kernel   (row tiles: full forward + backward-data of encoder/decoder through the
+//                                        frozen critics, every (delta, activation) pair written for dw_adam)
+//                          dw_adam      (Adam or Riemannian Adam)
+// No gradient buffer exists: a weight's gradient tile lives in MFMA accumulators and is consumed by the update.
+// Formulas: oracle/manual.py (CPU derivation sheet, validated against autograd and the reference fixtures).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/hypad.h"
+#include "nets.h"
+
+using namespace hypad;
+
+namespace {
+
+constexpr int THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct CritWs {
+  int in_right, act[4], left[5], dm[4], partial, total;
+};
+HD CritWs crit_ws(int B, int in_dim, int L, int nh) {
+  CritWs w; int o = 0;
+  w.in_right = o; o += pad4(3 * B * in_dim);
+  for (int i = 0; i < 4; ++i) { w.act[i] = o; if (i < nh) o += pad4(3 * B * L); }
+  for (int i = 0; i < 5; ++i) { w.left[i] = o; if (i < nh) o += pad4(3 * B * L); else if (i == nh) o += pad4(3 * B); }
+  for (int i = 0; i < 4; ++i) { w.dm[i] = o; if (i < nh) o += pad4(B * L); }
+  w.partial = o; o += pad4((B / 16) * 4);
+  w.total = o;
+  return w;
+}
+struct GenWs {
+  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, dbrows, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, total;
+};
+HD GenWs gen_ws(int B, int S, int L) {
+  GenWs w; int o = 0;
+  w.xg = o; o += pad4(B * S);
+  w.enc_g = o; o += pad4(B * 8 * ENC_H);
+  w.enc_h = o; o += pad4(B * 2 * ENC_H);
+  w.zcat = o; o += pad4(2 * B * L);
+  w.a0 = o; o += pad4(2 * B * DEC_D1);
+  w.g0 = o; o += pad4(2 * B * 8 * DEC_H);
+  w.h0d = o; o += pad4(2 * B * 2 * DEC_H);
+  w.mask = o; o += pad4(2 * B * 2 * DEC_H);
+  w.g1 = o; o += pad4(2 * B * 8 * DEC_H);
+  w.h1 = o; o += pad4(2 * B * 2 * DEC_H);
+  w.ecat = o; o += pad4(3 * B * S);
+  w.u = o; o += pad4(3 * B * S);
+  w.du = o; o += pad4(3 * B * S);
+  w.dbrows = o; o += pad4(3 * B * S);
+  w.dpre2 = o; o += pad4(2 * B * S);
+  w.dg1 = o; o += pad4(2 * B * 6 * DEC_H);
+  w.dg0 = o; o += pad4(2 * B * 6 * DEC_H);
+  w.da0 = o; o += pad4(2 * B * DEC_D1);
+  w.dzenc = o; o += pad4(B * L);
+  w.dgenc = o; o += pad4(B * 6 * ENC_H);
+  w.partial = o; o += pad4((B / 16) * 4);
+  w.total = o;
+  return w;
+}
+inline int64_t ws_floats_per_signal(const hypad_dims& d) {
+  int64_t a = crit_ws(d.batch, d.signal_shape, d.latent_dim, 4).total;
+  int64_t b = crit_ws(d.batch, d.latent_dim, d.latent_dim, 2).total;
+  int64_t c = gen_ws(d.batch, d.signal_shape, d.latent_dim).total;
+  int64_t m = a > b ? a : b;
+  return m > c ? m : c;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel arguments
+struct IterArgs {
+  int S, L, B, hyperbolic;
+  hypad_nets P, M, V;
+  int pe, pd, pcx, pcz;            // floats per signal in each arena
+  int32_t* counters;
+  const float* x; int64_t x_sig_stride; const int32_t* row_index;
+  const float* z; const float* alpha;
+  int drop_mode;                   // 0 eval, 1 injected, 2 Philox
+  const float* masks; int64_t mask_sig_stride;
+  uint64_t seed;
+  float* losses; int64_t loss_sig_stride;
+  float* ws; int64_t ws_sig_stride;
+  float lr, b1, b2, eps, wd; int stabilize; int riemannian;
+  int opt;                         // counters index of the optimizer stepped by this iteration
+};
+
+struct LdsPlan {
+  int xs, zs, bufA, bufB, crit, small, total, ldS, bufFloats;
+};
+HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head) {
+  LdsPlan p;
+  p.ldS = pad4(S) + 4;
+  int a = rows_lstm * (6 * DEC_H + 4), b = rows_head * p.ldS;
+  p.bufFloats = a > b ? a : b;
+  int o = 0;
+  p.xs = o; o += 16 * p.ldS;
+  p.zs = o; o += 32 * LP;
+  p.bufA = o; o += p.bufFloats;
+  p.bufB = o; o += p.bufFloats;
+  p.crit = o; o += CRITIC_LDS_FLOATS;
+  p.small = o; o += 4 * 16 * LP + 64;     // three (16, LP) scratch tiles + reduction slots
+  p.total = o;
+  return p;
+}
+
+__device__ __forceinline__ DropSrc drop_src(const IterArgs& a, int sig, const float* ptr, uint32_t stream, uint32_t tick, float p) {
+  DropSrc s;
+  s.mode = a.drop_mode; s.ptr = ptr; s.batch = a.B; s.seed = a.seed; s.tick = tick; s.stream = stream; s.sig = (uint32_t)sig; s.p = p;
+  return s;
+}
+
+// block-wide sum of per-thread values (256 threads); result valid in thread 0.  red: LDS >= 4 floats
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------------------------------------ critic passes
+// One critic pass on a tile: forward, save what dW needs, first-order backward chain from a constant dout.
+// pass p in {0 real, 1 fake, 2 interpolated}.  Returns pointer (LDS) to delta of layer 0.
+__device__ __forceinline__ const float* critic_pass(const float* in, int ldin, int p, float dout_val, const float* P,
+                                                    const CriticLayout& cl, int L, const CriticLds& cs, const DropSrc& drop,
+                                                    float* ws, const CritWs& cw, int B, int tile, float* out_sum) {
+  const int grow0 = tile * 16;
+  const int64_t prow0 = (int64_t)p * B + grow0;
+  critic_fwd_tile(in, ldin, P, cl, L, cs, drop, grow0);
+  if (p < 2) {
+    tile_store(ws + cw.in_right + prow0 * cl.in_dim, cl.in_dim, in, ldin, 16, cl.in_dim, 16);
+    for (int li = 0; li < cl.nh; ++li) tile_store(ws + cw.act[li] + prow0 * L, L, cs.act + li * 16 * LP, LP, 16, L, 16);
+  } else {
+    for (int li = 0; li < cl.nh; ++li) tile_store(ws + cw.dm[li] + (int64_t)grow0 * L, L, cs.dm + li * 16 * LP, LP, 16, L, 16);
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += cs.out[r];
+    *out_sum = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    cs.out[threadIdx.x] = dout_val;
+    ws[cw.left[cl.nh] + prow0 + threadIdx.x] = dout_val;
+  }
+  __syncthreads();
+  return critic_bwd_chain_tile(cs.out, P, cl, L, cs, [&](int li, const float* delta) {
+    tile_store(ws + cw.left[li] + prow0 * L, L, delta, LP, 16, L, 16);
+  });
+}
+
+// real / fake: LDS tiles (in_dim columns).  inter: LDS [16][ldi] scratch for the interpolation; gbuf: LDS [16][ldg] for g.
+// gbuf may alias `real` (it is written only after the last read of `real`).
+__device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, int tile, uint32_t tick, const float* real, int ldr,
+                                                    const float* fake, int ldf, float* inter, int ldi, float* gbuf, int ldgb,
+                                                    const float* P, const CriticLayout& cl, const CriticLds& cs, float* ws,
+                                                    const CritWs& cw, int mask_real, int mask_fake, int mask_inter, float* red) {
+  const int L = a.L, B = a.B, nh = cl.nh, in_dim = cl.in_dim;
+  const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
+  const int64_t mblk = (int64_t)nh * B * L;
+  float* sums = red + 8;   // [0] real, [1] fake, [2] inter (unused)
+  critic_pass(real, ldr, 0, -1.f / B, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_real * mblk : nullptr,
+                                                                RS_DROP_CRITIC + 8 * mask_real, tick, cl.p_drop), ws, cw, B, tile, sums + 0);
+  critic_pass(fake, ldf, 1, 1.f / B, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_fake * mblk : nullptr,
+                                                               RS_DROP_CRITIC + 8 * mask_fake, tick, cl.p_drop), ws, cw, B, tile, sums + 1);
+  // interpolation (train.py:64-69 / 149-154)
+  const float* ainj = a.alpha ? a.alpha + ((int64_t)sig * B + tile * 16) * in_dim : nullptr;
+  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
+    int r = i / in_dim, c = i - r * in_dim;
+    float al = ainj ? ainj[i] : rng_uniform(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)((tile * 16 + r) * in_dim + c));
+    inter[r * ldi + c] = al * real[r * ldr + c] + (1.f - al) * fake[r * ldf + c];
+  }
+  __syncthreads();
+  const float* d0 = critic_pass(inter, ldi, 2, 1.f, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_inter * mblk : nullptr,
+                                                                            RS_DROP_CRITIC + 8 * mask_inter, tick, cl.p_drop),
+                                ws, cw, B, tile, sums + 2);
+  // g = delta_0 W_0  (rows of d(prob)/d(interpolated), train.py:75-81)
+  gemm_nn<1>(d0, LP, 0, P + cl.w[0], in_dim, L, identity_map(), in_dim, gbuf, ldgb, false);
+  __syncthreads();
+  tile_store(ws + cw.in_right + ((int64_t)2 * B + tile * 16) * in_dim, in_dim, gbuf, ldgb, 16, in_dim, 16);
+  float sq = 0.f;
+  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
+    int r = i / in_dim, c = i - r * in_dim;
+    float v = gbuf[r * ldgb + c];
+    sq += v * v;
+  }
+  sq = block_sum(sq, red);
+  if (threadIdx.x == 0) {
+    float* part = ws + cw.partial + tile * 4;
+    part[0] = sq; part[1] = sums[0]; part[2] = sums[1]; part[3] = 0.f;
+  }
+}
+
+__device__ __forceinline__ void load_z(const IterArgs& a, int sig, int tile, uint32_t tick, float* zs /* [16][LP] */) {
+  const float* zinj = a.z ? a.z + ((int64_t)sig * a.B + tile * 16) * a.L : nullptr;
+  for (int i = threadIdx.x; i < 16 * a.L; i += THREADS) {
+    int r = i / a.L, c = i - r * a.L;
+    zs[r * LP + c] = zinj ? zinj[i] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * a.L + c));
+  }
+}
+
+// ---- critic_x pass kernel (train.py:18-81)
+__global__ __launch_bounds__(THREADS) void cx_pass_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
+  const LdsPlan lp = lds_plan(S, 16, 16);
+  const DecLayout dl = dec_layout(S, L, a.hyperbolic);
+  const CriticLayout cl = cx_layout(S, L);
+  const CritWs cw = crit_ws(B, S, L, 4);
+  const float* PD = a.P.dec + (int64_t)sig * a.pd;
+  const float* PC = a.P.cx + (int64_t)sig * a.pcx;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  float* red = smem + lp.small + 3 * 16 * LP;
+  const CriticLds cs = critic_lds(smem + lp.crit);
+  const uint32_t tick = (uint32_t)a.counters[3];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
+  load_z(a, sig, tile, tick, zs);
+  __syncthreads();
+  // decoder (frozen, train-mode dropout): x_ = decoder(z)
+  const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
+  DropSrc ddrop = drop_src(a, sig, mbase ? mbase + (int64_t)12 * B * L : nullptr, RS_DROP_DEC0, tick, 0.2f);
+  DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const int grow0 = tile * 16;
+  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, lp.ldS, ddrop, [grow0](int r) { return grow0 + r; }, none, 16);
+  float* gen = bufA; float* other = bufB;
+  if (a.hyperbolic) {
+    gemm_nt<1>(bufA, lp.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, lp.ldS, 0);
+    __syncthreads();
+    head_rows_tile(bufB, lp.ldS, 16, S, PD + dl.head_b);
+    __syncthreads();
+    gen = bufB; other = bufA;
+  }
+  // `other` receives the interpolation; g reuses the x tile (dead once the interpolation exists)
+  critic_three_passes(a, sig, tile, tick, xs, lp.ldS, gen, lp.ldS, other, lp.ldS, xs, lp.ldS, PC, cl, cs, ws, cw, 0, 1, 2, red);
+}
+
+// ---- critic_z pass kernel (train.py:107-166)
+__global__ __launch_bounds__(THREADS) void cz_pass_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
+  const LdsPlan lp = lds_plan(S, 16, 16);
+  const EncLayout el = enc_layout(S, L);
+  const CriticLayout cl = cz_layout(L);
+  const CritWs cw = crit_ws(B, L, L, 2);
+  const float* PE = a.P.enc + (int64_t)sig * a.pe;
+  const float* PC = a.P.cz + (int64_t)sig * a.pcz;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  float* small = smem + lp.small;
+  float* red = small + 3 * 16 * LP;
+  const CriticLds cs = critic_lds(smem + lp.crit);
+  const uint32_t tick = (uint32_t)a.counters[3];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
+  load_z(a, sig, tile, tick, zs);                       // real = z ~ N(0,1)
+  __syncthreads();
+  float* zenc = zs + 16 * LP;                           // fake = encoder(x)
+  encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
+  // injected mask order (hypad.h): fake | valid | interpolated
+  critic_three_passes(a, sig, tile, tick, zs, LP, zenc, LP, small, LP, small + 16 * LP, LP, PC, cl, cs, ws, cw, 1, 0, 2, red);
+}
+
+// ---- gradient-penalty kernel: whole-batch norm and the second-order chain (oracle/manual.py
+// critic_gp_pairs): GP rows of every `right` matrix.
+template <bool IS_X>
+__global__ __launch_bounds__(THREADS) void critic_gp_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sig = blockIdx.y, tile = blockIdx.x, L = a.L, B = a.B;
+  const int in_dim = IS_X ? a.S : a.L;
+  const int nh = IS_X ? 4 : 2;
+  const CriticLayout cl = IS_X ? cx_layout(a.S, L) : cz_layout(L);
+  const CritWs cw = crit_ws(B, in_dim, L, nh);
+  const float* PC = IS_X ? a.P.cx + (int64_t)sig * a.pcx : a.P.cz + (int64_t)sig * a.pcz;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  const int ldu = pad4(in_dim) + 4;
+  float* us = smem;                         // [16][ldu]
+  float* e0 = us + 16 * ldu;                // [16][LP]
+  float* e1 = e0 + 16 * LP;                 // [16][LP]
+  const int ntiles = B / 16;
+  float gsum = 0.f, sreal = 0.f, sfake = 0.f;
+  for (int t = 0; t < ntiles; ++t) {        // fixed order: deterministic
+    const float* part = ws + cw.partial + t * 4;
+    gsum += part[0]; sreal += part[1]; sfake += part[2];
+  }
+  const float nrm = sqrtf(gsum + 1e-12f);                       // train.py:90
+  const float gp = (nrm - 1.f) * (nrm - 1.f);
+  const float coef = 10.f * 2.f * (nrm - 1.f) / nrm;            // d(10 gp)/d g = coef * g
+  if (tile == 0 && threadIdx.x == 0) {
+    float* lo = a.losses + sig * a.loss_sig_stride;
+    lo[0] = sfake / B - sreal / B + 10.f * gp;                  // train.py:98-99
+    lo[1] = gp; lo[2] = sreal / B; lo[3] = sfake / B;
+  }
+  float* grow = ws + cw.in_right + ((int64_t)2 * B + tile * 16) * in_dim;
+  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
+    int r = i / in_dim, c = i - r * in_dim;
+    float u = coef * grow[i];
+    grow[i] = u;                             // right of layer 0 (GP rows) = ugrad
+    us[r * ldu + c] = u;
+  }
+  __syncthreads();
+  gemm_nt<1>(us, ldu, PC + cl.w[0], in_dim, in_dim, L, identity_map(), nullptr, nullptr, e0, LP, 0);
+  __syncthreads();
+  float* cur = e0; float* nxt = e1;
+  for (int li = 1; li <= nh; ++li) {
+    // ep_{li-1} = e_{li-1} * dm_{li-1}: right of layer li (GP rows)
+    const float* dm = ws + cw.dm[li - 1] + (int64_t)tile * 16 * L;
+    float* dst = ws + cw.act[li - 1] + ((int64_t)2 * B + tile * 16) * L;
+    for (int i = threadIdx.x; i < 16 * L; i += THREADS) {
+      int r = i / L, c = i - r * L;
+      float v = cur[r * LP + c] * dm[i];
+      cur[r * LP + c] = v;
+      dst[i] = v;
+    }
+    __syncthreads();
+    if (li < nh) {
+      gemm_nt<1>(cur, LP, PC + cl.w[li], L, L, L, identity_map(), nullptr, nullptr, nxt, LP, 0);
+      __syncthreads();
+      float* t = cur; cur = nxt; nxt = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ generator kernel
+// decoder_iteration (train.py:189-249): rows of a tile: pass 0 = decoder(z), pass 1 = decoder(encoder(x)),
+// pass 2 (hyperbolic only) = hyperbolic_linear(x).
+template <bool HYPER>
+__global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
+  const LdsPlan lp = lds_plan(S, 32, HYPER ? 48 : 32);
+  const int ldS = lp.ldS;
+  const EncLayout el = enc_layout(S, L);
+  const DecLayout dl = dec_layout(S, L, HYPER ? 1 : 0);
+  const CriticLayout clx = cx_layout(S, L);
+  const CriticLayout clz = cz_layout(L);
+  const GenWs gw = gen_ws(B, S, L);
+  const float* PE = a.P.enc + (int64_t)sig * a.pe;
+  const float* PD = a.P.dec + (int64_t)sig * a.pd;
+  const float* PX = a.P.cx + (int64_t)sig * a.pcx;
+  const float* PZ = a.P.cz + (int64_t)sig * a.pcz;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  float* small = smem + lp.small;
+  float* dzc = small;                       // [16][LP] gradient of -mean(critic_z) w.r.t. encoder output
+  float* dzs = small + 16 * LP;             // [16][LP] total gradient of the encoder output
+  float* red = small + 3 * 16 * LP;
+  const CriticLds cs = critic_lds(smem + lp.crit);
+  const uint32_t tick = (uint32_t)a.counters[3];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+  const int g0 = tile * 16;                 // first batch row of this tile
+  const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
+  const int64_t BL = (int64_t)B * L;
+  float sum_fz = 0.f, sum_fx = 0.f, sum_aux = 0.f;
+
+  // ---- encoder(x)
+  tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, S, a.row_index, g0, 16, S, 16);
+  __syncthreads();
+  tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
+  float* zenc = zs + 16 * LP;
+  encoder_fwd_tile(xs, ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc,
+                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16);
+  // ---- critic_z(encoder(x)) and its input gradient (frozen critic; loss term -mean(fake_z), train.py:215-217)
+  {
+    DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
+    critic_fwd_tile(zenc, LP, PZ, clz, L, cs, dz, g0);
+    if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fz = s; }
+    __syncthreads();
+    if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
+    __syncthreads();
+    const float* d0 = critic_bwd_chain_tile(cs.out, PZ, clz, L, cs, [](int, const float*) {});
+    gemm_nn<1>(d0, LP, 0, PZ + clz.w[0], L, L, identity_map(), L, dzc, LP, false);
+    __syncthreads();
+  }
+  // ---- both decoder passes together: rows 0..15 = z ~ N(0,1), rows 16..31 = encoder(x)
+  load_z(a, sig, tile, tick, zs);
+  __syncthreads();
+  tile_store_p(ws + gw.zcat + (int64_t)g0 * L, L, B, zs, LP, 32, L, 32);
+  DecSave sv;
+  sv.ps = B;
+  sv.a0 = ws + gw.a0 + (int64_t)g0 * DEC_D1;
+  sv.g0 = ws + gw.g0 + (int64_t)g0 * 8 * DEC_H;
+  sv.h0d = ws + gw.h0d + (int64_t)g0 * 2 * DEC_H;
+  sv.mask = ws + gw.mask + (int64_t)g0 * 2 * DEC_H;
+  sv.g1 = ws + gw.g1 + (int64_t)g0 * 8 * DEC_H;
+  sv.h1 = ws + gw.h1 + (int64_t)g0 * 2 * DEC_H;
+  // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
+  // (layer, batch, 128) array with "layer" = pass, the two decoder masks are layers 0 and 1 of one block.
+  DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
+  // pass-aware row function: mask row of LDS row r is (pass, g0 + r%16); encode pass into the row index for both modes
+  const int Bq = B;
+  decoder_trunk_fwd_tile<2>(zs, L, S, PD, dl, bufA, bufB, ldS, dd, [g0, Bq](int r) { return (r >> 4) * Bq + g0 + (r & 15); }, sv, 32);
+  // E = tanh output in bufA[0..31]
+  if (HYPER) {
+    for (int i = threadIdx.x; i < 16 * ldS; i += THREADS) bufA[32 * ldS + i] = xs[i];     // pass 2 input: the real window
+    __syncthreads();
+    tile_store_p(ws + gw.ecat + (int64_t)g0 * S, S, B, bufA, ldS, 48, S, 48);
+    gemm_nt<3>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0);
+    __syncthreads();
+    tile_store_p(ws + gw.u + (int64_t)g0 * S, S, B, bufB, ldS, 48, S, 48);
+    __syncthreads();
+    head_rows_tile(bufB, ldS, 48, S, PD + dl.head_b);
+    __syncthreads();
+  } else {
+    tile_store_p(ws + gw.ecat + (int64_t)g0 * S, S, B, bufA, ldS, 32, S, 32);
+  }
+  float* R = HYPER ? bufB : bufA;           // decoder outputs (pass 0 = x_gen, pass 1 = x_rec [, pass 2 = hyper_x])
+  float* dR = HYPER ? bufA : bufB;          // their gradients
+  // ---- critic_x(x_gen) and its input gradient (loss term -mean(fake_x))
+  {
+    DropSrc dx = drop_src(a, sig, mbase ? mbase + 2 * BL : nullptr, RS_DROP_CRITIC + 8 * 1, tick, clx.p_drop);
+    critic_fwd_tile(R, ldS, PX, clx, L, cs, dx, g0);
+    if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fx = s; }
+    __syncthreads();
+    if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
+    __syncthreads();
+    const float* d0 = critic_bwd_chain_tile(cs.out, PX, clx, L, cs, [](int, const float*) {});
+    gemm_nn<1>(d0, LP, 0, PX + clx.w[0], S, L, identity_map(), S, dR, ldS, false);
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (HYPER) {
+    // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
+    float part = 0.f;
+    for (int r = wave; r < 16; r += 4) {
+      RowVec du, dv;
+      float d = rowdist_row_bwd(row_load(R + (16 + r) * ldS, S, lane), row_load(R + (32 + r) * ldS, S, lane), 10.f / B, du, dv);
+      row_store(dR + (16 + r) * ldS, du, S, lane);
+      row_store(dR + (32 + r) * ldS, dv, S, lane);
+      part += d;
+    }
+    if (lane == 0) red[16 + wave] = part;
+    __syncthreads();
+    sum_aux = red[16] + red[17] + red[18] + red[19];
+    // ---- Moebius head backward, row-wise: dR -> dU (in place), per-row bias gradients to the workspace
+    const RowVec hb = row_load(PD + dl.head_b, S, lane);
+    for (int r = wave; r < 48; r += 4) {
+      RowVec du, db;
+      head_row_bwd(row_load(ws + gw.u + (prow(r, B) + g0) * S, S, lane), hb, row_load(dR + r * ldS, S, lane), du, db);
+      row_store(dR + r * ldS, du, S, lane);
+      row_store(ws + gw.dbrows + (prow(r, B) + g0) * S, db, S, lane);
+    }
+    __syncthreads();
+    tile_store_p(ws + gw.du + (int64_t)g0 * S, S, B, dR, ldS, 48, S, 48);
+    // dE = dU W_h for the two decoder passes
+    gemm_nn<2>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
+    __syncthreads();
+    // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
+    for (int i = threadIdx.x; i < 32 * S; i += THREADS) {
+      int r = i / S, c = i - r * S;
+      float e = ws[gw.ecat + (prow(r, B) + g0) * S + c];
+      R[r * ldS + c] *= 1.f - e * e;
+    }
+    __syncthreads();
+  } else {
+    // ---- 10 * MSE(x, x_rec) (train.py:241-242): E in bufA (= R), gradients into bufB (= dR)
+    float part = 0.f;
+    for (int i = threadIdx.x; i < 16 * S; i += THREADS) {
+      int r = i / S, c = i - r * S;
+      float diff = R[(16 + r) * ldS + c] - xs[r * ldS + c];
+      part += diff * diff;
+      dR[(16 + r) * ldS + c] = 20.f * diff / ((float)B * (float)S);
+    }
+    sum_aux = block_sum(part, red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * S; i += THREADS) {
+      int r = i / S, c = i - r * S;
+      float e = R[r * ldS + c];
+      dR[r * ldS + c] *= 1.f - e * e;
+    }
+    __syncthreads();
+  }
+  float* dP = HYPER ? R : dR;               // d(pre-tanh) [32][ldS]
+  float* oth = HYPER ? dR : R;
+  tile_store_p(ws + gw.dpre2 + (int64_t)g0 * S, S, B, dP, ldS, 32, S, 32);
+  constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
+  // dH1 = dpre W2
+  gemm_nn<2>(dP, ldS, 0, PD + dl.d2_w, 2 * DEC_H, S, identity_map(), 2 * DEC_H, oth, ldH, false);
+  __syncthreads();
+  // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
+  lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + (int64_t)g0 * 8 * DEC_H, DEC_H, 32, dP, ldG, 32, B);
+  __syncthreads();
+  tile_store_p(ws + gw.dg1 + (int64_t)g0 * 6 * DEC_H, 6 * DEC_H, B, dP, ldG, 32, 6 * DEC_H, 32);
+  lstm_bwd_data_tile<2>(dP, ldG, PD, dl.l[1][0], dl.l[1][1], DEC_H, 2 * DEC_H, oth, ldH);
+  __syncthreads();
+  if (a.drop_mode != 0) {
+    for (int i = threadIdx.x; i < 32 * 2 * DEC_H; i += THREADS) {
+      int r = i / (2 * DEC_H), c = i - r * (2 * DEC_H);
+      oth[r * ldH + c] *= ws[gw.mask + (prow(r, B) + g0) * 2 * DEC_H + c];
+    }
+    __syncthreads();
+  }
+  // layer 0
+  lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + (int64_t)g0 * 8 * DEC_H, DEC_H, 32, dP, ldG, 32, B);
+  __syncthreads();
+  tile_store_p(ws + gw.dg0 + (int64_t)g0 * 6 * DEC_H, 6 * DEC_H, B, dP, ldG, 32, 6 * DEC_H, 32);
+  lstm_bwd_data_tile<2>(dP, ldG, PD, dl.l[0][0], dl.l[0][1], DEC_H, DEC_D1, oth, ldA0);
+  __syncthreads();
+  tile_store_p(ws + gw.da0 + (int64_t)g0 * DEC_D1, DEC_D1, B, oth, ldA0, 32, DEC_D1, 32);
+  // dZ = dA0 W1 ; only pass 1 (the encoder's output) is needed further
+  gemm_nn<2>(oth, ldA0, 0, PD + dl.d1_w, L, DEC_D1, identity_map(), L, dP, LP, false);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * L; i += THREADS) {
+    int r = i / L, c = i - r * L;
+    dzs[r * LP + c] = dP[(16 + r) * LP + c] + dzc[r * LP + c];
+  }
+  __syncthreads();
+  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
+  // ---- encoder backward
+  gemm_nn<1>(dzs, LP, 0, PE + el.dense_w, 2 * ENC_H, L, identity_map(), 2 * ENC_H, oth, 2 * ENC_H + 4, false);
+  __syncthreads();
+  lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
+  __syncthreads();
+  tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
+  if (threadIdx.x == 0) {
+    float* part = ws + gw.partial + tile * 4;
+    part[0] = sum_aux; part[1] = sum_fx; part[2] = sum_fz; part[3] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dW + Adam
+enum DwKind : int { DW_WEIGHT = 0, DW_BIAS = 1, DW_DECAY = 2, DW_BALL = 3 };
+struct DwDesc {
+  int16_t kind, net;
+  int32_t p_off, p_ld, nrows, ncols;          // destination block (weights: nrows x ncols at row stride p_ld)
+  int32_t left_off, left_ld, right_off, right_ld;
+  int32_t red_rows;
+  int32_t p_off2;                             // second destination with the same gradient (b_hh), or -1
+  int32_t begin;                              // first work item
+};
+constexpr int MAX_DESC = 60;
+struct DwTable {
+  int n, total_items;
+  int finalize;                               // 0 none, 1 generator losses
+  DwDesc d[MAX_DESC];
+};
+
+struct AdamCoef {
+  float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2;
+  int riemannian, step, stabilize;
+};
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& c) {
+  if (c.riemannian) {     // oracle/radam.py, Euclidean branch
+    g += c.wd * p;
+    m = c.b1 * m + (1.f - c.b1) * g;
+    v = c.b2 * v + (1.f - c.b2) * g * g;
+    float den = sqrtf(v / c.bc2) + c.eps;
+    p -= c.lr * (m / c.bc1) / den;
+  } else {                // torch.optim.Adam (single-tensor rule)
+    m = c.b1 * m + (1.f - c.b1) * g;
+    v = c.b2 * v + (1.f - c.b2) * g * g;
+    float denom = sqrtf(v) / c.sqrt_bc2 + c.eps;
+    p -= (c.lr / c.bc1) * (m / denom);
+  }
+}
+__device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, float wd, int riem, int stab, int step) {
+  AdamCoef c;
+  c.lr = lr; c.b1 = b1; c.b2 = b2; c.eps = eps; c.wd = wd; c.riemannian = riem; c.stabilize = stab; c.step = step;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  c.bc1 = (float)bc1; c.bc2 = (float)bc2; c.sqrt_bc2 = (float)sqrt(bc2);
+  return c;
+}
+
+// Riemannian Adam on one ball-valued vector held by a wave (oracle/manual.py radam_ball_step)
+__device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, RowVec g, int dim, int lane, const AdamCoef& c) {
+  RowVec P = row_load(p, dim, lane), Mv = row_load(m, dim, lane), V = row_load(v, dim, lane);
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) g.v[e] += c.wd * P.v[e];
+  float lam = 2.f / fmaxf(1.f - row_dot(P, P), MIN_NORM);
+  RowVec rg;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) rg.v[e] = g.v[e] / (lam * lam);
+  float inner = lam * lam * row_dot(rg, rg);
+  RowVec np;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) {
+    Mv.v[e] = c.b1 * Mv.v[e] + (1.f - c.b1) * rg.v[e];
+    V.v[e] = c.b2 * V.v[e] + (1.f - c.b2) * inner;
+    float den = sqrtf(V.v[e] / c.bc2) + c.eps;
+    np.v[e] = P.v[e] - c.lr * (Mv.v[e] / c.bc1) / den;
+  }
+  np = project_row(np);
+  // parallel transport of the first moment: gyr[np, -p] m * lambda_p / lambda_np (math_.py:1738-1746, 656-676)
+  RowVec nb;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) nb.v[e] = -P.v[e];
+  float u2 = row_dot(np, np), v2 = row_dot(nb, nb), uv = row_dot(np, nb), uw = row_dot(np, Mv), vw = row_dot(nb, Mv);
+  float ca = -uw * v2 + vw + 2.f * uv * vw;
+  float cb = -vw * u2 - uw;
+  float d = fmaxf(1.f + 2.f * uv + u2 * v2, MIN_NORM);
+  float lam_n = 2.f / fmaxf(1.f - u2, MIN_NORM);
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) Mv.v[e] = (Mv.v[e] + 2.f * (ca * np.v[e] + cb * nb.v[e]) / d) * lam / lam_n;
+  if (c.stabilize > 0 && c.step % c.stabilize == 0) np = project_row(np);
+  row_store(p, np, dim, lane);
+  row_store(m, Mv, dim, lane);
+  row_store(v, V, dim, lane);
+}
+
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
+  const int sig = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  const int step = a.counters[a.opt];          // already incremented by the iteration's first kernel
+  const AdamCoef co = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
+  float* Pn[4] = {a.P.enc + (int64_t)sig * a.pe, a.P.dec + (int64_t)sig * a.pd, a.P.cx + (int64_t)sig * a.pcx, a.P.cz + (int64_t)sig * a.pcz};
+  float* Mn[4] = {a.M.enc + (int64_t)sig * a.pe, a.M.dec + (int64_t)sig * a.pd, a.M.cx + (int64_t)sig * a.pcx, a.M.cz + (int64_t)sig * a.pcz};
+  float* Vn[4] = {a.V.enc + (int64_t)sig * a.pe, a.V.dec + (int64_t)sig * a.pd, a.V.cx + (int64_t)sig * a.pcx, a.V.cz + (int64_t)sig * a.pcz};
+  const int nwaves = gridDim.x * (THREADS / 64);
+  for (int item = blockIdx.x * (THREADS / 64) + wave; item < tab.total_items; item += nwaves) {
+    int di = 0;
+    while (di + 1 < tab.n && tab.d[di + 1].begin <= item) ++di;
+    const DwDesc& d = tab.d[di];
+    const int local = item - d.begin;
+    float* P = Pn[d.net]; float* M = Mn[d.net]; float* V = Vn[d.net];
+    if (d.kind == DW_WEIGHT) {
+      const int tk = (d.ncols + 15) >> 4;
+      const int n0 = (local / tk) * 16, k0 = (local % tk) * 16;
+      const float* left = ws + d.left_off;
+      const float* right = ws + d.right_off;
+      const bool av = n0 + j < d.nrows, bv = k0 + j < d.ncols;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int rr = 0; rr < d.red_rows; rr += 4) {
+        const int r = rr + q;
+        const bool rv = r < d.red_rows;
+        const float av_ = (rv && av) ? left[(int64_t)r * d.left_ld + n0 + j] : 0.f;
+        const float bv_ = (rv && bv) ? right[(int64_t)r * d.right_ld + k0 + j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv_, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * q + r, k = k0 + j;
+        if (n < d.nrows && k < d.ncols) {
+          const int64_t o = d.p_off + (int64_t)n * d.p_ld + k;
+          float p = P[o], m = M[o], v = V[o];
+          adam_update(p, m, v, acc[r], co);
+          P[o] = p; M[o] = m; V[o] = v;
+        }
+      }
+    } else if (d.kind == DW_BIAS) {
+      const int n = local * 64 + lane;
+      if (n < d.nrows) {
+        const float* left = ws + d.left_off;
+        float g = 0.f;
+        for (int r = 0; r < d.red_rows; ++r) g += left[(int64_t)r * d.left_ld + n];
+        int64_t o = d.p_off + n;
+        float p = P[o], m = M[o], v = V[o];
+        adam_update(p, m, v, g, co);
+        P[o] = p; M[o] = m; V[o] = v;
+        if (d.p_off2 >= 0) {
+          o = d.p_off2 + n;
+          p = P[o]; m = M[o]; v = V[o];
+          adam_update(p, m, v, g, co);
+          P[o] = p; M[o] = m; V[o] = v;
+        }
+      }
+    } else if (d.kind == DW_DECAY) {
+      for (int e = 0; e < 4; ++e) {
+        const int n = local * 256 + e * 64 + lane;
+        if (n < d.nrows) {
+          const int64_t o = d.p_off + n;
+          float p = P[o], m = M[o], v = V[o];
+          adam_update(p, m, v, 0.f, co);
+          P[o] = p; M[o] = m; V[o] = v;
+        }
+      }
+    } else {   // DW_BALL: hyperbolic_linear.bias
+      const float* left = ws + d.left_off;
+      RowVec g;
+#pragma unroll
+      for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
+      for (int r = 0; r < d.red_rows; ++r) {
+#pragma unroll
+        for (int e = 0; e < MAX_EPL; ++e) {
+          int c = lane + 64 * e;
+          if (c < d.nrows) g.v[e] += left[(int64_t)r * d.left_ld + c];
+        }
+      }
+      radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (tab.finalize == 1) {        // generator losses (train.py:232-234, 243-244)
+      const GenWs gw = gen_ws(a.B, a.S, a.L);
+      float aux = 0.f, fx = 0.f, fz = 0.f;
+      for (int t = 0; t < a.B / 16; ++t) {
+        const float* part = ws + gw.partial + t * 4;
+        aux += part[0]; fx += part[1]; fz += part[2];
+      }
+      aux = a.hyperbolic ? aux / a.B : aux / ((float)a.B * (float)a.S);
+      float* lo = a.losses + sig * a.loss_sig_stride;
+      lo[0] = 10.f * aux - fx / a.B - fz / a.B;
+      lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
+    }
+    if (blockIdx.y == 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host: tables
+struct TableBuilder {
+  DwTable t;
+  TableBuilder() { t.n = 0; t.total_items = 0; t.finalize = 0; }
+  void push(DwDesc d, int items) {
+    if (items <= 0) return;
+    d.begin = t.total_items;
+    t.d[t.n++] = d;
+    t.total_items += items;
+  }
+  void weight(int net, int p_off, int p_ld, int nrows, int ncols, int left_off, int left_ld, int right_off, int right_ld, int red) {
+    DwDesc d{};
+    d.kind = DW_WEIGHT; d.net = (int16_t)net; d.p_off = p_off; d.p_ld = p_ld; d.nrows = nrows; d.ncols = ncols;
+    d.left_off = left_off; d.left_ld = left_ld; d.right_off = right_off; d.right_ld = right_ld; d.red_rows = red; d.p_off2 = -1;
+    push(d, ((nrows + 15) / 16) * ((ncols + 15) / 16));
+  }
+  void bias(int net, int p_off, int p_off2, int n, int left_off, int left_ld, int red) {
+    DwDesc d{};
+    d.kind = DW_BIAS; d.net = (int16_t)net; d.p_off = p_off; d.p_off2 = p_off2; d.nrows = n; d.ncols = 1;
+    d.left_off = left_off; d.left_ld = left_ld; d.red_rows = red;
+    push(d, (n + 63) / 64);
+  }
+  void decay(int net, int p_off, int n) {
+    DwDesc d{};
+    d.kind = DW_DECAY; d.net = (int16_t)net; d.p_off = p_off; d.nrows = n; d.p_off2 = -1;
+    push(d, (n + 255) / 256);
+  }
+  void ball(int net, int p_off, int n, int left_off, int left_ld, int red) {
+    DwDesc d{};
+    d.kind = DW_BALL; d.net = (int16_t)net; d.p_off = p_off; d.nrows = n; d.left_off = left_off; d.left_ld = left_ld;
+    d.red_rows = red; d.p_off2 = -1;
+    push(d, 1);
+  }
+  // one LSTM direction: weight_ih rows [0,H) <- compact cols [c0, c0+H); rows [2H,4H) <- cols [c0+H, c0+3H)
+  void lstm_dir(int net, const LstmDir& ld, int H, int K, int left_off, int left_ld, int c0, int right_off, int right_ld, int red,
+                bool decay_too) {
+    weight(net, ld.w_ih, K, H, K, left_off + c0, left_ld, right_off, right_ld, red);
+    weight(net, ld.w_ih + 2 * H * K, K, 2 * H, K, left_off + c0 + H, left_ld, right_off, right_ld, red);
+    bias(net, ld.b_ih, ld.b_hh, H, left_off + c0, left_ld, red);
+    bias(net, ld.b_ih + 2 * H, ld.b_hh + 2 * H, 2 * H, left_off + c0 + H, left_ld, red);
+    if (decay_too) {   // no data gradient: f-gate rows and W_hh still decay under RiemannianAdam
+      decay(net, ld.w_ih + H * K, H * K);
+      decay(net, ld.w_hh, 4 * H * H);
+      decay(net, ld.b_ih + H, H);
+      decay(net, ld.b_hh + H, H);
+    }
+  }
+};
+
+DwTable critic_table(int net, const CriticLayout& cl, const CritWs& cw, int B, int L) {
+  TableBuilder tb;
+  for (int li = 0; li <= cl.nh; ++li) {
+    int k = li == 0 ? cl.in_dim : L, n = li == cl.nh ? 1 : L;
+    int right = li == 0 ? cw.in_right : cw.act[li - 1];
+    tb.weight(net, cl.w[li], k, n, k, cw.left[li], n, right, k, 3 * B);
+    tb.bias(net, cl.b[li], -1, n, cw.left[li], n, 2 * B);      // the GP rows carry no bias gradient
+  }
+  return tb.t;
+}
+
+DwTable gen_table(const hypad_dims& dm) {
+  const int B = dm.batch, S = dm.signal_shape, L = dm.latent_dim;
+  const bool hyp = dm.hyperbolic != 0;
+  const EncLayout el = enc_layout(S, L);
+  const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
+  const GenWs gw = gen_ws(B, S, L);
+  TableBuilder tb;
+  tb.t.finalize = 1;
+  for (int d = 0; d < 2; ++d)
+    tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, B, hyp);
+  tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, B);
+  tb.bias(HYPAD_NET_ENCODER, el.dense_b, -1, L, gw.dzenc, L, B);
+  tb.weight(HYPAD_NET_DECODER, dl.d1_w, L, DEC_D1, L, gw.da0, DEC_D1, gw.zcat, L, 2 * B);
+  tb.bias(HYPAD_NET_DECODER, dl.d1_b, -1, DEC_D1, gw.da0, DEC_D1, 2 * B);
+  for (int d = 0; d < 2; ++d) {
+    tb.lstm_dir(HYPAD_NET_DECODER, dl.l[0][d], DEC_H, DEC_D1, gw.dg0, 6 * DEC_H, d * 3 * DEC_H, gw.a0, DEC_D1, 2 * B, hyp);
+    tb.lstm_dir(HYPAD_NET_DECODER, dl.l[1][d], DEC_H, 2 * DEC_H, gw.dg1, 6 * DEC_H, d * 3 * DEC_H, gw.h0d, 2 * DEC_H, 2 * B, hyp);
+  }
+  tb.weight(HYPAD_NET_DECODER, dl.d2_w, 2 * DEC_H, S, 2 * DEC_H, gw.dpre2, S, gw.h1, 2 * DEC_H, 2 * B);
+  tb.bias(HYPAD_NET_DECODER, dl.d2_b, -1, S, gw.dpre2, S, 2 * B);
+  if (hyp) {
+    tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
+    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.dbrows, S, 3 * B);
+  }
+  return tb.t;
+}
+
+// ------------------------------------------------------------------------------------------------ host: launches
+int check_dims(const hypad_dims* d) {
+  if (!d || d->signal_shape <= 0 || d->latent_dim <= 0 || d->batch <= 0 || d->n_signals <= 0) return HYPAD_EINVAL;
+  if (d->batch % 16 != 0) return HYPAD_EINVAL;
+  if (d->signal_shape > MAX_S || d->latent_dim > MAX_L) return HYPAD_EUNSUPPORTED;
+  return HYPAD_OK;
+}
+
+hipError_t allow_lds(const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+struct IterCall {
+  const float* x; int64_t x_sig_stride; const int32_t* row_index;
+  const float* z; const float* alpha;
+  int train_mode; const float* masks; uint64_t seed;
+  float* losses; int64_t loss_sig_stride;
+  void* workspace; size_t workspace_bytes;
+};
+
+int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, const IterCall& io, int opt) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!st || !st->params.enc || !st->params.dec || !st->params.cx || !st->params.cz || !st->counters) return HYPAD_EINVAL;
+  if (!io.x || !io.losses) return HYPAD_EINVAL;
+  const int64_t per = ws_floats_per_signal(*d);
+  if (!io.workspace || io.workspace_bytes < (size_t)per * d->n_signals * sizeof(float)) return HYPAD_EWORKSPACE;
+  a.S = d->signal_shape; a.L = d->latent_dim; a.B = d->batch; a.hyperbolic = d->hyperbolic;
+  a.P = st->params; a.M = st->exp_avg; a.V = st->exp_avg_sq;
+  a.pe = enc_layout(a.S, a.L).total; a.pd = dec_layout(a.S, a.L, a.hyperbolic).total;
+  a.pcx = cx_layout(a.S, a.L).total; a.pcz = cz_layout(a.L).total;
+  a.counters = st->counters;
+  a.x = io.x; a.x_sig_stride = io.x_sig_stride; a.row_index = io.row_index;
+  a.z = io.z; a.alpha = io.alpha;
+  a.drop_mode = io.train_mode ? (io.masks ? 1 : 2) : 0;
+  a.masks = io.masks; a.mask_sig_stride = 0; a.seed = io.seed;
+  a.losses = io.losses; a.loss_sig_stride = io.loss_sig_stride;
+  a.ws = (float*)io.workspace; a.ws_sig_stride = per;
+  a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
+  a.opt = opt;
+  return HYPAD_OK;
+}
+
+int launch_dw(const IterArgs& a, const DwTable& tab, int n_signals, hipStream_t s) {
+  int blocks = (tab.total_items + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dw_adam_kernel, dim3(blocks, n_signals), dim3(THREADS), 0, s, a, tab);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+int run_cx(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+  IterArgs a;
+  int rc = fill_args(a, d, st, io, 0);
+  if (rc) return rc;
+  if (!st->exp_avg.cx || !st->exp_avg_sq.cx) return HYPAD_EINVAL;
+  a.mask_sig_stride = (int64_t)12 * a.B * a.L + (int64_t)a.B * 2 * DEC_H;
+  const LdsPlan lp = lds_plan(a.S, 16, 16);
+  size_t lds = (size_t)lp.total * sizeof(float);
+  hipError_t e = allow_lds((const void*)cx_pass_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(a.B / 16, d->n_signals);
+  hipLaunchKernelGGL(cx_pass_kernel, grid, dim3(THREADS), lds, s, a);
+  HYPAD_CHECK_LAUNCH();
+  size_t lds2 = (size_t)(16 * (pad4(a.S) + 4) + 2 * 16 * LP) * sizeof(float);
+  hipLaunchKernelGGL(critic_gp_kernel<true>, grid, dim3(THREADS), lds2, s, a);
+  HYPAD_CHECK_LAUNCH();
+  return launch_dw(a, critic_table(HYPAD_NET_CRITIC_X, cx_layout(a.S, a.L), crit_ws(a.B, a.S, a.L, 4), a.B, a.L), d->n_signals, s);
+}
+
+int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+  IterArgs a;
+  int rc = fill_args(a, d, st, io, 1);
+  if (rc) return rc;
+  if (!st->exp_avg.cz || !st->exp_avg_sq.cz) return HYPAD_EINVAL;
+  a.mask_sig_stride = (int64_t)6 * a.B * a.L;
+  const LdsPlan lp = lds_plan(a.S, 16, 16);
+  size_t lds = (size_t)lp.total * sizeof(float);
+  hipError_t e = allow_lds((const void*)cz_pass_kernel, lds);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(a.B / 16, d->n_signals);
+  hipLaunchKernelGGL(cz_pass_kernel, grid, dim3(THREADS), lds, s, a);
+  HYPAD_CHECK_LAUNCH();
+  size_t lds2 = (size_t)(16 * (pad4(a.L) + 4) + 2 * 16 * LP) * sizeof(float);
+  hipLaunchKernelGGL(critic_gp_kernel<false>, grid, dim3(THREADS), lds2, s, a);
+  HYPAD_CHECK_LAUNCH();
+  return launch_dw(a, critic_table(HYPAD_NET_CRITIC_Z, cz_layout(a.L), crit_ws(a.B, a.L, a.L, 2), a.B, a.L), d->n_signals, s);
+}
+
+int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+  IterArgs a;
+  int rc = fill_args(a, d, st, io, 2);
+  if (rc) return rc;
+  if (!st->exp_avg.enc || !st->exp_avg_sq.enc || !st->exp_avg.dec || !st->exp_avg_sq.dec) return HYPAD_EINVAL;
+  a.mask_sig_stride = (int64_t)6 * a.B * a.L + (int64_t)2 * a.B * 2 * DEC_H;
+  if (a.hyperbolic) { a.riemannian = 1; a.wd = st->gen_weight_decay; a.stabilize = st->gen_stabilize; }
+  dim3 grid(a.B / 16, d->n_signals);
+  if (a.hyperbolic) {
+    size_t lds = (size_t)lds_plan(a.S, 32, 48).total * sizeof(float);
+    if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
+    hipError_t e = allow_lds((const void*)gen_kernel<true>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gen_kernel<true>, grid, dim3(THREADS), lds, s, a);
+  } else {
+    size_t lds = (size_t)lds_plan(a.S, 32, 32).total * sizeof(float);
+    hipError_t e = allow_lds((const void*)gen_kernel<false>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gen_kernel<false>, grid, dim3(THREADS), lds, s, a);
+  }
+  HYPAD_CHECK_LAUNCH();
+  return launch_dw(a, gen_table(*d), d->n_signals, s);
+}
+
+IterCall from_io(const hypad_iter_io* io) {
+  IterCall c;
+  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.row_index = io->row_index; c.z = io->z; c.alpha = io->alpha;
+  c.train_mode = io->drop.train_mode; c.masks = io->drop.masks; c.seed = io->drop.seed;
+  c.losses = io->losses; c.loss_sig_stride = 4; c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
+  return c;
+}
+
+// ---- stand-alone optimizers
+__global__ __launch_bounds__(THREADS) void adam_flat_kernel(float* p, const float* g, float* m, float* v, int64_t n, int step,
+                                                             float lr, float b1, float b2, float eps, float wd, int riem,
+                                                             int64_t ball_off, int ball_dim) {
+  const AdamCoef co = adam_coef(lr, b1, b2, eps, wd, riem, 0, step);
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+    if (ball_dim > 0 && i >= ball_off && i < ball_off + ball_dim) continue;
+    float pp = p[i], mm = m[i], vv = v[i];
+    float gg = g[i];
+    if (!riem) gg += wd * pp;     // torch.optim.Adam weight_decay: L2 into the gradient
+    adam_update(pp, mm, vv, gg, co);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+__global__ __launch_bounds__(64) void radam_ball_kernel(float* p, const float* g, float* m, float* v, int dim, int step, float lr,
+                                                         float b1, float b2, float eps, float wd, int stabilize) {
+  const AdamCoef co = adam_coef(lr, b1, b2, eps, wd, 1, stabilize, step);
+  radam_ball_wave(p, m, v, row_load(g, dim, threadIdx.x), dim, threadIdx.x, co);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hypad_train_workspace_bytes(const hypad_dims* d) {
+  if (check_dims(d)) return 0;
+  return (size_t)ws_floats_per_signal(*d) * d->n_signals * sizeof(float);
+}
+
+int hypad_critic_x_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
+  if (!io) return HYPAD_EINVAL;
+  return run_cx(d, st, from_io(io), (hipStream_t)s);
+}
+int hypad_critic_z_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
+  if (!io) return HYPAD_EINVAL;
+  return run_cz(d, st, from_io(io), (hipStream_t)s);
+}
+int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
+  if (!io) return HYPAD_EINVAL;
+  return run_gen(d, st, from_io(io), (hipStream_t)s);
+}
+
+int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t s) {
+  if (!io || !io->row_index || io->n_batches <= 0 || io->n_critics < 0) return HYPAD_EINVAL;
+  int rc = check_dims(d);
+  if (rc) return rc;
+  IterCall c;
+  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.z = nullptr; c.alpha = nullptr;
+  c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
+  c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
+  const int iters = (2 * io->n_critics + 1) * io->n_batches;
+  c.loss_sig_stride = (int64_t)iters * 4;
+  int it = 0;
+  const int64_t pass_rows = (int64_t)io->n_batches * d->batch;
+  for (int k = 0; k < io->n_critics; ++k) {            // train.py:315-328
+    for (int b = 0; b < io->n_batches; ++b) {
+      c.row_index = io->row_index + k * pass_rows + (int64_t)b * d->batch;
+      c.losses = io->losses + (int64_t)(it++) * 4;
+      rc = run_cx(d, st, c, (hipStream_t)s);
+      if (rc) return rc;
+      c.losses = io->losses + (int64_t)(it++) * 4;
+      rc = run_cz(d, st, c, (hipStream_t)s);
+      if (rc) return rc;
+    }
+  }
+  for (int b = 0; b < io->n_batches; ++b) {            // train.py:347-352
+    c.row_index = io->row_index + io->n_critics * pass_rows + (int64_t)b * d->batch;
+    c.losses = io->losses + (int64_t)(it++) * 4;
+    rc = run_gen(d, st, c, (hipStream_t)s);
+    if (rc) return rc;
+  }
+  return HYPAD_OK;
+}
+
+int hypad_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps,
+                    float wd, hypad_stream_t s) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) return HYPAD_EINVAL;
+  if (n == 0) return HYPAD_OK;
+  int blocks = (int)((n + THREADS - 1) / THREADS);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)s, p, g, m, v, n, step, lr, b1, b2, eps, wd, 0,
+                     (int64_t)0, 0);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_radam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t ball_off, int ball_dim, int step, float lr,
+                     float b1, float b2, float eps, float wd, int stabilize, hypad_stream_t s) {
+  if (!p || !g || !m || !v || n < 0 || step < 1 || ball_dim < 0 || ball_dim > 64 * MAX_EPL) return HYPAD_EINVAL;
+  if (ball_dim > 0 && (ball_off < 0 || ball_off + ball_dim > n)) return HYPAD_EINVAL;
+  if (n == 0) return HYPAD_OK;
+  int blocks = (int)((n + THREADS - 1) / THREADS);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(THREADS), 0, (hipStream_t)s, p, g, m, v, n, step, lr, b1, b2, eps, wd, 1,
+                     ball_off, ball_dim);
+  HYPAD_CHECK_LAUNCH();
+  if (ball_dim > 0) {
+    hipLaunchKernelGGL(radam_ball_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, p + ball_off, g + ball_off, m + ball_off,
+                       v + ball_off, ball_dim, step, lr, b1, b2, eps, wd, stabilize);
+    HYPAD_CHECK_LAUNCH();
+  }
+  return HYPAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+"""Device-resident training engine: n_signals independent TadGAN models stepped side by side.
+
+The reference trains one model per signal (train.py:428-437) and nothing couples two signals, so the
+natural MI355X unit is a *group* of models advanced by the same kernel launches (grid.y = signal).  The
+engine owns, per network, one (n_signals, param_count) arena plus Adam moments, the device counters and the
+workspace, and exposes the three iterations and a whole epoch (train.py:299-356) over a window matrix that
+stays resident in HBM.  ``hypad_amd.train`` wraps it with n_signals = 1 around user-visible nn.Modules.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _C
+
+NETS = ("enc", "dec", "cx", "cz")
+_NET_ID = dict(enc=_C.NET_ENCODER, dec=_C.NET_DECODER, cx=_C.NET_CRITIC_X, cz=_C.NET_CRITIC_Z)
+
+
+class Engine:
+    def __init__(self, signal_shape, latent_dim, batch, hyperbolic, n_signals=1, device="cuda", lr=5e-4, betas=(0.9, 0.999),
+                 eps=1e-8, gen_weight_decay=1e-5, gen_stabilize=10, seed=0):
+        if batch % 16:
+            raise _C.HypadError("batch size must be a multiple of 16 (row tiles of the fused kernels)")
+        self.S, self.L, self.B, self.hyperbolic, self.n = int(signal_shape), int(latent_dim), int(batch), bool(hyperbolic), int(n_signals)
+        self.device = torch.device(device)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.gen_wd, self.gen_stab = float(gen_weight_decay), int(gen_stabilize or 0)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.count = {k: _C.lib.hypad_param_count(_NET_ID[k], self.S, self.L, int(self.hyperbolic)) for k in NETS}
+        z = lambda k: torch.zeros(self.n, self.count[k], dtype=torch.float32, device=self.device)
+        self.params = {k: z(k) for k in NETS}
+        self.exp_avg = {k: z(k) for k in NETS}
+        self.exp_avg_sq = {k: z(k) for k in NETS}
+        self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.dims = _C.Dims(self.S, self.L, self.B, int(self.hyperbolic), self.n)
+        nbytes = _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims))
+        if nbytes == 0:
+            raise _C.HypadError("unsupported dimensions for the fused training kernels")
+        self.workspace = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        self._ws_bytes = nbytes
+
+    # ---- weights in / out ------------------------------------------------------------------------------
+    def catalogue(self, net):
+        return _C.param_catalogue(_NET_ID[net], self.S, self.L, self.hyperbolic)[0]
+
+    def load_state_dict(self, net, sd, signal=0):
+        for name, off, shape in self.catalogue(net):
+            n = int(np.prod(shape))
+            self.params[net][signal, off:off + n].copy_(sd[name].detach().reshape(-1).to(torch.float32))
+
+    def state_dict(self, net, signal=0):
+        out = {}
+        for name, off, shape in self.catalogue(net):
+            n = int(np.prod(shape))
+            out[name] = self.params[net][signal, off:off + n].view(shape).clone()
+        return out
+
+    def adopt(self, arenas, exp_avg=None, exp_avg_sq=None):
+        """Use caller-owned flat arenas (n_signals == 1): the nn.Module views of hypad_amd.train."""
+        for k, t in arenas.items():
+            self.params[k] = t.view(1, -1)
+        for k, t in (exp_avg or {}).items():
+            self.exp_avg[k] = t.view(1, -1)
+        for k, t in (exp_avg_sq or {}).items():
+            self.exp_avg_sq[k] = t.view(1, -1)
+
+    # ---- C structs -------------------------------------------------------------------------------------
+    def _nets(self, d):
+        return _C.Nets(*(d[k].data_ptr() for k in NETS))
+
+    def _state(self):
+        return _C.TrainState(self._nets(self.params), self._nets(self.exp_avg), self._nets(self.exp_avg_sq),
+                             self.counters.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.gen_wd, self.gen_stab)
+
+    def _check_x(self, x):
+        _C.require_cuda(x, "x")
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        if x.shape[0] not in (1, self.n) or x.shape[2] != self.S:
+            raise _C.HypadError(f"x must be (n_signals, n_windows, {self.S})")
+        stride = 0 if (x.shape[0] == 1 and self.n > 1) else x.shape[1] * x.shape[2]
+        return x, stride
+
+    def _iter(self, fn, x, row_index, z, alpha, train_mode, masks):
+        x, stride = self._check_x(x)
+        losses = torch.empty(self.n, 4, dtype=torch.float32, device=self.device)
+        drop = _C.Dropout(int(train_mode), None if masks is None else masks.data_ptr(), self.seed, 0)
+        io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(),
+                       None if z is None else z.data_ptr(), None if alpha is None else alpha.data_ptr(), drop,
+                       losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
+        st = self._state()
+        _C.check(fn(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), fn.__name__)
+        return losses
+
+    def critic_x_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None):
+        return self._iter(_C.lib.hypad_critic_x_iteration, x, row_index, z, alpha, train_mode, masks)
+
+    def critic_z_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None):
+        return self._iter(_C.lib.hypad_critic_z_iteration, x, row_index, z, alpha, train_mode, masks)
+
+    def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None):
+        return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks)
+
+    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None):
+        """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device."""
+        x, stride = self._check_x(x)
+        iters = (2 * n_critics + 1) * n_batches
+        if losses is None:
+            losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
+        io = _C.EpochIO(x.data_ptr(), stride, row_index.data_ptr(), n_batches, n_critics, int(train_mode), self.seed,
+                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
+        st = self._state()
+        _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")
+        return losses

@@ -1,0 +1,132 @@
+"""TadGAN / HypAD networks on MI355X (reference: models/tadgan.py).
+
+Same class names, constructor signatures, ``state_dict`` keys and output shapes as the reference; each
+network's weights live in one flat device arena (hypad_amd/arena.py) consumed by the HIP kernels.
+``forward`` is inference-grade (no autograd graph): training goes through the fused iteration functions
+of ``hypad_amd.train`` exactly where the reference calls ``loss.backward(); optim.step()``.
+
+The LSTMs run the reference's effective configuration: the window is the feature axis, sequence length is 1
+and h0 = c0 = 0 (models/tadgan.py:24-25,59-60), so ``weight_hh`` is carried (and decayed by
+RiemannianAdam) but never read by a forward.
+"""
+import itertools
+
+import torch
+from torch import nn
+
+from .. import _C
+from ..arena import ArenaModule
+from ..hyperspace.hyrnn_nets import MobiusLinear
+
+_tick = itertools.count(1)
+
+
+def _drop(module, masks=None):
+    d = _C.Dropout()
+    d.train_mode = int(module.training)
+    d.masks = None if masks is None else masks.data_ptr()
+    d.seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    d.offset = next(_tick)
+    return d
+
+
+def _rows(x, width):
+    x = x.reshape(-1, width)
+    if not x.is_cuda:
+        raise _C.HypadError("inputs must be on the GPU (hypad_amd has no CPU path)")
+    return x.to(torch.float32).contiguous()
+
+
+def _named(module):
+    return {k: v for k, v in module.state_dict().items()}
+
+
+class Encoder(ArenaModule):
+    def __init__(self, signal_shape=100, latent_space_dim=20, hyperbolic=False):
+        super().__init__()
+        self.signal_shape, self.latent_space_dim = signal_shape, latent_space_dim
+        # same construction (and RNG consumption) order as models/tadgan.py:15-21
+        lstm = nn.LSTM(input_size=signal_shape, hidden_size=50, num_layers=1, bidirectional=True)
+        dense = nn.Linear(in_features=100, out_features=latent_space_dim)
+        init = {f"lstm.{k}": v for k, v in _named(lstm).items()}
+        init.update({f"dense.{k}": v for k, v in _named(dense).items()})
+        self._init_arena(_C.NET_ENCODER, signal_shape, latent_space_dim, False, init)
+
+    def forward(self, x):
+        x = _rows(x, self.signal_shape)
+        out = torch.empty(x.shape[0], self.latent_space_dim, device=x.device, dtype=torch.float32)
+        _C.check(_C.lib.hypad_encoder_fwd(_C.ptr(self.arena()), _C.ptr(x), _C.ptr(out), x.shape[0], self.signal_shape,
+                                          self.latent_space_dim, _C.stream()), "encoder_fwd")
+        return out.view(1, -1, self.latent_space_dim)
+
+
+class Decoder(ArenaModule):
+    def __init__(self, signal_shape=100, latent_space_dim=20, hyperbolic=False):
+        super().__init__()
+        self.signal_shape, self.latent_space_dim, self.hyperbolic = signal_shape, latent_space_dim, hyperbolic
+        dense1 = nn.Linear(in_features=latent_space_dim, out_features=50)                       # models/tadgan.py:34
+        lstm = nn.LSTM(input_size=50, hidden_size=64, num_layers=2, dropout=0.2, bidirectional=True)
+        dense2 = nn.Linear(in_features=128, out_features=signal_shape)
+        init = {f"dense1.{k}": v for k, v in _named(dense1).items()}
+        init.update({f"lstm.{k}": v for k, v in _named(lstm).items()})
+        init.update({f"dense2.{k}": v for k, v in _named(dense2).items()})
+        from ..arena import _Group
+        self.dense1, self.lstm, self.dense2 = _Group(), _Group(), _Group()      # registration order = the reference's
+        if hyperbolic:
+            self.hyperbolic_linear = MobiusLinear(signal_shape, signal_shape, hyperbolic_input=False, hyperbolic_bias=True,
+                                                  nonlin=None, fp64_hyper=False)                # models/tadgan.py:43-52
+            init["hyperbolic_linear.weight"] = self.hyperbolic_linear.weight
+            init["hyperbolic_linear.bias"] = self.hyperbolic_linear.bias
+        self._init_arena(_C.NET_DECODER, signal_shape, latent_space_dim, hyperbolic, init)
+
+    def forward(self, x, dropout_mask=None):
+        z = _rows(x, self.latent_space_dim)
+        rows, S = z.shape[0], self.signal_shape
+        eucl = torch.empty(rows, S, device=z.device, dtype=torch.float32)
+        hyper = torch.empty(rows, S, device=z.device, dtype=torch.float32) if self.hyperbolic else None
+        d = _drop(self, dropout_mask)
+        _C.check(_C.lib.hypad_decoder_fwd(_C.ptr(self.arena()), _C.ptr(z), _C.ptr(hyper), _C.ptr(eucl), rows, S,
+                                          self.latent_space_dim, int(self.hyperbolic), d, _C.stream()), "decoder_fwd")
+        if self.hyperbolic:
+            return hyper.view(1, -1, S), eucl.view(1, -1, S)
+        return eucl.view(1, -1, S)
+
+
+class CriticX(ArenaModule):
+    def __init__(self, signal_shape=10, latent_space_dim=20):
+        super().__init__()
+        self.signal_shape, self.latent_space_dim = signal_shape, latent_space_dim
+        self.dropout = nn.Dropout(p=0.25)
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        dims = [(signal_shape, latent_space_dim)] + [(latent_space_dim, latent_space_dim)] * 3 + [(latent_space_dim, 1)]
+        init = {}
+        for i, (a, b) in enumerate(dims, 1):                                                    # models/tadgan.py:77-89
+            init.update({f"dense{i}.{k}": v for k, v in _named(nn.Linear(a, b)).items()})
+        self._init_arena(_C.NET_CRITIC_X, signal_shape, latent_space_dim, False, init)
+
+    def forward(self, x, dropout_masks=None):
+        x = _rows(x, self.signal_shape)
+        out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        _C.check(_C.lib.hypad_critic_x_fwd(_C.ptr(self.arena()), _C.ptr(x), _C.ptr(out), x.shape[0], self.signal_shape,
+                                           self.latent_space_dim, _drop(self, dropout_masks), _C.stream()), "critic_x_fwd")
+        return out.view(1, -1, 1)
+
+
+class CriticZ(ArenaModule):
+    def __init__(self, latent_space_dim=20):
+        super().__init__()
+        self.latent_space_dim = latent_space_dim
+        init = {}
+        for i, (a, b) in enumerate([(latent_space_dim, latent_space_dim)] * 2 + [(latent_space_dim, 1)], 1):
+            init.update({f"dense{i}.{k}": v for k, v in _named(nn.Linear(a, b)).items()})      # models/tadgan.py:113-119
+        self.dropout = nn.Dropout(p=0.2)
+        self.leakyrelu = nn.LeakyReLU(0.2)
+        self._init_arena(_C.NET_CRITIC_Z, latent_space_dim, latent_space_dim, False, init)
+
+    def forward(self, x, dropout_masks=None):
+        lead = x.shape[:-1]
+        z = _rows(x, self.latent_space_dim)
+        out = torch.empty(z.shape[0], device=z.device, dtype=torch.float32)
+        _C.check(_C.lib.hypad_critic_z_fwd(_C.ptr(self.arena()), _C.ptr(z), _C.ptr(out), z.shape[0], self.latent_space_dim,
+                                           _drop(self, dropout_masks), _C.stream()), "critic_z_fwd")
+        return out.view(*lead, 1)

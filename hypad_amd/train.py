@@ -1,0 +1,252 @@
+"""Training surface of the reference (train.py) over the fused HIP iterations.
+
+``critic_x_iteration`` / ``critic_z_iteration`` / ``decoder_iteration`` keep the reference's positional
+signatures and return types (train.py:18, :107, :189); each is forward + backward + optimizer step in three
+(critics) or two (generator) kernel launches.  Host-side randomness follows the reference: the
+latent draw comes from NumPy's global generator and the interpolation weights from torch's CPU generator, then
+travel to the device; pass ``z=`` / ``alpha=`` to inject them, or use ``hypad_amd.engine.Engine`` for the
+device-RNG, HBM-resident fast path.
+
+The optimizer argument may be a ``torch.optim.Adam`` (as the reference builds, train.py:274-281), or
+``hypad_amd.optim.Adam`` / ``RiemannianAdam``: only its hyper-parameters are read; the moments live in flat
+arenas attached to it on first use and are mirrored into ``optimizer.state`` as views.
+"""
+import logging
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _C
+from .engine import Engine
+from .models import tadgan
+from .optim import Adam, RiemannianAdam
+
+_NET_OF = {tadgan.Encoder: "enc", tadgan.Decoder: "dec", tadgan.CriticX: "cx", tadgan.CriticZ: "cz"}
+
+
+class _Fused:
+    """Flat Adam moments + device counters attached to one optimizer."""
+
+    def __init__(self, optim, modules, dims):
+        g = optim.param_groups[0]
+        self.modules = modules
+        self.exp_avg = {k: torch.zeros_like(m.arena()) for k, m in modules.items()}
+        self.exp_avg_sq = {k: torch.zeros_like(m.arena()) for k, m in modules.items()}
+        dev = next(iter(modules.values())).arena().device
+        S, L, B, hyp = dims
+        salt = sum(ord(c) for k in modules for c in k) * 0x9E3779B97F4A7C15        # decorrelate the three optimizers' streams
+        self.engine = Engine(S, L, B, hyp, 1, dev, lr=g["lr"], betas=g.get("betas", (0.9, 0.999)), eps=g.get("eps", 1e-8),
+                             gen_weight_decay=g.get("weight_decay", 0.0), gen_stabilize=g.get("stabilize") or 0,
+                             seed=torch.initial_seed() + salt)
+        self.steps = 0
+        for k, m in modules.items():          # expose the moments the way torch optimizers do
+            for name, (p, off, n, shape) in m._slots.items():
+                optim.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[k][off:off + n].view(shape),
+                                  "exp_avg_sq": self.exp_avg_sq[k][off:off + n].view(shape)}
+        self.optim = optim
+
+    def bind(self, others):
+        arenas = {k: m.arena() for k, m in {**others, **self.modules}.items()}
+        for k in ("enc", "dec", "cx", "cz"):   # the ABI wants four valid pointers; untouched nets borrow one
+            arenas.setdefault(k, next(iter(arenas.values())))
+        self.engine.adopt(arenas, self.exp_avg, self.exp_avg_sq)
+        g = self.optim.param_groups[0]
+        self.engine.lr = float(g["lr"])
+        return self.engine
+
+    def stepped(self):
+        self.steps += 1
+        for st in self.optim.state.values():
+            if isinstance(st.get("step"), torch.Tensor):
+                st["step"].fill_(self.steps)
+
+
+def _fused(optim, modules, params, hyperbolic):
+    f = getattr(optim, "_hypad", None)
+    dims = (params.signal_shape, params.latent_space_dim, params.batch_size, bool(hyperbolic))
+    if f is None or f.engine.B != params.batch_size or f.engine.hyperbolic != bool(hyperbolic):
+        f = _Fused(optim, modules, dims)
+        optim._hypad = f
+    return f
+
+
+def _sample(sample, params):
+    x = sample.reshape(params.batch_size, params.signal_shape)
+    if not x.is_cuda:
+        x = x.cuda()
+    return x.to(torch.float32).contiguous().unsqueeze(0)
+
+
+def _draw_z(params, z, device):
+    if z is None:
+        z = np.random.normal(size=(1, params.batch_size, params.latent_space_dim))       # train.py:24,118,205
+    return torch.as_tensor(np.asarray(z), dtype=torch.float32).reshape(1, params.batch_size, -1).contiguous().to(device)
+
+
+def _draw_alpha(shape, alpha, device):
+    if alpha is None:
+        alpha = torch.rand(shape)                                                         # train.py:64,149 (CPU generator)
+    return torch.as_tensor(alpha, dtype=torch.float32).reshape(shape).contiguous().to(device)
+
+
+def _train_flag(*mods):
+    flags = {bool(m.training) for m in mods}
+    if len(flags) != 1:
+        raise _C.HypadError("mixed train()/eval() modes across the networks of one iteration are not supported")
+    return flags.pop()
+
+
+def critic_x_iteration(sample, decoder, critic_x, optim_cx, params, z=None, alpha=None, dropout_masks=None):
+    """train.py:18-104.  Returns the 0-d loss (float64, as the reference's loss is: SURVEY.md §7 hard part 2)."""
+    x = _sample(sample, params)
+    f = _fused(optim_cx, {"cx": critic_x}, params, decoder.hyperbolic)
+    eng = f.bind({"dec": decoder})
+    B, S = params.batch_size, params.signal_shape
+    losses = eng.critic_x_iteration(x, None, _draw_z(params, z, x.device), _draw_alpha((1, B, S), alpha, x.device),
+                                    _train_flag(decoder, critic_x), dropout_masks)
+    f.stepped()
+    return losses[0, 0].to(torch.float64)
+
+
+def critic_z_iteration(sample, encoder, critic_z, optim_cz, params, z=None, alpha=None, dropout_masks=None):
+    """train.py:107-186."""
+    x = _sample(sample, params)
+    f = _fused(optim_cz, {"cz": critic_z}, params, False)
+    eng = f.bind({"enc": encoder})
+    B, L = params.batch_size, params.latent_space_dim
+    losses = eng.critic_z_iteration(x, None, _draw_z(params, z, x.device), _draw_alpha((1, B, L), alpha, x.device),
+                                    _train_flag(encoder, critic_z), dropout_masks)
+    f.stepped()
+    return losses[0, 0].clone()
+
+
+def decoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_dec, params, err_loss=None, z=None,
+                      dropout_masks=None):
+    """train.py:189-249.  Returns (loss_dec, hyper_loss, mse) with the reference's conventions:
+    hyperbolic -> (loss, hyper_loss, torch.Tensor([0])); Euclidean -> (loss, 0, mse_loss)."""
+    if err_loss is not None and not isinstance(err_loss, nn.MSELoss):
+        raise NotImplementedError("decoder_iteration: only nn.MSELoss() (the reference's default) is fused")
+    x = _sample(sample, params)
+    f = _fused(optim_dec, {"dec": decoder, "enc": encoder}, params, decoder.hyperbolic)
+    if decoder.hyperbolic and not getattr(optim_dec, "riemannian", False) and "stabilize" not in optim_dec.param_groups[0]:
+        raise _C.HypadError("hyperbolic decoder_iteration needs a RiemannianAdam optimizer (train.py:282-288)")
+    eng = f.bind({"cx": critic_x, "cz": critic_z})
+    losses = eng.decoder_iteration(x, None, _draw_z(params, z, x.device), _train_flag(encoder, decoder, critic_x, critic_z),
+                                   dropout_masks)
+    f.stepped()
+    if decoder.hyperbolic:
+        return losses[0, 0].clone(), losses[0, 1].clone(), torch.Tensor([0])
+    return losses[0, 0].clone(), 0, losses[0, 1].clone()
+
+
+def _set_requires_grad(modules, flag):
+    for m in modules:
+        for p in m.parameters():
+            p.requires_grad = flag
+
+
+def make_optimizers(encoder, decoder, critic_x, critic_z, params):
+    """train.py:274-288."""
+    optim_cx = Adam(critic_x.parameters(), lr=params.lr, betas=(0.9, 0.999))
+    optim_cz = Adam(critic_z.parameters(), lr=params.lr, betas=(0.9, 0.999))
+    gen = list(decoder.parameters()) + list(encoder.parameters())
+    if params.hyperbolic:
+        optim_dec = RiemannianAdam(gen, lr=params.lr, weight_decay=1e-5, stabilize=10)
+    else:
+        optim_dec = Adam(gen, lr=params.lr, betas=(0.9, 0.999))
+    return optim_cx, optim_cz, optim_dec
+
+
+def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=2000, params=[], path=""):
+    """train.py:252-385: per epoch 5 passes of (critic_x, critic_z) over the loader, then one generator pass."""
+    logging.debug("Starting training")
+    optim_cx, optim_cz, optim_dec = make_optimizers(encoder, decoder, critic_x, critic_z, params)
+    cx_epoch_loss, cz_epoch_loss, decoder_epoch_loss, hyp_dec_loss, eucl_dec_loss = [], [], [], [], []
+    actual_epoch = 0
+    if params.resume:
+        n_epochs = n_epochs - params.resume_epoch
+        actual_epoch = params.resume_epoch + 1
+    for epoch in range(n_epochs):
+        logging.debug("Epoch {}".format(epoch))
+        n_critics = 5
+        cx_nc_loss, cz_nc_loss = [], []
+        _set_requires_grad((decoder, encoder), False)
+        _set_requires_grad((critic_x, critic_z), True)
+        for _ in range(n_critics):
+            cx_loss, cz_loss = [], []
+            for sample in train_loader:
+                sample = sample.cuda()
+                cx_loss.append(critic_x_iteration(sample, decoder, critic_x, optim_cx, params))
+                cz_loss.append(critic_z_iteration(sample, encoder, critic_z, optim_cz, params))
+            cx_nc_loss.append(torch.mean(torch.stack(cx_loss).float()))      # one device->host sync per pass
+            cz_nc_loss.append(torch.mean(torch.stack(cz_loss).float()))
+        _set_requires_grad((decoder, encoder), True)
+        _set_requires_grad((critic_x, critic_z), False)
+        logging.debug("Critic training done in epoch {}".format(epoch))
+        decoder_loss, hyp_loss, mse_losss = [], [], []
+        for sample in train_loader:
+            dec_loss, hyper_loss, mse_loss = decoder_iteration(sample.cuda(), encoder, decoder, critic_x, critic_z, optim_dec, params)
+            decoder_loss.append(dec_loss)
+            if params.hyperbolic:
+                hyp_loss.append(hyper_loss.float())
+            mse_losss.append(mse_loss.float().reshape(()).to(dec_loss.device))
+        cx_epoch_loss.append(torch.mean(torch.stack(cx_nc_loss)).item())
+        cz_epoch_loss.append(torch.mean(torch.stack(cz_nc_loss)).item())
+        decoder_epoch_loss.append(torch.mean(torch.stack(decoder_loss)).item())
+        if params.hyperbolic:
+            hyp_dec_loss.append(torch.mean(torch.stack(hyp_loss)).item())
+        eucl_dec_loss.append(torch.mean(torch.stack(mse_losss)).item())
+        print("Encoder decoder training done in epoch {}".format(epoch))
+        if params.hyperbolic:
+            print("Hyperbolic loss {}".format(hyp_dec_loss[-1]))
+        else:
+            print("Eucl mse loss {}".format(eucl_dec_loss[-1]))
+        print("critic x loss {:.3f} critic z loss {:.3f} \ndecoder loss {:.3f}\n".format(
+            cx_epoch_loss[-1], cz_epoch_loss[-1], decoder_epoch_loss[-1]))
+        actual_epoch += 1
+        if (actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1)):       # train.py:381 (cadence kept as is)
+            torch.save(encoder, path + "/encoder_{}.pt".format(actual_epoch))
+            torch.save(decoder, path + "/decoder_{}.pt".format(actual_epoch))
+            torch.save(critic_x, path + "/critic_x_{}.pt".format(actual_epoch))
+            torch.save(critic_z, path + "/critic_z_{}.pt".format(actual_epoch))
+    return SimpleNamespace(cx=cx_epoch_loss, cz=cz_epoch_loss, dec=decoder_epoch_loss, hyper=hyp_dec_loss, mse=eucl_dec_loss)
+
+
+def model_path(params):
+    """Directory naming of train.py:428-437."""
+    kind = "hyper" if params.hyperbolic else "eucl"
+    base = f"./trained_models/models_{kind}_{params.dataset}_{str(params.epochs)}_{str(params.lr)}/{params.dataset}"
+    return base if params.signal == "multivariate" else f"{base}/{params.signal}"
+
+
+def resume_ckpt(params):
+    """train.py:388-406 with the undefined ``resume_path`` of the reference resolved to the model directory."""
+    path = model_path(params) + "/"
+    load = lambda n: torch.load(path + n, weights_only=False).cuda().train()
+    print("model resumed from {}".format(path))
+    return load("encoder.pt"), load("decoder.pt"), load("critic_x.pt"), load("critic_z.pt")
+
+
+def train(train_loader, params, config_path):
+    """train.py:409-466."""
+    params.latent_space_dim = 20
+    encoder = tadgan.Encoder(params.signal_shape, params.latent_space_dim).cuda().train()
+    decoder = tadgan.Decoder(params.signal_shape, params.latent_space_dim, params.hyperbolic).cuda().train()
+    critic_x = tadgan.CriticX(params.signal_shape, params.latent_space_dim).cuda().train()
+    critic_z = tadgan.CriticZ(params.latent_space_dim).cuda().train()
+    PATH = model_path(params)
+    os.makedirs(PATH, exist_ok=True)
+    if config_path and os.path.exists(config_path):
+        import shutil
+        shutil.copyfile(config_path, os.path.join(PATH, "config.yaml"))
+    if params.resume:
+        encoder, decoder, critic_x, critic_z = resume_ckpt(params)
+    train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=params.epochs, params=params, path=PATH)
+    torch.save(encoder, PATH + "/encoder.pt")
+    torch.save(decoder, PATH + "/decoder.pt")
+    torch.save(critic_x, PATH + "/critic_x.pt")
+    torch.save(critic_z, PATH + "/critic_z.pt")
+    return encoder, decoder, critic_x, critic_z, PATH

@@ -1,0 +1,151 @@
+"""Window scoring on the GPU (reference: utils/anomaly_detection_utils.py).
+
+Same function names and argument meaning as the reference for the numerics on the hot path
+(SURVEY.md §8a rows S1-S6); inputs may be NumPy arrays (as the reference passes) or device tensors, results
+come back as NumPy arrays like the reference's.  File caches, plotting and interval extraction are outside
+the path and are not part of this module.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _C
+from ..hyperspace import gmath
+
+
+def _dev():
+    return torch.device("cuda")
+
+
+def _f32(a):
+    t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+    return t.to(_dev(), torch.float32).contiguous()
+
+
+def _f64(a):
+    t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+    return t.to(_dev(), torch.float64).contiguous()
+
+
+def unroll_true(y):
+    """First sample of every window plus the tail of the last (:908-910).  y: (N, S) or (N, S, 1)."""
+    y = _f64(y)
+    y = y.reshape(y.shape[0], -1)
+    n, w = y.shape
+    out = torch.empty(n + w - 1, device=y.device, dtype=torch.float64)
+    _C.check(_C.lib.hypad_unroll_true(_C.ptr(y), _C.ptr(out), n, w, _C.stream()), "unroll_true")
+    return out
+
+
+def unroll_predictions(y_hat, with_summary=True):
+    """Per-timestep median (float32) and [min, p25, p50, p75, max] over the anti-diagonals (:918-935)."""
+    y_hat = _f32(y_hat)
+    n, w = y_hat.shape
+    t = n + w - 1
+    med = torch.empty(t, device=y_hat.device, dtype=torch.float32)
+    summ = torch.empty(t, 5, device=y_hat.device, dtype=torch.float64) if with_summary else None
+    _C.check(_C.lib.hypad_unroll_median(_C.ptr(y_hat), _C.ptr(med), _C.ptr(summ), n, w, _C.stream()), "unroll_median")
+    return med, summ
+
+
+def _point_wise_error(y, y_hat):
+    y, y_hat = _f64(y), _f32(y_hat)
+    out = torch.empty_like(y)
+    _C.check(_C.lib.hypad_point_error(_C.ptr(y), _C.ptr(y_hat), _C.ptr(out), y.numel(), _C.stream()), "point_error")
+    return out
+
+
+def _area_error(y, y_hat, score_window=10):
+    y, y_hat = _f64(y), _f32(y_hat)
+    out = torch.empty_like(y)
+    _C.check(_C.lib.hypad_area_error(_C.ptr(y), _C.ptr(y_hat), _C.ptr(out), y.numel(), score_window, _C.stream()), "area_error")
+    return out
+
+
+def _dtw_error(y, y_hat, score_window=10):
+    y, y_hat = _f64(y), _f32(y_hat)
+    out = torch.empty_like(y)
+    _C.check(_C.lib.hypad_dtw_error(_C.ptr(y), _C.ptr(y_hat), _C.ptr(out), y.numel(), score_window, _C.stream()), "dtw_error")
+    return out
+
+
+def rolling_mean(x, window):
+    x = _f64(x)
+    out = torch.empty_like(x)
+    _C.check(_C.lib.hypad_rolling_mean(_C.ptr(x), _C.ptr(out), x.numel(), int(window), _C.stream()), "rolling_mean")
+    return out
+
+
+def zscore_clip(x):
+    """stats.zscore(x) -> clip(min=0) + 1  (:523-524)."""
+    x = _f64(x)
+    out = torch.empty_like(x)
+    ws = torch.empty(4, device=x.device, dtype=torch.float64)
+    _C.check(_C.lib.hypad_zscore_clip(_C.ptr(x), _C.ptr(out), x.numel(), _C.ptr(ws), 32, _C.stream()), "zscore_clip")
+    return out
+
+
+def reconstruction_errors(y, y_hat, step_size=1, score_window=10, smoothing_window=0.01, smooth=True, rec_error_type="point",
+                          with_summary=True):
+    """:866-962.  Returns (errors, predictions_vs) as NumPy arrays like the reference."""
+    if step_size != 1:
+        raise NotImplementedError("step_size != 1 (the reference's callers always use 1)")
+    n = len(y)
+    if isinstance(smoothing_window, float):
+        smoothing_window = min(math.trunc(n * smoothing_window), 200)
+    true = unroll_true(y)
+    pred, summ = unroll_predictions(y_hat, with_summary)
+    kind = rec_error_type.lower()
+    if kind == "point":
+        err = _point_wise_error(true, pred)
+    elif kind == "area":
+        err = _area_error(true, pred, score_window)
+    elif kind == "dtw":
+        err = _dtw_error(true, pred, score_window)
+    else:
+        raise ValueError(rec_error_type)
+    if smooth:
+        err = rolling_mean(err, smoothing_window)
+    pvs = summ.cpu().numpy().reshape(-1, 1, 5) if summ is not None else np.empty((0, 1, 5))
+    return err.cpu().numpy(), pvs
+
+
+def hyperbolic_rec_scores(recons_signal, true_signal, signal_shape):
+    """Row-wise Poincare distance between real windows on the ball and reconstructions (:54-66)."""
+    true_data = _f32(recons_signal).reshape(-1, signal_shape)
+    pred_data = _f32(true_signal).reshape(-1, signal_shape)
+    return gmath.poincare_rowdist(pred_data, true_data)
+
+
+def row_norms(x):
+    x = _f32(x)
+    out = torch.empty(x.shape[0], device=x.device, dtype=torch.float64)
+    _C.check(_C.lib.hypad_row_norms(_C.ptr(x), _C.ptr(out), x.shape[0], x.shape[1], _C.stream()), "row_norms")
+    return out
+
+
+def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[]):
+    """:336-362."""
+    if combination not in ("sum", "mult", "uncertainty", "critic", "critic_uncertainty", "sum_uncertainty", "rec", "rec_uncertainty"):
+        raise ValueError(combination)
+    c = _f64(critic_scores) if len(critic_scores) else None
+    r = _f64(rec_scores) if len(rec_scores) else None
+    n = (r if r is not None else c).numel()
+    u = row_norms(recons_signal)[:n].contiguous() if "uncertainty" in combination else None
+    if c is not None:
+        c = c[:n].contiguous()
+    out = torch.empty(n, device=_dev(), dtype=torch.float64)
+    _C.check(_C.lib.hypad_combine_scores(_C.COMB[combination], _C.ptr(c), _C.ptr(r), _C.ptr(u), _C.ptr(out), n, _C.stream()), "combine")
+    return out.cpu().numpy()
+
+
+def combine_euclidean(comb, critic_scores, rec_scores):
+    """Tail of score_anomalies (:553-570), lambda_rec = 0.5."""
+    mode = {"mult": "eucl_mult", "sum": "eucl_sum", "rec": "rec", "critic": "critic"}.get(comb)
+    if mode is None:
+        raise ValueError('Unknown combination specified {}, use "mult", "sum", or "rec" instead.'.format(comb))
+    c, r = _f64(critic_scores), _f64(rec_scores)
+    out = torch.empty_like(r)
+    _C.check(_C.lib.hypad_combine_scores(_C.COMB[mode], _C.ptr(c), _C.ptr(r), None, _C.ptr(out), r.numel(), _C.stream()), "combine")
+    return out.cpu().numpy()

@@ -1,0 +1,257 @@
+/*
+ * hypad.h -- C ABI of libhypad_hip.so: the HypAD / TadGAN train + score hot path on MI355X (gfx950).
+ *
+ * The reference (aleflabo/HypAD, pure Python) has no FFI: its hot path sits behind Python callables.
+ * Each entry point below names the reference code it replaces (file:line under /root/reference), so a
+ * maintainer can bind it (ctypes stub in INTEGRATION.md) where that code runs today.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  Every data pointer is a DEVICE pointer owned by the caller.
+ *   - `stream` is a hipStream_t passed as void*.  All work is enqueued on it; nothing synchronises,
+ *     allocates or frees, so every call may be captured into a hipGraph.
+ *   - return 0 on success, a negative HYPAD_E* code for argument errors, a positive hipError_t otherwise.
+ *   - fp32 arithmetic throughout unless a function says fp64 (scoring post-processing follows NumPy's fp64).
+ *   - matrices are dense row-major; weights keep PyTorch's (out_features, in_features) layout.
+ *   - curvature is fixed at k = -1 (the only value the reference uses: hyperspace/hyrnn_nets.py:20,166).
+ */
+#ifndef HYPAD_H_
+#define HYPAD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYPAD_ABI_VERSION 1
+
+enum {
+  HYPAD_OK = 0,
+  HYPAD_EINVAL = -1,       /* bad argument (null pointer, non-positive size, unsupported shape) */
+  HYPAD_EWORKSPACE = -2,   /* workspace missing or too small */
+  HYPAD_EUNSUPPORTED = -3  /* shape outside the fused path's limits (see hypad_limits) */
+};
+
+typedef void* hypad_stream_t; /* hipStream_t */
+
+int hypad_abi_version(void);
+const char* hypad_error_string(int code);
+/* signal_shape <= max_signal_shape, latent_dim <= max_latent for the fused network kernels */
+void hypad_limits(int* max_signal_shape, int* max_latent);
+
+/* ------------------------------------------------------------------------------------------------
+ * Parameter arenas.  One flat fp32 buffer per network; tensors sit at fixed, 16-byte aligned offsets
+ * and carry the reference's state_dict names and shapes (models/tadgan.py:11-21,31-56,71-89,110-121;
+ * SURVEY.md A.1).  The host side builds its torch views from these queries.
+ * ---------------------------------------------------------------------------------------------- */
+enum { HYPAD_NET_ENCODER = 0, HYPAD_NET_DECODER = 1, HYPAD_NET_CRITIC_X = 2, HYPAD_NET_CRITIC_Z = 3 };
+
+int hypad_param_count(int net, int signal_shape, int latent_dim, int hyperbolic);   /* floats, padded */
+int hypad_param_tensors(int net, int hyperbolic);
+int hypad_param_info(int net, int signal_shape, int latent_dim, int hyperbolic, int index,
+                     char* name, int name_cap, int* offset, int* rows, int* cols);   /* cols = 0 for 1-D */
+
+/* ------------------------------------------------------------------------------------------------
+ * Poincare-ball ops (geoopt.manifolds.stereographic.math, vendored as /root/reference/math_.py).
+ * Row-wise over (rows, dim) matrices.
+ * ---------------------------------------------------------------------------------------------- */
+/* gmath.expmap0  math_.py:1132-1136 (+ tan_k :217-238, tanh :51-53) */
+int hypad_expmap0_fwd(const float* u, float* out, int64_t rows, int dim, hypad_stream_t stream);
+int hypad_expmap0_bwd(const float* u, const float* grad_out, float* grad_u, int64_t rows, int dim, hypad_stream_t stream);
+/* gmath.logmap0  math_.py:1267-1270 (+ artan_k :241-262, artanh :56-59) */
+int hypad_logmap0_fwd(const float* y, float* out, int64_t rows, int dim, hypad_stream_t stream);
+int hypad_logmap0_bwd(const float* y, const float* grad_out, float* grad_y, int64_t rows, int dim, hypad_stream_t stream);
+/* gmath.mobius_add  math_.py:536-555.  y_rows == 1 broadcasts y over the rows of x (hyrnn_nets.py:31);
+ * then grad_y is the (rows, dim) matrix of per-row contributions, to be column-summed by the caller
+ * (hypad_column_sum). */
+int hypad_mobius_add_fwd(const float* x, const float* y, float* out, int64_t rows, int dim, int64_t y_rows, hypad_stream_t stream);
+int hypad_mobius_add_bwd(const float* x, const float* y, const float* grad_out, float* grad_x, float* grad_y,
+                         int64_t rows, int dim, int64_t y_rows, hypad_stream_t stream);
+/* gmath.project  math_.py:340-352 (fp32 eps 4e-3) */
+int hypad_project_fwd(const float* x, float* out, int64_t rows, int dim, hypad_stream_t stream);
+int hypad_project_bwd(const float* x, const float* grad_out, float* grad_x, int64_t rows, int dim, hypad_stream_t stream);
+/* fused expmap0 -> mobius_add(bias) -> project: the tail of mobius_linear, hyperspace/hyrnn_nets.py:27-34 */
+int hypad_mobius_head_fwd(const float* u, const float* bias, float* out, int64_t rows, int dim, hypad_stream_t stream);
+int hypad_mobius_head_bwd(const float* u, const float* bias, const float* grad_out, float* grad_u,
+                          float* grad_bias_rows, int64_t rows, int dim, hypad_stream_t stream);
+/* MobiusLinear.forward / mobius_linear  hyperspace/hyrnn_nets.py:186-200, :13-35
+ * (hyperbolic_input=False, hyperbolic_bias=True, nonlin=None).  weight (out_dim, in_dim), bias (out_dim).
+ * workspace: hypad_mobius_linear_workspace_bytes(rows, out_dim) -- holds u = x W^T for the backward. */
+size_t hypad_mobius_linear_workspace_bytes(int64_t rows, int out_dim);
+int hypad_mobius_linear_fwd(const float* x, const float* weight, const float* bias, float* out, float* u_save,
+                            int64_t rows, int in_dim, int out_dim, hypad_stream_t stream);
+int hypad_mobius_linear_bwd(const float* x, const float* weight, const float* bias, const float* u_saved,
+                            const float* grad_out, float* grad_x, float* grad_weight, float* grad_bias,
+                            void* workspace, size_t workspace_bytes,
+                            int64_t rows, int in_dim, int out_dim, hypad_stream_t stream);
+/* inline row-wise Poincare distance  train.py:226-230; utils/anomaly_detection_utils.py:58-66,167-175 */
+int hypad_poincare_rowdist_fwd(const float* u, const float* v, float* dist, int64_t rows, int dim, hypad_stream_t stream);
+int hypad_poincare_rowdist_bwd(const float* u, const float* v, const float* grad_dist, float* grad_u, float* grad_v,
+                               int64_t rows, int dim, hypad_stream_t stream);
+/* hyperbolic reconstruction loss  train.py:226-232: loss[0] = sum_r dist(u_r, v_r) / batch.
+ * bwd: gradients of (grad_loss * loss) w.r.t. u and v. */
+int hypad_hyper_loss_fwd(const float* u, const float* v, float* loss, int64_t rows, int dim, int batch, hypad_stream_t stream);
+int hypad_hyper_loss_bwd(const float* u, const float* v, float grad_loss, float* grad_u, float* grad_v,
+                         int64_t rows, int dim, int batch, hypad_stream_t stream);
+/* pair-wise distance  hyperspace/poincare_distance.py:5-16 (+ :19-25, :28-48): out (n, m) */
+int hypad_poincare_pairdist_fwd(const float* pred, const float* gt, float* out, int n, int m, int dim, hypad_stream_t stream);
+/* out[c] = sum_r in[r][c] */
+int hypad_column_sum(const float* in, float* out, int64_t rows, int dim, hypad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense building blocks (torch ATen calls of the reference: F.linear, nn.LSTM at T=1).
+ * ---------------------------------------------------------------------------------------------- */
+enum { HYPAD_ACT_NONE = 0, HYPAD_ACT_TANH = 1, HYPAD_ACT_LEAKY02 = 2 };
+/* y = act(x W^T + b): nn.Linear + nn.Tanh / nn.LeakyReLU(0.2)  models/tadgan.py:21,34,39,40,77-89 */
+int hypad_linear_act_fwd(const float* x, const float* weight, const float* bias, float* y,
+                         int64_t rows, int in_dim, int out_dim, int act, hypad_stream_t stream);
+/* grad_x = (grad_y * act'(y)) W ; grad_w = (grad_y * act')^T x ; grad_b = colsum(grad_y * act').  y = forward output. */
+int hypad_linear_act_bwd(const float* x, const float* weight, const float* y, const float* grad_y,
+                         float* grad_x, float* grad_weight, float* grad_bias, float* grad_pre_scratch,
+                         int64_t rows, int in_dim, int out_dim, int act, hypad_stream_t stream);
+/* One bidirectional LSTM layer at seq_len 1 with h0 = c0 = 0 (models/tadgan.py:15-20,35-37 as driven by
+ * :24-25,59-60): out (rows, 2*hidden) = [h_fwd | h_rev].  w_ih_* (4*hidden, in_dim) with
+ * PyTorch gate order [i,f,g,o]; W_hh cannot influence the result and is not read.
+ * gates_save (rows, 2, 4, hidden) receives (i, g, o, tanh(c)) for the backward (may be NULL). */
+int hypad_lstm_bidir_fwd(const float* x, const float* w_ih_f, const float* b_ih_f, const float* b_hh_f,
+                         const float* w_ih_r, const float* b_ih_r, const float* b_hh_r,
+                         float* out, float* gates_save, int64_t rows, int in_dim, int hidden, hypad_stream_t stream);
+/* grad_gates (rows, 2, 4*hidden) pre-activation gradients in PyTorch gate order (f block zero);
+ * grad_x (rows, in_dim); parameter gradients follow as grad_gates^T x (hypad_linear weight rule). */
+int hypad_lstm_bidir_bwd(const float* w_ih_f, const float* w_ih_r, const float* gates_saved, const float* grad_out,
+                         float* grad_gates, float* grad_x, int64_t rows, int in_dim, int hidden, hypad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Networks, forward (eval or train-mode dropout).  `params` = arena of that network.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hypad_dropout {
+  int train_mode;        /* 0: eval (no dropout).  1: dropout active as after .train() */
+  const float* masks;    /* optional injected masks holding 0 or 1/(1-p); layout stated per function */
+  uint64_t seed;         /* used when train_mode && !masks: device Philox4x32-10 */
+  uint64_t offset;       /* Philox stream offset (e.g. an iteration counter) */
+} hypad_dropout;
+
+/* Encoder.forward  models/tadgan.py:23-27: x (rows, S) -> (rows, L) */
+int hypad_encoder_fwd(const float* params, const float* x, float* out, int64_t rows, int signal_shape,
+                      int latent_dim, hypad_stream_t stream);
+/* Decoder.forward  models/tadgan.py:58-67: z (rows, L) -> eucl (rows, S) and, if hyperbolic, hyper (rows, S).
+ * dropout mask layout: (rows, 128) inter-layer LSTM mask (p = 0.2). */
+int hypad_decoder_fwd(const float* params, const float* z, float* hyper_out, float* eucl_out, int64_t rows,
+                      int signal_shape, int latent_dim, int hyperbolic, const hypad_dropout* drop, hypad_stream_t stream);
+/* CriticX.forward  models/tadgan.py:91-106: x (rows, S) -> (rows,).  masks: 4 x (rows, L), p = 0.25 */
+int hypad_critic_x_fwd(const float* params, const float* x, float* out, int64_t rows, int signal_shape,
+                       int latent_dim, const hypad_dropout* drop, hypad_stream_t stream);
+/* CriticZ.forward  models/tadgan.py:123-132: z (rows, L) -> (rows,).  masks: 2 x (rows, L), p = 0.2 */
+int hypad_critic_z_fwd(const float* params, const float* z, float* out, int64_t rows, int latent_dim,
+                       const hypad_dropout* drop, hypad_stream_t stream);
+/* test_tadgan batch body  anomaly_detection.py:67-113 (eval mode), fused: for every window row
+ *   lat = Encoder(x); (hyper, eucl) = Decoder(lat); hyper_real = hyperbolic_linear(x); critic = CriticX(x);
+ *   rowdist = poincare distance(hyper_real, hyper)  (utils/anomaly_detection_utils.py:58-66).
+ * Any output pointer may be NULL (that output is then not written).  Euclidean mode: recon = eucl only. */
+int hypad_score_forward(const float* enc, const float* dec, const float* cx, const float* x,
+                        float* hyper, float* eucl, float* hyper_real, float* critic, float* rowdist,
+                        int64_t rows, int signal_shape, int latent_dim, int hyperbolic, hypad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training iterations (train.py:18-104, :107-186, :189-249) with the optimizer step fused in
+ * (torch.optim.Adam train.py:274-281; geoopt RiemannianAdam train.py:282-288).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hypad_dims {
+  int signal_shape;  /* params.signal_shape */
+  int latent_dim;    /* params.latent_space_dim (train.py:413) */
+  int batch;         /* params.batch_size; multiple of 16 */
+  int hyperbolic;    /* params.hyperbolic */
+  int n_signals;     /* independent models trained side by side (one per signal); >= 1 */
+} hypad_dims;
+
+typedef struct hypad_nets { float *enc, *dec, *cx, *cz; } hypad_nets;
+
+typedef struct hypad_train_state {
+  hypad_nets params;       /* signal s of a net at base + s * hypad_param_count(net) */
+  hypad_nets exp_avg;      /* Adam first moment, same layout */
+  hypad_nets exp_avg_sq;   /* Adam second moment */
+  int32_t* counters;       /* device int32[4]: optimizer steps taken by {critic_x, critic_z, generator}, rng ticks */
+  float lr, beta1, beta2, eps;
+  float gen_weight_decay;  /* hyperbolic generator optimizer: 1e-5 (train.py:286); ignored otherwise */
+  int gen_stabilize;       /* 10 (train.py:287) */
+} hypad_train_state;
+
+typedef struct hypad_iter_io {
+  const float* x;            /* window matrix resident in HBM: (n_signals, n_windows, S) fp32 */
+  int64_t x_signal_stride;   /* floats between signals */
+  const int32_t* row_index;  /* (batch) rows of x forming this minibatch (shared by all signals); NULL = 0..batch-1 */
+  const float* z;            /* injected N(0,1) latent draw (n_signals, batch, L) or NULL = device Philox (train.py:24,118,205) */
+  const float* alpha;        /* injected U(0,1) interpolation weights (n_signals, batch, S or L) or NULL (train.py:64,149) */
+  hypad_dropout drop;        /* masks layout per signal:  critic_x_iteration: valid 4x(B,L) | fake 4x(B,L) | interpolated 4x(B,L) | decoder (B,128)
+                                                          critic_z_iteration: fake 2x(B,L) | valid 2x(B,L) | interpolated 2x(B,L)
+                                                          decoder_iteration : critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128) */
+  float* losses;             /* device out (n_signals, 4): [loss, aux (hyper_loss or mse), mean critic term a, mean critic term b] */
+  void* workspace;
+  size_t workspace_bytes;    /* >= hypad_train_workspace_bytes(dims) */
+} hypad_iter_io;
+
+size_t hypad_train_workspace_bytes(const hypad_dims* dims);
+int hypad_critic_x_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);
+int hypad_critic_z_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);
+int hypad_decoder_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);
+
+/* One epoch of train_tadgan's loops (train.py:299-356): n_critics passes of (critic_x, critic_z) over every
+ * minibatch, then one generator pass.  row_index: ((n_critics + 1), n_batches * batch) int32 window rows (the
+ * DataLoader's shuffles); noise and dropout come from device Philox (seed).  losses: (n_signals,
+ * (2 * n_critics + 1) * n_batches, 4) in launch order. */
+typedef struct hypad_epoch_io {
+  const float* x; int64_t x_signal_stride;
+  const int32_t* row_index;
+  int n_batches, n_critics;
+  int train_mode; uint64_t seed;
+  float* losses;
+  void* workspace; size_t workspace_bytes;
+} hypad_epoch_io;
+int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
+
+/* Stand-alone optimizer steps over a flat arena given its gradient arena.
+ * torch.optim.Adam (train.py:274-281): step_index = 1-based step number. */
+int hypad_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    int step_index, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    hypad_stream_t stream);
+/* geoopt.optim.RiemannianAdam (train.py:282-288; geoopt==0.5.0, restated -- see oracle/radam.py):
+ * Euclidean rule on [0, n) except the ball-valued vector [ball_offset, ball_offset + ball_dim) (ball_dim = 0: none). */
+int hypad_radam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     int64_t ball_offset, int ball_dim, int step_index, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int stabilize, hypad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Window scoring (utils/anomaly_detection_utils.py).  fp64 where NumPy computes in fp64.
+ * ---------------------------------------------------------------------------------------------- */
+/* reconstruction_errors un-roll, :918-935: for t in [0, n + S - 1) gather y_hat[t - j, j] over valid j;
+ * median (T,) in the input precision (np.median of float32) and, if summary != NULL, (T, 5) fp64
+ * [min, p25, p50, p75, max] with NumPy's linear-interpolated percentiles. */
+int hypad_unroll_median(const float* y_hat, float* median, double* summary, int64_t n, int window, hypad_stream_t stream);
+/* :908-910 -- true[t] = y[t][0] (t < n), y[n-1][t-n+1] otherwise; y (n, S) fp64 */
+int hypad_unroll_true(const double* y, double* out, int64_t n, int window, hypad_stream_t stream);
+/* _point_wise_error :761-777 */
+int hypad_point_error(const double* y, const float* y_hat, double* out, int64_t t, hypad_stream_t stream);
+/* _area_error :780-812 (centred rolling trapezoid, window score_window, min_periods score_window/2) */
+int hypad_area_error(const double* y, const float* y_hat, double* out, int64_t t, int score_window, hypad_stream_t stream);
+/* _dtw_error :815-863 (pyts.metrics.dtw classic, squared cost, sqrt of the accumulated cost) */
+int hypad_dtw_error(const double* y, const float* y_hat, double* out, int64_t t, int score_window, hypad_stream_t stream);
+/* pandas rolling(window, center=True, min_periods=window/2).mean()  :953-961, :325-330 */
+int hypad_rolling_mean(const double* in, double* out, int64_t t, int window, hypad_stream_t stream);
+/* stats.zscore -> clip(min=0) + 1  :523-524,542-543.  workspace: 4 doubles */
+int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
+/* np.linalg.norm(recons, axis=1)  :341,347,350,359 */
+int hypad_row_norms(const float* x, double* out, int64_t rows, int dim, hypad_stream_t stream);
+/* combine_scores :336-362 */
+enum { HYPAD_COMB_SUM = 0, HYPAD_COMB_MULT = 1, HYPAD_COMB_UNCERTAINTY = 2, HYPAD_COMB_CRITIC = 3,
+       HYPAD_COMB_CRITIC_UNCERTAINTY = 4, HYPAD_COMB_SUM_UNCERTAINTY = 5, HYPAD_COMB_REC = 6,
+       HYPAD_COMB_REC_UNCERTAINTY = 7,
+       /* score_anomalies tail :553-570 */
+       HYPAD_COMB_EUCL_MULT = 8, HYPAD_COMB_EUCL_SUM = 9 };
+int hypad_combine_scores(int combination, const double* critic_scores, const double* rec_scores,
+                         const double* uncertainty, double* out, int64_t n, hypad_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPAD_H_ */

@@ -1,0 +1,104 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol include/hypad.h declares; the
+parameter catalogue matches the reference's state_dict; host-side module plumbing (no compute calls)."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, sub_state
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hypad_amd import build
+    return ctypes.CDLL(build.build())
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "hypad.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(hypad_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 45
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hypad.h but not exported"
+    from hypad_amd import _C
+    assert set(_C.EXPORTS) == declared
+
+
+def test_abi_version_limits_and_errors(lib):
+    assert lib.hypad_abi_version() == 1
+    a, b = ctypes.c_int(), ctypes.c_int()
+    lib.hypad_limits(ctypes.byref(a), ctypes.byref(b))
+    assert a.value >= 150 and b.value >= 20
+    lib.hypad_error_string.restype = ctypes.c_char_p
+    assert lib.hypad_error_string(0) == b"ok" and b"workspace" in lib.hypad_error_string(-2)
+
+
+@pytest.mark.parametrize("S", [100, 150, 123, 51])
+def test_parameter_catalogue_matches_reference_state_dict(S):
+    from hypad_amd import _C
+    from oracle import tadgan as ot
+    mods = {_C.NET_ENCODER: ot.Encoder(S, 20), _C.NET_DECODER: ot.Decoder(S, 20, True), _C.NET_CRITIC_X: ot.CriticX(S, 20),
+            _C.NET_CRITIC_Z: ot.CriticZ(20)}
+    for net, m in mods.items():
+        cat, total = _C.param_catalogue(net, S, 20, True)
+        sd = m.state_dict()
+        assert [c[0] for c in cat] == list(sd.keys())
+        end = 0
+        for name, off, shape in cat:
+            assert tuple(sd[name].shape) == tuple(shape), name
+            assert off % 4 == 0 and off >= end          # 16-byte aligned, non-overlapping
+            end = off + int(np.prod(shape))
+        assert total >= end and total % 4 == 0
+    cat_e, _ = _C.param_catalogue(_C.NET_DECODER, S, 20, False)
+    assert not any("hyperbolic" in c[0] for c in cat_e)
+
+
+def test_modules_mirror_reference_surface():
+    from hypad_amd.models import tadgan
+    fx = load("fwd_S100_B64.npz")
+    enc, dec = tadgan.Encoder(100, 20), tadgan.Decoder(100, 20, True)
+    cx, cz = tadgan.CriticX(100, 20), tadgan.CriticZ(20)
+    for m, p in ((enc, "enc"), (dec, "dec"), (cx, "cx"), (cz, "cz")):
+        sd = sub_state(fx, p)
+        m.load_state_dict(sd)
+        assert m._glued()
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+        # the flat arena really backs the parameters
+        name, off, shape = m._catalogue[0]
+        assert torch.equal(m._arena[off:off + int(np.prod(shape))].view(shape), sd[name])
+        buf = io.BytesIO()
+        torch.save(m, buf)                      # the reference checkpoints whole modules (train.py:381-385)
+        buf.seek(0)
+        m2 = torch.load(buf, weights_only=False)
+        assert m2._glued() and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert dec.hyperbolic and hasattr(dec, "hyperbolic_linear") and getattr(dec.hyperbolic_linear.bias, "manifold", None) is not None
+    assert not hasattr(tadgan.Decoder(100, 20, False), "hyperbolic_linear")
+    # same seed -> same initial weights as the reference construction order (models/tadgan.py, hyrnn_nets.py:155-184)
+    from oracle import tadgan as ot
+    torch.manual_seed(3)
+    a = tadgan.Decoder(100, 20, True)
+    torch.manual_seed(3)
+    b = ot.Decoder(100, 20, True)
+    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+
+
+def test_product_path_has_no_cpu_fallback():
+    from hypad_amd import _C
+    from hypad_amd.models import tadgan
+    enc = tadgan.Encoder(100, 20)
+    with pytest.raises(_C.HypadError):
+        enc(torch.zeros(4, 100))
+    import subprocess
+    import sys
+    # nothing under hypad_amd/ may import the oracle
+    out = subprocess.run(["grep", "-rl", "--include=*.py", "-E", r"^\s*(from|import) oracle", os.path.join(ROOT, "hypad_amd")],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", out
