@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the HypAD / TadGAN training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): one univariate signal per GPU, hyperbolic=True, batch 64, window 100,
+1 916 synthetic windows (sine + noise + one jump) resident in HBM as fp32.  One *step* = one
+training epoch of train.py:299-356 over those windows: 5 passes of (critic_x_iteration, critic_z_iteration) and one
+pass of decoder_iteration over the 29 minibatches = 319 optimizer steps, train-mode dropout and all noise drawn on
+the device.  Metric: epoch-windows/s = n_gpus * signals_per_gpu * 29 * 64 * steps / wall time.
+With N GPUs every rank trains its own signal(s) (one model per signal, no collective on the data path): weak scaling.
+
+The JSON line also carries
+  roofline     -- the kernel holding the largest share of the epoch, its algorithmic FLOPs per launch over its mean
+                  duration measured with HIP events on the launch stream (hypad_profile_iteration);
+  cpu_baseline -- the CPU oracle (oracle/train_iters.py: the reference's nn.LSTM / autograd / Adam structure)
+                  timed on this node's host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+S, L, B, N_WINDOWS = 100, 20, 64, 1916
+N_BATCHES = N_WINDOWS // B          # 29 (drop_last, main.py:38)
+N_CRITICS = 5                       # train.py:301
+
+# Algorithmic MACs per window, SURVEY.md §8(d) accounting (1 MAC = 2 FLOP), split by the kernel that does the work.
+F_ENC = 2 * (4 * 50) * S + 100 * L                                  # 42 000
+F_DEC = L * 50 + 2 * 256 * 50 + 2 * 256 * 128 + 128 * S             # 104 936
+F_CX = L * S + 3 * L * L + L                                        # 3 220
+F_CZ = 2 * L * L + L                                                # 820
+MAC_PER_WINDOW = {                                                  # hyperbolic=True
+    "cx_pass": F_DEC + S * S + 6 * F_CX,                            # decoder fwd + 3 critic fwd + 3 backward-data chains
+    "cz_pass": F_ENC + 6 * F_CZ,
+    "gp_x": F_CX, "gp_z": F_CZ,                                     # second-order chain
+    "dw_cx": 3 * F_CX, "dw_cz": 3 * F_CZ,
+    "gen": 2 * F_ENC + 4 * (F_DEC + S * S) + S * S + 2 * F_CX + 2 * F_CZ,   # fwd + backward-data of decoder_iteration
+    "dw_gen": F_ENC + 2 * (F_DEC + S * S) + S * S,                          # its weight-gradient third
+}
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
+
+
+def synth_windows(n, s, seed):
+    """SURVEY.md §8d synthetic stand-in for art_daily_jumpsup @interval 600."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n + s - 1)
+    period = 288.0 if seed == 0 else rng.uniform(200, 400)
+    series = np.sin(2 * np.pi * (t + rng.uniform(0, period) * (seed != 0)) / period) + 0.05 * rng.standard_normal(len(t))
+    series[n // 2: n // 2 + 40] += 0.8
+    series = np.clip(series, -1, 1)
+    return series[np.arange(n)[:, None] + np.arange(s)[None, :]]
+
+
+def build_engine(spg, rank, hyperbolic, device):
+    from hypad_amd.engine import Engine
+    from hypad_amd.models import tadgan
+    eng = Engine(S, L, B, hyperbolic, n_signals=spg, device=device, lr=5e-4, seed=1234 + rank)
+    xs = []
+    for s in range(spg):
+        sid = rank * spg + s
+        torch.manual_seed(sid)      # random-init weights of the reference architecture (train.py:415-426 order)
+        mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyperbolic), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
+        for k, m in mods.items():
+            eng.load_state_dict(k, m.state_dict(), s)
+        xs.append(synth_windows(N_WINDOWS, S, sid))
+    x = torch.from_numpy(np.stack(xs)).to(device, torch.float32).contiguous()
+    return eng, x
+
+
+def cpu_baseline(hyperbolic, budget_s=24.0):
+    """The oracle's epoch (same iteration mix) on a bounded number of minibatches, at 1 thread and at all cores."""
+    from types import SimpleNamespace
+    from oracle import tadgan as ot
+    from oracle import train_iters as oi
+    P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=hyperbolic)
+    data = torch.from_numpy(synth_windows(4 * B, S, 0)[:, :, None])
+    ncores = os.cpu_count() or 1
+    best = None
+    for threads in sorted({1, ncores}):
+        torch.set_num_threads(threads)
+        enc, dec, cx, cz = ot.build_models(S, L, hyperbolic, seed=0)
+        opt = oi.make_optimizers(enc, dec, cx, cz, P)
+        np.random.seed(0)
+        batches = [data[i * B:(i + 1) * B] for i in range(4)]
+        oi.train_epoch(batches[:1], enc, dec, cx, cz, opt, P)                  # warm-up: one minibatch's 11 iterations
+        t0 = time.perf_counter()
+        nb = 0
+        while nb < 2 or (time.perf_counter() - t0 < budget_s / 2 and nb < 4096):
+            oi.train_epoch(batches[nb % 4: nb % 4 + 1], enc, dec, cx, cz, opt, P)
+            nb += 1
+        dt = time.perf_counter() - t0
+        rate = nb * B / dt
+        if best is None or rate > best["value"]:
+            best = dict(value=rate, cores=threads, sample=f"{nb} minibatches x (5 critic_x + 5 critic_z + 1 decoder) iterations, "
+                                                               f"B={B}, window={S}, train-mode dropout, {dt:.1f} s")
+    torch.set_num_threads(ncores)
+    best.update(unit="windows/s", kind="port", host_cores=ncores)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--signals-per-gpu", type=int, default=1, help="independent signals (models) trained side by side on each GPU")
+    ap.add_argument("--euclidean", action="store_true", help="configs[0]-style hyperbolic=False instead of configs[1]")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a launcher with WORLD_SIZE={args.gpus} (torch.distributed.run)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    hyperbolic = not args.euclidean
+    spg = args.signals_per_gpu
+    eng, x = build_engine(spg, rank, hyperbolic, device)
+    gen = torch.Generator(device=device).manual_seed(100 + rank)
+    losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
+
+    def step():
+        # the DataLoader's shuffles: a fresh permutation for each of the 5 critic passes and the generator pass
+        perm = torch.stack([torch.randperm(N_WINDOWS, device=device, generator=gen)[: N_BATCHES * B] for _ in range(N_CRITICS + 1)])
+        eng.train_epoch(x, perm.to(torch.int32).contiguous(), N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    last = losses.float().mean(dim=(0, 1)).cpu().tolist()
+    assert all(np.isfinite(last)), "training diverged"
+
+    # ---- per-kernel durations, HIP events on the launch stream (same workload, after the timed region)
+    names = {0: ["cx_pass", "gp_x", "dw_cx"], 1: ["cz_pass", "gp_z", "dw_cz"], 2: ["gen", "dw_gen"]}
+    acc = {n: [] for v in names.values() for n in v}
+    idx = torch.arange(B, device=device, dtype=torch.int32)
+    for rep in range(60):
+        for kind in (0, 1, 2):
+            ms = eng.profile_iteration(kind, x, idx, train_mode=True)
+            if rep >= 10:
+                for n, v in zip(names[kind], ms):
+                    acc[n].append(v)
+    kern_ms = {n: float(np.mean(v)) for n, v in acc.items()}
+    launches = {n: (N_BATCHES if n in ("gen", "dw_gen") else N_CRITICS * N_BATCHES) for n in kern_ms}
+    share = {n: kern_ms[n] * launches[n] for n in kern_ms}
+    dom = max(share, key=share.get)
+    flop = 2.0 * MAC_PER_WINDOW[dom] * B * spg
+    achieved = flop / (kern_ms[dom] * 1e-3) / 1e12
+
+    if rank == 0:
+        windows = world * spg * N_BATCHES * B * args.steps
+        out = {
+            "metric": "training windows/sec (seq_len=100)",
+            "value": windows / elapsed,
+            "unit": "windows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": ("configs[1]: univariate synthetic (sine+noise+jump), hyperbolic=%s, batch=64, window=100, "
+                                    "latent=20, 1916 windows/signal, %d signal(s) per GPU; step = 1 epoch = 29 x "
+                                    "(5 critic_x + 5 critic_z + 1 decoder) iterations") % (hyperbolic, spg),
+                       "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,
+                       "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms, "epoch_share_ms": share, "flop_per_launch": flop},
+            "final_losses": {"loss": last[0], "aux": last[1]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hyperbolic)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

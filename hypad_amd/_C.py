@@ -103,6 +103,7 @@ _SIGS = {
     "hypad_critic_z_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
+    "hypad_profile_iteration": (c_int, [c_int, POINTER(Dims), POINTER(TrainState), POINTER(IterIO), POINTER(c_float), c_int, P]),
     "hypad_adam_step": (c_int, [P, P, P, P, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, P]),
     "hypad_radam_step": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P]),
     "hypad_unroll_median": (c_int, [P, P, P, c_int64, c_int, P]),

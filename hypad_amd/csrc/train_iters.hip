@@ -839,6 +839,9 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   return HYPAD_OK;
 }
 
+// Optional profiling marks: ev[k] is recorded on the stream after the k-th kernel of an iteration (ev[0] before the first).
+#define HYPAD_MARK(ev, k, s) do { if (ev) (void)hipEventRecord((ev)[k], s); } while (0)
+
 int launch_dw(const IterArgs& a, const DwTable& tab, int n_signals, hipStream_t s) {
   int blocks = (tab.total_items + 3) / 4;
   if (blocks < 1) blocks = 1;
@@ -847,7 +850,7 @@ int launch_dw(const IterArgs& a, const DwTable& tab, int n_signals, hipStream_t 
   return HYPAD_OK;
 }
 
-int run_cx(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+int run_cx(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 0);
   if (rc) return rc;
@@ -858,15 +861,20 @@ int run_cx(const hypad_dims* d, const hypad_train_state* st, const IterCall& io,
   hipError_t e = allow_lds((const void*)cx_pass_kernel, lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(a.B / 16, d->n_signals);
+  HYPAD_MARK(ev, 0, s);
   hipLaunchKernelGGL(cx_pass_kernel, grid, dim3(THREADS), lds, s, a);
   HYPAD_CHECK_LAUNCH();
+  HYPAD_MARK(ev, 1, s);
   size_t lds2 = (size_t)(16 * (pad4(a.S) + 4) + 2 * 16 * LP) * sizeof(float);
   hipLaunchKernelGGL(critic_gp_kernel<true>, grid, dim3(THREADS), lds2, s, a);
   HYPAD_CHECK_LAUNCH();
-  return launch_dw(a, critic_table(HYPAD_NET_CRITIC_X, cx_layout(a.S, a.L), crit_ws(a.B, a.S, a.L, 4), a.B, a.L), d->n_signals, s);
+  HYPAD_MARK(ev, 2, s);
+  rc = launch_dw(a, critic_table(HYPAD_NET_CRITIC_X, cx_layout(a.S, a.L), crit_ws(a.B, a.S, a.L, 4), a.B, a.L), d->n_signals, s);
+  HYPAD_MARK(ev, 3, s);
+  return rc;
 }
 
-int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 1);
   if (rc) return rc;
@@ -877,15 +885,20 @@ int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io,
   hipError_t e = allow_lds((const void*)cz_pass_kernel, lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid(a.B / 16, d->n_signals);
+  HYPAD_MARK(ev, 0, s);
   hipLaunchKernelGGL(cz_pass_kernel, grid, dim3(THREADS), lds, s, a);
   HYPAD_CHECK_LAUNCH();
+  HYPAD_MARK(ev, 1, s);
   size_t lds2 = (size_t)(16 * (pad4(a.L) + 4) + 2 * 16 * LP) * sizeof(float);
   hipLaunchKernelGGL(critic_gp_kernel<false>, grid, dim3(THREADS), lds2, s, a);
   HYPAD_CHECK_LAUNCH();
-  return launch_dw(a, critic_table(HYPAD_NET_CRITIC_Z, cz_layout(a.L), crit_ws(a.B, a.L, a.L, 2), a.B, a.L), d->n_signals, s);
+  HYPAD_MARK(ev, 2, s);
+  rc = launch_dw(a, critic_table(HYPAD_NET_CRITIC_Z, cz_layout(a.L), crit_ws(a.B, a.L, a.L, 2), a.B, a.L), d->n_signals, s);
+  HYPAD_MARK(ev, 3, s);
+  return rc;
 }
 
-int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s) {
+int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
@@ -893,6 +906,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   a.mask_sig_stride = (int64_t)6 * a.B * a.L + (int64_t)2 * a.B * 2 * DEC_H;
   if (a.hyperbolic) { a.riemannian = 1; a.wd = st->gen_weight_decay; a.stabilize = st->gen_stabilize; }
   dim3 grid(a.B / 16, d->n_signals);
+  HYPAD_MARK(ev, 0, s);
   if (a.hyperbolic) {
     size_t lds = (size_t)lds_plan(a.S, 32, 48).total * sizeof(float);
     if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
@@ -906,7 +920,10 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
     hipLaunchKernelGGL(gen_kernel<false>, grid, dim3(THREADS), lds, s, a);
   }
   HYPAD_CHECK_LAUNCH();
-  return launch_dw(a, gen_table(*d), d->n_signals, s);
+  HYPAD_MARK(ev, 1, s);
+  rc = launch_dw(a, gen_table(*d), d->n_signals, s);
+  HYPAD_MARK(ev, 2, s);
+  return rc;
 }
 
 IterCall from_io(const hypad_iter_io* io) {
@@ -957,6 +974,33 @@ int hypad_critic_z_iteration(const hypad_dims* d, const hypad_train_state* st, c
 int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
   if (!io) return HYPAD_EINVAL;
   return run_gen(d, st, from_io(io), (hipStream_t)s);
+}
+
+// Profiling aid for bench.py: runs ONE iteration with HIP events between its kernels on `stream`, synchronises the
+// stream and returns each kernel's duration in milliseconds (critic iterations: pass, gp, dw_adam; generator: gen,
+// dw_adam).  Not capturable (creates events, synchronises).
+int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, float* ms_out,
+                            int n_out, hypad_stream_t s) {
+  if (!io || !ms_out || kind < 0 || kind > 2) return HYPAD_EINVAL;
+  const int nk = kind == 2 ? 2 : 3;
+  if (n_out < nk) return HYPAD_EINVAL;
+  hipEvent_t ev[4];
+  for (int i = 0; i <= nk; ++i) {
+    hipError_t e = hipEventCreate(&ev[i]);
+    if (e != hipSuccess) return (int)e;
+  }
+  int rc = kind == 0 ? run_cx(d, st, from_io(io), (hipStream_t)s, ev) : kind == 1 ? run_cz(d, st, from_io(io), (hipStream_t)s, ev)
+                                                                                    : run_gen(d, st, from_io(io), (hipStream_t)s, ev);
+  if (rc == HYPAD_OK) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)s);
+    if (e != hipSuccess) rc = (int)e;
+  }
+  for (int i = 0; i < nk && rc == HYPAD_OK; ++i) {
+    hipError_t e = hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+    if (e != hipSuccess) rc = (int)e;
+  }
+  for (int i = 0; i <= nk; ++i) (void)hipEventDestroy(ev[i]);
+  return rc;
 }
 
 int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t s) {

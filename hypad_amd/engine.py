@@ -102,6 +102,19 @@ class Engine:
     def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None):
         return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks)
 
+    def profile_iteration(self, kind, x, row_index=None, train_mode=True):
+        """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder), HIP events on the current stream."""
+        x, stride = self._check_x(x)
+        losses = torch.empty(self.n, 4, dtype=torch.float32, device=self.device)
+        drop = _C.Dropout(int(train_mode), None, self.seed, 0)
+        io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(), None, None, drop,
+                       losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
+        st = self._state()
+        out = (ctypes.c_float * 3)()
+        _C.check(_C.lib.hypad_profile_iteration(int(kind), ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), out, 3,
+                                                _C.stream()), "profile_iteration")
+        return list(out)[: 2 if kind == 2 else 3]
+
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device."""
         x, stride = self._check_x(x)

@@ -210,6 +210,13 @@ typedef struct hypad_epoch_io {
 } hypad_epoch_io;
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
+/* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder) with HIP events
+ * recorded on `stream` between its kernels, synchronise, and return the per-kernel durations in ms:
+ * critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam}; decoder -> {generator kernel, dW+Adam}.
+ * Not capturable into a graph. */
+int hypad_profile_iteration(int kind, const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io,
+                            float* ms_out, int n_out, hypad_stream_t stream);
+
 /* Stand-alone optimizer steps over a flat arena given its gradient arena.
  * torch.optim.Adam (train.py:274-281): step_index = 1-based step number. */
 int hypad_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
