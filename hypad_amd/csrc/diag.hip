@@ -1,0 +1,297 @@
+// Diagnostic build of the decoder forward with per-phase clock stamps (development aid, not on the product path):
+// answers "where does a 16-row tile spend its time" -- shader cycles (s_memtime) and 100 MHz wall ticks per phase.
+#include <hip/hip_runtime.h>
+
+#include "../../include/hypad.h"
+#include "nets.h"
+
+using namespace hypad;
+
+namespace {
+
+__device__ __forceinline__ void stamp(long long* out, int& k) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * k] = (long long)__builtin_amdgcn_s_memtime();
+    out[2 * k + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+  ++k;
+}
+
+template <int MT>
+__global__ void diag_decoder_kernel(const float* __restrict__ P, const float* __restrict__ z, float* __restrict__ hyper,
+                                    int64_t rows, int S, int L, long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = MT * 16;
+  const int ldS = pad4(S) + 4;
+  const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
+  float* zs = smem;
+  float* bufA = zs + R * LP;
+  float* bufB = bufA + R * per_row;
+  float* wst = bufB + R * per_row;
+  const DecLayout dl = dec_layout(S, L, 1);
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int valid = (int)min((int64_t)R, rows - r0);
+  long long* st = stamps + (size_t)blockIdx.x * 64;
+  int k = 0;
+  constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
+  for (int rep = 0; rep < 2; ++rep) {
+  stamp(st, k);                                                                                         // 0 start
+  tile_load(zs, LP, z + r0 * L, L, R, L, valid);
+  stamp(st, k);                                                                                         // 1 z loaded
+  gemm_nt<MT>(zs, LP, P + dl.d1_w, L, L, DEC_D1, identity_map(), P + dl.d1_b, nullptr, bufB, ldA0, 0, wst);
+  stamp(st, k);                                                                                         // 2 dense1
+  lstm_gates_tile<MT>(bufB, ldA0, DEC_D1, P, dl.l[0][0], dl.l[0][1], DEC_H, bufA, ldG, wst);
+  stamp(st, k);                                                                                         // 3 l0 gates (K=50 scalar path)
+  lstm_cell_tile(bufA, ldG, DEC_H, R, bufB, ldH, nullptr, valid, 16);
+  stamp(st, k);                                                                                         // 4 l0 cell
+  lstm_gates_tile<MT>(bufB, ldH, 2 * DEC_H, P, dl.l[1][0], dl.l[1][1], DEC_H, bufA, ldG, wst);
+  stamp(st, k);                                                                                         // 5 l1 gates (K=128 vec)
+  lstm_cell_tile(bufA, ldG, DEC_H, R, bufB, ldH, nullptr, valid, 16);
+  stamp(st, k);                                                                                         // 6 l1 cell
+  gemm_nt<MT>(bufB, ldH, P + dl.d2_w, 2 * DEC_H, 2 * DEC_H, S, identity_map(), P + dl.d2_b, nullptr, bufA, ldS, 0, wst);
+  stamp(st, k);                                                                                         // 7 dense2
+  tile_for(R, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
+  stamp(st, k);                                                                                         // 8 tanh
+  gemm_nt<MT>(bufA, ldS, P + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
+  stamp(st, k);                                                                                         // 9 head gemm
+  head_rows_tile(bufB, ldS, R, S, P + dl.head_b);
+  stamp(st, k);                                                                                         // 10 head rows
+  tile_store(hyper + r0 * S, S, bufB, ldS, R, S, valid);
+  stamp(st, k);                                                                                         // 11 store
+  }
+}
+
+}  // namespace
+
+extern "C" int hypad_diag_decoder_timeline(const float* P, const float* z, float* hyper, int64_t rows, int S, int L, int mt,
+                                           int threads, long long* stamps, hypad_stream_t s) {
+  const int R = mt * 16;
+  const int ldS = pad4(S) + 4;
+  const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
+  size_t lds = (size_t)(R * LP + 2 * R * per_row + 16 * WSTAGE_FLOATS) * sizeof(float);
+  int blocks = (int)((rows + R - 1) / R);
+  if (mt == 1) {
+    (void)hipFuncSetAttribute((const void*)diag_decoder_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(diag_decoder_kernel<1>, dim3(blocks), dim3(threads), lds, (hipStream_t)s, P, z, hyper, rows, S, L, stamps);
+  } else {
+    (void)hipFuncSetAttribute((const void*)diag_decoder_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(diag_decoder_kernel<2>, dim3(blocks), dim3(threads), lds, (hipStream_t)s, P, z, hyper, rows, S, L, stamps);
+  }
+  return (int)hipGetLastError();
+}
+
+// ---- MFMA issue-rate microbenchmark: cycles per instruction for dependent / independent accumulator chains
+namespace {
+template <int NACC>
+__global__ void diag_mfma_kernel(long long* out, float seed) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{seed, 0.f, 0.f, 0.f};
+  float a = seed + threadIdx.x, b = seed * 0.5f;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < 256; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0];
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (long long)s; }
+}
+__global__ void diag_mfma32_kernel(long long* out, float seed) {
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  f32x16 acc[2];
+  for (int i = 0; i < 2; ++i) for (int k = 0; k < 16; ++k) acc[i][k] = seed;
+  float a = seed + threadIdx.x, b = seed * 0.5f;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < 256; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (long long)(acc[0][0] + acc[1][0]); }
+}
+}  // namespace
+extern "C" int hypad_diag_mfma(int variant, int threads, long long* out, hypad_stream_t s) {
+  if (variant == 1) hipLaunchKernelGGL(diag_mfma_kernel<1>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
+  else if (variant == 2) hipLaunchKernelGGL(diag_mfma_kernel<2>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
+  else if (variant == 4) hipLaunchKernelGGL(diag_mfma_kernel<4>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
+  else hipLaunchKernelGGL(diag_mfma32_kernel, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
+  return (int)hipGetLastError();
+}
+
+// ---- weight-tile load latency: the exact access pattern of nt_tile (16 rows x 8 float4 per lane), timed per tile
+namespace {
+__global__ void diag_load_kernel(const float* __restrict__ W, int ldw, int ntiles, int mode, long long* out, float* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  float acc = 0.f;
+  for (int rep = 0; rep < 2; ++rep)
+    for (int t = 0; t < ntiles; ++t) {
+      const float* wp = W + (size_t)((wave * ntiles + t) * 16 + j) * ldw;
+      long long t0 = __builtin_amdgcn_s_memtime();
+      if (mode == 0) {
+        float4 b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(wp + 16 * u + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += b[u].x + b[u].y + b[u].z + b[u].w;
+      } else {   // one row per lane-quad, fully contiguous 1 KiB per instruction
+        float4 b[8];
+        const float* cp = W + (size_t)(wave * ntiles + t) * 16 * ldw;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(cp + u * 256 + lane * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += b[u].x + b[u].y + b[u].z + b[u].w;
+      }
+      asm volatile("" :: "v"(acc));
+      long long t1 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) out[(rep * 16 + wave) * 32 + t] = t1 - t0;
+    }
+  if (acc == 123.456f) sink[0] = acc;
+}
+}  // namespace
+extern "C" int hypad_diag_load(const float* W, int ldw, int ntiles, int mode, int threads, long long* out, float* sink, hypad_stream_t s) {
+  hipLaunchKernelGGL(diag_load_kernel, dim3(1), dim3(threads), 0, (hipStream_t)s, W, ldw, ntiles, mode, out, sink);
+  return (int)hipGetLastError();
+}
+
+// ---- gemm_nt / gemm_nn scaling probe: cycles for one call as a function of (K, N, MT, threads)
+namespace {
+template <int MT, int KIND>
+__global__ void diag_gemm_kernel(const float* __restrict__ W, int K, int N, long long* out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = pad4(K > N ? K : N) + 4;
+  float* xs = smem;
+  float* ys = xs + MT * 16 * ldx;
+  float* wst = ys + MT * 16 * ldx;
+  for (int i = threadIdx.x; i < MT * 16 * ldx; i += blockDim.x) xs[i] = 0.001f * (i % 97);
+  __syncthreads();
+  long long t[5];
+  for (int rep = 0; rep < 4; ++rep) {
+    __syncthreads();
+    t[rep] = __builtin_amdgcn_s_memtime();
+    if (KIND == 0) gemm_nt<MT>(xs, ldx, W, K, K, N, identity_map(), nullptr, nullptr, ys, ldx, 0, wst);
+    else gemm_nn<MT>(xs, ldx, 0, W, K, N, identity_map(), K, ys, ldx, false);
+    __syncthreads();
+  }
+  t[4] = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out[0] = t[1] - t[0]; out[1] = t[4] - t[3]; out[2] = (long long)ys[0]; }
+}
+}  // namespace
+extern "C" int hypad_diag_gemm(const float* W, int K, int N, int mt, int kind, int threads, long long* out, hypad_stream_t s) {
+  const int ldx = pad4(K > N ? K : N) + 4;
+  size_t lds = (size_t)(2 * mt * 16 * ldx + 16 * WSTAGE_FLOATS) * sizeof(float);
+#define LAUNCH(MT, KIND)                                                                                              \
+  (void)hipFuncSetAttribute((const void*)diag_gemm_kernel<MT, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+  hipLaunchKernelGGL((diag_gemm_kernel<MT, KIND>), dim3(1), dim3(threads), lds, (hipStream_t)s, W, K, N, out)
+  if (mt == 1 && kind == 0) { LAUNCH(1, 0); } else if (mt == 2 && kind == 0) { LAUNCH(2, 0); }
+  else if (mt == 1) { LAUNCH(1, 1); } else { LAUNCH(2, 1); }
+  return (int)hipGetLastError();
+}
+
+// ---- ablation of one 16x128 weight tile (1 tile per wave): which part of the per-tile chain costs the time?
+namespace {
+template <int MODE>
+__global__ void diag_tile_kernel(const float* __restrict__ W, long long* out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  constexpr int K = 128, ldx = 132;
+  float* xs = smem;
+  float* stage = xs + 16 * ldx + (threadIdx.x >> 6) * WSTAGE_FLOATS;
+  for (int i = threadIdx.x; i < 16 * ldx; i += blockDim.x) xs[i] = 0.001f * (i % 97);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const float* wp = W + (size_t)(wave * 16 + j) * K;
+  long long t0 = 0, t1 = 0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int rep = 0; rep < 3; ++rep) {
+    __syncthreads();
+    t0 = __builtin_amdgcn_s_memtime();
+    if (MODE == 0) {                       // MFMA only, operands in registers
+      float a = xs[lane], b = xs[lane + 64];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc2, 0, 0, 0);
+      }
+    } else if (MODE == 1) {                // direct fragment loads (8 x float4), A from LDS, no select
+      float4 b[8], a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { b[u] = *reinterpret_cast<const float4*>(wp + 16 * u + 4 * q); a[u] = *reinterpret_cast<const float4*>(xs + j * ldx + 16 * u + 4 * q); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc2, 0, 0, 0);
+      }
+    } else if (MODE == 2) {                // only the 8 direct loads + a dependent add (no MFMA)
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = *reinterpret_cast<const float4*>(wp + 16 * u + 4 * q);
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += b[u].x + b[u].y + b[u].z + b[u].w;
+      acc[0] += s;
+    } else if (MODE == 3) {                // A reads from LDS + MFMA, B constant
+      float4 a[8];
+      float b = xs[lane];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4*>(xs + j * ldx + 16 * u + 4 * q);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b, acc2, 0, 0, 0);
+      }
+    } else {                               // MODE 4: contiguous loads (8 rows x 128 B) -> LDS slab -> fragments -> MFMA
+      const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+      float4 w[4][2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w[s][i] = *reinterpret_cast<const float4*>(W + (size_t)(wave * 16 + lrow + 8 * i) * K + 32 * s + lcol);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(stage + (lrow + 8 * i) * WSTAGE_LD + lcol) = w[s][i];
+        float4 b[2], a[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { b[u] = *reinterpret_cast<const float4*>(stage + j * WSTAGE_LD + 16 * u + 4 * q); a[u] = *reinterpret_cast<const float4*>(xs + j * ldx + 32 * s + 16 * u + 4 * q); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc2, 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("" :: "v"(acc[0]), "v"(acc2[0]));
+    t1 = __builtin_amdgcn_s_memtime();
+  }
+  if (lane == 0) out[wave] = t1 - t0;
+  if (acc[0] + acc2[0] == 123.456f) out[63] = 1;
+}
+}  // namespace
+extern "C" int hypad_diag_tile(const float* W, int mode, int threads, long long* out, hypad_stream_t s) {
+  size_t lds = (size_t)(16 * 132 + 16 * WSTAGE_FLOATS) * sizeof(float);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(diag_tile_kernel<0>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
+    case 1: hipLaunchKernelGGL(diag_tile_kernel<1>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
+    case 2: hipLaunchKernelGGL(diag_tile_kernel<2>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
+    case 3: hipLaunchKernelGGL(diag_tile_kernel<3>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
+    default: hipLaunchKernelGGL(diag_tile_kernel<4>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
+  }
+  return (int)hipGetLastError();
+}

@@ -1,6 +1,7 @@
 // Tile-level building blocks of the TadGAN networks: a workgroup carries MT*16 rows through whole layers,
 // activations in LDS, weights streamed from the parameter arena.  Closed forms follow SURVEY.md A.2 and
-// oracle/manual.py (the CPU derivation sheet these functions transcribe).
+// oracle/manual.py (the CPU derivation sheet these functions transcribe).  All loops are written for any
+// workgroup size that is a multiple of 64 (waves over rows, lanes over columns).
 #pragma once
 #include "layout.h"
 #include "rowops.h"
@@ -27,104 +28,85 @@ struct DropSrc {
 __device__ __forceinline__ DropSrc no_drop() { return DropSrc{0, nullptr, 0, 0, 0, 0, 0, 0.f}; }
 
 // ---------------------------------------------------------------------------------------- tile movement
+// Multi-pass tiles: LDS row r belongs to pass r>>4; its global row is (r>>4)*ps + (r&15) (ps = rows between passes;
+// ps = 16 means plain contiguous rows).
+__device__ __forceinline__ int64_t prow(int r, int ps) { return (int64_t)(r >> 4) * ps + (r & 15); }
+
 // global (row stride gld) -> LDS [rows][ld]; rows >= valid are zero-filled
 __device__ __forceinline__ void tile_load(float* __restrict__ dst, int ld, const float* __restrict__ src, int64_t gld,
                                           int rows, int cols, int valid) {
-  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-    int r = i / cols, c = i - r * cols;
-    dst[r * ld + c] = r < valid ? src[(int64_t)r * gld + c] : 0.f;
-  }
+  tile_for(rows, cols, [&](int r, int c) { dst[r * ld + c] = r < valid ? src[(int64_t)r * gld + c] : 0.f; });
 }
 __device__ __forceinline__ void tile_load_rows(float* __restrict__ dst, int ld, const float* __restrict__ base, int64_t gld,
                                                const int32_t* __restrict__ row_index, int row0, int rows, int cols, int valid) {
-  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-    int r = i / cols, c = i - r * cols;
-    float v = 0.f;
-    if (r < valid) {
-      int64_t gr = row_index ? (int64_t)row_index[row0 + r] : (int64_t)(row0 + r);
-      v = base[gr * gld + c];
-    }
-    dst[r * ld + c] = v;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int r = wave; r < rows; r += nw) {
+    const bool ok = r < valid;
+    const int64_t gr = ok ? (row_index ? (int64_t)row_index[row0 + r] : (int64_t)(row0 + r)) : 0;
+    for (int c = lane; c < cols; c += 64) dst[r * ld + c] = ok ? base[gr * gld + c] : 0.f;
   }
 }
 __device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t gld, const float* __restrict__ src, int ld,
                                            int rows, int cols, int valid) {
-  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-    int r = i / cols, c = i - r * cols;
-    if (r < valid) dst[(int64_t)r * gld + c] = src[r * ld + c];
-  }
+  tile_for(rows, cols, [&](int r, int c) { if (r < valid) dst[(int64_t)r * gld + c] = src[r * ld + c]; });
 }
-// Multi-pass tiles: LDS row r belongs to pass r>>4; its global row is (r>>4)*ps + (r&15) (ps = rows between passes;
-// ps = 16 means plain contiguous rows).
-__device__ __forceinline__ int64_t prow(int r, int ps) { return (int64_t)(r >> 4) * ps + (r & 15); }
 __device__ __forceinline__ void tile_store_p(float* __restrict__ dst, int64_t gld, int ps, const float* __restrict__ src, int ld,
                                              int rows, int cols, int valid) {
-  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-    int r = i / cols, c = i - r * cols;
-    if (r < valid) dst[prow(r, ps) * gld + c] = src[r * ld + c];
-  }
+  tile_for(rows, cols, [&](int r, int c) { if (r < valid) dst[prow(r, ps) * gld + c] = src[r * ld + c]; });
 }
 __device__ __forceinline__ void tile_load_p(float* __restrict__ dst, int ld, const float* __restrict__ src, int64_t gld, int ps,
                                             int rows, int cols, int valid) {
-  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-    int r = i / cols, c = i - r * cols;
-    dst[r * ld + c] = r < valid ? src[prow(r, ps) * gld + c] : 0.f;
-  }
+  tile_for(rows, cols, [&](int r, int c) { dst[r * ld + c] = r < valid ? src[prow(r, ps) * gld + c] : 0.f; });
 }
 
 // ---------------------------------------------------------------------------------------- LSTM layer, T = 1
 // Gate pre-activations for both directions into Gs[rows][ldg] as compact [dir][i|g|o] blocks of H columns.
 template <int MT>
 __device__ __forceinline__ void lstm_gates_tile(const float* As, int lda, int K, const float* P, const LstmDir& d0,
-                                                const LstmDir& d1, int H, float* Gs, int ldg) {
-  gemm_nt<MT>(As, lda, P + d0.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d0.b_ih, P + d0.b_hh, Gs, ldg, 0);
-  gemm_nt<MT>(As, lda, P + d1.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d1.b_ih, P + d1.b_hh, Gs, ldg, 3 * H);
+                                                const LstmDir& d1, int H, float* Gs, int ldg, float* wst) {
+  gemm_nt<MT>(As, lda, P + d0.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d0.b_ih, P + d0.b_hh, Gs, ldg, 0, wst);
+  gemm_nt<MT>(As, lda, P + d1.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d1.b_ih, P + d1.b_hh, Gs, ldg, 3 * H, wst);
 }
 // cell: c = sig(i)*tanh(g), h = sig(o)*tanh(c).  Hs[rows][ldh] <- [h_fwd | h_rev].
-// gates_save (global, may be null): row r at gates_save + r*8H, layout [dir][i,g,o,tanh c][H].
+// gates_save (global, may be null): row r at gates_save + prow(r)*8H, layout [dir][i,g,o,tanh c][H].
 __device__ __forceinline__ void lstm_cell_tile(const float* Gs, int ldg, int H, int rows, float* Hs, int ldh,
                                                float* gates_save, int valid, int ps = 16) {
-  const int per = 2 * H;
-  for (int idx = threadIdx.x; idx < rows * per; idx += blockDim.x) {
-    int r = idx / per, c = idx - r * per;
-    int d = c / H, jj = c - d * H;
+  tile_for(rows, 2 * H, [&](int r, int c) {
+    const int d = c >= H ? 1 : 0, jj = c - d * H;
     const float* g = Gs + r * ldg + d * 3 * H;
-    float gi = sigmoidf_(g[jj]), gg = tanhf(g[H + jj]), go = sigmoidf_(g[2 * H + jj]);
-    float tc = tanhf(gi * gg);
+    const float gi = sigmoidf_(g[jj]), gg = tanhf_(g[H + jj]), go = sigmoidf_(g[2 * H + jj]);
+    const float tc = tanhf_(gi * gg);
     Hs[r * ldh + c] = go * tc;
     if (gates_save && r < valid) {
       float* s = gates_save + prow(r, ps) * 8 * H + d * 4 * H + jj;
       s[0] = gi; s[H] = gg; s[2 * H] = go; s[3 * H] = tc;
     }
-  }
+  });
 }
 // backward of the cell: dHs[rows][ldh] -> dGs[rows][ldg] compact [dir][di|dg|do] (oracle/manual.py lstm_dir_bwd)
 __device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, const float* gates_saved, int H, int rows,
                                                    float* dGs, int ldg, int valid, int ps = 16) {
-  const int per = 2 * H;
-  for (int idx = threadIdx.x; idx < rows * per; idx += blockDim.x) {
-    int r = idx / per, c = idx - r * per;
-    int d = c / H, jj = c - d * H;
+  tile_for(rows, 2 * H, [&](int r, int c) {
+    const int d = c >= H ? 1 : 0, jj = c - d * H;
     float di = 0.f, dg = 0.f, dov = 0.f;
     if (r < valid) {
       const float* s = gates_saved + prow(r, ps) * 8 * H + d * 4 * H + jj;
-      float gi = s[0], gg = s[H], go = s[2 * H], tc = s[3 * H];
-      float dh = dHs[r * ldh + c];
+      const float gi = s[0], gg = s[H], go = s[2 * H], tc = s[3 * H];
+      const float dh = dHs[r * ldh + c];
       dov = dh * tc * go * (1.f - go);
-      float dc = dh * go * (1.f - tc * tc);
+      const float dc = dh * go * (1.f - tc * tc);
       di = dc * gg * gi * (1.f - gi);
       dg = dc * gi * (1.f - gg * gg);
     }
     float* o = dGs + r * ldg + d * 3 * H;
     o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
-  }
+  });
 }
 // dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)
 template <int MT>
 __device__ __forceinline__ void lstm_bwd_data_tile(const float* dGs, int ldg, const float* P, const LstmDir& d0,
                                                    const LstmDir& d1, int H, int K, float* dAs, int lda) {
   gemm_nn<MT>(dGs, ldg, 0, P + d0.w_ih, K, 3 * H, lstm_gate_map(H), K, dAs, lda, false);
-  __syncthreads();
   gemm_nn<MT>(dGs, ldg, 3 * H, P + d1.w_ih, K, 3 * H, lstm_gate_map(H), K, dAs, lda, true);
 }
 
@@ -144,22 +126,22 @@ __device__ __forceinline__ CriticLds critic_lds(float* base) {
 }
 
 // forward.  Xs: LDS [16][ldx] input (in_dim columns).  grow0: global batch row of tile row 0 (dropout indexing).
+// P may point at a copy of the critic's arena staged in LDS (flat pointer).
 __device__ __forceinline__ void critic_fwd_tile(const float* Xs, int ldx, const float* P, const CriticLayout& cl, int L,
-                                                const CriticLds& s, const DropSrc& drop, int grow0) {
+                                                const CriticLds& s, const DropSrc& drop, int grow0, float* wst) {
   const float* in = Xs;
   int ldin = ldx, kin = cl.in_dim;
   for (int li = 0; li < cl.nh; ++li) {
     float* a = s.act + li * 16 * LP;
     float* d = s.dm + li * 16 * LP;
-    gemm_nt<1>(in, ldin, P + cl.w[li], kin, kin, L, identity_map(), P + cl.b[li], nullptr, a, LP, 0);
+    gemm_nt<1>(in, ldin, P + cl.w[li], kin, kin, L, identity_map(), P + cl.b[li], nullptr, a, LP, 0, wst);
     __syncthreads();
-    for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
-      int r = i / L, c = i - r * L;
-      float pre = a[r * LP + c];
-      float dd = leaky_slope(pre) * drop.get(li, grow0 + r, c, L);
+    tile_for(16, L, [&](int r, int c) {
+      const float pre = a[r * LP + c];
+      const float dd = leaky_slope(pre) * drop.get(li, grow0 + r, c, L);
       d[r * LP + c] = dd;
       a[r * LP + c] = pre * dd;
-    }
+    });
     __syncthreads();
     in = a; ldin = LP; kin = L;
   }
@@ -183,20 +165,14 @@ __device__ __forceinline__ const float* critic_bwd_chain_tile(const float* dout,
   float* nxt = s.dl + 16 * LP;
   const float* wl = P + cl.w[cl.nh];
   const float* d = s.dm + (cl.nh - 1) * 16 * LP;
-  for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
-    int r = i / L, c = i - r * L;
-    cur[r * LP + c] = dout[r] * wl[c] * d[r * LP + c];
-  }
+  tile_for(16, L, [&](int r, int c) { cur[r * LP + c] = dout[r] * wl[c] * d[r * LP + c]; });
   __syncthreads();
   sink(cl.nh - 1, cur);
   for (int li = cl.nh - 2; li >= 0; --li) {
     gemm_nn<1>(cur, LP, 0, P + cl.w[li + 1], L, L, identity_map(), L, nxt, LP, false);
     __syncthreads();
     const float* dd = s.dm + li * 16 * LP;
-    for (int i = threadIdx.x; i < 16 * L; i += blockDim.x) {
-      int r = i / L, c = i - r * L;
-      nxt[r * LP + c] *= dd[r * LP + c];
-    }
+    tile_for(16, L, [&](int r, int c) { nxt[r * LP + c] *= dd[r * LP + c]; });
     __syncthreads();
     sink(li, nxt);
     float* t = cur; cur = nxt; nxt = t;
@@ -209,13 +185,13 @@ __device__ __forceinline__ const float* critic_bwd_chain_tile(const float* dout,
 // bufH: LDS scratch [16][ldh >= 2*ENC_H].  Optionally saves gates / h for the backward.
 __device__ __forceinline__ void encoder_fwd_tile(const float* Xs, int ldx, int S, int L, const float* P, const EncLayout& el,
                                                  float* bufG, int ldg, float* bufH, int ldh, float* Zs,
-                                                 float* gates_save, float* h_save, int valid) {
-  lstm_gates_tile<1>(Xs, ldx, S, P, el.dir[0], el.dir[1], ENC_H, bufG, ldg);
+                                                 float* gates_save, float* h_save, int valid, float* wst) {
+  lstm_gates_tile<1>(Xs, ldx, S, P, el.dir[0], el.dir[1], ENC_H, bufG, ldg, wst);
   __syncthreads();
   lstm_cell_tile(bufG, ldg, ENC_H, 16, bufH, ldh, gates_save, valid);
   __syncthreads();
   if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
-  gemm_nt<1>(bufH, ldh, P + el.dense_w, 2 * ENC_H, 2 * ENC_H, L, identity_map(), P + el.dense_b, nullptr, Zs, LP, 0);
+  gemm_nt<1>(bufH, ldh, P + el.dense_w, 2 * ENC_H, 2 * ENC_H, L, identity_map(), P + el.dense_b, nullptr, Zs, LP, 0, wst);
   __syncthreads();
 }
 
@@ -234,41 +210,37 @@ struct DecSave {           // global workspace rows for this tile (null = do not
 template <int MT, class RowFn>
 __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, int S, const float* P, const DecLayout& dl,
                                                        float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
-                                                       const DecSave& sv, int valid) {
+                                                       const DecSave& sv, int valid, float* wst) {
   constexpr int rows = MT * 16;
   constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
   // dense1
-  gemm_nt<MT>(Zs, LP, P + dl.d1_w, L, L, DEC_D1, identity_map(), P + dl.d1_b, nullptr, bufB, ldA0, 0);
+  gemm_nt<MT>(Zs, LP, P + dl.d1_w, L, L, DEC_D1, identity_map(), P + dl.d1_b, nullptr, bufB, ldA0, 0, wst);
   __syncthreads();
   if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
   // layer 0
-  lstm_gates_tile<MT>(bufB, ldA0, DEC_D1, P, dl.l[0][0], dl.l[0][1], DEC_H, bufA, ldG);
+  lstm_gates_tile<MT>(bufB, ldA0, DEC_D1, P, dl.l[0][0], dl.l[0][1], DEC_H, bufA, ldG, wst);
   __syncthreads();
   lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g0, valid, sv.ps);
   __syncthreads();
   if (drop.mode != 0) {
-    for (int i = threadIdx.x; i < rows * 2 * DEC_H; i += blockDim.x) {
-      int r = i / (2 * DEC_H), c = i - r * (2 * DEC_H);
-      float m = drop.get(0, grow(r), c, 2 * DEC_H);
+    tile_for(rows, 2 * DEC_H, [&](int r, int c) {
+      const float m = drop.get(0, grow(r), c, 2 * DEC_H);
       bufB[r * ldH + c] *= m;
       if (sv.mask && r < valid) sv.mask[prow(r, sv.ps) * 2 * DEC_H + c] = m;
-    }
+    });
     __syncthreads();
   }
   if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
   // layer 1
-  lstm_gates_tile<MT>(bufB, ldH, 2 * DEC_H, P, dl.l[1][0], dl.l[1][1], DEC_H, bufA, ldG);
+  lstm_gates_tile<MT>(bufB, ldH, 2 * DEC_H, P, dl.l[1][0], dl.l[1][1], DEC_H, bufA, ldG, wst);
   __syncthreads();
   lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g1, valid, sv.ps);
   __syncthreads();
   if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
   // dense2 + tanh
-  gemm_nt<MT>(bufB, ldH, P + dl.d2_w, 2 * DEC_H, 2 * DEC_H, S, identity_map(), P + dl.d2_b, nullptr, bufA, ldS, 0);
+  gemm_nt<MT>(bufB, ldH, P + dl.d2_w, 2 * DEC_H, 2 * DEC_H, S, identity_map(), P + dl.d2_b, nullptr, bufA, ldS, 0, wst);
   __syncthreads();
-  for (int i = threadIdx.x; i < rows * S; i += blockDim.x) {
-    int r = i / S, c = i - r * S;
-    bufA[r * ldS + c] = tanhf(bufA[r * ldS + c]);
-  }
+  tile_for(rows, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
   __syncthreads();
 }
 
@@ -277,6 +249,12 @@ __device__ __forceinline__ void head_rows_tile(float* Us, int ld, int rows, int 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const RowVec b = row_load(bias_g, S, lane);
   for (int r = wave; r < rows; r += nw) row_store(Us + r * ld, head_row(row_load(Us + r * ld, S, lane), b), S, lane);
+}
+
+// copy n floats (n % 4 == 0, 16-byte aligned) global -> LDS: the weights of a small network, whole workgroup
+__device__ __forceinline__ void stage_params(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+    *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
 }
 
 }  // namespace hypad

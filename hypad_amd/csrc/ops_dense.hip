@@ -10,6 +10,7 @@ using namespace hypad;
 namespace {
 
 constexpr int THREADS = 256;
+constexpr int WST = (THREADS / 64) * WSTAGE_FLOATS;     // wave-private weight slabs of gemm_nt
 
 __host__ __device__ inline int ld_of(int n) { return pad4(n) + 4; }
 
@@ -33,11 +34,12 @@ __global__ __launch_bounds__(THREADS) void linear_fwd_kernel(const float* __rest
   const int ldx = ld_of(K), ldy = ld_of(N);
   float* xs = smem;
   float* ys = xs + 16 * ldx;
+  float* wst = ys + 16 * ldy;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
   __syncthreads();
-  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), b, nullptr, ys, ldy, 0);
+  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), b, nullptr, ys, ldy, 0, wst);
   __syncthreads();
   for (int i = threadIdx.x; i < valid * N; i += THREADS) {
     int r = i / N, c = i - r * N;
@@ -121,12 +123,13 @@ __global__ __launch_bounds__(THREADS) void lstm_fwd_kernel(const float* __restri
   float* xs = smem;
   float* gs = xs + 16 * ldx;
   float* hs = gs + 16 * ldg;
+  float* wst = hs + 16 * ldh;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
   __syncthreads();
-  gemm_nt<1>(xs, ldx, wf, K, K, 3 * H, lstm_gate_map(H), bif, bhf, gs, ldg, 0);
-  gemm_nt<1>(xs, ldx, wr, K, K, 3 * H, lstm_gate_map(H), bir, bhr, gs, ldg, 3 * H);
+  gemm_nt<1>(xs, ldx, wf, K, K, 3 * H, lstm_gate_map(H), bif, bhf, gs, ldg, 0, wst);
+  gemm_nt<1>(xs, ldx, wr, K, K, 3 * H, lstm_gate_map(H), bir, bhr, gs, ldg, 3 * H, wst);
   __syncthreads();
   lstm_cell_tile(gs, ldg, H, 16, hs, ldh, gates_save ? gates_save + r0 * 8 * H : nullptr, valid);
   __syncthreads();
@@ -158,7 +161,6 @@ __global__ __launch_bounds__(THREADS) void lstm_bwd_kernel(const float* wf, cons
   }
   if (gx) {
     gemm_nn<1>(dgs, ldg, 0, wf, K, 3 * H, lstm_gate_map(H), K, xs, ldx, false);
-    __syncthreads();
     gemm_nn<1>(dgs, ldg, 3 * H, wr, K, 3 * H, lstm_gate_map(H), K, xs, ldx, true);
     __syncthreads();
     tile_store(gx + r0 * K, K, xs, ldx, 16, K, valid);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void lstm_bwd_kernel(const float* wf, cons
 
 // ------------------------------------------------------------------------------------------ networks
 struct NetLds {          // float offsets into dynamic LDS for the network kernels
-  int xs, zs, bufA, bufB, crit, total;
+  int xs, zs, bufA, bufB, crit, wst, total;
   int ldS, bufFloats;
 };
 __host__ __device__ inline NetLds net_lds(int S, int MT) {
@@ -182,6 +184,7 @@ __host__ __device__ inline NetLds net_lds(int S, int MT) {
   n.bufA = o; o += n.bufFloats;
   n.bufB = o; o += n.bufFloats;
   n.crit = o; o += CRITIC_LDS_FLOATS;
+  n.wst = o; o += WST;
   n.total = o;
   return n;
 }
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void encoder_fwd_kernel(const float* __res
   tile_load(smem + nl.xs, nl.ldS, x + r0 * S, S, 16, S, valid);
   __syncthreads();
   encoder_fwd_tile(smem + nl.xs, nl.ldS, S, L, P, el, smem + nl.bufA, 6 * ENC_H + 4, smem + nl.bufB, 2 * ENC_H + 4,
-                   smem + nl.zs, nullptr, nullptr, valid);
+                   smem + nl.zs, nullptr, nullptr, valid, smem + nl.wst);
   tile_store(out + r0 * L, L, smem + nl.zs, LP, 16, L, valid);
 }
 
@@ -216,10 +219,11 @@ __global__ __launch_bounds__(THREADS) void decoder_fwd_kernel(const float* __res
   DropSrc drop = make_drop(dp, (int)rows, RS_DROP_DEC0, 0.2f);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const int base_row = (int)r0;
-  decoder_trunk_fwd_tile<MT>(zs, L, S, P, dl, bufA, bufB, nl.ldS, drop, [base_row](int r) { return base_row + r; }, none, valid);
+  decoder_trunk_fwd_tile<MT>(zs, L, S, P, dl, bufA, bufB, nl.ldS, drop, [base_row](int r) { return base_row + r; }, none, valid,
+                             smem + nl.wst);
   if (eucl) tile_store(eucl + r0 * S, S, bufA, nl.ldS, R, S, valid);
   if (hyperbolic && hyper) {
-    gemm_nt<MT>(bufA, nl.ldS, P + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0);
+    gemm_nt<MT>(bufA, nl.ldS, P + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0, smem + nl.wst);
     __syncthreads();
     head_rows_tile(bufB, nl.ldS, R, S, P + dl.head_b);
     __syncthreads();
@@ -234,13 +238,14 @@ __global__ __launch_bounds__(THREADS) void critic_fwd_kernel(const float* __rest
   const int ldx = pad4(in_dim) + 4;
   float* xs = smem;
   CriticLds cs = critic_lds(smem + 16 * ldx);
+  float* wst = smem + 16 * ldx + CRITIC_LDS_FLOATS;
   const CriticLayout cl = critic_layout(in_dim, L, nh, p);
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(xs, ldx, x + r0 * in_dim, in_dim, 16, in_dim, valid);
   __syncthreads();
   DropSrc drop = make_drop(dp, (int)rows, RS_DROP_CRITIC, p);
-  critic_fwd_tile(xs, ldx, P, cl, L, cs, drop, (int)r0);
+  critic_fwd_tile(xs, ldx, P, cl, L, cs, drop, (int)r0, wst);
   if (threadIdx.x < valid) out[r0 + threadIdx.x] = cs.out[threadIdx.x];
 }
 
@@ -252,11 +257,12 @@ __global__ __launch_bounds__(THREADS) void mobius_linear_fwd_kernel(const float*
   const int ldx = ld_of(K), ldy = ld_of(N);
   float* xs = smem;
   float* ys = xs + 16 * ldx;
+  float* wst = ys + 16 * ldy;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(xs, ldx, x + r0 * K, K, 16, K, valid);
   __syncthreads();
-  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), nullptr, nullptr, ys, ldy, 0);
+  gemm_nt<1>(xs, ldx, w, K, K, N, identity_map(), nullptr, nullptr, ys, ldy, 0, wst);
   __syncthreads();
   if (u_save) tile_store(u_save + r0 * N, N, ys, ldy, 16, N, valid);
   __syncthreads();
@@ -284,18 +290,18 @@ __global__ __launch_bounds__(THREADS) void score_forward_kernel(const float* __r
   tile_load(xs, nl.ldS, x + r0 * S, S, 16, S, valid);
   __syncthreads();
   if (critic) {
-    critic_fwd_tile(xs, nl.ldS, PC, cl, L, cs, no_drop(), 0);
+    critic_fwd_tile(xs, nl.ldS, PC, cl, L, cs, no_drop(), 0, smem + nl.wst);
     if (threadIdx.x < valid) critic[r0 + threadIdx.x] = cs.out[threadIdx.x];
   }
-  encoder_fwd_tile(xs, nl.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid);
+  encoder_fwd_tile(xs, nl.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid, smem + nl.wst);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, nl.ldS, no_drop(), [](int r) { return r; }, none, valid);
+  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, nl.ldS, no_drop(), [](int r) { return r; }, none, valid, smem + nl.wst);
   if (eucl) tile_store(eucl + r0 * S, S, bufA, nl.ldS, 16, S, valid);
   if (hyperbolic) {
     // rows 16..31 of bufA <- x: one head GEMM serves decoder output and the real window
     for (int i = threadIdx.x; i < 16 * nl.ldS; i += THREADS) bufA[16 * nl.ldS + i] = xs[i];
     __syncthreads();
-    gemm_nt<2>(bufA, nl.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0);
+    gemm_nt<2>(bufA, nl.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, nl.ldS, 0, smem + nl.wst);
     __syncthreads();
     head_rows_tile(bufB, nl.ldS, 32, S, PD + dl.head_b);
     __syncthreads();
@@ -322,7 +328,7 @@ int hypad_linear_act_fwd(const float* x, const float* w, const float* b, float* 
                          hypad_stream_t s) {
   if (!x || !w || !y || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  size_t lds = (size_t)16 * (ld_of(K) + ld_of(N)) * sizeof(float);
+  size_t lds = (size_t)(16 * (ld_of(K) + ld_of(N)) + WST) * sizeof(float);
   if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
   hipError_t e = allow_lds((const void*)linear_fwd_kernel, lds);
   if (e != hipSuccess) return (int)e;
@@ -361,7 +367,7 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
                          hypad_stream_t s) {
   if (!x || !wf || !bif || !bhf || !wr || !bir || !bhr || !out || rows < 0 || K <= 0 || H <= 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  size_t lds = (size_t)16 * (ld_of(K) + ld_of(6 * H) + ld_of(2 * H)) * sizeof(float);
+  size_t lds = (size_t)(16 * (ld_of(K) + ld_of(6 * H) + ld_of(2 * H)) + WST) * sizeof(float);
   if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
   hipError_t e = allow_lds((const void*)lstm_fwd_kernel, lds);
   if (e != hipSuccess) return (int)e;
@@ -433,7 +439,7 @@ static int critic_fwd(const float* P, const float* x, float* out, int64_t rows, 
   if (!P || !x || !out || rows < 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
   hypad_dropout dp = drop ? *drop : hypad_dropout{0, nullptr, 0, 0};
-  size_t lds = (size_t)(16 * (pad4(in_dim) + 4) + CRITIC_LDS_FLOATS) * sizeof(float);
+  size_t lds = (size_t)(16 * (pad4(in_dim) + 4) + CRITIC_LDS_FLOATS + WST) * sizeof(float);
   hipLaunchKernelGGL(critic_fwd_kernel, dim3(tiles16(rows)), dim3(THREADS), lds, (hipStream_t)s, P, x, out, rows, in_dim, L,
                      nh, p, dp);
   HYPAD_CHECK_LAUNCH();
@@ -460,7 +466,7 @@ int hypad_mobius_linear_fwd(const float* x, const float* w, const float* bias, f
   if (!x || !w || !bias || !out || rows < 0 || K <= 0 || N <= 0) return HYPAD_EINVAL;
   if (N > 64 * MAX_EPL) return HYPAD_EUNSUPPORTED;
   if (rows == 0) return HYPAD_OK;
-  size_t lds = (size_t)16 * (ld_of(K) + ld_of(N)) * sizeof(float);
+  size_t lds = (size_t)(16 * (ld_of(K) + ld_of(N)) + WST) * sizeof(float);
   if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
   hipError_t e = allow_lds((const void*)mobius_linear_fwd_kernel, lds);
   if (e != hipSuccess) return (int)e;

@@ -1,16 +1,29 @@
 // Row-tile GEMMs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
 //
-// A workgroup owns MT*16 rows of activations in LDS and streams weights from global memory (L2-resident,
-// ~1 MB per model).  Two shapes cover every layer of the TadGAN networks:
+// A workgroup owns MT*16 rows of activations in LDS and streams weights from global memory (Infinity-Cache / L2
+// resident, ~1 MB per model).  Two shapes cover every layer of the TadGAN networks:
 //   gemm_nt :  Y[r][n] = sum_k X[r][k] * W[wrow(n)][k]  (+ bias)      forward of Linear / LSTM gates
 //   gemm_nn :  Y[r][c] = sum_n D[r][n] * W[wrow(n)][c]                 backward-data
 // wrow(n) = n + (n >= split ? gap : 0) lets the LSTM layers skip the f-gate block of W_ih (never used at
 // seq_len 1 with c0 = 0: SURVEY.md A.2) while keeping PyTorch's [i,f,g,o] weight layout.
 //
+// What bounds these layers (measured on MI355X, scripts/diag_*.py, profiles/README.md):
+//   * a 16..48-row tile is ~1 CU-us of MFMA work, so everything is latency / issue bound;
+//   * the MFMA B operand of gemm_nt is "16 weight rows x 4 consecutive k": loading it straight from the row-major
+//     (out, in) weight is a 16-row gather of 64-byte half lines -- the CU's texture path sustains only ~19 B/clk
+//     on that pattern (3 470 cycles per 8 KiB tile with 8 waves) against ~76 B/clk on full 128-byte lines.
+// Hence:
+//   gemm_nt stages every 16-row x 32-k weight slab through a small wave-private LDS tile: global loads are
+//   8 rows x 128 B (full lines) per instruction, fragments are re-read from LDS with ds_read_b128;
+//   gemm_nn reads W rows directly (its B operand is contiguous along the output index) as float4 = four 16-column
+//   tiles per load, and splits the reduction range over the waves with a fixed-order (deterministic) combine;
+//   all inner loops are branch-free (clamped addresses + zero-selects) so that the loads of a tile are issued
+//   together and the MFMAs run back to back.
+//
 // MFMA 16x16x4 f32 lane map (cdna_hip_programming.md §3): lane l, j = l & 15, q = l >> 4
 //   A[i = j][k = q],  B[k = q][col = j],  D[row = 4*q + reg][col = j].
-// The reduction index may be permuted freely as long as A and B agree, which is what the 16-byte path does:
-// one float4 per lane feeds four consecutive MFMAs (lane (.,q) carries k = k0 + 4q + i at step i).
+// The reduction index may be permuted freely as long as A and B agree: a float4 per lane feeds four consecutive
+// MFMAs (lane (.,q) carries k = k0 + 4q + i at step i).
 #pragma once
 #include "device_utils.h"
 
@@ -26,58 +39,142 @@ __device__ __forceinline__ RowMap identity_map() { return RowMap{0x7fffffff, 0};
 // compact (i,g,o) gate column c in [0,3H) -> row of the (4H, in) PyTorch weight
 __device__ __forceinline__ RowMap lstm_gate_map(int H) { return RowMap{H, H}; }
 
-__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+constexpr int WSTAGE_LD = 36;                        // floats per row of the wave-private weight slab (32 + pad)
+constexpr int WSTAGE_FLOATS = 16 * WSTAGE_LD;        // per wave
+__device__ __forceinline__ float f4get(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-// Y (LDS) [MT*16][ldy], columns ycol0 .. ycol0+N-1.  X (LDS) [MT*16][ldx], K columns, ldx % 4 == 0.
-// W (global) rows of length ldw; bias pointers (global, indexed like W rows) may be null.
-template <int MT>
-__device__ void gemm_nt(const float* __restrict__ Xs, int ldx, const float* __restrict__ W, int ldw, int K, int N,
-                        RowMap map, const float* __restrict__ bias0, const float* __restrict__ bias1,
-                        float* __restrict__ Ys, int ldy, int ycol0) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// ---------------------------------------------------------------------------------------------------- gemm_nt
+// One output tile (16 weight rows n0..n0+15), K % V == 0, W rows V*4-byte aligned.  `stage`: this wave's LDS slab.
+// Super-chunks of up to 128 k: all global loads first, then per 32-k slab: LDS write -> fragment reads -> MFMAs.
+template <int MT, int V>
+__device__ __forceinline__ void nt_tile_staged(const float* __restrict__ Xs, int ldx, const float* __restrict__ W, int ldw, int K,
+                                               int N, int n0, RowMap map, float* __restrict__ stage, int lane, f32x4 (&acc)[MT]) {
+  constexpr int RPI = 64 * V / 32;                   // weight rows covered by one load instruction (V=4: 8, V=2: 4)
+  constexpr int NI = 16 / RPI;                       // load instructions per 32-k slab
+  constexpr int SC = 4;                              // slabs per super-chunk (128 k)
   const int j = lane & 15, q = lane >> 4;
-  const int ntiles = (N + 15) >> 4;
-  const bool vec = ((K & 3) == 0) && ((ldw & 3) == 0) && aligned16(W);
-  for (int t = wave; t < ntiles; t += nwaves) {
-    const int n = t * 16 + j;
-    const bool nv = n < N;
-    const int wr = nv ? map(n) : 0;
-    const float* __restrict__ wp = W + (size_t)wr * ldw;
-    f32x4 acc[MT];
+  const int lrow = lane / (32 / V), lcol = V * (lane % (32 / V));   // this lane's (row within instruction, k offset)
+  const int klast = K - V;
+  f32x4 acc2[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-#pragma unroll 2
-      for (int k0 = 0; k0 < K; k0 += 16) {
-        const int kk = k0 + 4 * q;
-        const bool kv = kk < K;
-        float4 b = (kv && nv) ? *reinterpret_cast<const float4*>(wp + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = 0; m < MT; ++m) acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* rowp[NI];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          float4 a = kv ? *reinterpret_cast<const float4*>(Xs + (m * 16 + j) * ldx + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[m], 0, 0, 0);
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[m], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll 4
-      for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + q;
-        const bool kv = k < K;
-        const float b = (kv && nv) ? wp[k] : 0.f;
+  for (int i = 0; i < NI; ++i) {
+    int n = n0 + lrow + RPI * i;
+    n = n < N ? n : N - 1;                           // rows past N: valid duplicate, result dropped by the caller
+    rowp[i] = W + (size_t)map(n) * ldw;
+  }
+  for (int k0 = 0; k0 < K; k0 += 32 * SC) {
+    float wreg[SC][NI][V];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float a = kv ? Xs[(m * 16 + j) * ldx + k] : 0.f;
-          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+    for (int s = 0; s < SC; ++s) {
+      int kk = k0 + 32 * s + lcol;
+      kk = kk < klast ? kk : klast;                  // clamp: always a valid address (A is zeroed there)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (V == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(rowp[i] + kk);
+          wreg[s][i][0] = t.x; wreg[s][i][1] = t.y; wreg[s][i][2] = t.z; wreg[s][i][3] = t.w;
+        } else {
+          const float2 t = *reinterpret_cast<const float2*>(rowp[i] + kk);
+          wreg[s][i][0] = t.x; wreg[s][i][1] = t.y;
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < SC; ++s) {
+      const int ks = k0 + 32 * s;
+      if (ks < K) {                                  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          float* d = stage + (lrow + RPI * i) * WSTAGE_LD + lcol;
+          if (V == 4) *reinterpret_cast<float4*>(d) = make_float4(wreg[s][i][0], wreg[s][i][1], wreg[s][i][2], wreg[s][i][3]);
+          else *reinterpret_cast<float2*>(d) = make_float2(wreg[s][i][0], wreg[s][i][1]);
+        }
+        float4 b[2], a[MT][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          b[u] = *reinterpret_cast<const float4*>(stage + j * WSTAGE_LD + 16 * u + 4 * q);
+          int ka = ks + 16 * u + 4 * q;
+          ka = ka < ldx - 4 ? ka : ldx - 4;          // stay inside the activation row (values beyond K are masked)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m][u] = *reinterpret_cast<const float4*>(Xs + (m * 16 + j) * ldx + ka);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool live = ks + 16 * u + 4 * q + i < K;
+            const float bv = f4get(b[u], i);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float av = live ? f4get(a[m][u], i) : 0.f;
+              if (i & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc2[m], 0, 0, 0);
+              else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+            }
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] += acc2[m];
+}
+
+// direct (un-staged) tile for odd K / unaligned weights: scalar loads, branch-free
+template <int MT>
+__device__ __forceinline__ void nt_tile_scalar(const float* __restrict__ Xs, int ldx, const float* __restrict__ wp, int K, int j, int q,
+                                               f32x4 (&acc)[MT]) {
+  constexpr int CH = MT == 1 ? 16 : 8;
+  const int G = (K + 3) >> 2;
+  for (int g0 = 0; g0 < G; g0 += CH) {
+    float b[CH], a[MT][CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      int k = (g0 + u) * 4 + q;
+      k = k < K ? k : K - 1;
+      b[u] = wp[k];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m][u] = Xs[(m * 16 + j) * ldx + k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const bool live = (g0 + u) * 4 + q < K;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? a[m][u] : 0.f, b[u], acc[m], 0, 0, 0);
+    }
+  }
+}
+
+// Y (LDS) [MT*16][ldy], columns ycol0 .. ycol0+N-1.  X (LDS) [MT*16][ldx], K columns, ldx % 4 == 0, X 16-byte aligned.
+// W rows of length ldw (global, or LDS through a flat pointer); bias pointers (indexed like W rows) may be null.
+// wstage: LDS, WSTAGE_FLOATS per wave of the workgroup (wave-private weight slabs).
+template <int MT>
+__device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, const float* __restrict__ W, int ldw, int K, int N,
+                        RowMap map, const float* __restrict__ bias0, const float* __restrict__ bias1,
+                        float* __restrict__ Ys, int ldy, int ycol0, float* __restrict__ wstage) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4;
+  const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
+  const int vw = (((K | ldw) & 3) == 0 && (wa & 15) == 0) ? 4 : (((K | ldw) & 1) == 0 && (wa & 7) == 0) ? 2 : 1;
+  float* stage = wstage + wave * WSTAGE_FLOATS;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const int n = t * 16 + j;
+    const bool nv = n < N;
+    const int wr = map(nv ? n : N - 1);                // clamp: lanes past N read a valid row and drop the result
+    float bsum = 0.f;
+    if (bias0) bsum += bias0[wr];
+    if (bias1) bsum += bias1[wr];
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (vw == 4) nt_tile_staged<MT, 4>(Xs, ldx, W, ldw, K, N, t * 16, map, stage, lane, acc);
+    else if (vw == 2) nt_tile_staged<MT, 2>(Xs, ldx, W, ldw, K, N, t * 16, map, stage, lane, acc);
+    else nt_tile_scalar<MT>(Xs, ldx, W + (size_t)wr * ldw, K, j, q, acc);
     if (nv) {
-      float bsum = 0.f;
-      if (bias0) bsum += bias0[wr];
-      if (bias1) bsum += bias1[wr];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -86,30 +183,118 @@ __device__ void gemm_nt(const float* __restrict__ Xs, int ldx, const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- gemm_nn
 // Y (LDS) [MT*16][ldy] columns 0..C-1  (+)= D (LDS) [MT*16][ldd] columns dcol0..dcol0+Nred-1  times  W rows wrow(n).
+// Contains __syncthreads(): every wave of the workgroup must call it.  The caller needs no barrier between two
+// accumulating calls on the same Y.
 template <int MT>
-__device__ void gemm_nn(const float* __restrict__ Ds, int ldd, int dcol0, const float* __restrict__ W, int ldw,
+__device__ __forceinline__ void gemm_nn(const float* __restrict__ Ds, int ldd, int dcol0, const float* __restrict__ W, int ldw,
                         int Nred, RowMap map, int C, float* __restrict__ Ys, int ldy, bool accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
+  const bool vec = ((C | ldw) & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && Nred >= 64;
+  if (vec) {
+    // quad path: one float4 of W = columns c0+4j..c0+4j+3 of row n -> four 16-column tiles (tile i owns columns
+    // c0 + 4*jj + i).  Waves = (column quad) x (slice of the reduction range); partial tiles are combined in a fixed order.
+    const int nquads = (C + 63) >> 6;
+    int nsplit = nwaves / nquads;
+    if (nsplit < 1) nsplit = 1;
+    const int G = (Nred + 3) >> 2;
+    const int gper = (G + nsplit - 1) / nsplit;
+    const int rounds = (nquads + (nwaves / nsplit) - 1) / (nwaves / nsplit);     // quads per wave slot (normally 1)
+    for (int rd = 0; rd < rounds; ++rd) {
+      const int quad = rd * (nwaves / nsplit) + wave / nsplit;
+      const int sp = wave % nsplit;
+      const bool work = quad < nquads && wave < (nwaves / nsplit) * nsplit;
+      const int c0 = quad * 64;
+      int cb = c0 + 4 * j;
+      const bool cvalid = work && cb < C;
+      cb = cvalid ? cb : 0;
+      f32x4 acc[MT][4];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (work) {
+        const int gbeg = sp * gper, gend = (gbeg + gper < G) ? gbeg + gper : G;
+        constexpr int CH = MT == 1 ? 8 : 4;
+        for (int g0 = gbeg; g0 < gend; g0 += CH) {
+          float4 b[CH];
+          float a[MT][CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            int n = (g0 + u) * 4 + q;
+            n = n < Nred ? n : Nred - 1;
+            b[u] = *reinterpret_cast<const float4*>(W + (size_t)map(n) * ldw + cb);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m][u] = Ds[(m * 16 + j) * ldd + dcol0 + n];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const bool live = (g0 + u) < gend && (g0 + u) * 4 + q < Nred;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float av = live ? a[m][u] : 0.f;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f4get(b[u], i), acc[m][i], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // fixed-order combine: slice 0 stores (or adds to the existing Y), slices 1.. add in turn
+      for (int s = 0; s < nsplit; ++s) {
+        if (cvalid && sp == s) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float4* y = reinterpret_cast<float4*>(Ys + (m * 16 + 4 * q + r) * ldy + cb);
+              float4 v = make_float4(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]);
+              if (s > 0 || accumulate) { const float4 o = *y; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+              *y = v;
+            }
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  // scalar path (narrow / odd outputs): one 16-column tile per wave, branch-free
   const int ntiles = (C + 15) >> 4;
+  constexpr int CH = MT == 1 ? 16 : 8;
+  const int G = (Nred + 3) >> 2;
   for (int t = wave; t < ntiles; t += nwaves) {
     const int c = t * 16 + j;
     const bool cv = c < C;
-    f32x4 acc[MT];
+    const int cc = cv ? c : C - 1;
+    f32x4 acc[MT], acc2[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int n0 = 0; n0 < Nred; n0 += 4) {
-      const int n = n0 + q;
-      const bool nv = n < Nred;
-      const float b = (nv && cv) ? W[(size_t)map(n) * ldw + c] : 0.f;
+    for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int g0 = 0; g0 < G; g0 += CH) {
+      float b[CH];
+      float a[MT][CH];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const float a = nv ? Ds[(m * 16 + j) * ldd + dcol0 + n] : 0.f;
-        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+      for (int u = 0; u < CH; ++u) {
+        int n = (g0 + u) * 4 + q;
+        n = n < Nred ? n : Nred - 1;
+        b[u] = W[(size_t)map(n) * ldw + cc];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m][u] = Ds[(m * 16 + j) * ldd + dcol0 + n];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const bool live = (g0 + u) * 4 + q < Nred;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (u & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? a[m][u] : 0.f, b[u], acc2[m], 0, 0, 0);
+          else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(live ? a[m][u] : 0.f, b[u], acc[m], 0, 0, 0);
+        }
       }
     }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] += acc2[m];
     if (cv) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -120,6 +305,7 @@ __device__ void gemm_nn(const float* __restrict__ Ds, int ldd, int dcol0, const 
         }
     }
   }
+  __syncthreads();
 }
 
 }  // namespace hypad

@@ -15,13 +15,16 @@
 #include <vector>
 
 #include "../../include/hypad.h"
+#include "critic_valu.h"
 #include "nets.h"
 
 using namespace hypad;
 
 namespace {
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 256;      // dW + Adam kernel
+constexpr int TB = 512;           // row-tile kernels: 16 waves share one tile (the layers are latency-bound: more waves
+                                  // = more weight tiles in flight per layer)
 
 // ------------------------------------------------------------------------------------------------ workspace
 struct CritWs {
@@ -38,7 +41,7 @@ HD CritWs crit_ws(int B, int in_dim, int L, int nh) {
   return w;
 }
 struct GenWs {
-  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, dbrows, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, total;
+  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, total;
 };
 HD GenWs gen_ws(int B, int S, int L) {
   GenWs w; int o = 0;
@@ -55,7 +58,7 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.ecat = o; o += pad4(3 * B * S);
   w.u = o; o += pad4(3 * B * S);
   w.du = o; o += pad4(3 * B * S);
-  w.dbrows = o; o += pad4(3 * B * S);
+  w.ballpart = o; o += pad4((B / 16) * S);          // per-tile column sums of the head-bias gradient rows
   w.dpre2 = o; o += pad4(2 * B * S);
   w.dg1 = o; o += pad4(2 * B * 6 * DEC_H);
   w.dg0 = o; o += pad4(2 * B * 6 * DEC_H);
@@ -66,12 +69,13 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.total = o;
   return w;
 }
+// critic_x and critic_z iterations of one minibatch may run side by side (train.py:320-327 touch disjoint weights):
+// their workspaces are disjoint, the generator's overlays both.
+inline int64_t ws_cz_offset(const hypad_dims& d) { return crit_ws(d.batch, d.signal_shape, d.latent_dim, 4).total; }
 inline int64_t ws_floats_per_signal(const hypad_dims& d) {
-  int64_t a = crit_ws(d.batch, d.signal_shape, d.latent_dim, 4).total;
-  int64_t b = crit_ws(d.batch, d.latent_dim, d.latent_dim, 2).total;
+  int64_t a = ws_cz_offset(d) + crit_ws(d.batch, d.latent_dim, d.latent_dim, 2).total;
   int64_t c = gen_ws(d.batch, d.signal_shape, d.latent_dim).total;
-  int64_t m = a > b ? a : b;
-  return m > c ? m : c;
+  return a > c ? a : c;
 }
 
 // ------------------------------------------------------------------------------------------------ kernel arguments
@@ -89,12 +93,15 @@ struct IterArgs {
   float* ws; int64_t ws_sig_stride;
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
+  int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
 };
 
 struct LdsPlan {
-  int xs, zs, bufA, bufB, crit, small, total, ldS, bufFloats;
+  int xs, zs, bufA, bufB, crit, small, wst, cparams, total, ldS, bufFloats;
+  int stage;      // 1: the critics' weights are staged in LDS (fits the 160 KiB budget)
 };
-HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head) {
+constexpr int LDS_LIMIT_FLOATS = 160 * 1024 / 4;
+HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head, int critic_floats, int crit_scratch = CRITIC_LDS_FLOATS) {
   LdsPlan p;
   p.ldS = pad4(S) + 4;
   int a = rows_lstm * (6 * DEC_H + 4), b = rows_head * p.ldS;
@@ -104,11 +111,16 @@ HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head) {
   p.zs = o; o += 32 * LP;
   p.bufA = o; o += p.bufFloats;
   p.bufB = o; o += p.bufFloats;
-  p.crit = o; o += CRITIC_LDS_FLOATS;
-  p.small = o; o += 4 * 16 * LP + 64;     // three (16, LP) scratch tiles + reduction slots
+  p.crit = o; o += crit_scratch;
+  p.small = o; o += 3 * 16 * LP + 64;     // three (16, LP) scratch tiles + 64 reduction slots
+  p.wst = o; o += (TB / 64) * WSTAGE_FLOATS;   // wave-private weight slabs of gemm_nt
+  p.cparams = o;
+  p.stage = (o + critic_floats <= LDS_LIMIT_FLOATS) ? 1 : 0;
+  if (p.stage) o += critic_floats;
   p.total = o;
   return p;
 }
+// reduction slots inside `small`: [0,16) block_sum, [16,32) per-wave partials, [32,36) pass sums
 
 __device__ __forceinline__ DropSrc drop_src(const IterArgs& a, int sig, const float* ptr, uint32_t stream, uint32_t tick, float p) {
   DropSrc s;
@@ -116,81 +128,77 @@ __device__ __forceinline__ DropSrc drop_src(const IterArgs& a, int sig, const fl
   return s;
 }
 
-// block-wide sum of per-thread values (256 threads); result valid in thread 0.  red: LDS >= 4 floats
+// block-wide sum of per-thread values; result valid in every thread.  red: LDS >= 16 floats
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
 }
 
 // ------------------------------------------------------------------------------------------------ critic passes
-// One critic pass on a tile: forward, save what dW needs, first-order backward chain from a constant dout.
-// pass p in {0 real, 1 fake, 2 interpolated}.  Returns pointer (LDS) to delta of layer 0.
-__device__ __forceinline__ const float* critic_pass(const float* in, int ldin, int p, float dout_val, const float* P,
-                                                    const CriticLayout& cl, int L, const CriticLds& cs, const DropSrc& drop,
-                                                    float* ws, const CritWs& cw, int B, int tile, float* out_sum) {
-  const int grow0 = tile * 16;
-  const int64_t prow0 = (int64_t)p * B + grow0;
-  critic_fwd_tile(in, ldin, P, cl, L, cs, drop, grow0);
-  if (p < 2) {
-    tile_store(ws + cw.in_right + prow0 * cl.in_dim, cl.in_dim, in, ldin, 16, cl.in_dim, 16);
-    for (int li = 0; li < cl.nh; ++li) tile_store(ws + cw.act[li] + prow0 * L, L, cs.act + li * 16 * LP, LP, 16, L, 16);
-  } else {
-    for (int li = 0; li < cl.nh; ++li) tile_store(ws + cw.dm[li] + (int64_t)grow0 * L, L, cs.dm + li * 16 * LP, LP, 16, L, 16);
-  }
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int r = 0; r < 16; ++r) s += cs.out[r];
-    *out_sum = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    cs.out[threadIdx.x] = dout_val;
-    ws[cw.left[cl.nh] + prow0 + threadIdx.x] = dout_val;
-  }
-  __syncthreads();
-  return critic_bwd_chain_tile(cs.out, P, cl, L, cs, [&](int li, const float* delta) {
-    tile_store(ws + cw.left[li] + prow0 * L, L, delta, LP, 16, L, 16);
-  });
-}
-
-// real / fake: LDS tiles (in_dim columns).  inter: LDS [16][ldi] scratch for the interpolation; gbuf: LDS [16][ldg] for g.
-// gbuf may alias `real` (it is written only after the last read of `real`).
+// The three passes of a WGAN-GP critic update on one 16-row tile -- real (dout -1/B), fake (+1/B), interpolated
+// (dout 1: the first backward of the gradient penalty, train.py:72-81) -- carried together as 48 rows on the VALU path
+// (critic_valu.h).  Writes every (left, right) pair the dW kernel needs, the interpolated pass's masks for the
+// gradient-penalty kernel, g = d(prob)/d(interpolated) and the tile's partial sums.
+// real / fake: LDS tiles (in_dim columns).  inter: LDS [16][ldi] scratch; gbuf: LDS [16][ldgb] for g (may alias `real`:
+// it is written after the last read of `real`).  P: the critic's weights (staged in LDS when they fit).
 __device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, int tile, uint32_t tick, const float* real, int ldr,
                                                     const float* fake, int ldf, float* inter, int ldi, float* gbuf, int ldgb,
-                                                    const float* P, const CriticLayout& cl, const CriticLds& cs, float* ws,
+                                                    const float* P, const CriticLayout& cl, const CriticBatchLds& cb, float* ws,
                                                     const CritWs& cw, int mask_real, int mask_fake, int mask_inter, float* red) {
-  const int L = a.L, B = a.B, nh = cl.nh, in_dim = cl.in_dim;
+  const int L = a.L, B = a.B, nh = cl.nh, in_dim = cl.in_dim, LQ = cb.LQ;
+  const int g0 = tile * 16;
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const int64_t mblk = (int64_t)nh * B * L;
-  float* sums = red + 8;   // [0] real, [1] fake, [2] inter (unused)
-  critic_pass(real, ldr, 0, -1.f / B, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_real * mblk : nullptr,
-                                                                RS_DROP_CRITIC + 8 * mask_real, tick, cl.p_drop), ws, cw, B, tile, sums + 0);
-  critic_pass(fake, ldf, 1, 1.f / B, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_fake * mblk : nullptr,
-                                                               RS_DROP_CRITIC + 8 * mask_fake, tick, cl.p_drop), ws, cw, B, tile, sums + 1);
+  const int midx[3] = {mask_real, mask_fake, mask_inter};
+  DropSrc ds[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+    ds[p] = drop_src(a, sig, mbase ? mbase + midx[p] * mblk : nullptr, RS_DROP_CRITIC + 8 * midx[p], tick, cl.p_drop);
   // interpolation (train.py:64-69 / 149-154)
-  const float* ainj = a.alpha ? a.alpha + ((int64_t)sig * B + tile * 16) * in_dim : nullptr;
-  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
-    int r = i / in_dim, c = i - r * in_dim;
-    float al = ainj ? ainj[i] : rng_uniform(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)((tile * 16 + r) * in_dim + c));
+  const float* ainj = a.alpha ? a.alpha + ((int64_t)sig * B + g0) * in_dim : nullptr;
+  tile_for(16, in_dim, [&](int r, int c) {
+    float al = ainj ? ainj[r * in_dim + c] : rng_uniform(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)((g0 + r) * in_dim + c));
     inter[r * ldi + c] = al * real[r * ldr + c] + (1.f - al) * fake[r * ldf + c];
+  });
+  __syncthreads();
+  critic_batch_fwd([&](int r) { return r < 16 ? real + r * ldr : r < 32 ? fake + (r - 16) * ldf : inter + (r - 32) * ldi; },
+                   P, cl, L, cb,
+                   [&](int li, int r, int c) {
+                     const int p = r >> 4;
+                     return p == 0 ? ds[0].get(li, g0 + (r & 15), c, L) : p == 1 ? ds[1].get(li, g0 + (r & 15), c, L)
+                                                                                   : ds[2].get(li, g0 + (r & 15), c, L);
+                   });
+  // what dW needs from the forward: layer inputs of the real / fake passes, masks of the interpolated pass
+  tile_store(ws + cw.in_right + (int64_t)g0 * in_dim, in_dim, real, ldr, 16, in_dim, 16);
+  tile_store(ws + cw.in_right + ((int64_t)B + g0) * in_dim, in_dim, fake, ldf, 16, in_dim, 16);
+  for (int li = 0; li < nh; ++li) {
+    tile_store_p(ws + cw.act[li] + (int64_t)g0 * L, L, B, cb.act + li * cb.R * LQ, LQ, 32, L, 32);
+    tile_store(ws + cw.dm[li] + (int64_t)g0 * L, L, cb.dm + (li * cb.R + 32) * LQ, LQ, 16, L, 16);
   }
+  float* sums = red + 32;
+  if (threadIdx.x < 2) {
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += cb.out[threadIdx.x * 16 + r];
+    sums[threadIdx.x] = s;
+  }
+  if (threadIdx.x < 48) {
+    const int p = threadIdx.x >> 4;
+    ws[cw.left[nh] + (int64_t)p * B + g0 + (threadIdx.x & 15)] = p == 0 ? -1.f / B : p == 1 ? 1.f / B : 1.f;
+  }
+  const float invB = 1.f / B;
+  const float* d0 = critic_batch_bwd([&](int r) { return r < 16 ? -invB : r < 32 ? invB : 1.f; }, P, cl, L, cb,
+                                     [&](int li, const float* delta) { tile_store_p(ws + cw.left[li] + (int64_t)g0 * L, L, B, delta, LQ, 48, L, 48); });
+  // g = delta_0 W_0 for the interpolated rows (train.py:75-81)
+  dense_rows_valu_t(d0 + 32 * LQ, LQ, L, P + cl.w[0], in_dim, 16, [&](int r, int c, float v) { gbuf[r * ldgb + c] = v; });
   __syncthreads();
-  const float* d0 = critic_pass(inter, ldi, 2, 1.f, P, cl, L, cs, drop_src(a, sig, mbase ? mbase + mask_inter * mblk : nullptr,
-                                                                            RS_DROP_CRITIC + 8 * mask_inter, tick, cl.p_drop),
-                                ws, cw, B, tile, sums + 2);
-  // g = delta_0 W_0  (rows of d(prob)/d(interpolated), train.py:75-81)
-  gemm_nn<1>(d0, LP, 0, P + cl.w[0], in_dim, L, identity_map(), in_dim, gbuf, ldgb, false);
-  __syncthreads();
-  tile_store(ws + cw.in_right + ((int64_t)2 * B + tile * 16) * in_dim, in_dim, gbuf, ldgb, 16, in_dim, 16);
+  tile_store(ws + cw.in_right + ((int64_t)2 * B + g0) * in_dim, in_dim, gbuf, ldgb, 16, in_dim, 16);
   float sq = 0.f;
-  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
-    int r = i / in_dim, c = i - r * in_dim;
-    float v = gbuf[r * ldgb + c];
-    sq += v * v;
-  }
+  tile_for(16, in_dim, [&](int r, int c) { float v = gbuf[r * ldgb + c]; sq += v * v; });
   sq = block_sum(sq, red);
   if (threadIdx.x == 0) {
     float* part = ws + cw.partial + tile * 4;
@@ -200,28 +208,28 @@ __device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, 
 
 __device__ __forceinline__ void load_z(const IterArgs& a, int sig, int tile, uint32_t tick, float* zs /* [16][LP] */) {
   const float* zinj = a.z ? a.z + ((int64_t)sig * a.B + tile * 16) * a.L : nullptr;
-  for (int i = threadIdx.x; i < 16 * a.L; i += THREADS) {
-    int r = i / a.L, c = i - r * a.L;
-    zs[r * LP + c] = zinj ? zinj[i] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * a.L + c));
-  }
+  const int L = a.L;
+  tile_for(16, L, [&](int r, int c) {
+    zs[r * LP + c] = zinj ? zinj[r * L + c] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * L + c));
+  });
 }
 
-// ---- critic_x pass kernel (train.py:18-81)
-__global__ __launch_bounds__(THREADS) void cx_pass_kernel(IterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// ---- critic_x pass (train.py:18-81)
+__device__ __forceinline__ void cx_pass_body(const IterArgs& a, float* smem) {
   const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
-  const LdsPlan lp = lds_plan(S, 16, 16);
-  const DecLayout dl = dec_layout(S, L, a.hyperbolic);
   const CriticLayout cl = cx_layout(S, L);
+  const LdsPlan lp = lds_plan(S, 16, 16, cl.total, critic_batch_lds_floats(48, L));
+  const DecLayout dl = dec_layout(S, L, a.hyperbolic);
   const CritWs cw = crit_ws(B, S, L, 4);
   const float* PD = a.P.dec + (int64_t)sig * a.pd;
   const float* PC = a.P.cx + (int64_t)sig * a.pcx;
   float* ws = a.ws + sig * a.ws_sig_stride;
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* red = smem + lp.small + 3 * 16 * LP;
-  const CriticLds cs = critic_lds(smem + lp.crit);
+  const CriticBatchLds cs = critic_batch_lds(smem + lp.crit, 48, L);
   const uint32_t tick = (uint32_t)a.counters[3];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+  if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
   tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);
@@ -231,10 +239,11 @@ __global__ __launch_bounds__(THREADS) void cx_pass_kernel(IterArgs a) {
   DropSrc ddrop = drop_src(a, sig, mbase ? mbase + (int64_t)12 * B * L : nullptr, RS_DROP_DEC0, tick, 0.2f);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const int grow0 = tile * 16;
-  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, lp.ldS, ddrop, [grow0](int r) { return grow0 + r; }, none, 16);
+  float* wst = smem + lp.wst;
+  decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, lp.ldS, ddrop, [grow0](int r) { return grow0 + r; }, none, 16, wst);
   float* gen = bufA; float* other = bufB;
   if (a.hyperbolic) {
-    gemm_nt<1>(bufA, lp.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, lp.ldS, 0);
+    gemm_nt<1>(bufA, lp.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, lp.ldS, 0, wst);
     __syncthreads();
     head_rows_tile(bufB, lp.ldS, 16, S, PD + dl.head_b);
     __syncthreads();
@@ -244,13 +253,12 @@ __global__ __launch_bounds__(THREADS) void cx_pass_kernel(IterArgs a) {
   critic_three_passes(a, sig, tile, tick, xs, lp.ldS, gen, lp.ldS, other, lp.ldS, xs, lp.ldS, PC, cl, cs, ws, cw, 0, 1, 2, red);
 }
 
-// ---- critic_z pass kernel (train.py:107-166)
-__global__ __launch_bounds__(THREADS) void cz_pass_kernel(IterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// ---- critic_z pass (train.py:107-166)
+__device__ __forceinline__ void cz_pass_body(const IterArgs& a, float* smem) {
   const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
-  const LdsPlan lp = lds_plan(S, 16, 16);
-  const EncLayout el = enc_layout(S, L);
   const CriticLayout cl = cz_layout(L);
+  const LdsPlan lp = lds_plan(S, 16, 16, cl.total, critic_batch_lds_floats(48, L));
+  const EncLayout el = enc_layout(S, L);
   const CritWs cw = crit_ws(B, L, L, 2);
   const float* PE = a.P.enc + (int64_t)sig * a.pe;
   const float* PC = a.P.cz + (int64_t)sig * a.pcz;
@@ -258,24 +266,24 @@ __global__ __launch_bounds__(THREADS) void cz_pass_kernel(IterArgs a) {
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* small = smem + lp.small;
   float* red = small + 3 * 16 * LP;
-  const CriticLds cs = critic_lds(smem + lp.crit);
+  const CriticBatchLds cs = critic_batch_lds(smem + lp.crit, 48, L);
   const uint32_t tick = (uint32_t)a.counters[3];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+  if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
   tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);                       // real = z ~ N(0,1)
   __syncthreads();
   float* zenc = zs + 16 * LP;                           // fake = encoder(x)
-  encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
+  encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16, smem + lp.wst);
   // injected mask order (hypad.h): fake | valid | interpolated
   critic_three_passes(a, sig, tile, tick, zs, LP, zenc, LP, small, LP, small + 16 * LP, LP, PC, cl, cs, ws, cw, 1, 0, 2, red);
 }
 
-// ---- gradient-penalty kernel: whole-batch norm and the second-order chain (oracle/manual.py
+// ---- gradient-penalty body: whole-batch norm and the second-order chain (oracle/manual.py
 // critic_gp_pairs): GP rows of every `right` matrix.
 template <bool IS_X>
-__global__ __launch_bounds__(THREADS) void critic_gp_kernel(IterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void gp_body(const IterArgs& a, float* smem) {
   const int sig = blockIdx.y, tile = blockIdx.x, L = a.L, B = a.B;
   const int in_dim = IS_X ? a.S : a.L;
   const int nh = IS_X ? 4 : 2;
@@ -287,6 +295,9 @@ __global__ __launch_bounds__(THREADS) void critic_gp_kernel(IterArgs a) {
   float* us = smem;                         // [16][ldu]
   float* e0 = us + 16 * ldu;                // [16][LP]
   float* e1 = e0 + 16 * LP;                 // [16][LP]
+  float* pc = e1 + 16 * LP;                 // staged critic weights
+  stage_params(pc, PC, cl.total);
+  PC = pc;
   const int ntiles = B / 16;
   float gsum = 0.f, sreal = 0.f, sfake = 0.f;
   for (int t = 0; t < ntiles; ++t) {        // fixed order: deterministic
@@ -302,48 +313,46 @@ __global__ __launch_bounds__(THREADS) void critic_gp_kernel(IterArgs a) {
     lo[1] = gp; lo[2] = sreal / B; lo[3] = sfake / B;
   }
   float* grow = ws + cw.in_right + ((int64_t)2 * B + tile * 16) * in_dim;
-  for (int i = threadIdx.x; i < 16 * in_dim; i += THREADS) {
-    int r = i / in_dim, c = i - r * in_dim;
-    float u = coef * grow[i];
-    grow[i] = u;                             // right of layer 0 (GP rows) = ugrad
+  tile_for(16, in_dim, [&](int r, int c) {
+    const float u = coef * grow[r * in_dim + c];
+    grow[r * in_dim + c] = u;                // right of layer 0 (GP rows) = ugrad
     us[r * ldu + c] = u;
-  }
+  });
   __syncthreads();
-  gemm_nt<1>(us, ldu, PC + cl.w[0], in_dim, in_dim, L, identity_map(), nullptr, nullptr, e0, LP, 0);
+  dense_rows_valu(us, ldu, in_dim, PC + cl.w[0], nullptr, 16, L, [&](int r, int c, float v) { e0[r * LP + c] = v; });
   __syncthreads();
   float* cur = e0; float* nxt = e1;
   for (int li = 1; li <= nh; ++li) {
     // ep_{li-1} = e_{li-1} * dm_{li-1}: right of layer li (GP rows)
     const float* dm = ws + cw.dm[li - 1] + (int64_t)tile * 16 * L;
     float* dst = ws + cw.act[li - 1] + ((int64_t)2 * B + tile * 16) * L;
-    for (int i = threadIdx.x; i < 16 * L; i += THREADS) {
-      int r = i / L, c = i - r * L;
-      float v = cur[r * LP + c] * dm[i];
+    tile_for(16, L, [&](int r, int c) {
+      const float v = cur[r * LP + c] * dm[r * L + c];
       cur[r * LP + c] = v;
-      dst[i] = v;
-    }
+      dst[r * L + c] = v;
+    });
     __syncthreads();
     if (li < nh) {
-      gemm_nt<1>(cur, LP, PC + cl.w[li], L, L, L, identity_map(), nullptr, nullptr, nxt, LP, 0);
+      dense_rows_valu(cur, LP, L, PC + cl.w[li], nullptr, 16, L, [&](int r, int c, float v) { nxt[r * LP + c] = v; });
       __syncthreads();
       float* t = cur; cur = nxt; nxt = t;
     }
   }
 }
+HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) + 4) + 2 * 16 * LP + critic_floats; }
 
-// ------------------------------------------------------------------------------------------------ generator kernel
+// ------------------------------------------------------------------------------------------------ generator body
 // decoder_iteration (train.py:189-249): rows of a tile: pass 0 = decoder(z), pass 1 = decoder(encoder(x)),
 // pass 2 (hyperbolic only) = hyperbolic_linear(x).
 template <bool HYPER>
-__global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
-  const LdsPlan lp = lds_plan(S, 32, HYPER ? 48 : 32);
+  const CriticLayout clx = cx_layout(S, L);
+  const CriticLayout clz = cz_layout(L);
+  const LdsPlan lp = lds_plan(S, 32, HYPER ? 48 : 32, clx.total + clz.total);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, HYPER ? 1 : 0);
-  const CriticLayout clx = cx_layout(S, L);
-  const CriticLayout clz = cz_layout(L);
   const GenWs gw = gen_ws(B, S, L);
   const float* PE = a.P.enc + (int64_t)sig * a.pe;
   const float* PD = a.P.dec + (int64_t)sig * a.pd;
@@ -358,9 +367,15 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   const CriticLds cs = critic_lds(smem + lp.crit);
   const uint32_t tick = (uint32_t)a.counters[3];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+  if (lp.stage) {                           // frozen critics: stage both weight sets once
+    stage_params(smem + lp.cparams, PZ, clz.total);
+    stage_params(smem + lp.cparams + clz.total, PX, clx.total);
+    PZ = smem + lp.cparams; PX = smem + lp.cparams + clz.total;
+  }
   const int g0 = tile * 16;                 // first batch row of this tile
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const int64_t BL = (int64_t)B * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float sum_fz = 0.f, sum_fx = 0.f, sum_aux = 0.f;
 
   // ---- encoder(x)
@@ -368,12 +383,13 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   __syncthreads();
   tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
   float* zenc = zs + 16 * LP;
+  float* wst = smem + lp.wst;
   encoder_fwd_tile(xs, ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc,
-                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16);
+                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, wst);
   // ---- critic_z(encoder(x)) and its input gradient (frozen critic; loss term -mean(fake_z), train.py:215-217)
   {
     DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
-    critic_fwd_tile(zenc, LP, PZ, clz, L, cs, dz, g0);
+    critic_fwd_tile(zenc, LP, PZ, clz, L, cs, dz, g0, wst);
     if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fz = s; }
     __syncthreads();
     if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
@@ -395,17 +411,16 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   sv.g1 = ws + gw.g1 + (int64_t)g0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + (int64_t)g0 * 2 * DEC_H;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
-  // (layer, batch, 128) array with "layer" = pass, the two decoder masks are layers 0 and 1 of one block.
+  // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
-  // pass-aware row function: mask row of LDS row r is (pass, g0 + r%16); encode pass into the row index for both modes
   const int Bq = B;
-  decoder_trunk_fwd_tile<2>(zs, L, S, PD, dl, bufA, bufB, ldS, dd, [g0, Bq](int r) { return (r >> 4) * Bq + g0 + (r & 15); }, sv, 32);
+  decoder_trunk_fwd_tile<2>(zs, L, S, PD, dl, bufA, bufB, ldS, dd, [g0, Bq](int r) { return (r >> 4) * Bq + g0 + (r & 15); }, sv, 32, wst);
   // E = tanh output in bufA[0..31]
   if (HYPER) {
-    for (int i = threadIdx.x; i < 16 * ldS; i += THREADS) bufA[32 * ldS + i] = xs[i];     // pass 2 input: the real window
+    tile_for(16, S, [&](int r, int c) { bufA[(32 + r) * ldS + c] = xs[r * ldS + c]; });   // pass 2 input: the real window
     __syncthreads();
     tile_store_p(ws + gw.ecat + (int64_t)g0 * S, S, B, bufA, ldS, 48, S, 48);
-    gemm_nt<3>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0);
+    gemm_nt<3>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
     __syncthreads();
     tile_store_p(ws + gw.u + (int64_t)g0 * S, S, B, bufB, ldS, 48, S, 48);
     __syncthreads();
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   // ---- critic_x(x_gen) and its input gradient (loss term -mean(fake_x))
   {
     DropSrc dx = drop_src(a, sig, mbase ? mbase + 2 * BL : nullptr, RS_DROP_CRITIC + 8 * 1, tick, clx.p_drop);
-    critic_fwd_tile(R, ldS, PX, clx, L, cs, dx, g0);
+    critic_fwd_tile(R, ldS, PX, clx, L, cs, dx, g0, wst);
     if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fx = s; }
     __syncthreads();
     if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
@@ -428,11 +443,10 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
     gemm_nn<1>(d0, LP, 0, PX + clx.w[0], S, L, identity_map(), S, dR, ldS, false);
     __syncthreads();
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (HYPER) {
     // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
     float part = 0.f;
-    for (int r = wave; r < 16; r += 4) {
+    for (int r = wave; r < 16; r += nw) {
       RowVec du, dv;
       float d = rowdist_row_bwd(row_load(R + (16 + r) * ldS, S, lane), row_load(R + (32 + r) * ldS, S, lane), 10.f / B, du, dv);
       row_store(dR + (16 + r) * ldS, du, S, lane);
@@ -441,43 +455,51 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
     }
     if (lane == 0) red[16 + wave] = part;
     __syncthreads();
-    sum_aux = red[16] + red[17] + red[18] + red[19];
-    // ---- Moebius head backward, row-wise: dR -> dU (in place), per-row bias gradients to the workspace
+    for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
+    // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     const RowVec hb = row_load(PD + dl.head_b, S, lane);
-    for (int r = wave; r < 48; r += 4) {
+    RowVec dbacc;
+#pragma unroll
+    for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] = 0.f;
+    for (int r = wave; r < 48; r += nw) {
       RowVec du, db;
       head_row_bwd(row_load(ws + gw.u + (prow(r, B) + g0) * S, S, lane), hb, row_load(dR + r * ldS, S, lane), du, db);
       row_store(dR + r * ldS, du, S, lane);
-      row_store(ws + gw.dbrows + (prow(r, B) + g0) * S, db, S, lane);
+#pragma unroll
+      for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db.v[e];
     }
+    row_store(R + wave * ldS, dbacc, S, lane);          // R (the head outputs) is dead: reuse as [nw][ldS] scratch
     __syncthreads();
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += R[w * ldS + c];
+      ws[gw.ballpart + (int64_t)tile * S + c] = s;
+    }
     tile_store_p(ws + gw.du + (int64_t)g0 * S, S, B, dR, ldS, 48, S, 48);
+    __syncthreads();
     // dE = dU W_h for the two decoder passes
     gemm_nn<2>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
     __syncthreads();
     // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
-    for (int i = threadIdx.x; i < 32 * S; i += THREADS) {
-      int r = i / S, c = i - r * S;
-      float e = ws[gw.ecat + (prow(r, B) + g0) * S + c];
+    tile_for(32, S, [&](int r, int c) {
+      const float e = ws[gw.ecat + (prow(r, B) + g0) * S + c];
       R[r * ldS + c] *= 1.f - e * e;
-    }
+    });
     __syncthreads();
   } else {
     // ---- 10 * MSE(x, x_rec) (train.py:241-242): E in bufA (= R), gradients into bufB (= dR)
     float part = 0.f;
-    for (int i = threadIdx.x; i < 16 * S; i += THREADS) {
-      int r = i / S, c = i - r * S;
-      float diff = R[(16 + r) * ldS + c] - xs[r * ldS + c];
+    tile_for(16, S, [&](int r, int c) {
+      const float diff = R[(16 + r) * ldS + c] - xs[r * ldS + c];
       part += diff * diff;
       dR[(16 + r) * ldS + c] = 20.f * diff / ((float)B * (float)S);
-    }
+    });
     sum_aux = block_sum(part, red);
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * S; i += THREADS) {
-      int r = i / S, c = i - r * S;
-      float e = R[r * ldS + c];
+    tile_for(32, S, [&](int r, int c) {
+      const float e = R[r * ldS + c];
       dR[r * ldS + c] *= 1.f - e * e;
-    }
+    });
     __syncthreads();
   }
   float* dP = HYPER ? R : dR;               // d(pre-tanh) [32][ldS]
@@ -494,10 +516,7 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   lstm_bwd_data_tile<2>(dP, ldG, PD, dl.l[1][0], dl.l[1][1], DEC_H, 2 * DEC_H, oth, ldH);
   __syncthreads();
   if (a.drop_mode != 0) {
-    for (int i = threadIdx.x; i < 32 * 2 * DEC_H; i += THREADS) {
-      int r = i / (2 * DEC_H), c = i - r * (2 * DEC_H);
-      oth[r * ldH + c] *= ws[gw.mask + (prow(r, B) + g0) * 2 * DEC_H + c];
-    }
+    tile_for(32, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow(r, B) + g0) * 2 * DEC_H + c]; });
     __syncthreads();
   }
   // layer 0
@@ -510,10 +529,7 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   // dZ = dA0 W1 ; only pass 1 (the encoder's output) is needed further
   gemm_nn<2>(oth, ldA0, 0, PD + dl.d1_w, L, DEC_D1, identity_map(), L, dP, LP, false);
   __syncthreads();
-  for (int i = threadIdx.x; i < 16 * L; i += THREADS) {
-    int r = i / L, c = i - r * L;
-    dzs[r * LP + c] = dP[(16 + r) * LP + c] + dzc[r * LP + c];
-  }
+  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[(16 + r) * LP + c] + dzc[r * LP + c]; });
   __syncthreads();
   tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
   // ---- encoder backward
@@ -528,6 +544,34 @@ __global__ __launch_bounds__(THREADS) void gen_kernel(IterArgs a) {
   }
 }
 
+// ---- kernels: single iterations, and the critic_x || critic_z pair (blockIdx.z picks the critic)
+__global__ __launch_bounds__(TB) void cx_pass_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cx_pass_body(a, smem);
+}
+__global__ __launch_bounds__(TB) void cz_pass_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  cz_pass_body(a, smem);
+}
+__global__ __launch_bounds__(TB) void critic_pass_pair_kernel(IterArgs ax, IterArgs az) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.z == 0) cx_pass_body(ax, smem); else cz_pass_body(az, smem);
+}
+template <bool IS_X>
+__global__ __launch_bounds__(TB) void critic_gp_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gp_body<IS_X>(a, smem);
+}
+__global__ __launch_bounds__(TB) void critic_gp_pair_kernel(IterArgs ax, IterArgs az) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.z == 0) gp_body<true>(ax, smem); else gp_body<false>(az, smem);
+}
+template <bool HYPER>
+__global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gen_body<HYPER>(a, smem);
+}
+
 // ------------------------------------------------------------------------------------------------ dW + Adam
 enum DwKind : int { DW_WEIGHT = 0, DW_BIAS = 1, DW_DECAY = 2, DW_BALL = 3 };
 struct DwDesc {
@@ -538,12 +582,14 @@ struct DwDesc {
   int32_t p_off2;                             // second destination with the same gradient (b_hh), or -1
   int32_t begin;                              // first work item
 };
-constexpr int MAX_DESC = 60;
-struct DwTable {
+template <int CAP>
+struct DwTableT {
   int n, total_items;
   int finalize;                               // 0 none, 1 generator losses
-  DwDesc d[MAX_DESC];
+  DwDesc d[CAP];
 };
+using DwTable = DwTableT<60>;                 // generator
+using DwTableS = DwTableT<12>;                // one critic
 
 struct AdamCoef {
   float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2;
@@ -607,7 +653,10 @@ __device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, Ro
   row_store(v, V, dim, lane);
 }
 
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
+// One work item = one wave: a 16x16 weight tile (dW on MFMA, Adam in the accumulator registers), 16 bias columns,
+// 256 decay-only elements, or the ball-valued bias vector.
+template <class Table>
+__device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
   const int sig = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -627,17 +676,24 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable ta
     if (d.kind == DW_WEIGHT) {
       const int tk = (d.ncols + 15) >> 4;
       const int n0 = (local / tk) * 16, k0 = (local % tk) * 16;
-      const float* left = ws + d.left_off;
-      const float* right = ws + d.right_off;
-      const bool av = n0 + j < d.nrows, bv = k0 + j < d.ncols;
+      // out-of-range columns are clamped (their results are dropped below); rows past red_rows contribute zeros
+      const int nj = n0 + j < d.nrows ? n0 + j : d.nrows - 1, kj = k0 + j < d.ncols ? k0 + j : d.ncols - 1;
+      const float* left = ws + d.left_off + nj;
+      const float* right = ws + d.right_off + kj;
+      const int rlast = d.red_rows - 1;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int rr = 0; rr < d.red_rows; rr += 4) {
-        const int r = rr + q;
-        const bool rv = r < d.red_rows;
-        const float av_ = (rv && av) ? left[(int64_t)r * d.left_ld + n0 + j] : 0.f;
-        const float bv_ = (rv && bv) ? right[(int64_t)r * d.right_ld + k0 + j] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, bv_, acc, 0, 0, 0);
+      for (int rc = 0; rc < d.red_rows; rc += 64) {
+        float la[16], rb[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = rc + 4 * u + q;
+          const int rr = r < rlast ? r : rlast;
+          la[u] = left[(int64_t)rr * d.left_ld];
+          rb[u] = right[(int64_t)rr * d.right_ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -650,11 +706,25 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable ta
         }
       }
     } else if (d.kind == DW_BIAS) {
-      const int n = local * 64 + lane;
-      if (n < d.nrows) {
-        const float* left = ws + d.left_off;
-        float g = 0.f;
-        for (int r = 0; r < d.red_rows; ++r) g += left[(int64_t)r * d.left_ld + n];
+      // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
+      const int n = local * 16 + j;
+      const bool nv = n < d.nrows;
+      const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
+      const int rlast = d.red_rows - 1;
+      float g = 0.f;
+      for (int rc = 0; rc < d.red_rows; rc += 64) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = rc + 4 * u + q;
+          t[u] = left[(int64_t)(r < rlast ? r : rlast) * d.left_ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
+      }
+      g += __shfl_xor(g, 16, WAVE);
+      g += __shfl_xor(g, 32, WAVE);
+      if (nv && q == 0) {
         int64_t o = d.p_off + n;
         float p = P[o], m = M[o], v = V[o];
         adam_update(p, m, v, g, co);
@@ -667,6 +737,7 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable ta
         }
       }
     } else if (d.kind == DW_DECAY) {
+#pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int n = local * 256 + e * 64 + lane;
         if (n < d.nrows) {
@@ -676,7 +747,7 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable ta
           P[o] = p; M[o] = m; V[o] = v;
         }
       }
-    } else {   // DW_BALL: hyperbolic_linear.bias
+    } else {   // DW_BALL: hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
       const float* left = ws + d.left_off;
       RowVec g;
 #pragma unroll
@@ -704,13 +775,19 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable ta
       lo[0] = 10.f * aux - fx / a.B - fz / a.B;
       lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
     }
-    if (blockIdx.y == 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
+    if (blockIdx.y == 0 && a.tick_owner) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
+}
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body(a, tab); }
+__global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
+__global__ __launch_bounds__(THREADS) void dw_adam_pair_kernel(IterArgs ax, DwTableS tx, IterArgs az, DwTableS tz) {
+  if (blockIdx.z == 0) dw_adam_body(ax, tx); else dw_adam_body(az, tz);
 }
 
 // ------------------------------------------------------------------------------------------------ host: tables
+template <class Table>
 struct TableBuilder {
-  DwTable t;
+  Table t;
   TableBuilder() { t.n = 0; t.total_items = 0; t.finalize = 0; }
   void push(DwDesc d, int items) {
     if (items <= 0) return;
@@ -728,7 +805,7 @@ struct TableBuilder {
     DwDesc d{};
     d.kind = DW_BIAS; d.net = (int16_t)net; d.p_off = p_off; d.p_off2 = p_off2; d.nrows = n; d.ncols = 1;
     d.left_off = left_off; d.left_ld = left_ld; d.red_rows = red;
-    push(d, (n + 63) / 64);
+    push(d, (n + 15) / 16);
   }
   void decay(int net, int p_off, int n) {
     DwDesc d{};
@@ -757,8 +834,8 @@ struct TableBuilder {
   }
 };
 
-DwTable critic_table(int net, const CriticLayout& cl, const CritWs& cw, int B, int L) {
-  TableBuilder tb;
+DwTableS critic_table(int net, const CriticLayout& cl, const CritWs& cw, int B, int L) {
+  TableBuilder<DwTableS> tb;
   for (int li = 0; li <= cl.nh; ++li) {
     int k = li == 0 ? cl.in_dim : L, n = li == cl.nh ? 1 : L;
     int right = li == 0 ? cw.in_right : cw.act[li - 1];
@@ -774,7 +851,7 @@ DwTable gen_table(const hypad_dims& dm) {
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
   const GenWs gw = gen_ws(B, S, L);
-  TableBuilder tb;
+  TableBuilder<DwTable> tb;
   tb.t.finalize = 1;
   for (int d = 0; d < 2; ++d)
     tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, B, hyp);
@@ -790,7 +867,7 @@ DwTable gen_table(const hypad_dims& dm) {
   tb.bias(HYPAD_NET_DECODER, dl.d2_b, -1, S, gw.dpre2, S, 2 * B);
   if (hyp) {
     tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
-    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.dbrows, S, 3 * B);
+    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, B / 16);
   }
   return tb.t;
 }
@@ -816,6 +893,7 @@ struct IterCall {
   void* workspace; size_t workspace_bytes;
 };
 
+// opt: 0 critic_x, 1 critic_z, 2 generator
 int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, const IterCall& io, int opt) {
   int rc = check_dims(d);
   if (rc) return rc;
@@ -831,99 +909,148 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.x = io.x; a.x_sig_stride = io.x_sig_stride; a.row_index = io.row_index;
   a.z = io.z; a.alpha = io.alpha;
   a.drop_mode = io.train_mode ? (io.masks ? 1 : 2) : 0;
-  a.masks = io.masks; a.mask_sig_stride = 0; a.seed = io.seed;
+  a.masks = io.masks; a.seed = io.seed;
   a.losses = io.losses; a.loss_sig_stride = io.loss_sig_stride;
-  a.ws = (float*)io.workspace; a.ws_sig_stride = per;
+  a.ws = (float*)io.workspace + (opt == 1 ? ws_cz_offset(*d) : 0);
+  a.ws_sig_stride = per;
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
-  a.opt = opt;
+  a.opt = opt; a.tick_owner = 1;
+  if (opt == 0) {
+    if (!st->exp_avg.cx || !st->exp_avg_sq.cx) return HYPAD_EINVAL;
+    a.mask_sig_stride = (int64_t)12 * a.B * a.L + (int64_t)a.B * 2 * DEC_H;
+  } else if (opt == 1) {
+    if (!st->exp_avg.cz || !st->exp_avg_sq.cz) return HYPAD_EINVAL;
+    a.mask_sig_stride = (int64_t)6 * a.B * a.L;
+  } else {
+    if (!st->exp_avg.enc || !st->exp_avg_sq.enc || !st->exp_avg.dec || !st->exp_avg_sq.dec) return HYPAD_EINVAL;
+    a.mask_sig_stride = (int64_t)6 * a.B * a.L + (int64_t)2 * a.B * 2 * DEC_H;
+    if (a.hyperbolic) { a.riemannian = 1; a.wd = st->gen_weight_decay; a.stabilize = st->gen_stabilize; }
+  }
   return HYPAD_OK;
 }
 
 // Optional profiling marks: ev[k] is recorded on the stream after the k-th kernel of an iteration (ev[0] before the first).
 #define HYPAD_MARK(ev, k, s) do { if (ev) (void)hipEventRecord((ev)[k], s); } while (0)
 
-int launch_dw(const IterArgs& a, const DwTable& tab, int n_signals, hipStream_t s) {
-  int blocks = (tab.total_items + 3) / 4;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(dw_adam_kernel, dim3(blocks, n_signals), dim3(THREADS), 0, s, a, tab);
-  HYPAD_CHECK_LAUNCH();
-  return HYPAD_OK;
+inline int dw_blocks(int items) { int b = (items + 3) / 4; return b < 1 ? 1 : b; }
+inline size_t cx_pass_lds(const IterArgs& a) {
+  return (size_t)lds_plan(a.S, 16, 16, cx_layout(a.S, a.L).total, critic_batch_lds_floats(48, a.L)).total * sizeof(float);
 }
+inline size_t cz_pass_lds(const IterArgs& a) {
+  return (size_t)lds_plan(a.S, 16, 16, cz_layout(a.L).total, critic_batch_lds_floats(48, a.L)).total * sizeof(float);
+}
+inline size_t gp_x_lds(const IterArgs& a) { return (size_t)gp_lds_floats(a.S, cx_layout(a.S, a.L).total) * sizeof(float); }
+inline size_t gp_z_lds(const IterArgs& a) { return (size_t)gp_lds_floats(a.L, cz_layout(a.L).total) * sizeof(float); }
 
 int run_cx(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 0);
   if (rc) return rc;
-  if (!st->exp_avg.cx || !st->exp_avg_sq.cx) return HYPAD_EINVAL;
-  a.mask_sig_stride = (int64_t)12 * a.B * a.L + (int64_t)a.B * 2 * DEC_H;
-  const LdsPlan lp = lds_plan(a.S, 16, 16);
-  size_t lds = (size_t)lp.total * sizeof(float);
+  const size_t lds = cx_pass_lds(a), lds2 = gp_x_lds(a);
   hipError_t e = allow_lds((const void*)cx_pass_kernel, lds);
+  if (e == hipSuccess) e = allow_lds((const void*)critic_gp_kernel<true>, lds2);
   if (e != hipSuccess) return (int)e;
   dim3 grid(a.B / 16, d->n_signals);
   HYPAD_MARK(ev, 0, s);
-  hipLaunchKernelGGL(cx_pass_kernel, grid, dim3(THREADS), lds, s, a);
+  hipLaunchKernelGGL(cx_pass_kernel, grid, dim3(TB), lds, s, a);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
-  size_t lds2 = (size_t)(16 * (pad4(a.S) + 4) + 2 * 16 * LP) * sizeof(float);
-  hipLaunchKernelGGL(critic_gp_kernel<true>, grid, dim3(THREADS), lds2, s, a);
+  hipLaunchKernelGGL(critic_gp_kernel<true>, grid, dim3(TB), lds2, s, a);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
-  rc = launch_dw(a, critic_table(HYPAD_NET_CRITIC_X, cx_layout(a.S, a.L), crit_ws(a.B, a.S, a.L, 4), a.B, a.L), d->n_signals, s);
+  const DwTableS tab = critic_table(HYPAD_NET_CRITIC_X, cx_layout(a.S, a.L), crit_ws(a.B, a.S, a.L, 4), a.B, a.L);
+  hipLaunchKernelGGL(dw_adam_small_kernel, dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 3, s);
-  return rc;
+  return HYPAD_OK;
 }
 
 int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 1);
   if (rc) return rc;
-  if (!st->exp_avg.cz || !st->exp_avg_sq.cz) return HYPAD_EINVAL;
-  a.mask_sig_stride = (int64_t)6 * a.B * a.L;
-  const LdsPlan lp = lds_plan(a.S, 16, 16);
-  size_t lds = (size_t)lp.total * sizeof(float);
+  const size_t lds = cz_pass_lds(a), lds2 = gp_z_lds(a);
   hipError_t e = allow_lds((const void*)cz_pass_kernel, lds);
+  if (e == hipSuccess) e = allow_lds((const void*)critic_gp_kernel<false>, lds2);
   if (e != hipSuccess) return (int)e;
   dim3 grid(a.B / 16, d->n_signals);
   HYPAD_MARK(ev, 0, s);
-  hipLaunchKernelGGL(cz_pass_kernel, grid, dim3(THREADS), lds, s, a);
+  hipLaunchKernelGGL(cz_pass_kernel, grid, dim3(TB), lds, s, a);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
-  size_t lds2 = (size_t)(16 * (pad4(a.L) + 4) + 2 * 16 * LP) * sizeof(float);
-  hipLaunchKernelGGL(critic_gp_kernel<false>, grid, dim3(THREADS), lds2, s, a);
+  hipLaunchKernelGGL(critic_gp_kernel<false>, grid, dim3(TB), lds2, s, a);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
-  rc = launch_dw(a, critic_table(HYPAD_NET_CRITIC_Z, cz_layout(a.L), crit_ws(a.B, a.L, a.L, 2), a.B, a.L), d->n_signals, s);
+  const DwTableS tab = critic_table(HYPAD_NET_CRITIC_Z, cz_layout(a.L), crit_ws(a.B, a.L, a.L, 2), a.B, a.L);
+  hipLaunchKernelGGL(dw_adam_small_kernel, dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 3, s);
-  return rc;
+  return HYPAD_OK;
+}
+
+// critic_x_iteration and critic_z_iteration of one minibatch side by side (train.py:320-327: disjoint weights, frozen
+// generator): three launches with blockIdx.z selecting the critic.  losses_x / losses_z: where each writes its 4 floats.
+int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, float* losses_x, float* losses_z,
+                    hipStream_t s, hipEvent_t* ev = nullptr) {
+  IterArgs ax, az;
+  IterCall cx = io, cz = io;
+  cx.losses = losses_x; cz.losses = losses_z;
+  int rc = fill_args(ax, d, st, cx, 0);
+  if (rc) return rc;
+  rc = fill_args(az, d, st, cz, 1);
+  if (rc) return rc;
+  az.tick_owner = 0;                       // one rng tick per launch group; the two critics use distinct Philox streams
+  az.seed = ax.seed ^ 0x5851F42D4C957F2DULL;
+  size_t lds = cx_pass_lds(ax), l2 = cz_pass_lds(az);
+  if (l2 > lds) lds = l2;
+  size_t ldsg = gp_x_lds(ax), g2 = gp_z_lds(az);
+  if (g2 > ldsg) ldsg = g2;
+  hipError_t e = allow_lds((const void*)critic_pass_pair_kernel, lds);
+  if (e == hipSuccess) e = allow_lds((const void*)critic_gp_pair_kernel, ldsg);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(ax.B / 16, d->n_signals, 2);
+  HYPAD_MARK(ev, 0, s);
+  hipLaunchKernelGGL(critic_pass_pair_kernel, grid, dim3(TB), lds, s, ax, az);
+  HYPAD_CHECK_LAUNCH();
+  HYPAD_MARK(ev, 1, s);
+  hipLaunchKernelGGL(critic_gp_pair_kernel, grid, dim3(TB), ldsg, s, ax, az);
+  HYPAD_CHECK_LAUNCH();
+  HYPAD_MARK(ev, 2, s);
+  const DwTableS tx = critic_table(HYPAD_NET_CRITIC_X, cx_layout(ax.S, ax.L), crit_ws(ax.B, ax.S, ax.L, 4), ax.B, ax.L);
+  const DwTableS tz = critic_table(HYPAD_NET_CRITIC_Z, cz_layout(az.L), crit_ws(az.B, az.L, az.L, 2), az.B, az.L);
+  const int items = tx.total_items > tz.total_items ? tx.total_items : tz.total_items;
+  hipLaunchKernelGGL(dw_adam_pair_kernel, dim3(dw_blocks(items), d->n_signals, 2), dim3(THREADS), 0, s, ax, tx, az, tz);
+  HYPAD_CHECK_LAUNCH();
+  HYPAD_MARK(ev, 3, s);
+  return HYPAD_OK;
 }
 
 int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
-  if (!st->exp_avg.enc || !st->exp_avg_sq.enc || !st->exp_avg.dec || !st->exp_avg_sq.dec) return HYPAD_EINVAL;
-  a.mask_sig_stride = (int64_t)6 * a.B * a.L + (int64_t)2 * a.B * 2 * DEC_H;
-  if (a.hyperbolic) { a.riemannian = 1; a.wd = st->gen_weight_decay; a.stabilize = st->gen_stabilize; }
   dim3 grid(a.B / 16, d->n_signals);
+  const int cf = cx_layout(a.S, a.L).total + cz_layout(a.L).total;
   HYPAD_MARK(ev, 0, s);
   if (a.hyperbolic) {
-    size_t lds = (size_t)lds_plan(a.S, 32, 48).total * sizeof(float);
+    size_t lds = (size_t)lds_plan(a.S, 32, 48, cf).total * sizeof(float);
     if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
     hipError_t e = allow_lds((const void*)gen_kernel<true>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gen_kernel<true>, grid, dim3(THREADS), lds, s, a);
+    hipLaunchKernelGGL(gen_kernel<true>, grid, dim3(TB), lds, s, a);
   } else {
-    size_t lds = (size_t)lds_plan(a.S, 32, 32).total * sizeof(float);
+    size_t lds = (size_t)lds_plan(a.S, 32, 32, cf).total * sizeof(float);
     hipError_t e = allow_lds((const void*)gen_kernel<false>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gen_kernel<false>, grid, dim3(THREADS), lds, s, a);
+    hipLaunchKernelGGL(gen_kernel<false>, grid, dim3(TB), lds, s, a);
   }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
-  rc = launch_dw(a, gen_table(*d), d->n_signals, s);
+  const DwTable tab = gen_table(*d);
+  hipLaunchKernelGGL(dw_adam_kernel, dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
-  return rc;
+  return HYPAD_OK;
 }
 
 IterCall from_io(const hypad_iter_io* io) {
@@ -981,16 +1108,20 @@ int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, co
 // dw_adam).  Not capturable (creates events, synchronises).
 int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, float* ms_out,
                             int n_out, hypad_stream_t s) {
-  if (!io || !ms_out || kind < 0 || kind > 2) return HYPAD_EINVAL;
+  if (!io || !ms_out || kind < 0 || kind > 3) return HYPAD_EINVAL;
   const int nk = kind == 2 ? 2 : 3;
   if (n_out < nk) return HYPAD_EINVAL;
+  if (kind == 3 && !io->losses) return HYPAD_EINVAL;
   hipEvent_t ev[4];
   for (int i = 0; i <= nk; ++i) {
     hipError_t e = hipEventCreate(&ev[i]);
     if (e != hipSuccess) return (int)e;
   }
-  int rc = kind == 0 ? run_cx(d, st, from_io(io), (hipStream_t)s, ev) : kind == 1 ? run_cz(d, st, from_io(io), (hipStream_t)s, ev)
-                                                                                    : run_gen(d, st, from_io(io), (hipStream_t)s, ev);
+  int rc;
+  if (kind == 0) rc = run_cx(d, st, from_io(io), (hipStream_t)s, ev);
+  else if (kind == 1) rc = run_cz(d, st, from_io(io), (hipStream_t)s, ev);
+  else if (kind == 2) rc = run_gen(d, st, from_io(io), (hipStream_t)s, ev);
+  else rc = run_critic_pair(d, st, from_io(io), io->losses, io->losses + 4 * (int64_t)d->n_signals, (hipStream_t)s, ev);
   if (rc == HYPAD_OK) {
     hipError_t e = hipStreamSynchronize((hipStream_t)s);
     if (e != hipSuccess) rc = (int)e;
@@ -1018,11 +1149,9 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   for (int k = 0; k < io->n_critics; ++k) {            // train.py:315-328
     for (int b = 0; b < io->n_batches; ++b) {
       c.row_index = io->row_index + k * pass_rows + (int64_t)b * d->batch;
-      c.losses = io->losses + (int64_t)(it++) * 4;
-      rc = run_cx(d, st, c, (hipStream_t)s);
-      if (rc) return rc;
-      c.losses = io->losses + (int64_t)(it++) * 4;
-      rc = run_cz(d, st, c, (hipStream_t)s);
+      c.losses = io->losses;               // (validated by fill_args; the pair writes to the two pointers below)
+      rc = run_critic_pair(d, st, c, io->losses + (int64_t)it * 4, io->losses + (int64_t)(it + 1) * 4, (hipStream_t)s);
+      it += 2;
       if (rc) return rc;
     }
   }

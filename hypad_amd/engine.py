@@ -103,9 +103,10 @@ class Engine:
         return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks)
 
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
-        """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder), HIP events on the current stream."""
+        """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair),
+        HIP events on the current stream."""
         x, stride = self._check_x(x)
-        losses = torch.empty(self.n, 4, dtype=torch.float32, device=self.device)
+        losses = torch.empty(2 * self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None, self.seed, 0)
         io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(), None, None, drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)

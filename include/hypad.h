@@ -210,7 +210,8 @@ typedef struct hypad_epoch_io {
 } hypad_epoch_io;
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
-/* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder) with HIP events
+/* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder, 3 = the critic_x ||
+ * critic_z pair that hypad_train_epoch launches; its losses need room for 2 * n_signals * 4 floats) with HIP events
  * recorded on `stream` between its kernels, synchronise, and return the per-kernel durations in ms:
  * critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam}; decoder -> {generator kernel, dW+Adam}.
  * Not capturable into a graph. */
