@@ -25,19 +25,31 @@ __device__ __forceinline__ CriticBatchLds critic_batch_lds(float* base, int R, i
   return c;
 }
 
+// dot product of two 16-byte aligned rows (K % 4 == 0) or of arbitrary rows (scalar tail-free fallback)
+__device__ __forceinline__ float dot_rows(const float* __restrict__ x, const float* __restrict__ w, int K) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if ((K & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+#pragma unroll 5
+    for (int k = 0; k < K; k += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + k);
+      const float4 wv = *reinterpret_cast<const float4*>(w + k);
+      a0 += xv.x * wv.x; a1 += xv.y * wv.y; a2 += xv.z * wv.z; a3 += xv.w * wv.w;
+    }
+  } else {
+    int k = 0;
+    for (; k + 1 < K; k += 2) { a0 += x[k] * w[k]; a1 += x[k + 1] * w[k + 1]; }
+    if (k < K) a2 += x[k] * w[k];
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
 // out[r][c] = sum_k in[r][k] * W[c][k] + b[c]   (W row-major (N, K), in LDS or global through a flat pointer)
 template <class Epi>
 __device__ __forceinline__ void dense_rows_valu(const float* in, int ldin, int K, const float* W, const float* b, int R, int N, Epi epi) {
   const int total = R * N;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int r = idx / N, c = idx - r * N;
-    const float* x = in + r * ldin;
-    const float* w = W + c * K;
-    float a0 = b ? b[c] : 0.f, a1 = 0.f;
-    int k = 0;
-    for (; k + 1 < K; k += 2) { a0 += x[k] * w[k]; a1 += x[k + 1] * w[k + 1]; }
-    if (k < K) a0 += x[k] * w[k];
-    epi(r, c, a0 + a1);
+    epi(r, c, dot_rows(in + r * ldin, W + c * K, K) + (b ? b[c] : 0.f));
   }
 }
 // out[r][c] = sum_o d[r][o] * W[o][c]   (W row-major (No, C))
@@ -47,11 +59,15 @@ __device__ __forceinline__ void dense_rows_valu_t(const float* d, int ldd, int N
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int r = idx / C, c = idx - r * C;
     const float* dr = d + r * ldd;
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int o = 0;
-    for (; o + 1 < No; o += 2) { a0 += dr[o] * W[o * C + c]; a1 += dr[o + 1] * W[(o + 1) * C + c]; }
-    if (o < No) a0 += dr[o] * W[o * C + c];
-    epi(r, c, a0 + a1);
+#pragma unroll 2
+    for (; o + 3 < No; o += 4) {
+      a0 += dr[o] * W[o * C + c]; a1 += dr[o + 1] * W[(o + 1) * C + c];
+      a2 += dr[o + 2] * W[(o + 2) * C + c]; a3 += dr[o + 3] * W[(o + 3) * C + c];
+    }
+    for (; o < No; ++o) a0 += dr[o] * W[o * C + c];
+    epi(r, c, (a0 + a1) + (a2 + a3));
   }
 }
 
@@ -71,12 +87,7 @@ __device__ __forceinline__ void critic_batch_fwd(InRow in_row, const float* P, c
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
       const int r = idx / L, c = idx - r * L;
       const float* x = li == 0 ? in_row(r) : s.act + (li - 1) * R * LQ + r * LQ;
-      const float* w = W + c * K;
-      float a0 = b[c], a1 = 0.f;
-      int k = 0;
-      for (; k + 1 < K; k += 2) { a0 += x[k] * w[k]; a1 += x[k + 1] * w[k + 1]; }
-      if (k < K) a0 += x[k] * w[k];
-      const float pre = a0 + a1;
+      const float pre = dot_rows(x, W + c * K, K) + b[c];
       const float dd = leaky_slope(pre) * drop(li, r, c);
       dmk[r * LQ + c] = dd;
       a[r * LQ + c] = pre * dd;

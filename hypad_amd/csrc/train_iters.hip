@@ -682,18 +682,20 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       const float* right = ws + d.right_off + kj;
       const int rlast = d.red_rows - 1;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int rc = 0; rc < d.red_rows; rc += 64) {
-        float la[16], rb[16];
+      for (int rc = 0; rc < d.red_rows; rc += 192) {       // 48 k-steps per chunk: B <= 64 -> one memory round trip
+        float la[48], rb[48];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 48; ++u) {
           const int r = rc + 4 * u + q;
           const int rr = r < rlast ? r : rlast;
           la[u] = left[(int64_t)rr * d.left_ld];
           rb[u] = right[(int64_t)rr * d.right_ld];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
+        for (int u = 0; u < 48; ++u)
+          if (rc + 4 * u < d.red_rows)             // wave-uniform
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
