@@ -113,6 +113,8 @@ _SIGS = {
     "hypad_dtw_error": (c_int, [P, P, P, c_int64, c_int, P]),
     "hypad_rolling_mean": (c_int, [P, P, c_int64, c_int, P]),
     "hypad_zscore_clip": (c_int, [P, P, c_int64, P, c_size_t, P]),
+    "hypad_kde_mode": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_critic_zscore": (c_int, [P, c_double, c_double, P, c_int64, P, c_size_t, P]),
     "hypad_row_norms": (c_int, [P, P, c_int64, c_int, P]),
     "hypad_combine_scores": (c_int, [c_int, P, P, P, P, c_int64, P]),
 }

@@ -213,6 +213,111 @@ __global__ __launch_bounds__(THREADS) void zscore_apply_kernel(const double* __r
   }
 }
 
+// ---- critic smoothing: final_critic_scores :365-404.  Timestep t sees the critic values of the
+// windows covering it, critic[t - j] for the valid j (each window's score repeated along the window, un-rolled along
+// anti-diagonals).  Its score is the sample at which a Scott-bandwidth Gaussian KDE of those values is largest
+// (scipy.stats.gaussian_kde(v)(v), first arg-max), the median when fewer than two values or a singular covariance.
+__global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
+                                                            int64_t n, int W) {
+  __shared__ double vals[THREADS / 64][MAX_WINDOW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t T = n + W - 1;
+  double* v = vals[wave];
+  for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
+    const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
+    const int j1 = (int)(t + 1 < W ? t + 1 : W);
+    const int cnt = j1 - j0;
+    double s = 0.0;
+    for (int k = lane; k < cnt; k += 64) {
+      const double x = (double)critic[t - (j0 + k)];
+      v[k] = x;
+      s += x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const double mean = wave_sum(s) / (double)cnt;
+    double q = 0.0;
+    for (int k = lane; k < cnt; k += 64) { const double d = v[k] - mean; q += d * d; }
+    const double var = cnt > 1 ? wave_sum(q) / (double)(cnt - 1) : 0.0;          // np.cov: ddof = 1
+    const double cov = var * pow((double)cnt, -0.4);                              // Scott: factor = n^(-1/5), squared
+    double out;
+    if (cnt > 1 && cov > 0.0 && cov == cov) {
+      const double inv = 0.5 / cov;
+      double best = -1.0;
+      int besti = 0x7fffffff;
+      for (int k = lane; k < cnt; k += 64) {
+        const double xk = v[k];
+        double dens = 0.0;
+        for (int m = 0; m < cnt; ++m) { const double d = xk - v[m]; dens += exp(-d * d * inv); }
+        if (dens > best) { best = dens; besti = k; }                               // k ascending per lane: first max kept
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, WAVE);
+        const int oi = __shfl_xor(besti, off, WAVE);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      }
+      out = v[besti];
+    } else {
+      // median by rank counting (cnt <= 256)
+      double lo = 0.0, hi = 0.0;
+      for (int k = lane; k < cnt; k += 64) {
+        const double xk = v[k];
+        int rank = 0;
+        for (int m = 0; m < cnt; ++m) rank += (v[m] < xk) || (v[m] == xk && m < k);
+        if (rank == (cnt - 1) / 2) lo = xk;
+        if (rank == cnt / 2) hi = xk;
+      }
+      out = 0.5 * (wave_sum(lo) + wave_sum(hi));
+    }
+    if (lane == 0) modes[t] = out;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// _compute_critic_score :307-333 without the rolling mean: stats[0] = mean of the values inside [lo, hi],
+// stats[1] = population std of all values; out = |x - mean| / std + 1.
+__global__ __launch_bounds__(1024) void critic_stats_kernel(const double* __restrict__ in, double lo, double hi,
+                                                             double* __restrict__ stats, int64_t T) {
+  __shared__ double part[3][16];
+  __shared__ double mean_all;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s = 0.0, sr = 0.0, cr = 0.0;
+  for (int64_t i = threadIdx.x; i < T; i += 1024) {
+    const double x = in[i];
+    s += x;
+    if (x >= lo && x <= hi) { sr += x; cr += 1.0; }
+  }
+  s = wave_sum(s); sr = wave_sum(sr); cr = wave_sum(cr);
+  if (lane == 0) { part[0][wave] = s; part[1][wave] = sr; part[2][wave] = cr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int k = 0; k < 16; ++k) { a += part[0][k]; b += part[1][k]; c += part[2][k]; }
+    mean_all = a / (double)T;
+    stats[0] = b / c;
+  }
+  __syncthreads();
+  const double m = mean_all;
+  double q = 0.0;
+  for (int64_t i = threadIdx.x; i < T; i += 1024) { const double d = in[i] - m; q += d * d; }
+  q = wave_sum(q);
+  __syncthreads();
+  if (lane == 0) part[0][wave] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int k = 0; k < 16; ++k) a += part[0][k];
+    stats[1] = sqrt(a / (double)T);
+  }
+}
+__global__ __launch_bounds__(THREADS) void critic_apply_kernel(const double* __restrict__ in, const double* __restrict__ stats,
+                                                                double* __restrict__ out, int64_t T) {
+  const double mean = stats[0], sd = stats[1];
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS)
+    out[i] = fabs((in[i] - mean) / sd) + 1.0;
+}
+
 __global__ __launch_bounds__(THREADS) void row_norms_kernel(const float* __restrict__ x, double* __restrict__ out, int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
   for (int64_t r = (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * (THREADS / 64)) {
@@ -305,6 +410,23 @@ int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace,
   hipLaunchKernelGGL(zscore_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, in, (double*)workspace, t);
   HYPAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, (const double*)workspace, out, t);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hypad_stream_t s) {
+  if (!critic || !modes || n <= 0 || window <= 0) return HYPAD_EINVAL;
+  if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
+  hipLaunchKernelGGL(kde_mode_kernel, dim3(grid_for(n + window - 1, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_critic_zscore(const double* in, double q25, double q75, double* out, int64_t t, void* workspace, size_t workspace_bytes,
+                        hypad_stream_t s) {
+  if (!in || !out || t <= 0) return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < 4 * sizeof(double)) return HYPAD_EWORKSPACE;
+  hipLaunchKernelGGL(critic_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, in, q25, q75, (double*)workspace, t);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(critic_apply_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, (const double*)workspace, out, t);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

@@ -149,3 +149,55 @@ def combine_euclidean(comb, critic_scores, rec_scores):
     out = torch.empty_like(r)
     _C.check(_C.lib.hypad_combine_scores(_C.COMB[mode], _C.ptr(c), _C.ptr(r), None, _C.ptr(out), r.numel(), _C.stream()), "combine")
     return out.cpu().numpy()
+
+
+def _compute_critic_score(critics, smooth_window):
+    """:307-333 -- quantile-trimmed mean, |z| + 1, centred rolling mean.  The two quantiles are the only step left to
+    torch (a device sort); everything else is one reduction kernel + one elementwise kernel + the rolling mean."""
+    c = _f64(critics)
+    q = torch.quantile(c, torch.tensor([0.25, 0.75], dtype=torch.float64, device=c.device))
+    out = torch.empty_like(c)
+    ws = torch.empty(4, device=c.device, dtype=torch.float64)
+    _C.check(_C.lib.hypad_critic_zscore(_C.ptr(c), float(q[0]), float(q[1]), _C.ptr(out), c.numel(), _C.ptr(ws), 32, _C.stream()),
+             "critic_zscore")
+    return rolling_mean(out, smooth_window)
+
+
+def kde_modes(critic_score, window):
+    """Per un-rolled timestep, the KDE mode of the covering windows' critic values (:374-400)."""
+    c = _f32(critic_score).reshape(-1)
+    n = c.numel()
+    modes = torch.empty(n + window - 1, device=c.device, dtype=torch.float64)
+    _C.check(_C.lib.hypad_kde_mode(_C.ptr(c), _C.ptr(modes), n, int(window), _C.stream()), "kde_mode")
+    return modes
+
+
+def final_critic_scores(critic_score, true_signal):
+    """:365-404."""
+    n, w = true_signal.shape[0], true_signal.shape[1]
+    return _compute_critic_score(kde_modes(critic_score, w), math.trunc(n * 0.01)).cpu().numpy()
+
+
+def score_anomalies(y, y_hat, critic, index=None, score_window=10, critic_smooth_window=None, error_smooth_window=None,
+                    smooth=True, rec_error_type="point", comb="mult", lambda_rec=0.5, path=None, samples_num="0"):
+    """:407-576 without the pickle caches (``path`` is ignored).  Returns (final_scores, true_index, true, predictions)."""
+    if lambda_rec != 0.5:
+        raise NotImplementedError("lambda_rec != 0.5")
+    n = y.shape[0]
+    critic_smooth_window = critic_smooth_window or math.trunc(n * 0.01)
+    error_smooth_window = error_smooth_window or math.trunc(n * 0.01)
+    critic_scores = _compute_critic_score(kde_modes(critic, y_hat.shape[1]), critic_smooth_window)
+    rec, predictions = reconstruction_errors(y, y_hat, 1, score_window, error_smooth_window, smooth, rec_error_type)
+    rec_scores = zscore_clip(rec)
+    final = combine_euclidean(comb, critic_scores, rec_scores)
+    true = [[float(t)] for t in unroll_true(y).cpu().numpy()]
+    return final, index, true, predictions
+
+
+def hyperbolic_scores(recons_signal, true_signal, critic_score, signal_shape, combination="mult"):
+    """The hyperbolic branch of univariate_anomaly_detection (:54-86) up to final_scores."""
+    rec = hyperbolic_rec_scores(recons_signal, true_signal, signal_shape)
+    critic_scores = []
+    if combination in ("mult", "uncertainty", "sum", "sum_uncertainty", "critic", "critic_uncertainty"):
+        critic_scores = final_critic_scores(critic_score, np.asarray(true_signal).reshape(len(true_signal), -1))[: rec.shape[0]]
+    return combine_scores(combination, critic_scores, rec, recons_signal)

@@ -248,6 +248,13 @@ int hypad_dtw_error(const double* y, const float* y_hat, double* out, int64_t t,
 int hypad_rolling_mean(const double* in, double* out, int64_t t, int window, hypad_stream_t stream);
 /* stats.zscore -> clip(min=0) + 1  :523-524,542-543.  workspace: 4 doubles */
 int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
+/* final_critic_scores :365-404 (also :470-504), KDE step: modes (n + window - 1) fp64 -- for every un-rolled timestep
+ * the window-critic value at which scipy.stats.gaussian_kde of the covering windows' values peaks (median fallback). */
+int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hypad_stream_t stream);
+/* _compute_critic_score :307-322: out = |x - mean(x within [q25, q75])| / std(x) + 1 (quantiles supplied by the caller;
+ * the rolling mean of :325-330 is hypad_rolling_mean).  workspace: 4 doubles */
+int hypad_critic_zscore(const double* in, double q25, double q75, double* out, int64_t t, void* workspace,
+                        size_t workspace_bytes, hypad_stream_t stream);
 /* np.linalg.norm(recons, axis=1)  :341,347,350,359 */
 int hypad_row_norms(const float* x, double* out, int64_t rows, int dim, hypad_stream_t stream);
 /* combine_scores :336-362 */

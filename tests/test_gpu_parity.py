@@ -332,6 +332,54 @@ def test_every_step_matches_oracle_at_current_weights(dev, hyper):
         assert abs(float(g[0, 1]) - float(r[2] if not hyper else r[1])) < TOL, ("aux", i)
 
 
+@pytest.mark.parametrize("S,B,hyper", [(150, 256, True), (123, 64, True), (51, 32, False)])
+def test_other_window_sizes_match_oracle(dev, S, B, hyper):
+    """BASELINE configs[3] (multivariate: S=150, B=256) and the odd window sizes of the reference's YAMLs
+    (WADI 123, SWAT 51: configs/multivariate.yaml:5) -- the latter exercise the unaligned GEMM paths."""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    from oracle import train_iters as oi
+    torch.manual_seed(S)
+    mods = dict(enc=ot.Encoder(S, 20).eval(), dec=ot.Decoder(S, 20, hyper).eval(), cx=ot.CriticX(S, 20).eval(), cz=ot.CriticZ(20).eval())
+    if hyper:   # move the head off its tiny initialisation
+        with torch.no_grad():
+            mods["dec"].hyperbolic_linear.weight.mul_(50)
+    eng = Engine(S, 20, B, hyper, lr=5e-4)
+    for k, m in mods.items():
+        eng.load_state_dict(k, m.state_dict())
+    P = params_ns(B, S, hyper)
+    rng = np.random.default_rng(S)
+    x = rng.uniform(-1, 1, size=(B, S, 1))
+    xs = cu(x[:, :, 0]).reshape(1, B, S)
+    z = rng.standard_normal((B, 20)).astype(np.float32)
+    ax, az = rng.uniform(size=(B, S)).astype(np.float32), rng.uniform(size=(B, 20)).astype(np.float32)
+    o = oi.make_optimizers(mods["enc"], mods["dec"], mods["cx"], mods["cz"], P)
+    sample = torch.from_numpy(x)
+    ref = float(oi.critic_x_iteration(sample, mods["dec"], mods["cx"], o[0], P, z=z, alpha=ax))
+    got = float(eng.critic_x_iteration(xs, None, cu(z), cu(ax), train_mode=False)[0, 0])
+    assert abs(got - ref) < TOL * max(1, abs(ref)), ("cx", got, ref)
+    for nm, p in mods["cx"].named_parameters():                       # gradients, through Adam's first moment
+        g = p.grad.numpy()
+        assert maxdiff(_grad_from_moment(eng, "cx", nm), g) < 2e-5 * max(1.0, float(np.abs(g).max())), nm
+    ref = float(oi.critic_z_iteration(sample, mods["enc"], mods["cz"], o[1], P, z=z, alpha=az))
+    got = float(eng.critic_z_iteration(xs, None, cu(z), cu(az), train_mode=False)[0, 0])
+    assert abs(got - ref) < TOL * max(1, abs(ref)), ("cz", got, ref)
+    for k in ("cx", "cz"):                                             # generator step at identical critics
+        mods[k].load_state_dict({n: v.cpu() for n, v in eng.state_dict(k).items()})
+    r = oi.decoder_iteration(sample, mods["enc"], mods["dec"], mods["cx"], mods["cz"], o[2], P, z=z)
+    g = eng.decoder_iteration(xs, None, cu(z), train_mode=False)
+    assert abs(float(g[0, 0]) - float(r[0])) < 2 * TOL * max(1, abs(float(r[0])))
+    assert abs(float(g[0, 1]) - float(r[1] if hyper else r[2])) < TOL
+    wd = 1e-5 if hyper else 0.0
+    for net in ("dec", "enc"):
+        for nm, p in mods[net].named_parameters():
+            if nm == "hyperbolic_linear.bias" or p.grad is None:
+                continue
+            gref = p.grad.numpy()          # (the oracle's RiemannianAdam already added wd * p in place)
+            got_g = _grad_from_moment(eng, net, nm)
+            assert maxdiff(got_g, gref) < 5e-5 * max(1.0, float(np.abs(gref).max())), (net, nm, maxdiff(got_g, gref))
+
+
 def _rand_masks(gen, B, p, n, width=20):
     return [(torch.rand(B, width, generator=gen) >= p).float() / (1 - p) for _ in range(n)]
 
@@ -541,6 +589,38 @@ def test_scoring_kernels_match_reference_fixtures(dev):
     for comb in ("mult", "sum", "rec", "critic"):
         got = adu.combine_euclidean(comb, fx["critic_scores"], rz)
         assert maxdiff(got, fx[f"eucl_{comb}"]) < 1e-9, comb
+
+
+def test_critic_kde_smoothing_and_full_score_paths(dev):
+    """final_critic_scores (KDE mode per timestep) and the two end-to-end score paths."""
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    from oracle import scoring as osc
+    fx = load("score.npz")
+    y, y_hat, critic = fx["y"], fx["y_hat"], fx["critic"]
+    cs = adu.final_critic_scores(critic, y.reshape(len(y), -1))
+    assert np.allclose(cs, fx["critic_scores"], rtol=0, atol=1e-9, equal_nan=True)
+    direct = adu._compute_critic_score(critic.astype(np.float64), 7).cpu().numpy()
+    # (the fixture fed float32 critics straight in: NumPy then takes quantiles / mean in float32)
+    assert np.allclose(direct, fx["critic_score_direct"], rtol=0, atol=1e-6, equal_nan=True)
+    for comb in ("mult", "sum", "rec", "critic"):
+        got, _, true, _ = adu.score_anomalies(y, y_hat, critic, None, rec_error_type="point", comb=comb)
+        assert np.allclose(got, fx[f"eucl_{comb}"], rtol=0, atol=1e-6, equal_nan=True), comb
+    assert maxdiff(np.asarray(true).reshape(-1), fx["true_unrolled"]) == 0
+    for comb in ("sum", "mult", "uncertainty", "critic", "rec_uncertainty"):
+        got = adu.hyperbolic_scores(fx["ball_recons"], fx["ball_real"], critic, 100, comb)
+        assert maxdiff(got, fx[f"comb_{comb}"]) < 1e-5, comb
+    # degenerate inputs: equal critic values (singular KDE covariance -> median), two windows, one window
+    for cr, n, w in ((np.ones(40, np.float32), 40, 10), (np.array([0.3, -1.2], np.float32), 2, 5), (np.array([0.7], np.float32), 1, 4)):
+        got = adu.kde_modes(cr, w).cpu().numpy()
+        ext = np.repeat(cr.astype(np.float64).reshape(-1, 1), w, axis=1)
+        ref = np.array([osc.kde_mode(osc.antidiagonal(ext, i)) for i in range(n + w - 1)])
+        assert np.allclose(got, ref, atol=1e-12), (n, w)
+    rng = np.random.default_rng(11)
+    cr = rng.standard_normal(700).astype(np.float32)
+    got = adu.kde_modes(cr, 100).cpu().numpy()
+    ext = np.repeat(cr.astype(np.float64).reshape(-1, 1), 100, axis=1)
+    ref = np.array([osc.kde_mode(osc.antidiagonal(ext, i)) for i in range(799)])
+    assert np.mean(got == ref) > 0.995          # arg-max of near-tied densities may legitimately differ in the last ulp
 
 
 def test_scoring_edge_cases(dev):
