@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libhypad_hip.so")
-SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "train_iters.hip", "scoring.hip", "diag.hip"]
+SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip", "diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 
 

@@ -1,0 +1,199 @@
+// Shared definitions of the training kernels (train_iters.hip, critic_fused.hip): workspace layouts, kernel arguments,
+// LDS plans, Adam / Riemannian-Adam update rules.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/hypad.h"
+#include "critic_valu.h"
+#include "nets.h"
+
+namespace hypad {
+namespace train {
+
+constexpr int THREADS = 256;      // dW + Adam kernel
+constexpr int TB = 512;           // row-tile kernels: 16 waves share one tile (the layers are latency-bound: more waves
+                                  // = more weight tiles in flight per layer)
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct CritWs {
+  int in_right, act[4], left[5], dm[4], partial, total;
+};
+HD CritWs crit_ws(int B, int in_dim, int L, int nh) {
+  CritWs w; int o = 0;
+  w.in_right = o; o += pad4(3 * B * in_dim);
+  for (int i = 0; i < 4; ++i) { w.act[i] = o; if (i < nh) o += pad4(3 * B * L); }
+  for (int i = 0; i < 5; ++i) { w.left[i] = o; if (i < nh) o += pad4(3 * B * L); else if (i == nh) o += pad4(3 * B); }
+  for (int i = 0; i < 4; ++i) { w.dm[i] = o; if (i < nh) o += pad4(B * L); }
+  w.partial = o; o += pad4((B / 16) * 4);
+  w.total = o;
+  return w;
+}
+struct GenWs {
+  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, total;
+};
+HD GenWs gen_ws(int B, int S, int L) {
+  GenWs w; int o = 0;
+  w.xg = o; o += pad4(B * S);
+  w.enc_g = o; o += pad4(B * 8 * ENC_H);
+  w.enc_h = o; o += pad4(B * 2 * ENC_H);
+  w.zcat = o; o += pad4(2 * B * L);
+  w.a0 = o; o += pad4(2 * B * DEC_D1);
+  w.g0 = o; o += pad4(2 * B * 8 * DEC_H);
+  w.h0d = o; o += pad4(2 * B * 2 * DEC_H);
+  w.mask = o; o += pad4(2 * B * 2 * DEC_H);
+  w.g1 = o; o += pad4(2 * B * 8 * DEC_H);
+  w.h1 = o; o += pad4(2 * B * 2 * DEC_H);
+  w.ecat = o; o += pad4(3 * B * S);
+  w.u = o; o += pad4(3 * B * S);
+  w.du = o; o += pad4(3 * B * S);
+  w.ballpart = o; o += pad4((B / 16) * S);          // per-tile column sums of the head-bias gradient rows
+  w.dpre2 = o; o += pad4(2 * B * S);
+  w.dg1 = o; o += pad4(2 * B * 6 * DEC_H);
+  w.dg0 = o; o += pad4(2 * B * 6 * DEC_H);
+  w.da0 = o; o += pad4(2 * B * DEC_D1);
+  w.dzenc = o; o += pad4(B * L);
+  w.dgenc = o; o += pad4(B * 6 * ENC_H);
+  w.partial = o; o += pad4((B / 16) * 4);
+  w.total = o;
+  return w;
+}
+// critic_x and critic_z iterations of one minibatch may run side by side (train.py:320-327 touch disjoint weights):
+// their workspaces are disjoint, the generator's overlays both.
+inline int64_t ws_cz_offset(const hypad_dims& d) { return crit_ws(d.batch, d.signal_shape, d.latent_dim, 4).total; }
+inline int64_t ws_floats_per_signal(const hypad_dims& d) {
+  int64_t a = ws_cz_offset(d) + crit_ws(d.batch, d.latent_dim, d.latent_dim, 2).total;
+  int64_t c = gen_ws(d.batch, d.signal_shape, d.latent_dim).total;
+  return a > c ? a : c;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel arguments
+struct IterArgs {
+  int S, L, B, hyperbolic;
+  hypad_nets P, M, V;
+  int pe, pd, pcx, pcz;            // floats per signal in each arena
+  int32_t* counters;
+  const float* x; int64_t x_sig_stride; const int32_t* row_index;
+  const float* z; const float* alpha;
+  int drop_mode;                   // 0 eval, 1 injected, 2 Philox
+  const float* masks; int64_t mask_sig_stride;
+  uint64_t seed;
+  float* losses; int64_t loss_sig_stride;
+  float* ws; int64_t ws_sig_stride;
+  float lr, b1, b2, eps, wd; int stabilize; int riemannian;
+  int opt;                         // counters index of the optimizer stepped by this iteration
+  int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
+};
+
+struct LdsPlan {
+  int xs, zs, bufA, bufB, crit, small, wst, cparams, total, ldS, bufFloats;
+  int stage;      // 1: the critics' weights are staged in LDS (fits the 160 KiB budget)
+};
+constexpr int LDS_LIMIT_FLOATS = 160 * 1024 / 4;
+HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head, int critic_floats, int crit_scratch = CRITIC_LDS_FLOATS) {
+  LdsPlan p;
+  p.ldS = pad4(S) + 4;
+  int a = rows_lstm * (6 * DEC_H + 4), b = rows_head * p.ldS;
+  p.bufFloats = a > b ? a : b;
+  int o = 0;
+  p.xs = o; o += 16 * p.ldS;
+  p.zs = o; o += 32 * LP;
+  p.bufA = o; o += p.bufFloats;
+  p.bufB = o; o += p.bufFloats;
+  p.crit = o; o += crit_scratch;
+  p.small = o; o += 3 * 16 * LP + 64;     // three (16, LP) scratch tiles + 64 reduction slots
+  p.wst = o; o += (TB / 64) * WSTAGE_FLOATS;   // wave-private weight slabs of gemm_nt
+  p.cparams = o;
+  p.stage = (o + critic_floats <= LDS_LIMIT_FLOATS) ? 1 : 0;
+  if (p.stage) o += critic_floats;
+  p.total = o;
+  return p;
+}
+// reduction slots inside `small`: [0,16) block_sum, [16,32) per-wave partials, [32,36) pass sums
+
+__device__ __forceinline__ DropSrc drop_src(const IterArgs& a, int sig, const float* ptr, uint32_t stream, uint32_t tick, float p) {
+  DropSrc s;
+  s.mode = a.drop_mode; s.ptr = ptr; s.batch = a.B; s.seed = a.seed; s.tick = tick; s.stream = stream; s.sig = (uint32_t)sig; s.p = p;
+  return s;
+}
+
+// block-wide sum of per-thread values; result valid in every thread.  red: LDS >= 16 floats
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+  return s;
+}
+
+
+struct AdamCoef {
+  float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2;
+  int riemannian, step, stabilize;
+};
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& c) {
+  if (c.riemannian) {     // oracle/radam.py, Euclidean branch
+    g += c.wd * p;
+    m = c.b1 * m + (1.f - c.b1) * g;
+    v = c.b2 * v + (1.f - c.b2) * g * g;
+    float den = sqrtf(v / c.bc2) + c.eps;
+    p -= c.lr * (m / c.bc1) / den;
+  } else {                // torch.optim.Adam (single-tensor rule)
+    m = c.b1 * m + (1.f - c.b1) * g;
+    v = c.b2 * v + (1.f - c.b2) * g * g;
+    float denom = sqrtf(v) / c.sqrt_bc2 + c.eps;
+    p -= (c.lr / c.bc1) * (m / denom);
+  }
+}
+__device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, float wd, int riem, int stab, int step) {
+  AdamCoef c;
+  c.lr = lr; c.b1 = b1; c.b2 = b2; c.eps = eps; c.wd = wd; c.riemannian = riem; c.stabilize = stab; c.step = step;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  c.bc1 = (float)bc1; c.bc2 = (float)bc2; c.sqrt_bc2 = (float)sqrt(bc2);
+  return c;
+}
+
+// Riemannian Adam on one ball-valued vector held by a wave (oracle/manual.py radam_ball_step)
+__device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, RowVec g, int dim, int lane, const AdamCoef& c) {
+  RowVec P = row_load(p, dim, lane), Mv = row_load(m, dim, lane), V = row_load(v, dim, lane);
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) g.v[e] += c.wd * P.v[e];
+  float lam = 2.f / fmaxf(1.f - row_dot(P, P), MIN_NORM);
+  RowVec rg;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) rg.v[e] = g.v[e] / (lam * lam);
+  float inner = lam * lam * row_dot(rg, rg);
+  RowVec np;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) {
+    Mv.v[e] = c.b1 * Mv.v[e] + (1.f - c.b1) * rg.v[e];
+    V.v[e] = c.b2 * V.v[e] + (1.f - c.b2) * inner;
+    float den = sqrtf(V.v[e] / c.bc2) + c.eps;
+    np.v[e] = P.v[e] - c.lr * (Mv.v[e] / c.bc1) / den;
+  }
+  np = project_row(np);
+  // parallel transport of the first moment: gyr[np, -p] m * lambda_p / lambda_np (math_.py:1738-1746, 656-676)
+  RowVec nb;
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) nb.v[e] = -P.v[e];
+  float u2 = row_dot(np, np), v2 = row_dot(nb, nb), uv = row_dot(np, nb), uw = row_dot(np, Mv), vw = row_dot(nb, Mv);
+  float ca = -uw * v2 + vw + 2.f * uv * vw;
+  float cb = -vw * u2 - uw;
+  float d = fmaxf(1.f + 2.f * uv + u2 * v2, MIN_NORM);
+  float lam_n = 2.f / fmaxf(1.f - u2, MIN_NORM);
+#pragma unroll
+  for (int e = 0; e < MAX_EPL; ++e) Mv.v[e] = (Mv.v[e] + 2.f * (ca * np.v[e] + cb * nb.v[e]) / d) * lam / lam_n;
+  if (c.stabilize > 0 && c.step % c.stabilize == 0) np = project_row(np);
+  row_store(p, np, dim, lane);
+  row_store(m, Mv, dim, lane);
+  row_store(v, V, dim, lane);
+}
+
+// critic_fused.hip: the critic phase of an epoch with the frozen generator's forwards hoisted out of the chain
+size_t critic_phase_floats_per_iter(const hypad_dims& d);
+int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
+                     int n_signals, hipStream_t s, hipEvent_t* ev);
+
+}  // namespace train
+}  // namespace hypad

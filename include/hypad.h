@@ -206,15 +206,22 @@ typedef struct hypad_epoch_io {
   int n_batches, n_critics;
   int train_mode; uint64_t seed;
   float* losses;
-  void* workspace; size_t workspace_bytes;
+  void* workspace; size_t workspace_bytes;   /* >= hypad_train_workspace_bytes(dims); with >= hypad_epoch_workspace_bytes(...)
+                                                the critic phase runs in its hoisted form (see below) */
 } hypad_epoch_io;
+/* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
+ * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up
+ * to 512 iterations of precomputed rows (longer phases are processed in chunks).  Same random streams and the same
+ * arithmetic per row as the per-iteration entry points; only floating-point summation order differs. */
+size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_critics);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
 /* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder, 3 = the critic_x ||
- * critic_z pair that hypad_train_epoch launches; its losses need room for 2 * n_signals * 4 floats) with HIP events
- * recorded on `stream` between its kernels, synchronise, and return the per-kernel durations in ms:
- * critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam}; decoder -> {generator kernel, dW+Adam}.
- * Not capturable into a graph. */
+ * critic_z pair of the per-iteration path, 4 = one iteration of the hoisted critic phase of hypad_train_epoch; kinds
+ * 3 and 4 need losses with room for 2 * n_signals * 4 floats, kind 4 a workspace of hypad_epoch_workspace_bytes(dims,
+ * 1, 1)) with HIP events recorded on `stream` between its kernels, synchronise, and return the per-kernel durations in
+ * ms: critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam}; decoder -> {generator kernel, dW+Adam};
+ * kind 4 -> {precompute kernel (one iteration's rows), fused critic pair kernel}.  Not capturable into a graph. */
 int hypad_profile_iteration(int kind, const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io,
                             float* ms_out, int n_out, hypad_stream_t stream);
 

@@ -493,6 +493,45 @@ def test_train_epoch_device_rng(dev):
     assert not torch.equal(l3, outs[0][0])          # dropout changes the trajectory
 
 
+@pytest.mark.parametrize("hyper,train_mode", [(True, True), (False, False)])
+def test_train_epoch_hoisted_critic_phase_matches_per_minibatch_path(dev, hyper, train_mode):
+    """The hoisted critic phase (critic_fused.hip: generator forwards precomputed, one workgroup per critic) consumes the
+    same random streams and follows the same arithmetic as the per-minibatch launch groups: same losses / weights up
+    to fp32 summation order."""
+    fx = load("iters_hyper_S100.npz" if hyper else "iters_eucl_S100.npz")
+    xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100)
+    for nb, nc, tight in ((1, 1, True), (3, 2, False)):
+        perm = torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+        res = []
+        for hoist in (True, False):
+            eng = _engine_from(fx, hyper, n=2)
+            for net in ("enc", "dec", "cx", "cz"):
+                eng.params[net][1].mul_(1.01)
+            eng.seed = 4321
+            losses = eng.train_epoch(xs, perm, nb, nc, train_mode, hoist=hoist)
+            torch.cuda.synchronize()
+            assert eng.counters.cpu().tolist() == [nb * nc, nb * nc, nb, nb * nc + nb]
+            res.append((losses.clone(), {k: eng.params[k].clone() for k in ("cx", "cz", "dec", "enc")},
+                        {k: eng.exp_avg[k].clone() for k in ("cx", "cz")}))
+        (la, pa, ma), (lb, pb, mb) = res
+        n_crit = 2 * nb * nc
+        assert bool(torch.isfinite(la).all())
+        if tight:
+            # one step: losses to fp32 summation order; exp_avg = (1 - beta1) * gradient checks every weight / bias gradient
+            np.testing.assert_allclose(la[:, :n_crit].cpu().numpy(), lb[:, :n_crit].cpu().numpy(), rtol=1e-5, atol=1e-6)
+            for k in ("cx", "cz"):
+                d = (ma[k] - mb[k]).abs().max().item()
+                scale = mb[k].abs().max().item()
+                assert scale > 0 and d <= 1e-4 * scale, (k, d, scale)
+        else:
+            # several Adam steps: ill-conditioned on the ~1e-8 bias gradients (see _assert_params_after_steps), so trajectories
+            # may drift by a few lr on those entries
+            np.testing.assert_allclose(la[:, :n_crit].cpu().numpy(), lb[:, :n_crit].cpu().numpy(), rtol=2e-2, atol=2e-3)
+        for k in ("cx", "cz"):
+            assert (pa[k] - pb[k]).abs().max().item() <= 2.2 * 5e-4 * nb * nc
+        np.testing.assert_allclose(la[:, n_crit:].cpu().numpy(), lb[:, n_crit:].cpu().numpy(), rtol=5e-2, atol=5e-3)
+
+
 def test_drop_in_iteration_functions_follow_host_rng(dev):
     """hypad_amd.train.* consume NumPy / torch CPU randomness exactly like train.py."""
     from hypad_amd import train as ht
