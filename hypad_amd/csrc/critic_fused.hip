@@ -1,18 +1,25 @@
 // Critic phase of an epoch (train.py:306-328) restructured for the GPU.
 //
-// During the n_critics passes the generator is frozen (train.py:306-309), so decoder(z_i) and encoder(x_i) of ALL
-// critic iterations of the phase do not depend on anything the phase updates.  They are hoisted out of the
-// sequential chain and computed by ONE wide launch (`critic_phase_precompute_kernel`: iterations x row tiles x
-// signals x {decoder, encoder} workgroups -- 1 160 workgroups for 29 batches x 5 passes, it fills the chip).
-// What remains sequential -- critic forward on real / fake / interpolated rows, the whole-batch gradient penalty, its
-// double backward, the weight gradients and Adam -- is ~0.8 MFLOP per iteration and fits ONE workgroup per
-// (signal, critic): `critic_fused_pair_kernel` keeps everything in LDS / registers (no workspace round trip, no
-// inter-workgroup reduction for the whole-batch norm, one launch per (critic_x || critic_z) pair instead of three).
+// During the n_critics passes the generator is frozen (train.py:306-309), so nothing the phase updates feeds
+// decoder(z_i), encoder(x_i), the noise, the interpolation weights or the dropout masks of ANY of its iterations.
+// `critic_phase_precompute_kernel` hoists all of it out of the sequential chain: one wide launch (iterations x
+// row tiles x signals x {critic_x side, critic_z side} workgroups -- 1 160 workgroups for 29 batches x 5 passes) writes,
+// per iteration and 16-row chunk, a *record*: the real | fake | interpolated rows exactly as the critic's first layer
+// wants them in LDS (zero padded, with the constant-one column that carries the biases) and the dropout scales of every
+// layer and pass.
 //
-// Gradient-penalty algebra used to make it single-pass: the second-order chain is linear in u = coef * g with
-// coef = 20 (||g|| - 1) / ||g|| known only after all rows; the kernel accumulates the GP part of every weight
-// gradient with the *unscaled* g in its own accumulators and applies coef at the end (oracle/manual.py
-// critic_gp_pairs is linear in `ugrad`).
+// What remains sequential is the critic arithmetic itself: ~0.9 MFLOP per iteration, a chain of ~14 dependent small
+// matrix products.  `critic_iteration_kernel` gives each 16-row chunk of the minibatch to one workgroup (B / 16
+// workgroups per critic, blockIdx.z picks critic_x / critic_z): forward of the 48 rows (3 passes), first backward,
+// g = d out / d interpolated, the second-order chain (unscaled: it is linear in coef * g, and coef = 20 (||g|| - 1) /
+// ||g|| needs the WHOLE batch), and the chunk's share of every weight gradient, all on
+// v_mfma_f32_16x16x4_f32 out of LDS.  The shares go to a slab in HBM; the NEXT launch's prologue (every workgroup,
+// redundantly and in a fixed order, so the replicas stay bit-identical) sums the slabs, forms coef, applies Adam and
+// rebuilds the weights in LDS.  The kernel boundary is the only inter-workgroup synchronisation; state and slabs are
+// double-buffered by iteration parity so no workgroup overwrites what a sibling of the same launch still reads.
+//
+// Biases ride in the matrix products: every layer input has a constant-one column at index K, the weight rows carry
+// the bias there, and the bias gradient is column K of the weight-gradient tile.
 #include <hip/hip_runtime.h>
 
 #include "../../include/hypad.h"
@@ -23,95 +30,190 @@ using namespace hypad::train;
 
 namespace {
 
-constexpr int FT = 512;     // threads of the fused critic kernel (8 waves)
-constexpr int MAXT = 4;     // weight tiles per wave (critic_x: 28 tiles over 8 waves)
+constexpr int FT = 512;                      // threads of the critic iteration kernel (8 waves)
+constexpr int NW = FT / 64;
+constexpr int MAXT = 5;                      // weight tiles per wave
+constexpr int MAX_ROW4 = 4, MAX_MASK4 = 3;   // float4 record loads per thread (rows / masks)
+constexpr int NITEM = 3;                     // accumulator quads per thread in the reduction prologue
+
+HD int up16(int n) { return (n + 15) & ~15; }
+
+// Geometry of one critic inside the phase: padded lengths, record and slab sizes, weight-tile census
+struct CritGeom {
+  int in_dim, L, nh, params;
+  int Kin, Lp, ldin, LQ, L4;
+  int rec_rows4, rec_mask4, rec_floats;      // record = [48][Kin] rows then [nh][48][L4] dropout scales
+  int tk0, tn, tkh, tiles0, tilesh, ntiles;
+  int slab_floats;                           // [ntiles][2][256] accumulator images + 4 scalars
+};
+HD CritGeom crit_geom(int in_dim, int L, int nh, int params) {
+  CritGeom g;
+  g.in_dim = in_dim; g.L = L; g.nh = nh; g.params = params;
+  g.Kin = up16(in_dim + 1); g.Lp = up16(L + 1);
+  g.ldin = g.Kin + 4; g.LQ = g.Lp + 4; g.L4 = pad4(L);
+  g.rec_rows4 = 12 * g.Kin; g.rec_mask4 = 12 * nh * g.L4;
+  g.rec_floats = 4 * (g.rec_rows4 + g.rec_mask4);
+  g.tk0 = g.Kin >> 4; g.tn = (L + 15) >> 4; g.tkh = g.Lp >> 4;
+  g.tiles0 = g.tn * g.tk0; g.tilesh = g.tn * g.tkh;
+  g.ntiles = g.tiles0 + (nh - 1) * g.tilesh + g.tkh;
+  g.slab_floats = g.ntiles * 512 + 4;
+  return g;
+}
+HD CritGeom cx_geom(int S, int L) { return crit_geom(S, L, 4, cx_layout(S, L).total); }
+HD CritGeom cz_geom(int L) { return crit_geom(L, L, 2, cz_layout(L).total); }
+HD bool geom_supported(const CritGeom& g) {
+  const int Q = (g.L + 3) >> 2;
+  const int nitems = (g.tk0 + (g.nh - 1) * g.tkh) * 16 * Q + g.tkh * 16;
+  return g.ntiles <= MAXT * NW && g.rec_rows4 <= MAX_ROW4 * FT && g.rec_mask4 <= MAX_MASK4 * FT && nitems <= NITEM * FT;
+}
+
+// LDS plan of the iteration kernel (floats).  Row strides are (multiple of 16) + 4: operand fetches are ds_read_b128
+// (lane (i, q) supplies k = 16 g + 4 q + s to the s-th MFMA of k-group g -- the reduction index may be permuted as long
+// as A and B agree), which needs 16-byte aligned rows and zero padding up to the next multiple of 16 columns.
+struct IterLds {
+  int in0;      // [48][ldin]  rows 0-15 real, 16-31 fake, 32-47 interpolated; after the first backward rows 32-47 hold g
+  int act;      // [nh][48][LQ] layer outputs (+ ones column); rows 32-47 are overwritten by the second-order chain ep_li
+  int dl;       // [nh+1][48][LQ] first-order deltas of every layer (dl[nh]: column 0 = d loss / d out)   (follows act)
+  int dm;       // [nh][48][LQ] leaky'(pre) * dropout scale
+  int w0;       // [L][ldin]      weights of layer 0, bias in column in_dim
+  int wh;       // [nh-1][L][LQ]  hidden layers, bias in column L
+  int wl;       // [LQ]           output layer, bias at index L
+  int red;      // [64]
+  int total;
+};
+HD IterLds iter_lds(const CritGeom& g) {
+  IterLds f; int o = 0;
+  f.in0 = o; o += 48 * g.ldin;
+  f.act = o; o += g.nh * 48 * g.LQ;
+  f.dl = o; o += (g.nh + 1) * 48 * g.LQ;
+  f.dm = o; o += g.nh * 48 * g.LQ;
+  f.w0 = o; o += g.L * g.ldin;
+  f.wh = o; o += (g.nh - 1) * g.L * g.LQ;
+  f.wl = o; o += g.LQ;
+  f.red = o; o += 64;
+  f.total = o;
+  return f;
+}
 
 struct PhaseArgs {
-  float* gen_pre;           // (n_signals, n_iters, B, S)  decoder(z_it)
-  float* zenc_pre;          // (n_signals, n_iters, B, L)  encoder(x_it)
+  float* rec_x;             // (n_signals, n_iters, B/16, cx record)
+  float* rec_z;             // (n_signals, n_iters, B/16, cz record)
+  float* state_x;           // (n_signals, 2, 3, cx params)   P | exp_avg | exp_avg_sq, double-buffered by iteration parity
+  float* state_z;
+  float* slab_x;            // (n_signals, 2, B/16, cx slab)
+  float* slab_z;
   const int32_t* row_index; // (n_iters, B)
+  float* losses;            // first loss row of this phase chunk (row 2 it: critic_x, 2 it + 1: critic_z)
+  float* bias_corr;         // (2 critics, n_iters + 1, 2): Adam's {1 - beta1^t, sqrt(1 - beta2^t)} of the step applied by launch `it`
   int n_iters;
-  int it;                   // iteration index of a fused launch
-  long long* stamps;        // development aid: per-stage shader-clock stamps of the fused kernel (64 per critic), or null
+  int it;                   // iteration index of an iteration launch; == n_iters: finalise only
+  long long* stamps;        // development aid: shader-clock stamps of workgroup (0, 0, z) (64 per critic), or null
 };
 long long* g_stamps = nullptr;
-#define STAMP(k) do { if (ph.stamps && threadIdx.x == 0) ph.stamps[blockIdx.z * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(k) do { if (ph.stamps && ph.it == 1 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ph.stamps[blockIdx.z * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+
+// four consecutive uniforms of a stream: the numbers rng_uniform gives for idx = 4 group + e, from one Philox evaluation
+__device__ __forceinline__ float4 rng_uniform4(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t group) {
+  Philox ph(seed);
+  const uint4 r = ph(group, stream, tick, sig);
+  return make_float4(u32_to_unit(r.x), u32_to_unit(r.y), u32_to_unit(r.z), u32_to_unit(r.w));
+}
 
 // ---------------------------------------------------------------------------------------------- precompute
-__global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs a, PhaseArgs ph) {
+// Writes one record: rows real | fake | interpolated ([48][Kin], ones column at in_dim, zeros after) and the dropout
+// scales [nh][48][L4] (pass order real, fake, interpolated).  real / fake: LDS tiles of 16 rows.
+template <bool IS_X>
+__device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g, float* rec, const float* real, int ldr, const float* fake,
+                                            int ldf, int sig, int g0, uint32_t tick, float p_drop) {
+  const int in_dim = g.in_dim, Kin = g.Kin, L = g.L, nh = g.nh;
+  tile_for(16, Kin, [&](int r, int c) {
+    const float pad = c == in_dim ? 1.f : 0.f;
+    rec[r * Kin + c] = c < in_dim ? real[r * ldr + c] : pad;
+    rec[(16 + r) * Kin + c] = c < in_dim ? fake[r * ldf + c] : pad;
+    if (c >= in_dim) rec[(32 + r) * Kin + c] = pad;
+  });
+  for (int gi = threadIdx.x; gi < 4 * in_dim; gi += blockDim.x) {      // interpolation (train.py:64-69 / 149-154)
+    const float4 al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)(g0 * in_dim) / 4 + gi);
+    const float alv[4] = {al.x, al.y, al.z, al.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = 4 * gi + e;
+      const int r = f / in_dim, c = f - r * in_dim;
+      rec[(32 + r) * Kin + c] = alv[e] * real[r * ldr + c] + (1.f - alv[e]) * fake[r * ldf + c];
+    }
+  }
+  float* rm = rec + 48 * Kin;
+  const float keep = 1.f / (1.f - p_drop);
+  const int per = 4 * L;                                               // groups per (pass, layer)
+  for (int w = threadIdx.x; w < 3 * nh * per; w += blockDim.x) {
+    const int pl = w / per, gi = w - pl * per;
+    const int p = pl / nh, li = pl - p * nh;
+    float v[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.drop_mode == 2) {
+      const int pass = p == 2 ? 2 : (IS_X ? p : 1 - p);                // stream numbering of the per-iteration entry points
+      const float4 uu = rng_uniform4(a.seed, tick, RS_DROP_CRITIC + 8 * pass + li, (uint32_t)sig, (uint32_t)(g0 * L) / 4 + gi);
+      v[0] = uu.x >= p_drop ? keep : 0.f; v[1] = uu.y >= p_drop ? keep : 0.f;
+      v[2] = uu.z >= p_drop ? keep : 0.f; v[3] = uu.w >= p_drop ? keep : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int f = 4 * gi + e;
+      const int r = f / L, c = f - r * L;
+      rm[(li * 48 + p * 16 + r) * g.L4 + c] = v[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
+  const int sig = blockIdx.y, tile = blockIdx.x, S = ax.S, L = ax.L, B = ax.B;
   const int it = blockIdx.z >> 1, role = blockIdx.z & 1;
   const LdsPlan lp = lds_plan(S, 16, 16, 0);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* wst = smem + lp.wst;
-  const uint32_t tick = (uint32_t)a.counters[3] + (uint32_t)it;
-  const int g0 = tile * 16;
-  if (role == 0) {          // x_ = decoder(z), train-mode dropout (train.py:24-33)
-    const DecLayout dl = dec_layout(S, L, a.hyperbolic);
-    const float* PD = a.P.dec + (int64_t)sig * a.pd;
-    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
+  const uint32_t tick = (uint32_t)ax.counters[3] + (uint32_t)it;
+  const int g0 = tile * 16, nchunks = B / 16;
+  if (tile == 0 && sig == 0 && threadIdx.x == 0) {   // Adam bias corrections of the step that launch it + 1 applies (train.py:274-281)
+    const IterArgs& c = role == 0 ? ax : az;
+    const AdamCoef co = adam_coef(c.lr, c.b1, c.b2, c.eps, 0.f, 0, 0, c.counters[c.opt] + it + 1);
+    float* bc = ph.bias_corr + ((int64_t)role * (ph.n_iters + 1) + it + 1) * 2;
+    bc[0] = co.bc1; bc[1] = co.sqrt_bc2;
+  }
+  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, S, ph.row_index ? ph.row_index + (int64_t)it * B : nullptr, g0, 16, S, 16);
+  if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
+    const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
+    const float* PD = ax.P.dec + (int64_t)sig * ax.pd;
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(ax.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
-    DropSrc ddrop = drop_src(a, sig, nullptr, RS_DROP_DEC0, tick, 0.2f);
+    DropSrc ddrop = drop_src(ax, sig, nullptr, RS_DROP_DEC0, tick, 0.2f);
     DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, lp.ldS, ddrop, [g0](int r) { return g0 + r; }, none, 16, wst);
     float* gen = bufA;
-    if (a.hyperbolic) {
+    if (ax.hyperbolic) {
       gemm_nt<1>(bufA, lp.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, lp.ldS, 0, wst);
       __syncthreads();
       head_rows_tile(bufB, lp.ldS, 16, S, PD + dl.head_b);
       __syncthreads();
       gen = bufB;
     }
-    tile_store(ph.gen_pre + (((int64_t)sig * ph.n_iters + it) * B + g0) * S, S, gen, lp.ldS, 16, S, 16);
-  } else {                  // z_ = encoder(x)  (train.py:111)
+    const CritGeom g = cx_geom(S, L);
+    emit_record<true>(ax, g, ph.rec_x + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, xs, lp.ldS, gen, lp.ldS, sig, g0,
+                      tick, 0.25f);
+  } else {                  // critic_z side: z_ = encoder(x), z ~ N(0, 1)  (train.py:111-116)
     const EncLayout el = enc_layout(S, L);
-    const float* PE = a.P.enc + (int64_t)sig * a.pe;
-    tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, ph.row_index + (int64_t)it * B, g0, 16, S, 16);
+    const float* PE = az.P.enc + (int64_t)sig * az.pe;
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
-    encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, 16, wst);
-    tile_store(ph.zenc_pre + (((int64_t)sig * ph.n_iters + it) * B + g0) * L, L, zs, LP, 16, L, 16);
+    float* zenc = zs + 16 * LP;
+    encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16, wst);
+    __syncthreads();
+    const CritGeom g = cz_geom(L);
+    emit_record<false>(az, g, ph.rec_z + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, zs, LP, zenc, LP, sig, g0, tick,
+                       0.2f);
   }
 }
 
-// ---------------------------------------------------------------------------------------------- fused critic iteration
-// LDS plan (floats).  Row strides are (multiple of 16) + 4: every matrix product of the iteration runs on
-// v_mfma_f32_16x16x4_f32 with ds_read_b128 operand fetches (lane (i, q) supplies k = 16 g + 4 q + s to the s-th MFMA of
-// k-group g -- the reduction index may be permuted as long as A and B agree), which needs 16-byte aligned rows and
-// zero padding up to the next multiple of 16 columns.  The padding is written once (the whole region is zeroed at kernel
-// start) and never touched again.
-struct FusedLds {
-  int in0;      // [48][ldin]  rows 0-15 real, 16-31 fake, 32-47 interpolated; after the first backward rows 32-47 hold g
-  int act;      // [nh][48][LQ] layer outputs; rows 32-47 are overwritten by the second-order chain ep_li
-  int dm;       // [nh][48][LQ] leaky'(pre) * dropout scale
-  int dl;       // [nh+1][48][LQ] first-order deltas of every layer (dl[nh]: column 0 = d loss / d out)
-  int w0;       // [L][ldin]
-  int wh;       // [nh-1][L][LQ]
-  int wl;       // [LQ]
-  int bias;     // [nh+1][LQ]
-  int dbias;    // [nh+1][LQ]
-  int red;      // [64]
-  int total, ldin, LQ, Kin, Lp;
-};
-HD int up16(int n) { return (n + 15) & ~15; }
-HD FusedLds fused_lds(int in_dim, int L, int nh) {
-  FusedLds f; int o = 0;
-  f.Kin = up16(in_dim); f.Lp = up16(L);
-  f.ldin = f.Kin + 4; f.LQ = f.Lp + 4;
-  f.in0 = o; o += 48 * f.ldin;
-  f.act = o; o += nh * 48 * f.LQ;
-  f.dm = o; o += nh * 48 * f.LQ;
-  f.dl = o; o += (nh + 1) * 48 * f.LQ;
-  f.w0 = o; o += L * f.ldin;
-  f.wh = o; o += (nh - 1) * L * f.LQ;
-  f.wl = o; o += f.LQ;
-  f.bias = o; o += (nh + 1) * f.LQ;
-  f.dbias = o; o += (nh + 1) * f.LQ;
-  f.red = o; o += 64;
-  f.total = o;
-  return f;
-}
-
+// ---------------------------------------------------------------------------------------------- iteration kernel
 __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
@@ -119,14 +221,16 @@ __device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 a
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
   return acc;
 }
-// out[r][n] = sum_k A[r][k] W[n][k];  A: LDS [16 RT][lda], W: LDS [N][ldw], both zero-padded to Kp columns.
-// epi(r, n, value) is called for n < 16 ceil(N / 16); columns >= N repeat column N - 1 (the caller drops them).
+// out[r][n] = sum_k A[r][k] W[n][k];  A: LDS [16 RT][lda], W: LDS [Nrows][ldw], both zero-padded to Kp columns.
+// epi(r, n, value) for n < 16 ceil(Ncols / 16); columns >= Nrows repeat row Nrows - 1 of W (the caller overrides them).
+// Tile t is computed by the wave whose wslot == t mod NW.
 template <class Epi>
-__device__ __forceinline__ void lds_gemm_nt(const float* A, int lda, int RT, const float* W, int ldw, int N, int Kp, int wave, int lane, Epi epi) {
-  const int j = lane & 15, q = lane >> 4, CT = (N + 15) >> 4;
-  for (int t = wave; t < RT * CT; t += FT / 64) {
+__device__ __forceinline__ void lds_gemm_nt(const float* A, int lda, int RT, const float* W, int ldw, int Nrows, int Ncols, int Kp, int wslot,
+                                            int lane, Epi epi) {
+  const int j = lane & 15, q = lane >> 4, CT = (Ncols + 15) >> 4;
+  for (int t = wslot; t < RT * CT; t += NW) {
     const int rt = t / CT, ct = t - rt * CT;
-    int n = ct * 16 + j; n = n < N ? n : N - 1;
+    int n = ct * 16 + j; n = n < Nrows ? n : Nrows - 1;
     const float* a = A + (rt * 16 + j) * lda + 4 * q;
     const float* b = W + n * ldw + 4 * q;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -137,14 +241,15 @@ __device__ __forceinline__ void lds_gemm_nt(const float* A, int lda, int RT, con
     for (int r = 0; r < 4; ++r) epi(rt * 16 + 4 * q + r, ct * 16 + j, acc[r]);
   }
 }
-// out[r][c] = sum_o A[r][o] W[o][c];  A: LDS [16 RT][lda] zero-padded to Kp columns, W: LDS [No][ldw], c < C.
+// out[r][c] = sum_o A[r][o] W[o][c];  A: LDS [16 RT][lda] zero-padded to Kp columns, W: LDS [No][ldw]; epi for
+// c < 16 ceil(Ccols / 16), columns >= Cvalid repeat column Cvalid - 1.
 template <class Epi>
-__device__ __forceinline__ void lds_gemm_nn(const float* A, int lda, int RT, const float* W, int ldw, int No, int C, int Kp, int wave, int lane,
-                                            Epi epi) {
-  const int j = lane & 15, q = lane >> 4, CT = (C + 15) >> 4;
-  for (int t = wave; t < RT * CT; t += FT / 64) {
+__device__ __forceinline__ void lds_gemm_nn(const float* A, int lda, int RT, const float* W, int ldw, int No, int Cvalid, int Ccols, int Kp,
+                                            int wslot, int lane, Epi epi) {
+  const int j = lane & 15, q = lane >> 4, CT = (Ccols + 15) >> 4;
+  for (int t = wslot; t < RT * CT; t += NW) {
     const int rt = t / CT, ct = t - rt * CT;
-    int c = ct * 16 + j; c = c < C ? c : C - 1;
+    int c = ct * 16 + j; c = c < Cvalid ? c : Cvalid - 1;
     const float* a = A + (rt * 16 + j) * lda + 4 * q;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -162,292 +267,311 @@ __device__ __forceinline__ void lds_gemm_nn(const float* A, int lda, int RT, con
   }
 }
 
-// four consecutive uniforms / two consecutive normals of a stream: the same numbers rng_uniform / rng_normal give for
-// idx = 4 group + e / 2 pair + e, one Philox evaluation instead of four / two
-__device__ __forceinline__ float4 rng_uniform4(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t group) {
-  Philox ph(seed);
-  const uint4 r = ph(group, stream, tick, sig);
-  return make_float4(u32_to_unit(r.x), u32_to_unit(r.y), u32_to_unit(r.z), u32_to_unit(r.w));
-}
-__device__ __forceinline__ float2 rng_normal2(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t pair) {
-  Philox ph(seed);
-  const uint4 r = ph(pair, stream, tick, sig);
-  const float a = sqrtf(-2.0f * __logf(u32_to_unit_open(r.x))) * __cosf(6.28318530717958647692f * u32_to_unit(r.y));
-  const float b = sqrtf(-2.0f * __logf(u32_to_unit_open(r.z))) * __cosf(6.28318530717958647692f * u32_to_unit(r.w));
-  return make_float2(a, b);
-}
-
-constexpr int NG = 2;       // element groups (4 consecutive elements of the 16 x in_dim chunk) per thread: 16 * 256 / 4 / 512
-
 template <bool IS_X>
-__device__ __forceinline__ void critic_fused_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
-  const int sig = blockIdx.y, L = a.L, B = a.B, S = a.S;
-  const int in_dim = IS_X ? S : L;
+__device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
+  const int sig = blockIdx.y, chunk = blockIdx.x, nchunks = a.B / 16, L = a.L, B = a.B, S = a.S;
   constexpr int nh = IS_X ? 4 : 2;
   const CriticLayout cl = IS_X ? cx_layout(S, L) : cz_layout(L);
-  const FusedLds fl = fused_lds(in_dim, L, nh);
-  const int ldin = fl.ldin, LQ = fl.LQ, Kin = fl.Kin, Lp = fl.Lp;
+  const CritGeom g = IS_X ? cx_geom(S, L) : cz_geom(L);
+  const IterLds fl = iter_lds(g);
+  const int in_dim = g.in_dim, ldin = g.ldin, LQ = g.LQ, Kin = g.Kin, Lp = g.Lp;
   float* in0 = smem + fl.in0; float* act = smem + fl.act; float* dm = smem + fl.dm; float* dl = smem + fl.dl;
-  float* w0 = smem + fl.w0; float* wh = smem + fl.wh; float* wl = smem + fl.wl; float* bias = smem + fl.bias;
-  float* dbias = smem + fl.dbias; float* red = smem + fl.red;
-  float* Pg = (IS_X ? a.P.cx + (int64_t)sig * a.pcx : a.P.cz + (int64_t)sig * a.pcz);
-  float* Mg = (IS_X ? a.M.cx + (int64_t)sig * a.pcx : a.M.cz + (int64_t)sig * a.pcz);
-  float* Vg = (IS_X ? a.V.cx + (int64_t)sig * a.pcx : a.V.cz + (int64_t)sig * a.pcz);
+  float* w0 = smem + fl.w0; float* wh = smem + fl.wh; float* wl = smem + fl.wl; float* red = smem + fl.red;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
-  const uint32_t tick = (uint32_t)a.counters[3] + (uint32_t)ph.it;     // counters advance once per phase (no reader/writer race)
-  const int step = a.counters[a.opt] + ph.it + 1;
+  const int it = ph.it;
+  const bool fin = it == ph.n_iters;
   const float invB = 1.f / B;
-  const float keep = 1.f / (1.f - cl.p_drop);
-  const int32_t* ridx = ph.row_index + (int64_t)ph.it * B;
-  const float* fake_rows = IS_X ? ph.gen_pre + ((int64_t)sig * ph.n_iters + ph.it) * B * S
-                                : ph.zenc_pre + ((int64_t)sig * ph.n_iters + ph.it) * B * L;
-  const float* xbase = a.x + sig * a.x_sig_stride;
-  const int ngroups = 4 * in_dim;              // 16 rows * in_dim / 4
-
   STAMP(0);
-  // ---- zero the whole plan (padding!), stage the weights with padded strides, constant d loss / d out
-  for (int i = threadIdx.x; i < fl.total; i += FT) smem[i] = 0.f;
-  __syncthreads();
-  for (int i = threadIdx.x; i < L * in_dim; i += FT) { const int n = i / in_dim, k = i - n * in_dim; w0[n * ldin + k] = Pg[cl.w[0] + i]; }
-  for (int li = 1; li < nh; ++li)
-    for (int i = threadIdx.x; i < L * L; i += FT) { const int n = i / L, k = i - n * L; wh[((li - 1) * L + n) * LQ + k] = Pg[cl.w[li] + i]; }
-  for (int i = threadIdx.x; i < L; i += FT) wl[i] = Pg[cl.w[nh] + i];
-  for (int i = threadIdx.x; i < (nh + 1) * L; i += FT) { const int li = i / L, c = i - li * L; if (li < nh || c == 0) bias[li * LQ + c] = Pg[cl.b[li] + c]; }
-  if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
 
-  // weight tiles: tile t = wave + 8 i belongs to this wave (accumulators stay in its registers for the whole iteration)
-  const int tk0 = (in_dim + 15) >> 4, tn = (L + 15) >> 4, tkh = (L + 15) >> 4;
-  const int tiles0 = tn * tk0, tilesh = tn * tkh, ntiles = tiles0 + (nh - 1) * tilesh + tkh;
-  auto tile_desc = [&](int t, int& li, int& n0, int& k0) {
-    if (t < tiles0) { li = 0; n0 = (t / tk0) * 16; k0 = (t % tk0) * 16; return; }
-    t -= tiles0;
-    li = 1 + t / tilesh;
-    t -= (li - 1) * tilesh;
-    n0 = (t / tkh) * 16; k0 = (t % tkh) * 16;
+  // ---- this iteration's record -> registers (HBM latency overlaps the reduction below); clear act | dl (padding)
+  const float* rec = (IS_X ? ph.rec_x : ph.rec_z) + (((int64_t)sig * ph.n_iters + it) * nchunks + chunk) * g.rec_floats;
+  float4 rrow[MAX_ROW4], rmask[MAX_MASK4];
+  if (!fin) {
+#pragma unroll
+    for (int u = 0; u < MAX_ROW4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rrow[u] = i < g.rec_rows4 ? reinterpret_cast<const float4*>(rec)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < MAX_MASK4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rmask[u] = i < g.rec_mask4 ? reinterpret_cast<const float4*>(rec + 4 * g.rec_rows4)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = threadIdx.x * 4; i < (2 * nh + 1) * 48 * LQ; i += FT * 4)
+      *reinterpret_cast<float4*>(act + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- prologue: weights of this iteration = Adam(previous weights, gradient of iteration it - 1 summed over the chunks)
+  float* arena_p = (IS_X ? a.P.cx + (int64_t)sig * a.pcx : a.P.cz + (int64_t)sig * a.pcz);
+  float* arena_m = (IS_X ? a.M.cx + (int64_t)sig * a.pcx : a.M.cz + (int64_t)sig * a.pcz);
+  float* arena_v = (IS_X ? a.V.cx + (int64_t)sig * a.pcx : a.V.cz + (int64_t)sig * a.pcz);
+  float* state = (IS_X ? ph.state_x : ph.state_z) + (int64_t)sig * 6 * g.params;
+  float* slabs = (IS_X ? ph.slab_x : ph.slab_z) + (int64_t)sig * 2 * nchunks * g.slab_floats;
+  const float* __restrict__ src_p = it == 0 ? arena_p : state + ((it - 1) & 1) * 3 * g.params;
+  const float* __restrict__ src_m = it == 0 ? arena_m : src_p + g.params;
+  const float* __restrict__ src_v = it == 0 ? arena_v : src_p + 2 * g.params;
+  float* __restrict__ dst_p = fin ? arena_p : state + (it & 1) * 3 * g.params;
+  float* __restrict__ dst_m = fin ? arena_m : dst_p + g.params;
+  float* __restrict__ dst_v = fin ? arena_v : dst_p + 2 * g.params;
+  const float* __restrict__ prev = slabs + (int64_t)((it - 1) & 1) * nchunks * g.slab_floats;
+  const bool writer = chunk == 0;
+  AdamCoef co;
+  co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = 0.f; co.riemannian = 0; co.stabilize = 0; co.step = 0;
+  {
+    const float* bc = ph.bias_corr + ((int64_t)(IS_X ? 0 : 1) * (ph.n_iters + 1) + it) * 2;   // written by the precompute launch
+    co.bc1 = it > 0 ? bc[0] : 1.f; co.sqrt_bc2 = it > 0 ? bc[1] : 1.f; co.bc2 = 1.f;
+  }
+  STAMP(50);
+
+  auto tile_desc = [&](int t, int& li, int& n0, int& k0) __attribute__((always_inline)) {
+    if (t < g.tiles0) { li = 0; n0 = (t / g.tk0) * 16; k0 = (t % g.tk0) * 16; return; }
+    t -= g.tiles0;
+    li = 1 + t / g.tilesh;
+    t -= (li - 1) * g.tilesh;
+    n0 = (t / g.tkh) * 16; k0 = (t % g.tkh) * 16;
   };
+  // Reduction + Adam over *valid accumulator quads* (a lane's 4 rows of one weight tile that hold real parameters),
+  // dealt round-robin to the 512 threads; every load is issued before the first use (one HBM round trip for the
+  // previous launch's slabs and the optimiser state together): clamped indices instead of branches around the loads.
+  const int Q = (L + 3) >> 2;                              // valid quad rows of an L-row layer
+  const int I0 = g.tk0 * 16 * Q, Ih = g.tkh * 16 * Q, nitems = I0 + (nh - 1) * Ih + g.tkh * 16;
+  float4 sx[NITEM][4], sy[NITEM][4];
+  float pv[NITEM][4], mv[NITEM][4], vv[NITEM][4];
+  int off[NITEM][4], i_li[NITEM], i_n[NITEM], i_k[NITEM], i_so[NITEM];
+#pragma unroll
+  for (int u = 0; u < NITEM; ++u) {
+    int e = threadIdx.x + u * FT;
+    const bool live = e < nitems;
+    e = live ? e : 0;
+    int li, tk, base, QQ = Q;
+    if (e < I0) { li = 0; tk = g.tk0; base = 0; }
+    else {
+      e -= I0;
+      const int lh = e / Ih;
+      if (lh < nh - 1) { li = 1 + lh; e -= lh * Ih; tk = g.tkh; base = g.tiles0 + lh * g.tilesh; }
+      else { li = nh; e -= (nh - 1) * Ih; tk = g.tkh; base = g.tiles0 + (nh - 1) * g.tilesh; QQ = 1; }
+    }
+    const int kt = e / (16 * QQ), rem = e - kt * 16 * QQ, qq = rem >> 4, jj = rem & 15;
+    const int t = base + (qq >> 2) * tk + kt;
+    const int so = t * 512 + ((qq & 3) * 16 + jj) * 4;
+    const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;            // K = index of the bias column
+    const int n = 4 * qq, k = 16 * kt + jj;
+    i_li[u] = live ? li : -1; i_n[u] = n; i_k[u] = k; i_so[u] = so;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* sl = prev + (int64_t)(w < nchunks ? w : 0) * g.slab_floats + so;
+      sx[u][w] = *reinterpret_cast<const float4*>(sl); sy[u][w] = *reinterpret_cast<const float4*>(sl + 256);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = live && n + r < N && k <= K;
+      const int o = ok ? (k < K ? cl.w[li] + (n + r) * K + k : cl.b[li] + n + r) : -1;
+      off[u][r] = o;
+      const int oc = ok ? o : 0;
+      pv[u][r] = src_p[oc]; mv[u][r] = src_m[oc]; vv[u][r] = src_v[oc];
+    }
+  }
+  float coef = 0.f;
+  if (it > 0) {
+    float gsum = 0.f, sreal = 0.f, sfake = 0.f;
+    for (int w = 0; w < nchunks; ++w) {                 // fixed order: every workgroup gets the same bits
+      const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
+      gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
+    }
+    const float nrm = sqrtf(gsum + 1e-12f);             // train.py:90, whole batch
+    const float gp = (nrm - 1.f) * (nrm - 1.f);
+    coef = 20.f * (nrm - 1.f) / nrm;                    // d(10 gp) / d g = coef * g
+    if (writer && threadIdx.x == 0) {
+      float* lo = ph.losses + sig * a.loss_sig_stride + (int64_t)(2 * (it - 1) + (IS_X ? 0 : 1)) * 4;
+      lo[0] = sfake * invB - sreal * invB + 10.f * gp;  // train.py:98-99
+      lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
+    }
+  }
+  STAMP(51);
+#pragma unroll
+  for (int u = 0; u < NITEM; ++u) {
+    const int li = i_li[u];
+    if (li >= 0) {
+      f32x4 grf = {0.f, 0.f, 0.f, 0.f}, ggp = {0.f, 0.f, 0.f, 0.f};
+      if (it > 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (w < nchunks) {
+            grf[0] += sx[u][w].x; grf[1] += sx[u][w].y; grf[2] += sx[u][w].z; grf[3] += sx[u][w].w;
+            ggp[0] += sy[u][w].x; ggp[1] += sy[u][w].y; ggp[2] += sy[u][w].z; ggp[3] += sy[u][w].w;
+          }
+        }
+        for (int w = 4; w < nchunks; ++w) {                               // batches above 64 rows: the rest, in order
+          const float* sl = prev + (int64_t)w * g.slab_floats + i_so[u];
+          const float4 x = *reinterpret_cast<const float4*>(sl), y = *reinterpret_cast<const float4*>(sl + 256);
+          grf[0] += x.x; grf[1] += x.y; grf[2] += x.z; grf[3] += x.w;
+          ggp[0] += y.x; ggp[1] += y.y; ggp[2] += y.z; ggp[3] += y.w;
+        }
+      }
+      const int N = li == nh ? 1 : L;
+      const int n = i_n[u], k = i_k[u];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r < N) {
+          float p = 0.f;
+          const int o = off[u][r];
+          if (o >= 0) {
+            p = pv[u][r];
+            float m = mv[u][r], v = vv[u][r];
+            if (it > 0) adam_update(p, m, v, grf[r] + coef * ggp[r], co);
+            if (writer) { dst_p[o] = p; dst_m[o] = m; dst_v[o] = v; }
+          }
+          if (li == 0) w0[(n + r) * ldin + k] = p;
+          else if (li < nh) wh[((li - 1) * L + n + r) * LQ + k] = p;
+          else wl[k] = p;
+        }
+      }
+    }
+  }
+  if (fin) return;
+  STAMP(1);
+
+  // ---- record -> LDS; constant d loss / d out
+#pragma unroll
+  for (int u = 0; u < MAX_ROW4; ++u) {
+    const int i = threadIdx.x + u * FT;
+    if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<float4*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
+  }
+#pragma unroll
+  for (int u = 0; u < MAX_MASK4; ++u) {
+    const int i = threadIdx.x + u * FT;
+    if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
+  }
+  if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
+  __syncthreads();
+  STAMP(2);
+  int sk = 3;
+
+  // ---- forward, 48 rows.  The last hidden layer's epilogue also starts the backward chain.
+  const float* dout = dl + nh * 48 * LQ;
+  for (int li = 0; li < nh; ++li) {
+    const float* A = li == 0 ? in0 : act + (li - 1) * 48 * LQ;
+    const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
+    float* ao = act + li * 48 * LQ; float* dmo = dm + li * 48 * LQ;
+    float* dtop = dl + (nh - 1) * 48 * LQ;
+    lds_gemm_nt(A, li == 0 ? ldin : LQ, 3, W, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? Kin : Lp, wave, lane, [&](int r, int c, float pre) {
+      if (c < L) {
+        const float dd = leaky_slope(pre) * dmo[r * LQ + c];
+        dmo[r * LQ + c] = dd;
+        ao[r * LQ + c] = pre * dd;
+        if (li == nh - 1) dtop[r * LQ + c] = dout[r * LQ] * wl[c] * dd;
+      } else if (c == L) {
+        ao[r * LQ + c] = 1.f;                      // ones column: carries the next layer's bias
+      }
+    });
+    __syncthreads();
+    STAMP(sk++);
+  }
+  // ---- critic outputs (loss terms) on the last wave, which owns no tile of the next products
+  float osum = 0.f;
+  if (wave == NW - 1) {
+    float o = 0.f;
+    if (lane < 32) {
+      const float* x = act + ((nh - 1) * 48 + lane) * LQ;
+      for (int c = 0; c <= L; ++c) o += x[c] * wl[c];
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+    osum = o;                                      // lane 0: sum over the real rows, lane 16: over the fake rows
+  }
+  // ---- first-order backward chain, all 48 rows, every layer's delta kept
+  for (int li = nh - 2; li >= 0; --li) {
+    float* dst = dl + li * 48 * LQ; const float* dmo = dm + li * 48 * LQ;
+    lds_gemm_nn(dl + (li + 1) * 48 * LQ, LQ, 3, wh + li * L * LQ, LQ, L, L, L, Lp, wave, lane,
+                [&](int r, int c, float v) { if (c < L) dst[r * LQ + c] = v * dmo[r * LQ + c]; });
+    __syncthreads();
+    STAMP(sk++);
+  }
+  // ---- g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47 (ones column cleared), sum of squares
+  float gsq = 0.f;
+  lds_gemm_nn(dl + 32 * LQ, LQ, 1, w0, ldin, L, in_dim, in_dim + 1, Lp, wave, lane, [&](int r, int c, float v) {
+    if (c < in_dim) { in0[(32 + r) * ldin + c] = v; gsq += v * v; }
+    else if (c == in_dim) in0[(32 + r) * ldin + c] = 0.f;
+  });
+  __syncthreads();
+  STAMP(sk++);
+
+  // ---- weight-gradient tiles: dW += left^T right over the chunk's rows; rows 0-31 (real, fake) -> acc_rf, GP rows -> acc_gp
   f32x4 acc_rf[MAXT], acc_gp[MAXT];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) { acc_rf[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_gp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  float gsq = 0.f;
-
-  // prefetch of a chunk's real / fake rows (critic_x: both from HBM; critic_z: fake only, real is noise)
-  float pre_x[NG][4], pre_f[NG][4];
-  auto prefetch = [&](int g0) {
+  auto dw_tile = [&](int i, bool rf, bool gpp) __attribute__((always_inline)) {
+    const int t = wave + NW * i;
+    if (t < g.ntiles) {
+      int li, n0, k0;
+      tile_desc(t, li, n0, k0);
+      const int N = li == nh ? 1 : L;
+      const int nj = n0 + j < N ? n0 + j : N - 1;                        // clamped; dropped at the update
+      const float* left = dl + li * 48 * LQ + nj;
+      const float* right = li == 0 ? in0 + k0 + j : act + (li - 1) * 48 * LQ + k0 + j;
+      const int ldr = li == 0 ? ldin : LQ;
+      if (rf) {
+        float la[8], rb[8];
 #pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int gi = threadIdx.x + u * FT;
+        for (int u = 0; u < 8; ++u) { la[u] = left[(4 * u + q) * LQ]; rb[u] = right[(4 * u + q) * ldr]; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int f = 4 * gi + e;
-        const int r = f / in_dim, c = f - r * in_dim;
-        const bool ok = gi < ngroups;
-        if (IS_X) pre_x[u][e] = ok ? xbase[(int64_t)(ridx ? ridx[g0 + r] : g0 + r) * S + c] : 0.f;
-        pre_f[u][e] = ok ? fake_rows[(int64_t)(g0 + r) * in_dim + c] : 0.f;
+        for (int u = 0; u < 8; ++u) acc_rf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_rf[i], 0, 0, 0);
+      }
+      if (gpp) {
+        float la[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { la[u] = left[(32 + 4 * u + q) * LQ]; rb[u] = right[(32 + 4 * u + q) * ldr]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc_gp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_gp[i], 0, 0, 0);
       }
     }
   };
-  prefetch(0);
-  __syncthreads();
-  STAMP(1);
-  int sk = 2;
-
-  for (int g0 = 0; g0 < B; g0 += 16) {
-    // ---- P0: real / fake / interpolated rows, dropout scales of every layer and pass
+  // ---- unscaled second-order chain: ep_0 = (g W_0^T) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
+  // (ones column cleared: the GP rows carry no bias term).  Only two tiles per step: the other waves fill the time with
+  // the real / fake part of their weight-gradient tiles, which is complete after the first backward.
 #pragma unroll
-    for (int u = 0; u < NG; ++u) {
-      const int gi = threadIdx.x + u * FT;
-      if (gi < ngroups) {
-        const uint32_t grp = (uint32_t)(g0 * in_dim) / 4 + gi;
-        const float4 al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)sig, grp);
-        const float alv[4] = {al.x, al.y, al.z, al.w};
-        float xr[4];
-        if (IS_X) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xr[e] = pre_x[u][e];
-        } else {
-          const float2 n0 = rng_normal2(a.seed, tick, RS_Z, (uint32_t)sig, 2 * grp), n1 = rng_normal2(a.seed, tick, RS_Z, (uint32_t)sig, 2 * grp + 1);
-          xr[0] = n0.x; xr[1] = n0.y; xr[2] = n1.x; xr[3] = n1.y;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int f = 4 * gi + e;
-          const int r = f / in_dim, c = f - r * in_dim;
-          const float xv = xr[e], fv = pre_f[u][e];
-          in0[r * ldin + c] = xv;
-          in0[(16 + r) * ldin + c] = fv;
-          in0[(32 + r) * ldin + c] = alv[e] * xv + (1.f - alv[e]) * fv;
-        }
-      }
-    }
-    if (g0 < 16) STAMP(sk++);
-    if (g0 + 16 < B) prefetch(g0 + 16);
-    {
-      const int per = 4 * L;                    // groups per (pass, layer)
-      for (int w = threadIdx.x; w < 3 * nh * per; w += FT) {
-        const int pl = w / per, gi = w - pl * per;
-        const int p = pl / nh, li = pl - p * nh;
-        float v[4] = {1.f, 1.f, 1.f, 1.f};
-        if (a.drop_mode == 2) {
-          const int pass = p == 2 ? 2 : (IS_X ? p : 1 - p);          // stream numbering of the per-iteration entry points
-          const float4 uu = rng_uniform4(a.seed, tick, RS_DROP_CRITIC + 8 * pass + li, (uint32_t)sig, (uint32_t)(g0 * L) / 4 + gi);
-          v[0] = uu.x >= cl.p_drop ? keep : 0.f; v[1] = uu.y >= cl.p_drop ? keep : 0.f;
-          v[2] = uu.z >= cl.p_drop ? keep : 0.f; v[3] = uu.w >= cl.p_drop ? keep : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int f = 4 * gi + e;
-          const int r = f / L, c = f - r * L;
-          dm[(li * 48 + p * 16 + r) * LQ + c] = v[e];
-        }
-      }
-    }
+  for (int li = 0; li < nh; ++li) {
+    const float* A = li == 0 ? in0 + 32 * ldin : act + ((li - 1) * 48 + 32) * LQ;
+    const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
+    float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
+    lds_gemm_nt(A, li == 0 ? ldin : LQ, 1, W, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? Kin : Lp, NW - 1 - wave, lane,
+                [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; else if (c == L) eo[r * LQ + c] = 0.f; });
+    dw_tile(li, true, false);
     __syncthreads();
-    if (g0 < 16) STAMP(sk++);
-    // ---- P1..: forward, 48 rows.  The last hidden layer's epilogue also starts the backward chain.
-    for (int li = 0; li < nh; ++li) {
-      const float* A = li == 0 ? in0 : act + (li - 1) * 48 * LQ;
-      const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
-      float* ao = act + li * 48 * LQ; float* dmo = dm + li * 48 * LQ;
-      const float* bb = bias + li * LQ;
-      float* dtop = dl + (nh - 1) * 48 * LQ;
-      const float* dout = dl + nh * 48 * LQ;
-      lds_gemm_nt(A, li == 0 ? ldin : LQ, 3, W, li == 0 ? ldin : LQ, L, li == 0 ? Kin : Lp, wave, lane, [&](int r, int c, float v) {
-        if (c < L) {
-          const float pre = v + bb[c];
-          const float dd = leaky_slope(pre) * dmo[r * LQ + c];
-          dmo[r * LQ + c] = dd;
-          ao[r * LQ + c] = pre * dd;
-          if (li == nh - 1) dtop[r * LQ + c] = dout[r * LQ] * wl[c] * dd;
-        }
-      });
-      __syncthreads();
-      if (g0 < 16) STAMP(sk++);
-    }
-    // ---- critic outputs (loss terms) on the last wave, which owns no tile of the next products
-    if (wave == FT / 64 - 1) {
-      float o = 0.f;
-      if (lane < 32) {
-        const float* x = act + ((nh - 1) * 48 + lane) * LQ;
-        o = bias[nh * LQ];
-        for (int c = 0; c < L; ++c) o += x[c] * wl[c];
-      }
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
-      if (lane == 0) red[32] += o;
-      if (lane == 16) red[33] += o;
-    }
-    // ---- first-order backward chain, all 48 rows, every layer's delta kept
-    for (int li = nh - 2; li >= 0; --li) {
-      float* dst = dl + li * 48 * LQ; const float* dmo = dm + li * 48 * LQ;
-      lds_gemm_nn(dl + (li + 1) * 48 * LQ, LQ, 3, wh + li * L * LQ, LQ, L, L, Lp, wave, lane,
-                  [&](int r, int c, float v) { if (c < L) dst[r * LQ + c] = v * dmo[r * LQ + c]; });
-      __syncthreads();
-      if (g0 < 16) STAMP(sk++);
-    }
-    // ---- g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47, sum of squares
-    lds_gemm_nn(dl + 32 * LQ, LQ, 1, w0, ldin, L, in_dim, Lp, wave, lane, [&](int r, int c, float v) {
-      if (c < in_dim) { in0[(32 + r) * ldin + c] = v; gsq += v * v; }
-    });
-    __syncthreads();
-    if (g0 < 16) STAMP(sk++);
-    // ---- unscaled second-order chain: ep_0 = (g W_0^T) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
-    for (int li = 0; li < nh; ++li) {
-      const float* A = li == 0 ? in0 + 32 * ldin : act + ((li - 1) * 48 + 32) * LQ;
-      const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
-      float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
-      lds_gemm_nt(A, li == 0 ? ldin : LQ, 1, W, li == 0 ? ldin : LQ, L, li == 0 ? Kin : Lp, wave, lane,
-                  [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; });
-      __syncthreads();
-      if (g0 < 16) STAMP(sk++);
-    }
-    // ---- bias gradients (real + fake rows only: LeakyReLU'' = 0 leaves the GP rows without a bias term)
-    for (int idx = threadIdx.x; idx < (nh + 1) * L; idx += FT) {
-      const int li = idx / L, c = idx - li * L;
-      if (li < nh || c == 0) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < 32; r += 2) { s0 += dl[(li * 48 + r) * LQ + c]; s1 += dl[(li * 48 + r + 1) * LQ + c]; }
-        dbias[li * LQ + c] += s0 + s1;
-      }
-    }
-    if (g0 < 16) STAMP(sk++);
-    // ---- weight-gradient tiles: dW += left^T right over this chunk's rows (rows 0-31 -> acc_rf, GP rows -> acc_gp)
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
-      const int t = wave + (FT / 64) * i;
-      if (t < ntiles) {
-        int li, n0, k0;
-        tile_desc(t, li, n0, k0);
-        const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
-        const int nj = n0 + j < N ? n0 + j : N - 1, kj = k0 + j < K ? k0 + j : K - 1;   // clamped; dropped at the update
-        const float* left = dl + li * 48 * LQ + nj;
-        const float* right = li == 0 ? in0 + kj : act + (li - 1) * 48 * LQ + kj;
-        const int ldr = li == 0 ? ldin : LQ;
-        float la[12], rb[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) { la[u] = left[(4 * u + q) * LQ]; rb[u] = right[(4 * u + q) * ldr]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc_rf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_rf[i], 0, 0, 0);
-#pragma unroll
-        for (int u = 8; u < 12; ++u) acc_gp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_gp[i], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (g0 < 16) STAMP(sk++);
+    STAMP(sk++);
   }
-  STAMP(40);
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) dw_tile(i, i >= nh, true);
+  STAMP(sk++);
 
-  // ---- whole-batch norm, loss, Adam
-  float tot = wave_sum(gsq);
-  if (lane == 0) red[wave] = tot;
-  __syncthreads();
-  float gsum = 0.f;
-  for (int w = 0; w < FT / 64; ++w) gsum += red[w];
-  const float nrm = sqrtf(gsum + 1e-12f);
-  const float gp = (nrm - 1.f) * (nrm - 1.f);
-  const float coef = 20.f * (nrm - 1.f) / nrm;
-  if (threadIdx.x == 0) {
-    float* lo = a.losses + sig * a.loss_sig_stride;
-    const float sreal = red[32], sfake = red[33];
-    lo[0] = sfake * invB - sreal * invB + 10.f * gp;
-    lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
-  }
-  const AdamCoef co = adam_coef(a.lr, a.b1, a.b2, a.eps, 0.f, 0, 0, step);
+  // ---- publish the chunk's shares: accumulator images + {sum g^2, sum real out, sum fake out}
+  float* mine = slabs + ((int64_t)(it & 1) * nchunks + chunk) * g.slab_floats;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
-    const int t = wave + (FT / 64) * i;
-    if (t < ntiles) {
-      int li, n0, k0;
-      tile_desc(t, li, n0, k0);
-      const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 4 * q + r, k = k0 + j;
-        if (n < N && k < K) {
-          const int64_t o = cl.w[li] + (int64_t)n * K + k;
-          float p = Pg[o], m = Mg[o], v = Vg[o];
-          adam_update(p, m, v, acc_rf[i][r] + coef * acc_gp[i][r], co);
-          Pg[o] = p; Mg[o] = m; Vg[o] = v;
-        }
-      }
+    const int t = wave + NW * i;
+    if (t < g.ntiles) {
+      *reinterpret_cast<float4*>(mine + t * 512 + lane * 4) = make_float4(acc_rf[i][0], acc_rf[i][1], acc_rf[i][2], acc_rf[i][3]);
+      *reinterpret_cast<float4*>(mine + t * 512 + 256 + lane * 4) = make_float4(acc_gp[i][0], acc_gp[i][1], acc_gp[i][2], acc_gp[i][3]);
     }
   }
-  for (int idx = threadIdx.x; idx < (nh + 1) * L; idx += FT) {
-    const int li = idx / L, c = idx - li * L;
-    if (li < nh || c == 0) {
-      const int64_t o = cl.b[li] + c;
-      float p = Pg[o], m = Mg[o], v = Vg[o];
-      adam_update(p, m, v, dbias[li * LQ + c], co);
-      Pg[o] = p; Mg[o] = m; Vg[o] = v;
-    }
+  const float tot = wave_sum(gsq);
+  if (lane == 0) red[wave] = tot;
+  if (wave == NW - 1) { if (lane == 0) red[32] = osum; if (lane == 16) red[33] = osum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float gs = 0.f;
+    for (int w = 0; w < NW; ++w) gs += red[w];
+    float* sc = mine + g.ntiles * 512;
+    sc[0] = gs; sc[1] = red[32]; sc[2] = red[33]; sc[3] = 0.f;
   }
-  STAMP(41);
+  STAMP(sk++);
+  STAMP(40);
 }
 
-__global__ __launch_bounds__(FT) void critic_fused_pair_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
+__global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (blockIdx.z == 0) critic_fused_body<true>(ax, ph, smem); else critic_fused_body<false>(az, ph, smem);
+  if (blockIdx.z == 0) critic_iteration_body<true>(ax, ph, smem); else critic_iteration_body<false>(az, ph, smem);
 }
 
 __global__ void advance_counters_kernel(int32_t* counters, int n) {
@@ -459,22 +583,39 @@ __global__ void advance_counters_kernel(int32_t* counters, int n) {
 namespace hypad {
 namespace train {
 
+bool critic_phase_supported(const hypad_dims& d) {
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  if (!geom_supported(gx) || !geom_supported(gz)) return false;
+  const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
+  return (size_t)(lx > lz ? lx : lz) * sizeof(float) <= 160 * 1024;
+}
+// double-buffered optimiser state and gradient slabs
+size_t critic_phase_fixed_floats(const hypad_dims& d) {
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  const size_t nchunks = d.batch / 16;
+  return (size_t)d.n_signals * (6 * (size_t)(gx.params + gz.params) + 2 * nchunks * (size_t)(gx.slab_floats + gz.slab_floats)) + 8;
+}
+// records of one iteration
 size_t critic_phase_floats_per_iter(const hypad_dims& d) {
-  return (size_t)d.n_signals * d.batch * (pad4(d.signal_shape) + pad4(d.latent_dim));
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  return (size_t)d.n_signals * (d.batch / 16) * (size_t)(gx.rec_floats + gz.rec_floats) + 4;      // + Adam bias corrections
 }
 
 // Runs the critic phase of an epoch (train.py:315-328) for n_iters = n_critics * n_batches (critic_x || critic_z)
-// iterations.  ax / az: arguments of the two iterations (row_index and losses are set per iteration here).  extra:
-// `extra_floats` floats of scratch; the phase is cut into chunks of as many iterations as fit.  losses: iteration `it`
-// writes rows 2*it (critic_x) and 2*it+1 (critic_z) of each signal's loss table.  ev (optional, 3 events): recorded
-// before the precompute, before the first fused launch and after it (profiling; only with n_iters == 1).
+// iterations.  ax / az: arguments of the two iterations (loss_sig_stride set; row_index and losses are taken from the
+// arguments here).  extra: `extra_floats` floats of scratch; the phase is cut into chunks of as many iterations as fit.
+// losses: iteration `it` writes rows 2*it (critic_x) and 2*it+1 (critic_z) of each signal's loss table.  ev (optional,
+// 3 events, profiling, n_iters == 1): recorded before the precompute, before the iteration launch and after it.
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
-  const size_t per_iter = critic_phase_floats_per_iter(d);
-  int chunk = (int)(extra_floats / per_iter);
-  if (chunk < 1) return HYPAD_EWORKSPACE;
-  if (chunk > n_iters) chunk = n_iters;
+  if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
+  const size_t fixed = critic_phase_fixed_floats(d), per_iter = critic_phase_floats_per_iter(d);
+  if (extra_floats < fixed + per_iter) return HYPAD_EWORKSPACE;
+  int cap = (int)((extra_floats - fixed) / per_iter);
+  if (cap > n_iters) cap = n_iters;
+  const CritGeom gx = cx_geom(ax.S, ax.L), gz = cz_geom(ax.L);
+  const int nchunks = ax.B / 16;
   // the generator-side randomness (z, decoder dropout) keeps the critic_x seed; critic_z draws from its own
   az.seed = ax.seed ^ 0x5851F42D4C957F2DULL;
   const size_t lds_pre = (size_t)lds_plan(ax.S, 16, 16, 0).total * sizeof(float);
@@ -482,32 +623,37 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     hipError_t e = hipFuncSetAttribute((const void*)critic_phase_precompute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
     if (e != hipSuccess) return (int)e;
   }
-  const FusedLds fx = fused_lds(ax.S, ax.L, 4);
-  const FusedLds fz = fused_lds(az.L, az.L, 2);
-  const size_t lds = (size_t)(fx.total > fz.total ? fx.total : fz.total) * sizeof(float);
-  if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
+  const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
+  const size_t lds = (size_t)(lx > lz ? lx : lz) * sizeof(float);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)critic_fused_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)critic_iteration_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  for (int it0 = 0; it0 < n_iters; it0 += chunk) {
-    const int n = n_iters - it0 < chunk ? n_iters - it0 : chunk;
-    PhaseArgs ph;
+  PhaseArgs ph;
+  float* p = extra;
+  ph.state_x = p; p += (size_t)n_signals * 6 * gx.params;
+  ph.state_z = p; p += (size_t)n_signals * 6 * gz.params;
+  ph.slab_x = p; p += (size_t)n_signals * 2 * nchunks * gx.slab_floats;
+  ph.slab_z = p; p += (size_t)n_signals * 2 * nchunks * gz.slab_floats;
+  float* bcorr = p; p += pad4(4 * (cap + 1));
+  float* recs = p;
+  ph.stamps = g_stamps;
+  for (int it0 = 0; it0 < n_iters; it0 += cap) {
+    const int n = n_iters - it0 < cap ? n_iters - it0 : cap;
     ph.n_iters = n;
-    ph.row_index = row_index + (int64_t)it0 * ax.B;
-    ph.gen_pre = extra;
-    ph.zenc_pre = extra + (size_t)n_signals * n * ax.B * pad4(ax.S);
+    ph.row_index = row_index ? row_index + (int64_t)it0 * ax.B : nullptr;
+    ph.losses = losses + (int64_t)(2 * it0) * 4;
+    ph.rec_x = recs;
+    ph.rec_z = recs + (size_t)n_signals * n * nchunks * gx.rec_floats;
+    ph.bias_corr = bcorr;
     ph.it = 0;
-    ph.stamps = g_stamps;
     if (ev) (void)hipEventRecord(ev[0], s);
-    hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(ax.B / 16, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, ph);
+    hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
     HYPAD_CHECK_LAUNCH();
     if (ev) (void)hipEventRecord(ev[1], s);
-    for (int it = 0; it < n; ++it) {
+    for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
       ph.it = it;
-      ax.losses = losses + (int64_t)(2 * (it0 + it)) * 4;
-      az.losses = losses + (int64_t)(2 * (it0 + it) + 1) * 4;
-      hipLaunchKernelGGL(critic_fused_pair_kernel, dim3(1, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
+      hipLaunchKernelGGL(critic_iteration_kernel, dim3(it == n ? 1 : nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
       if (ev && it == 0) (void)hipEventRecord(ev[2], s);
     }
@@ -520,5 +666,5 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
 }  // namespace train
 }  // namespace hypad
 
-// development aid (not declared in hypad.h): device buffer of 128 int64 that the next fused launches stamp, or null
+// development aid (not declared in hypad.h): device buffer of 128 int64 that the next critic launches stamp, or null
 extern "C" void hypad_diag_set_fused_stamps(long long* p) { g_stamps = p; }

@@ -191,7 +191,9 @@ __device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, Ro
 }
 
 // critic_fused.hip: the critic phase of an epoch with the frozen generator's forwards hoisted out of the chain
-size_t critic_phase_floats_per_iter(const hypad_dims& d);
+bool critic_phase_supported(const hypad_dims& d);          // LDS / register budget of the iteration kernel
+size_t critic_phase_fixed_floats(const hypad_dims& d);     // double-buffered optimiser state + gradient slabs
+size_t critic_phase_floats_per_iter(const hypad_dims& d);  // precomputed records of one (critic_x || critic_z) iteration
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev);
 

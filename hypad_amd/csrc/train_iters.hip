@@ -952,7 +952,8 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
     rc = fill_args(ax, d, st, c, 0);
     if (!rc) rc = fill_args(az, d, st, c, 1);
     const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
-    if (!rc && io->workspace_bytes < (base + critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
+    if (!rc && !critic_phase_supported(*d)) rc = HYPAD_EUNSUPPORTED;
+    if (!rc && io->workspace_bytes < (base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
     if (!rc) rc = run_critic_phase(ax, az, io->row_index, 1, io->losses, (float*)io->workspace + base,
                                    io->workspace_bytes / sizeof(float) - base, d->n_signals, (hipStream_t)s, ev);
   }
@@ -972,7 +973,9 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* d, int n_batches, int n_cri
   if (check_dims(d) || n_batches <= 0 || n_critics < 0) return 0;
   int64_t n = (int64_t)n_batches * n_critics;
   if (n > 512) n = 512;
-  return ((size_t)ws_floats_per_signal(*d) * d->n_signals + (size_t)n * critic_phase_floats_per_iter(*d)) * sizeof(float);
+  const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
+  if (!critic_phase_supported(*d) || n == 0) return base * sizeof(float);      // per-minibatch launch groups only
+  return (base + critic_phase_fixed_floats(*d) + (size_t)n * critic_phase_floats_per_iter(*d)) * sizeof(float);
 }
 
 int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t s) {
@@ -990,7 +993,8 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
   const size_t have = io->workspace_bytes / sizeof(float);
   const char* legacy = getenv("HYPAD_EPOCH_LEGACY");
-  const bool hoisted = io->n_critics > 0 && have >= base + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
+  const bool hoisted = io->n_critics > 0 && critic_phase_supported(*d) &&
+                       have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
   if (hoisted) {                                       // train.py:315-328, generator forwards hoisted (critic_fused.hip)
     IterArgs ax, az;
     c.row_index = io->row_index; c.losses = io->losses;

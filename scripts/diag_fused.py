@@ -1,4 +1,4 @@
-"""Per-stage shader-clock timeline of critic_fused_pair_kernel (first chunk), configs[1] shape."""
+"""Per-stage shader-clock timeline of critic_iteration_kernel (workgroup 0 of each critic), configs[1] shape."""
 import sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -11,17 +11,18 @@ st = torch.zeros(128, dtype=torch.int64, device=dev)
 fn = _C.lib.hypad_diag_set_fused_stamps
 fn.restype = None; fn.argtypes = [ctypes.c_void_p]
 fn(st.data_ptr())
-idx = torch.arange(bench.B, device=dev, dtype=torch.int32)
-for _ in range(5):
-    ms = eng.profile_iteration(4, x, idx, True)
+perm = torch.stack([torch.randperm(bench.N_WINDOWS, device=dev)[: 3 * bench.B] for _ in range(3)]).to(torch.int32).contiguous()
+for _ in range(3):
+    eng.train_epoch(x, perm, 3, 2, True)
 torch.cuda.synchronize()
+ms = None
 s = st.cpu().numpy().reshape(2, 64)
 print("events ms", ms)
 for z, nm in ((0, "critic_x"), (1, "critic_z")):
     nh = 4 if z == 0 else 2
-    names = ["zero+stage", "P0 rows+interp", "P0 prefetch+masks+sync"] + [f"fwd{l}" for l in range(nh)] + [f"bwd{l}" for l in range(nh - 2, -1, -1)] + ["g"] + [f"ep{l}" for l in range(nh)] + ["dbias", "dW+sync"]
+    names = ["prologue (record loads, reduce+Adam)", "record->LDS"] + [f"fwd{l}" for l in range(nh)] + [f"bwd{l}" for l in range(nh - 2, -1, -1)] + ["g"] + [f"ep{l}+dWrf" for l in range(nh)] + ["dW rest", "publish"]
     t = s[z]
     n = len(names)
     d = np.diff(t[: n + 1])
-    print(nm, "total cycles", t[41] - t[0], "first chunk", t[n] - t[1], "rest(3 chunks)", t[40] - t[n], "tail", t[41] - t[40])
+    print(nm, "total cycles", t[40] - t[0], "| prologue: to adam-coef", t[50] - t[0], "barrier", t[51] - t[50], "tiles", t[1] - t[51])
     print("   " + ", ".join(f"{a} {b}" for a, b in zip(names, d)))
