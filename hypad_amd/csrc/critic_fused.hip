@@ -605,7 +605,8 @@ size_t critic_phase_floats_per_iter(const hypad_dims& d) {
 // iterations.  ax / az: arguments of the two iterations (loss_sig_stride set; row_index and losses are taken from the
 // arguments here).  extra: `extra_floats` floats of scratch; the phase is cut into chunks of as many iterations as fit.
 // losses: iteration `it` writes rows 2*it (critic_x) and 2*it+1 (critic_z) of each signal's loss table.  ev (optional,
-// 3 events, profiling, n_iters == 1): recorded before the precompute, before the iteration launch and after it.
+// 4 events, profiling, n_iters == 2): recorded before the precompute, after it, after the first iteration launch (no
+// Adam prologue) and after the second (steady state).
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
@@ -655,7 +656,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
       ph.it = it;
       hipLaunchKernelGGL(critic_iteration_kernel, dim3(it == n ? 1 : nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
-      if (ev && it == 0) (void)hipEventRecord(ev[2], s);
+      if (ev && it < 2) (void)hipEventRecord(ev[2 + it], s);
     }
     hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
     HYPAD_CHECK_LAUNCH();

@@ -932,7 +932,7 @@ int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, co
 int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, float* ms_out,
                             int n_out, hypad_stream_t s) {
   if (!io || !ms_out || kind < 0 || kind > 4) return HYPAD_EINVAL;
-  const int nk = (kind == 2 || kind == 4) ? 2 : 3;
+  const int nk = kind == 2 ? 2 : 3;
   if (n_out < nk) return HYPAD_EINVAL;
   if (kind >= 3 && !io->losses) return HYPAD_EINVAL;
   hipEvent_t ev[4];
@@ -948,13 +948,13 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
   else {
     IterArgs ax, az;
     IterCall c = from_io(io);
-    c.loss_sig_stride = 8;                 // per signal: critic_x row, critic_z row
+    c.loss_sig_stride = 16;                // per signal: 2 iterations x (critic_x row, critic_z row)
     rc = fill_args(ax, d, st, c, 0);
     if (!rc) rc = fill_args(az, d, st, c, 1);
     const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
     if (!rc && !critic_phase_supported(*d)) rc = HYPAD_EUNSUPPORTED;
-    if (!rc && io->workspace_bytes < (base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
-    if (!rc) rc = run_critic_phase(ax, az, io->row_index, 1, io->losses, (float*)io->workspace + base,
+    if (!rc && io->workspace_bytes < (base + critic_phase_fixed_floats(*d) + 2 * critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
+    if (!rc) rc = run_critic_phase(ax, az, nullptr, 2, io->losses, (float*)io->workspace + base,
                                    io->workspace_bytes / sizeof(float) - base, d->n_signals, (hipStream_t)s, ev);
   }
   if (rc == HYPAD_OK) {

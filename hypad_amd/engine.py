@@ -109,11 +109,11 @@ class Engine:
 
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
-        4 one iteration of train_epoch's hoisted critic phase), HIP events on the current stream."""
+        4 two iterations of train_epoch's hoisted critic phase: precompute, first launch, steady-state launch), HIP events on the current stream."""
         x, stride = self._check_x(x)
         if kind == 4:
-            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 1, 1))
-        losses = torch.empty(2 * self.n, 4, dtype=torch.float32, device=self.device)
+            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 2, 1))
+        losses = torch.empty(4 * self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None, self.seed, 0)
         io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(), None, None, drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
@@ -121,7 +121,7 @@ class Engine:
         out = (ctypes.c_float * 3)()
         _C.check(_C.lib.hypad_profile_iteration(int(kind), ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), out, 3,
                                                 _C.stream()), "profile_iteration")
-        return list(out)[: 2 if kind in (2, 4) else 3]
+        return list(out)[: 2 if kind == 2 else 3]
 
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
