@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/hypad.h"
+#include "critic_mfma.h"
 #include "train_common.h"
 
 using namespace hypad;
@@ -32,11 +33,10 @@ namespace {
 
 constexpr int FT = 512;                      // threads of the critic iteration kernel (8 waves)
 constexpr int NW = FT / 64;
+static_assert(NW == CM_NW, "critic_mfma.h deals tiles over 8 waves");
 constexpr int MAXT = 5;                      // weight tiles per wave
 constexpr int MAX_ROW4 = 4, MAX_MASK4 = 3;   // float4 record loads per thread (rows / masks)
 constexpr int NITEM = 3;                     // accumulator quads per thread in the reduction prologue
-
-HD int up16(int n) { return (n + 15) & ~15; }
 
 // Geometry of one critic inside the phase: padded lengths, record and slab sizes, weight-tile census
 struct CritGeom {
@@ -214,59 +214,6 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
 }
 
 // ---------------------------------------------------------------------------------------------- iteration kernel
-__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
-  return acc;
-}
-// out[r][n] = sum_k A[r][k] W[n][k];  A: LDS [16 RT][lda], W: LDS [Nrows][ldw], both zero-padded to Kp columns.
-// epi(r, n, value) for n < 16 ceil(Ncols / 16); columns >= Nrows repeat row Nrows - 1 of W (the caller overrides them).
-// Tile t is computed by the wave whose wslot == t mod NW.
-template <class Epi>
-__device__ __forceinline__ void lds_gemm_nt(const float* A, int lda, int RT, const float* W, int ldw, int Nrows, int Ncols, int Kp, int wslot,
-                                            int lane, Epi epi) {
-  const int j = lane & 15, q = lane >> 4, CT = (Ncols + 15) >> 4;
-  for (int t = wslot; t < RT * CT; t += NW) {
-    const int rt = t / CT, ct = t - rt * CT;
-    int n = ct * 16 + j; n = n < Nrows ? n : Nrows - 1;
-    const float* a = A + (rt * 16 + j) * lda + 4 * q;
-    const float* b = W + n * ldw + 4 * q;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int g = 0; g < Kp; g += 16)
-      acc = mfma4(*reinterpret_cast<const float4*>(a + g), *reinterpret_cast<const float4*>(b + g), acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) epi(rt * 16 + 4 * q + r, ct * 16 + j, acc[r]);
-  }
-}
-// out[r][c] = sum_o A[r][o] W[o][c];  A: LDS [16 RT][lda] zero-padded to Kp columns, W: LDS [No][ldw]; epi for
-// c < 16 ceil(Ccols / 16), columns >= Cvalid repeat column Cvalid - 1.
-template <class Epi>
-__device__ __forceinline__ void lds_gemm_nn(const float* A, int lda, int RT, const float* W, int ldw, int No, int Cvalid, int Ccols, int Kp,
-                                            int wslot, int lane, Epi epi) {
-  const int j = lane & 15, q = lane >> 4, CT = (Ccols + 15) >> 4;
-  for (int t = wslot; t < RT * CT; t += NW) {
-    const int rt = t / CT, ct = t - rt * CT;
-    int c = ct * 16 + j; c = c < Cvalid ? c : Cvalid - 1;
-    const float* a = A + (rt * 16 + j) * lda + 4 * q;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int g = 0; g < Kp; g += 16) {
-      const int o = g + 4 * q;
-      float4 bv;
-      bv.x = W[(o < No ? o : No - 1) * ldw + c];
-      bv.y = W[(o + 1 < No ? o + 1 : No - 1) * ldw + c];
-      bv.z = W[(o + 2 < No ? o + 2 : No - 1) * ldw + c];
-      bv.w = W[(o + 3 < No ? o + 3 : No - 1) * ldw + c];
-      acc = mfma4(*reinterpret_cast<const float4*>(a + g), bv, acc);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) epi(rt * 16 + 4 * q + r, ct * 16 + j, acc[r]);
-  }
-}
-
 template <bool IS_X>
 __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
   const int sig = blockIdx.y, chunk = blockIdx.x, nchunks = a.B / 16, L = a.L, B = a.B, S = a.S;

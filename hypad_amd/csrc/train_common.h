@@ -46,7 +46,7 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.ecat = o; o += pad4(3 * B * S);
   w.u = o; o += pad4(3 * B * S);
   w.du = o; o += pad4(3 * B * S);
-  w.ballpart = o; o += pad4((B / 16) * S);          // per-tile column sums of the head-bias gradient rows
+  w.ballpart = o; o += pad4(2 * (B / 16) * S);      // per (role, tile) column sums of the head-bias gradient rows
   w.dpre2 = o; o += pad4(2 * B * S);
   w.dg1 = o; o += pad4(2 * B * 6 * DEC_H);
   w.dg0 = o; o += pad4(2 * B * 6 * DEC_H);
@@ -82,7 +82,9 @@ struct IterArgs {
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
+  long long* stamps;               // development aid: shader-clock stamps of workgroup (0, 0) of the generator kernel, or null
 };
+#define GEN_STAMP(k) do { if (a.stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[(k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 struct LdsPlan {
   int xs, zs, bufA, bufB, crit, small, wst, cparams, total, ldS, bufFloats;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/hypad.h"
+#include "critic_mfma.h"
 #include "train_common.h"
 
 using namespace hypad;
@@ -227,206 +228,246 @@ __device__ __forceinline__ void gp_body(const IterArgs& a, float* smem) {
 HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) + 4) + 2 * 16 * LP + critic_floats; }
 
 // ------------------------------------------------------------------------------------------------ generator body
-// decoder_iteration (train.py:189-249): rows of a tile: pass 0 = decoder(z), pass 1 = decoder(encoder(x)),
-// pass 2 (hyperbolic only) = hyperbolic_linear(x).
+// decoder_iteration (train.py:189-249).  Its two chains are independent until the weight gradients are summed:
+//   role 0 (G):  z ~ N(0,1) -> decoder -> critic_x -> -mean(fake_x)                      and back through the decoder;
+//   role 1 (R):  x -> encoder -> critic_z -> -mean(fake_z);  encoder(x) -> decoder -> reconstruction loss against x
+//                (hyperbolic: Poincare distance between the Moebius heads of x_rec and of x) and back through decoder
+//                and encoder.
+// One workgroup per (16-row tile, role): blockIdx.z = role.  Operand rows in the workspace are pass-major as before:
+// pass 0 = decoder(z), pass 1 = decoder(encoder(x)), pass 2 (hyperbolic only) = hyperbolic_linear(x).
+struct GenLds {
+  int xs, zs, bufA, bufB, small, wst, cw, ct, total, ldS;
+};
+HD GenLds gen_lds(int S, int L, int hyper, int role) {
+  GenLds p;
+  p.ldS = pad4(S) + 4;
+  const CriticPad cp = role == 0 ? critic_pad(S, L, 4) : critic_pad(L, L, 2);
+  const int rows_head = (role == 1 && hyper) ? 32 : 16;
+  const int a = 16 * (6 * DEC_H + 4), b = rows_head * p.ldS;
+  const int bufFloats = a > b ? a : b;
+  int o = 0;
+  p.xs = o; o += role == 1 ? 16 * p.ldS : 0;     // the real windows: role R only
+  p.zs = o; o += 32 * LP;
+  p.bufA = o; o += bufFloats;
+  p.bufB = o; o += bufFloats;
+  p.small = o; o += 3 * 16 * LP + 64;             // dzc | dzs | spare, then 64 reduction slots
+  p.wst = o; o += (TB / 64) * WSTAGE_FLOATS;
+  p.cw = o; o += cp.total;                        // the role's frozen critic, padded image (critic_mfma.h)
+  p.ct = o; o += critic_tile_floats(cp, role == 0 ? 4 : 2);
+  p.total = o;
+  return p;
+}
+
 template <bool HYPER>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
-  const int sig = blockIdx.y, tile = blockIdx.x, S = a.S, L = a.L, B = a.B;
-  const CriticLayout clx = cx_layout(S, L);
-  const CriticLayout clz = cz_layout(L);
-  const LdsPlan lp = lds_plan(S, 32, HYPER ? 48 : 32, clx.total + clz.total);
+  const int sig = blockIdx.y, tile = blockIdx.x, role = blockIdx.z, S = a.S, L = a.L, B = a.B;
+  const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, HYPER ? 1 : 0);
   const GenWs gw = gen_ws(B, S, L);
   const float* PE = a.P.enc + (int64_t)sig * a.pe;
   const float* PD = a.P.dec + (int64_t)sig * a.pd;
-  const float* PX = a.P.cx + (int64_t)sig * a.pcx;
-  const float* PZ = a.P.cz + (int64_t)sig * a.pcz;
   float* ws = a.ws + sig * a.ws_sig_stride;
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* small = smem + lp.small;
   float* dzc = small;                       // [16][LP] gradient of -mean(critic_z) w.r.t. encoder output
   float* dzs = small + 16 * LP;             // [16][LP] total gradient of the encoder output
   float* red = small + 3 * 16 * LP;
-  const CriticLds cs = critic_lds(smem + lp.crit);
+  float* wst = smem + lp.wst;
+  float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   const uint32_t tick = (uint32_t)a.counters[3];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
-  if (lp.stage) {                           // frozen critics: stage both weight sets once
-    stage_params(smem + lp.cparams, PZ, clz.total);
-    stage_params(smem + lp.cparams + clz.total, PX, clx.total);
-    PZ = smem + lp.cparams; PX = smem + lp.cparams + clz.total;
-  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
   const int g0 = tile * 16;                 // first batch row of this tile
+  const int pass = role;                    // decoder pass carried by this workgroup
+  const int64_t prow0 = (int64_t)pass * B + g0;          // its first operand row in the pass-major workspace arrays
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const int64_t BL = (int64_t)B * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float sum_fz = 0.f, sum_fx = 0.f, sum_aux = 0.f;
+  float sum_crit = 0.f, sum_aux = 0.f;
+  constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
+  GEN_STAMP(0);
 
-  // ---- encoder(x)
-  tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, S, a.row_index, g0, 16, S, 16);
-  __syncthreads();
-  tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
-  float* zenc = zs + 16 * LP;
-  float* wst = smem + lp.wst;
-  encoder_fwd_tile(xs, ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc,
-                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, wst);
-  // ---- critic_z(encoder(x)) and its input gradient (frozen critic; loss term -mean(fake_z), train.py:215-217)
-  {
-    DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
-    critic_fwd_tile(zenc, LP, PZ, clz, L, cs, dz, g0, wst);
-    if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fz = s; }
-    __syncthreads();
-    if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
-    __syncthreads();
-    const float* d0 = critic_bwd_chain_tile(cs.out, PZ, clz, L, cs, [](int, const float*) {});
-    gemm_nn<1>(d0, LP, 0, PZ + clz.w[0], L, L, identity_map(), L, dzc, LP, false);
-    __syncthreads();
-  }
-  // ---- both decoder passes together: rows 0..15 = z ~ N(0,1), rows 16..31 = encoder(x)
-  load_z(a, sig, tile, tick, zs);
-  __syncthreads();
-  tile_store_p(ws + gw.zcat + (int64_t)g0 * L, L, B, zs, LP, 32, L, 32);
-  DecSave sv;
-  sv.ps = B;
-  sv.a0 = ws + gw.a0 + (int64_t)g0 * DEC_D1;
-  sv.g0 = ws + gw.g0 + (int64_t)g0 * 8 * DEC_H;
-  sv.h0d = ws + gw.h0d + (int64_t)g0 * 2 * DEC_H;
-  sv.mask = ws + gw.mask + (int64_t)g0 * 2 * DEC_H;
-  sv.g1 = ws + gw.g1 + (int64_t)g0 * 8 * DEC_H;
-  sv.h1 = ws + gw.h1 + (int64_t)g0 * 2 * DEC_H;
-  // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
-  // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
-  DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
-  const int Bq = B;
-  decoder_trunk_fwd_tile<2>(zs, L, S, PD, dl, bufA, bufB, ldS, dd, [g0, Bq](int r) { return (r >> 4) * Bq + g0 + (r & 15); }, sv, 32, wst);
-  // E = tanh output in bufA[0..31]
-  if (HYPER) {
-    tile_for(16, S, [&](int r, int c) { bufA[(32 + r) * ldS + c] = xs[r * ldS + c]; });   // pass 2 input: the real window
-    __syncthreads();
-    tile_store_p(ws + gw.ecat + (int64_t)g0 * S, S, B, bufA, ldS, 48, S, 48);
-    gemm_nt<3>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
-    __syncthreads();
-    tile_store_p(ws + gw.u + (int64_t)g0 * S, S, B, bufB, ldS, 48, S, 48);
-    __syncthreads();
-    head_rows_tile(bufB, ldS, 48, S, PD + dl.head_b);
+  float* zin;                               // decoder input rows [16][LP]
+  if (role == 0) {
+    const CriticLayout clx = cx_layout(S, L);
+    stage_critic_padded(cw, a.P.cx + (int64_t)sig * a.pcx, clx, L, critic_pad(S, L, 4));
+    load_z(a, sig, tile, tick, zs);
+    zin = zs;
     __syncthreads();
   } else {
-    tile_store_p(ws + gw.ecat + (int64_t)g0 * S, S, B, bufA, ldS, 32, S, 32);
+    // ---- encoder(x), critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
+    const CriticLayout clz = cz_layout(L);
+    const CriticPad cpz = critic_pad(L, L, 2);
+    stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
+    tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, S, a.row_index, g0, 16, S, 16);
+    __syncthreads();
+    tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
+    zin = zs + 16 * LP;
+    encoder_fwd_tile(xs, ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
+                     ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, wst);
+    GEN_STAMP(1);
+    const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
+    sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
   }
-  float* R = HYPER ? bufB : bufA;           // decoder outputs (pass 0 = x_gen, pass 1 = x_rec [, pass 2 = hyper_x])
-  float* dR = HYPER ? bufA : bufB;          // their gradients
-  // ---- critic_x(x_gen) and its input gradient (loss term -mean(fake_x))
-  {
-    DropSrc dx = drop_src(a, sig, mbase ? mbase + 2 * BL : nullptr, RS_DROP_CRITIC + 8 * 1, tick, clx.p_drop);
-    critic_fwd_tile(R, ldS, PX, clx, L, cs, dx, g0, wst);
-    if (threadIdx.x == 0) { float s = 0.f; for (int r = 0; r < 16; ++r) s += cs.out[r]; sum_fx = s; }
-    __syncthreads();
-    if (threadIdx.x < 16) cs.out[threadIdx.x] = -1.f / B;
-    __syncthreads();
-    const float* d0 = critic_bwd_chain_tile(cs.out, PX, clx, L, cs, [](int, const float*) {});
-    gemm_nn<1>(d0, LP, 0, PX + clx.w[0], S, L, identity_map(), S, dR, ldS, false);
-    __syncthreads();
-  }
+  GEN_STAMP(2);
+  // ---- decoder trunk on this role's pass
+  tile_store(ws + gw.zcat + prow0 * L, L, zin, LP, 16, L, 16);
+  DecSave sv;
+  sv.ps = 16;
+  sv.a0 = ws + gw.a0 + prow0 * DEC_D1;
+  sv.g0 = ws + gw.g0 + prow0 * 8 * DEC_H;
+  sv.h0d = ws + gw.h0d + prow0 * 2 * DEC_H;
+  sv.mask = ws + gw.mask + prow0 * 2 * DEC_H;
+  sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
+  sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
+  // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
+  // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
+  const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
+  const int growp = pass * B + g0;
+  decoder_trunk_fwd_tile<1>(zin, L, S, PD, dl, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16, wst);
+  GEN_STAMP(3);
+  // E = tanh output in bufA[0..15]
+  const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
   if (HYPER) {
-    // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
-    float part = 0.f;
-    for (int r = wave; r < 16; r += nw) {
-      RowVec du, dv;
-      float d = rowdist_row_bwd(row_load(R + (16 + r) * ldS, S, lane), row_load(R + (32 + r) * ldS, S, lane), 10.f / B, du, dv);
-      row_store(dR + (16 + r) * ldS, du, S, lane);
-      row_store(dR + (32 + r) * ldS, dv, S, lane);
-      part += d;
+    if (role == 1) {
+      tile_for(16, S, [&](int r, int c) { bufA[(16 + r) * ldS + c] = xs[r * ldS + c]; });
+      __syncthreads();
     }
-    if (lane == 0) red[16 + wave] = part;
+    tile_store_p(ws + gw.ecat + prow0 * S, S, B, bufA, ldS, hrows, S, hrows);
+    if (role == 1) gemm_nt<2>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
+    else gemm_nt<1>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
     __syncthreads();
-    for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
+    tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
+    __syncthreads();
+    head_rows_tile(bufB, ldS, hrows, S, PD + dl.head_b);
+    __syncthreads();
+  } else {
+    tile_store(ws + gw.ecat + prow0 * S, S, bufA, ldS, 16, S, 16);
+  }
+  float* R = HYPER ? bufB : bufA;           // decoder outputs (rows 0-15: this pass [, rows 16-31: hyper_x])
+  float* dR = HYPER ? bufA : bufB;          // their gradients
+  GEN_STAMP(4);
+  if (role == 0) {
+    // ---- critic_x(x_gen) and its input gradient (loss term -mean(fake_x), train.py:205-207)
+    const CriticLayout clx = cx_layout(S, L);
+    const DropSrc dx = drop_src(a, sig, mbase ? mbase + 2 * BL : nullptr, RS_DROP_CRITIC + 8 * 1, tick, clx.p_drop);
+    sum_crit = critic_tile_fwd_bwd(R, ldS, cw, clx, L, critic_pad(S, L, 4), ct, -1.f / B,
+                                   [&](int li, int r, int c) { return dx.get(li, g0 + r, c, L); }, dR, ldS);
+  }
+  GEN_STAMP(5);
+  if (HYPER) {
+    if (role == 1) {
+      // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
+      float part = 0.f;
+      for (int r = wave; r < 16; r += nw) {
+        RowVec du, dv;
+        float d = rowdist_row_bwd(row_load(R + r * ldS, S, lane), row_load(R + (16 + r) * ldS, S, lane), 10.f / B, du, dv);
+        row_store(dR + r * ldS, du, S, lane);
+        row_store(dR + (16 + r) * ldS, dv, S, lane);
+        part += d;
+      }
+      if (lane == 0) red[16 + wave] = part;
+      __syncthreads();
+      for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
+    }
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     const RowVec hb = row_load(PD + dl.head_b, S, lane);
     RowVec dbacc;
 #pragma unroll
     for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] = 0.f;
-    for (int r = wave; r < 48; r += nw) {
+    for (int r = wave; r < hrows; r += nw) {
       RowVec du, db;
-      head_row_bwd(row_load(ws + gw.u + (prow(r, B) + g0) * S, S, lane), hb, row_load(dR + r * ldS, S, lane), du, db);
+      head_row_bwd(row_load(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane), hb, row_load(dR + r * ldS, S, lane), du, db);
       row_store(dR + r * ldS, du, S, lane);
 #pragma unroll
       for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db.v[e];
     }
-    row_store(R + wave * ldS, dbacc, S, lane);          // R (the head outputs) is dead: reuse as [nw][ldS] scratch
+    __syncthreads();                                    // R (the head outputs) is dead: reuse as [nw][ldS] scratch
+    row_store(R + wave * ldS, dbacc, S, lane);
     __syncthreads();
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
       float s = 0.f;
       for (int w = 0; w < nw; ++w) s += R[w * ldS + c];
-      ws[gw.ballpart + (int64_t)tile * S + c] = s;
+      ws[gw.ballpart + ((int64_t)role * (B / 16) + tile) * S + c] = s;
     }
-    tile_store_p(ws + gw.du + (int64_t)g0 * S, S, B, dR, ldS, 48, S, 48);
+    tile_store_p(ws + gw.du + prow0 * S, S, B, dR, ldS, hrows, S, hrows);
     __syncthreads();
-    // dE = dU W_h for the two decoder passes
-    gemm_nn<2>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
+    // dE = dU W_h for the decoder pass
+    gemm_nn<1>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
     __syncthreads();
     // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
-    tile_for(32, S, [&](int r, int c) {
-      const float e = ws[gw.ecat + (prow(r, B) + g0) * S + c];
+    tile_for(16, S, [&](int r, int c) {
+      const float e = ws[gw.ecat + (prow0 + r) * S + c];
       R[r * ldS + c] *= 1.f - e * e;
     });
     __syncthreads();
   } else {
-    // ---- 10 * MSE(x, x_rec) (train.py:241-242): E in bufA (= R), gradients into bufB (= dR)
-    float part = 0.f;
+    if (role == 1) {
+      // ---- 10 * MSE(x, x_rec) (train.py:241-242): E in bufA (= R), gradients into bufB (= dR)
+      float part = 0.f;
+      tile_for(16, S, [&](int r, int c) {
+        const float diff = R[r * ldS + c] - xs[r * ldS + c];
+        part += diff * diff;
+        dR[r * ldS + c] = 20.f * diff / ((float)B * (float)S);
+      });
+      sum_aux = block_sum(part, red);
+      __syncthreads();
+    }
     tile_for(16, S, [&](int r, int c) {
-      const float diff = R[(16 + r) * ldS + c] - xs[r * ldS + c];
-      part += diff * diff;
-      dR[(16 + r) * ldS + c] = 20.f * diff / ((float)B * (float)S);
-    });
-    sum_aux = block_sum(part, red);
-    __syncthreads();
-    tile_for(32, S, [&](int r, int c) {
       const float e = R[r * ldS + c];
       dR[r * ldS + c] *= 1.f - e * e;
     });
     __syncthreads();
   }
-  float* dP = HYPER ? R : dR;               // d(pre-tanh) [32][ldS]
+  float* dP = HYPER ? R : dR;               // d(pre-tanh) [16][ldS]
   float* oth = HYPER ? dR : R;
-  tile_store_p(ws + gw.dpre2 + (int64_t)g0 * S, S, B, dP, ldS, 32, S, 32);
-  constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
+  GEN_STAMP(6);
+  tile_store(ws + gw.dpre2 + prow0 * S, S, dP, ldS, 16, S, 16);
   // dH1 = dpre W2
-  gemm_nn<2>(dP, ldS, 0, PD + dl.d2_w, 2 * DEC_H, S, identity_map(), 2 * DEC_H, oth, ldH, false);
+  gemm_nn<1>(dP, ldS, 0, PD + dl.d2_w, 2 * DEC_H, S, identity_map(), 2 * DEC_H, oth, ldH, false);
   __syncthreads();
+  GEN_STAMP(7);
   // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
-  lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + (int64_t)g0 * 8 * DEC_H, DEC_H, 32, dP, ldG, 32, B);
+  lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
-  tile_store_p(ws + gw.dg1 + (int64_t)g0 * 6 * DEC_H, 6 * DEC_H, B, dP, ldG, 32, 6 * DEC_H, 32);
-  lstm_bwd_data_tile<2>(dP, ldG, PD, dl.l[1][0], dl.l[1][1], DEC_H, 2 * DEC_H, oth, ldH);
+  tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
+  lstm_bwd_data_tile<1>(dP, ldG, PD, dl.l[1][0], dl.l[1][1], DEC_H, 2 * DEC_H, oth, ldH);
   __syncthreads();
   if (a.drop_mode != 0) {
-    tile_for(32, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow(r, B) + g0) * 2 * DEC_H + c]; });
+    tile_for(16, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow0 + r) * 2 * DEC_H + c]; });
     __syncthreads();
   }
+  GEN_STAMP(8);
   // layer 0
-  lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + (int64_t)g0 * 8 * DEC_H, DEC_H, 32, dP, ldG, 32, B);
+  lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
-  tile_store_p(ws + gw.dg0 + (int64_t)g0 * 6 * DEC_H, 6 * DEC_H, B, dP, ldG, 32, 6 * DEC_H, 32);
-  lstm_bwd_data_tile<2>(dP, ldG, PD, dl.l[0][0], dl.l[0][1], DEC_H, DEC_D1, oth, ldA0);
+  tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
+  lstm_bwd_data_tile<1>(dP, ldG, PD, dl.l[0][0], dl.l[0][1], DEC_H, DEC_D1, oth, ldA0);
   __syncthreads();
-  tile_store_p(ws + gw.da0 + (int64_t)g0 * DEC_D1, DEC_D1, B, oth, ldA0, 32, DEC_D1, 32);
-  // dZ = dA0 W1 ; only pass 1 (the encoder's output) is needed further
-  gemm_nn<2>(oth, ldA0, 0, PD + dl.d1_w, L, DEC_D1, identity_map(), L, dP, LP, false);
+  tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, oth, ldA0, 16, DEC_D1, 16);
+  GEN_STAMP(9);
+  float* part_out = ws + gw.partial + tile * 4;
+  if (role == 0) {
+    if (threadIdx.x == 0) part_out[1] = sum_crit;
+    GEN_STAMP(11);
+    return;
+  }
+  // dZ = dA0 W1: the gradient reaching the encoder's output
+  gemm_nn<1>(oth, ldA0, 0, PD + dl.d1_w, L, DEC_D1, identity_map(), L, dP, LP, false);
   __syncthreads();
-  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[(16 + r) * LP + c] + dzc[r * LP + c]; });
+  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c] + dzc[r * LP + c]; });
   __syncthreads();
   tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
+  GEN_STAMP(10);
   // ---- encoder backward
   gemm_nn<1>(dzs, LP, 0, PE + el.dense_w, 2 * ENC_H, L, identity_map(), 2 * ENC_H, oth, 2 * ENC_H + 4, false);
   __syncthreads();
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
   tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
-  if (threadIdx.x == 0) {
-    float* part = ws + gw.partial + tile * 4;
-    part[0] = sum_aux; part[1] = sum_fx; part[2] = sum_fz; part[3] = 0.f;
-  }
+  if (threadIdx.x == 0) { part_out[0] = sum_aux; part_out[2] = sum_crit; part_out[3] = 0.f; }
+  GEN_STAMP(11);
 }
 
 // ---- kernels: single iterations, and the critic_x || critic_z pair (blockIdx.z picks the critic)
@@ -690,7 +731,7 @@ DwTable gen_table(const hypad_dims& dm) {
   tb.bias(HYPAD_NET_DECODER, dl.d2_b, -1, S, gw.dpre2, S, 2 * B);
   if (hyp) {
     tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
-    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, B / 16);
+    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, 2 * (B / 16));      // per (role, tile) partial column sums
   }
   return tb.t;
 }
@@ -707,6 +748,8 @@ hipError_t allow_lds(const void* fn, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+
+long long* g_gen_stamps = nullptr;
 
 struct IterCall {
   const float* x; int64_t x_sig_stride; const int32_t* row_index;
@@ -737,7 +780,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.ws = (float*)io.workspace + (opt == 1 ? ws_cz_offset(*d) : 0);
   a.ws_sig_stride = per;
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
-  a.opt = opt; a.tick_owner = 1;
+  a.opt = opt; a.tick_owner = 1; a.stamps = g_gen_stamps;
   if (opt == 0) {
     if (!st->exp_avg.cx || !st->exp_avg_sq.cx) return HYPAD_EINVAL;
     a.mask_sig_stride = (int64_t)12 * a.B * a.L + (int64_t)a.B * 2 * DEC_H;
@@ -852,17 +895,16 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
-  dim3 grid(a.B / 16, d->n_signals);
-  const int cf = cx_layout(a.S, a.L).total + cz_layout(a.L).total;
+  dim3 grid(a.B / 16, d->n_signals, 2);                  // blockIdx.z: role G / role R
+  const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
+  const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
+  if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
   HYPAD_MARK(ev, 0, s);
   if (a.hyperbolic) {
-    size_t lds = (size_t)lds_plan(a.S, 32, 48, cf).total * sizeof(float);
-    if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
     hipError_t e = allow_lds((const void*)gen_kernel<true>, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gen_kernel<true>, grid, dim3(TB), lds, s, a);
   } else {
-    size_t lds = (size_t)lds_plan(a.S, 32, 32, cf).total * sizeof(float);
     hipError_t e = allow_lds((const void*)gen_kernel<false>, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gen_kernel<false>, grid, dim3(TB), lds, s, a);
@@ -905,6 +947,9 @@ __global__ __launch_bounds__(64) void radam_ball_kernel(float* p, const float* g
 }
 
 }  // namespace
+
+// development aid (not declared in hypad.h): device buffer of 64 int64 stamped by the generator kernel, or null
+extern "C" void hypad_diag_set_gen_stamps(long long* p) { g_gen_stamps = p; }
 
 extern "C" {
 
