@@ -216,7 +216,7 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
 // ---------------------------------------------------------------------------------------------- iteration kernel
 template <bool IS_X>
 __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
-  const int sig = blockIdx.y, chunk = blockIdx.x, nchunks = a.B / 16, L = a.L, B = a.B, S = a.S;
+  const int sig = blockIdx.y, chunk = blockIdx.x >> 3, nchunks = a.B / 16, L = a.L, B = a.B, S = a.S;
   constexpr int nh = IS_X ? 4 : 2;
   const CriticLayout cl = IS_X ? cx_layout(S, L) : cz_layout(L);
   const CritGeom g = IS_X ? cx_geom(S, L) : cz_geom(L);
@@ -516,8 +516,12 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   STAMP(40);
 }
 
+// blockIdx.x is stretched by 8 and only the blocks dealt to XCD (signal mod 8) work (MI355X_MICROARCH.md, dispatch:
+// round-robin over the XCDs): the workgroups of one model -- which all read the same slabs and optimiser state --
+// share an L2.  A speed matter only.
 __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
   if (blockIdx.z == 0) critic_iteration_body<true>(ax, ph, smem); else critic_iteration_body<false>(az, ph, smem);
 }
 
@@ -601,7 +605,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     if (ev) (void)hipEventRecord(ev[1], s);
     for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
       ph.it = it;
-      hipLaunchKernelGGL(critic_iteration_kernel, dim3(it == n ? 1 : nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
+      hipLaunchKernelGGL(critic_iteration_kernel, dim3(8 * (it == n ? 1 : nchunks), n_signals, 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
       if (ev && it < 2) (void)hipEventRecord(ev[2 + it], s);
     }

@@ -260,7 +260,7 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 
 template <bool HYPER>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
-  const int sig = blockIdx.y, tile = blockIdx.x, role = blockIdx.z, S = a.S, L = a.L, B = a.B;
+  const int sig = blockIdx.y, tile = blockIdx.x >> 3, role = blockIdx.z, S = a.S, L = a.L, B = a.B;
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
@@ -287,6 +287,20 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float sum_crit = 0.f, sum_aux = 0.f;
   constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
   GEN_STAMP(0);
+  // L2 warm-up: the generator's weights were rewritten by the previous launch (any XCD), so their first touch here
+  // misses this XCD's L2.  The working workgroups of a signal share one XCD (see gen_kernel): together they touch every
+  // 128-byte line once, now, and the layers find the weights in L2 when they get there.  Role R starts with the encoder.
+  float warm[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int ntile = B / 16;
+    const float* base = role == 1 ? PE : PD;
+    const int lines = (role == 1 ? a.pe : a.pd) / 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int line = (u * ntile + tile) * TB + threadIdx.x;
+      if (line < lines) warm[u] = base[line * 32];
+    }
+  }
 
   float* zin;                               // decoder input rows [16][LP]
   if (role == 0) {
@@ -335,11 +349,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
       __syncthreads();
     }
     tile_store_p(ws + gw.ecat + prow0 * S, S, B, bufA, ldS, hrows, S, hrows);
+    GEN_STAMP(20);
     if (role == 1) gemm_nt<2>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
     else gemm_nt<1>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
     __syncthreads();
+    GEN_STAMP(21);
     tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
     __syncthreads();
+    GEN_STAMP(22);
     head_rows_tile(bufB, ldS, hrows, S, PD + dl.head_b);
     __syncthreads();
   } else {
@@ -371,6 +388,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
       __syncthreads();
       for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
     }
+    GEN_STAMP(23);
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     const RowVec hb = row_load(PD + dl.head_b, S, lane);
     RowVec dbacc;
@@ -384,6 +402,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
       for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db.v[e];
     }
     __syncthreads();                                    // R (the head outputs) is dead: reuse as [nw][ldS] scratch
+    GEN_STAMP(24);
     row_store(R + wave * ldS, dbacc, S, lane);
     __syncthreads();
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
@@ -393,9 +412,11 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     }
     tile_store_p(ws + gw.du + prow0 * S, S, B, dR, ldS, hrows, S, hrows);
     __syncthreads();
+    GEN_STAMP(25);
     // dE = dU W_h for the decoder pass
     gemm_nn<1>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
     __syncthreads();
+    GEN_STAMP(26);
     // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
     tile_for(16, S, [&](int r, int c) {
       const float e = ws[gw.ecat + (prow0 + r) * S + c];
@@ -450,6 +471,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* part_out = ws + gw.partial + tile * 4;
   if (role == 0) {
     if (threadIdx.x == 0) part_out[1] = sum_crit;
+    if (warm[0] + warm[1] + warm[2] + warm[3] == 1.2345e-30f) part_out[3] = 1.f;      // keeps the warm-up loads alive
     GEN_STAMP(11);
     return;
   }
@@ -466,7 +488,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
   tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
-  if (threadIdx.x == 0) { part_out[0] = sum_aux; part_out[2] = sum_crit; part_out[3] = 0.f; }
+  if (threadIdx.x == 0) { part_out[0] = sum_aux; part_out[2] = sum_crit; }
+  if (warm[0] + warm[1] + warm[2] + warm[3] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
   GEN_STAMP(11);
 }
 
@@ -492,9 +515,14 @@ __global__ __launch_bounds__(TB) void critic_gp_pair_kernel(IterArgs ax, IterArg
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (blockIdx.z == 0) gp_body<true>(ax, smem); else gp_body<false>(az, smem);
 }
+// Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, dispatch): blockIdx.x is stretched by 8 and
+// only the blocks that land on XCD (signal mod 8) work, so the 2 * B/16 workgroups of one model share an L2 -- each
+// generator weight is fetched from HBM once per launch instead of once per workgroup.  Placement is a speed matter
+// only: results do not depend on it.
 template <bool HYPER>
 __global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
   gen_body<HYPER>(a, smem);
 }
 
@@ -895,7 +923,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
-  dim3 grid(a.B / 16, d->n_signals, 2);                  // blockIdx.z: role G / role R
+  dim3 grid(8 * (a.B / 16), d->n_signals, 2);            // blockIdx.x >> 3: tile (see gen_kernel); blockIdx.z: role G / role R
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;

@@ -15,8 +15,12 @@ idx = torch.arange(bench.B, device=dev, dtype=torch.int32)
 for _ in range(5):
     eng.decoder_iteration(x, idx, None, True)
 torch.cuda.synchronize()
-t = st.cpu().numpy()
-names = ["encoder fwd", "critic_z fwd+bwd", "decoder fwd x2 (trunk)", "head fwd", "critic_x fwd+bwd", "loss + head bwd + dE", "dH1 = dpre W2", "l1 cell bwd + bwd data", "l0 cell bwd + bwd data", "dZ", "encoder bwd"]
-d = np.diff(t[:12])
-print("total cycles", t[11] - t[0], "=", (t[11] - t[0]) / 2400.0, "us @2.4GHz")
-print(", ".join(f"{n} {v}" for n, v in zip(names, d)))
+t = st.cpu().numpy().reshape(2, 32)
+names = ["start/enc fwd", "critic_z", "(z store)", "trunk", "head fwd", "critic_x", "loss+head bwd+dE+tanh'", "dH1", "l1 bwd", "l0 bwd", "dZ", "enc bwd"]
+for role, nm in ((0, "G"), (1, "R")):
+    r = t[role]
+    print(f"role {nm}: total {r[11] - r[0]} cycles = {(r[11] - r[0]) / 2400.0:.1f} us")
+    ks = [k for k in range(12) if r[k] > 0]
+    print("   " + ", ".join(f"{names[k1]} {r[k2] - r[k1]}" for k1, k2 in zip(ks[:-1], ks[1:])))
+    sub = {"ecat store": (3, 20), "head gemm": (20, 21), "u store": (21, 22), "head rows": (22, 4), "rowdist": (5, 23), "head bwd rows": (23, 24), "ballpart+du store": (24, 25), "dE gemm": (25, 26), "tanh'": (26, 6)}
+    print("   sub: " + ", ".join(f"{k} {r[b] - r[a]}" for k, (a, b) in sub.items() if r[a] > 0 and r[b] > 0))
