@@ -214,9 +214,13 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
 }
 
 // ---------------------------------------------------------------------------------------------- iteration kernel
-template <bool IS_X>
+// SC / LC / BC: window length, latent width and batch as compile-time constants (0 = read them from the arguments): the
+// kernel runs every stage exactly once, so its index arithmetic is not amortised by any loop -- folding the strides and
+// tile counts of the reference configuration (100, 20, 64) removes a third of its instructions.
+template <bool IS_X, int SC, int LC, int BC>
 __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
-  const int sig = blockIdx.y, chunk = blockIdx.x >> 3, nchunks = a.B / 16, L = a.L, B = a.B, S = a.S;
+  const int L = LC ? LC : a.L, B = BC ? BC : a.B, S = SC ? SC : a.S;
+  const int sig = blockIdx.y, chunk = blockIdx.x >> 3, nchunks = B / 16;
   constexpr int nh = IS_X ? 4 : 2;
   const CriticLayout cl = IS_X ? cx_layout(S, L) : cz_layout(L);
   const CritGeom g = IS_X ? cx_geom(S, L) : cz_geom(L);
@@ -519,10 +523,11 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 // blockIdx.x is stretched by 8 and only the blocks dealt to XCD (signal mod 8) work (MI355X_MICROARCH.md, dispatch:
 // round-robin over the XCDs): the workgroups of one model -- which all read the same slabs and optimiser state --
 // share an L2.  A speed matter only.
+template <int SC, int LC, int BC>
 __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
-  if (blockIdx.z == 0) critic_iteration_body<true>(ax, ph, smem); else critic_iteration_body<false>(az, ph, smem);
+  if (blockIdx.z == 0) critic_iteration_body<true, SC, LC, BC>(ax, ph, smem); else critic_iteration_body<false, SC, LC, BC>(az, ph, smem);
 }
 
 __global__ void advance_counters_kernel(int32_t* counters, int n) {
@@ -577,8 +582,10 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   }
   const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
   const size_t lds = (size_t)(lx > lz ? lx : lz) * sizeof(float);
+  const bool ref_cfg = ax.S == 100 && ax.L == 20 && ax.B == 64;       // BASELINE.json configs[0..1]
+  const void* kfn = ref_cfg ? (const void*)critic_iteration_kernel<100, 20, 64> : (const void*)critic_iteration_kernel<0, 0, 0>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)critic_iteration_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   PhaseArgs ph;
@@ -605,7 +612,9 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     if (ev) (void)hipEventRecord(ev[1], s);
     for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
       ph.it = it;
-      hipLaunchKernelGGL(critic_iteration_kernel, dim3(8 * (it == n ? 1 : nchunks), n_signals, 2), dim3(FT), lds, s, ax, az, ph);
+      const dim3 grid(8 * (it == n ? 1 : nchunks), n_signals, 2);
+      if (ref_cfg) hipLaunchKernelGGL((critic_iteration_kernel<100, 20, 64>), grid, dim3(FT), lds, s, ax, az, ph);
+      else hipLaunchKernelGGL((critic_iteration_kernel<0, 0, 0>), grid, dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
       if (ev && it < 2) (void)hipEventRecord(ev[2 + it], s);
     }
