@@ -12,10 +12,23 @@ constexpr float ARTANH_EPS = 1e-7f;         // math_.py:58
 constexpr float BALL_MAXNORM = 1.0f - 4e-3f;// math_.py:343-349 (fp32), k = -1
 constexpr float LEAK = 0.2f;                // models/tadgan.py:76,121
 
+// Sum over the 64 lanes, result in every lane.  Four DPP butterfly steps inside each row of 16 lanes (quad swaps, then
+// the half-row and row mirrors), then the four row sums through v_readlane: ~12 VALU instructions and no LDS crossbar
+// round trip, against six ds_bpermute hops for the shuffle form (the Moebius head rows are chains of 5-14 of these).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
+  v += dpp_move_<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_move_<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_move_<0x141>(v);       // row_half_mirror
+  v += dpp_move_<0x140>(v);       // row_mirror
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (a + b) + (c + d);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

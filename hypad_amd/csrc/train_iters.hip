@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include <vector>
 
@@ -260,6 +261,7 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 
 // SC / LC / BC: window length, latent width, batch as compile-time constants (0 = from the arguments); see
 // critic_fused.hip: every layer of the chain runs once per launch, so index arithmetic is never amortised.
+static_assert(TB == 512, "gen_body deals rows over 8 waves");
 template <bool HYPER, int SC, int LC, int BC>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
@@ -380,12 +382,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     if (role == 1) {
       // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
       float part = 0.f;
-      for (int r = wave; r < 16; r += nw) {
-        RowVec du, dv;
-        float d = rowdist_row_bwd(row_load(R + r * ldS, S, lane), row_load(R + (16 + r) * ldS, S, lane), 10.f / B, du, dv);
-        row_store(dR + r * ldS, du, S, lane);
-        row_store(dR + (16 + r) * ldS, dv, S, lane);
-        part += d;
+      {                                               // 16 rows over 8 waves: both rows of a wave together (overlapped chains)
+        RowVec du[2], dv[2], ru[2], rv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int r = (wave & 7) + 8 * i; ru[i] = row_load(R + r * ldS, S, lane); rv[i] = row_load(R + (16 + r) * ldS, S, lane); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) part += rowdist_row_bwd(ru[i], rv[i], 10.f / B, du[i], dv[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int r = (wave & 7) + 8 * i; row_store(dR + r * ldS, du[i], S, lane); row_store(dR + (16 + r) * ldS, dv[i], S, lane); }
       }
       if (lane == 0) red[16 + wave] = part;
       __syncthreads();
@@ -397,13 +401,25 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     RowVec dbacc;
 #pragma unroll
     for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] = 0.f;
-    for (int r = wave; r < hrows; r += nw) {
-      RowVec du, db;
-      head_row_bwd(row_load(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane), hb, row_load(dR + r * ldS, S, lane), du, db);
-      row_store(dR + r * ldS, du, S, lane);
+    auto head_bwd_rows = [&](auto rpw_tag) __attribute__((always_inline)) {
+      constexpr int RPW = decltype(rpw_tag)::value;   // rows per wave, carried through the chain together
+      RowVec u[RPW], g[RPW], du[RPW], db[RPW];
 #pragma unroll
-      for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db.v[e];
-    }
+      for (int i = 0; i < RPW; ++i) {
+        const int r = wave + 8 * i;
+        u[i] = row_load(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane);
+        g[i] = row_load(dR + r * ldS, S, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) head_row_bwd(u[i], hb, g[i], du[i], db[i]);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        row_store(dR + (wave + 8 * i) * ldS, du[i], S, lane);
+#pragma unroll
+        for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db[i].v[e];
+      }
+    };
+    if (hrows == 32) head_bwd_rows(std::integral_constant<int, 4>{}); else head_bwd_rows(std::integral_constant<int, 2>{});
     __syncthreads();                                    // R (the head outputs) is dead: reuse as [nw][ldS] scratch
     GEN_STAMP(24);
     row_store(R + wave * ldS, dbacc, S, lane);
