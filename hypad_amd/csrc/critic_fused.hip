@@ -290,24 +290,29 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   float4 sx[NITEM][4], sy[NITEM][4];
   float pv[NITEM][4], mv[NITEM][4], vv[NITEM][4];
   int off[NITEM][4], i_li[NITEM], i_n[NITEM], i_k[NITEM], i_so[NITEM];
+  const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
 #pragma unroll
-  for (int u = 0; u < NITEM; ++u) {
-    int e = threadIdx.x + u * FT;
-    const bool live = e < nitems;
-    e = live ? e : 0;
-    int li, tk, base, QQ = Q;
-    if (e < I0) { li = 0; tk = g.tk0; base = 0; }
-    else {
-      e -= I0;
-      const int lh = e / Ih;
-      if (lh < nh - 1) { li = 1 + lh; e -= lh * Ih; tk = g.tkh; base = g.tiles0 + lh * g.tilesh; }
-      else { li = nh; e -= (nh - 1) * Ih; tk = g.tkh; base = g.tiles0 + (nh - 1) * g.tilesh; QQ = 1; }
-    }
-    const int kt = e / (16 * QQ), rem = e - kt * 16 * QQ, qq = rem >> 4, jj = rem & 15;
+  for (int u = 0; u < NITEM; ++u) {            // straight-line code: selects, no branches, so all loads leave together
+    const int e0 = threadIdx.x + u * FT;
+    const bool live = e0 < nitems;
+    const int e = live ? e0 : 0;
+    const bool first = e < I0;
+    const int e1 = e - I0;
+    const int lh = first ? 0 : e1 / Ih;
+    const bool last = !first && lh >= nh - 1;
+    const int li = first ? 0 : (last ? nh : 1 + lh);
+    const int er = first ? e : (last ? e1 - (nh - 1) * Ih : e1 - lh * Ih);
+    const int tk = first ? g.tk0 : g.tkh;
+    const int base = first ? 0 : g.tiles0 + (last ? nh - 1 : lh) * g.tilesh;
+    const int kt = last ? er >> 4 : er / (16 * Q);
+    const int rem = er - kt * (last ? 16 : 16 * Q), qq = rem >> 4, jj = rem & 15;
     const int t = base + (qq >> 2) * tk + kt;
     const int so = t * 512 + ((qq & 3) * 16 + jj) * 4;
-    const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;            // K = index of the bias column
+    const int N = last ? 1 : L, K = first ? in_dim : L;                   // K = index of the bias column
     const int n = 4 * qq, k = 16 * kt + jj;
+    int wof = cw_[0], bof = cb_[0];
+#pragma unroll
+    for (int x = 1; x <= nh; ++x) { wof = li == x ? cw_[x] : wof; bof = li == x ? cb_[x] : bof; }
     i_li[u] = live ? li : -1; i_n[u] = n; i_k[u] = k; i_so[u] = so;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -317,66 +322,60 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = live && n + r < N && k <= K;
-      const int o = ok ? (k < K ? cl.w[li] + (n + r) * K + k : cl.b[li] + n + r) : -1;
-      off[u][r] = o;
+      const int o = k < K ? wof + (n + r) * K + k : bof + n + r;
+      off[u][r] = ok ? o : -1;
       const int oc = ok ? o : 0;
       pv[u][r] = src_p[oc]; mv[u][r] = src_m[oc]; vv[u][r] = src_v[oc];
     }
   }
-  float coef = 0.f;
-  if (it > 0) {
-    float gsum = 0.f, sreal = 0.f, sfake = 0.f;
-    for (int w = 0; w < nchunks; ++w) {                 // fixed order: every workgroup gets the same bits
-      const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
-      gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
-    }
+  float coef = 0.f, gsum = 0.f, sreal = 0.f, sfake = 0.f;
+#pragma unroll 4
+  for (int w = 0; w < nchunks; ++w) {                   // fixed order: every workgroup gets the same bits
+    const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
+    gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
+  }
+  {
     const float nrm = sqrtf(gsum + 1e-12f);             // train.py:90, whole batch
     const float gp = (nrm - 1.f) * (nrm - 1.f);
-    coef = 20.f * (nrm - 1.f) / nrm;                    // d(10 gp) / d g = coef * g
-    if (writer && threadIdx.x == 0) {
+    coef = it > 0 ? 20.f * (nrm - 1.f) / nrm : 0.f;     // d(10 gp) / d g = coef * g
+    if (it > 0 && writer && threadIdx.x == 0) {
       float* lo = ph.losses + sig * a.loss_sig_stride + (int64_t)(2 * (it - 1) + (IS_X ? 0 : 1)) * 4;
       lo[0] = sfake * invB - sreal * invB + 10.f * gp;  // train.py:98-99
       lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
     }
   }
   STAMP(51);
+  const bool upd = it > 0;
 #pragma unroll
   for (int u = 0; u < NITEM; ++u) {
     const int li = i_li[u];
-    if (li >= 0) {
-      f32x4 grf = {0.f, 0.f, 0.f, 0.f}, ggp = {0.f, 0.f, 0.f, 0.f};
-      if (it > 0) {
+    f32x4 grf = {0.f, 0.f, 0.f, 0.f}, ggp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          if (w < nchunks) {
-            grf[0] += sx[u][w].x; grf[1] += sx[u][w].y; grf[2] += sx[u][w].z; grf[3] += sx[u][w].w;
-            ggp[0] += sy[u][w].x; ggp[1] += sy[u][w].y; ggp[2] += sy[u][w].z; ggp[3] += sy[u][w].w;
-          }
-        }
-        for (int w = 4; w < nchunks; ++w) {                               // batches above 64 rows: the rest, in order
-          const float* sl = prev + (int64_t)w * g.slab_floats + i_so[u];
-          const float4 x = *reinterpret_cast<const float4*>(sl), y = *reinterpret_cast<const float4*>(sl + 256);
-          grf[0] += x.x; grf[1] += x.y; grf[2] += x.z; grf[3] += x.w;
-          ggp[0] += y.x; ggp[1] += y.y; ggp[2] += y.z; ggp[3] += y.w;
-        }
-      }
-      const int N = li == nh ? 1 : L;
-      const int n = i_n[u], k = i_k[u];
+    for (int w = 0; w < 4; ++w) {
+      const float on = w < nchunks ? 1.f : 0.f;
+      grf[0] += on * sx[u][w].x; grf[1] += on * sx[u][w].y; grf[2] += on * sx[u][w].z; grf[3] += on * sx[u][w].w;
+      ggp[0] += on * sy[u][w].x; ggp[1] += on * sy[u][w].y; ggp[2] += on * sy[u][w].z; ggp[3] += on * sy[u][w].w;
+    }
+    for (int w = 4; w < nchunks; ++w) {                                   // batches above 64 rows: the rest, in order
+      const float* sl = prev + (int64_t)w * g.slab_floats + i_so[u];
+      const float4 x = *reinterpret_cast<const float4*>(sl), y = *reinterpret_cast<const float4*>(sl + 256);
+      grf[0] += x.x; grf[1] += x.y; grf[2] += x.z; grf[3] += x.w;
+      ggp[0] += y.x; ggp[1] += y.y; ggp[2] += y.z; ggp[3] += y.w;
+    }
+    const int N = li == nh ? 1 : L;
+    const int n = i_n[u], k = i_k[u];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (n + r < N) {
-          float p = 0.f;
-          const int o = off[u][r];
-          if (o >= 0) {
-            p = pv[u][r];
-            float m = mv[u][r], v = vv[u][r];
-            if (it > 0) adam_update(p, m, v, grf[r] + coef * ggp[r], co);
-            if (writer) { dst_p[o] = p; dst_m[o] = m; dst_v[o] = v; }
-          }
-          if (li == 0) w0[(n + r) * ldin + k] = p;
-          else if (li < nh) wh[((li - 1) * L + n + r) * LQ + k] = p;
-          else wl[k] = p;
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int o = off[u][r];
+      float p = pv[u][r], m = mv[u][r], v = vv[u][r];
+      float pn = p, mn = m, vn = v;
+      adam_update(pn, mn, vn, grf[r] + coef * ggp[r], co);
+      p = upd ? pn : p; m = upd ? mn : m; v = upd ? vn : v;
+      if (writer && o >= 0) { dst_p[o] = p; dst_m[o] = m; dst_v[o] = v; }
+      if (li >= 0 && n + r < N) {
+        const float pw = o >= 0 ? p : 0.f;
+        float* wdst = li == 0 ? w0 + (n + r) * ldin + k : (li < nh ? wh + ((li - 1) * L + n + r) * LQ + k : wl + k);
+        *wdst = pw;
       }
     }
   }
