@@ -29,7 +29,7 @@ HD CritWs crit_ws(int B, int in_dim, int L, int nh) {
   return w;
 }
 struct GenWs {
-  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, total;
+  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, adamc, total;
 };
 HD GenWs gen_ws(int B, int S, int L) {
   GenWs w; int o = 0;
@@ -54,6 +54,7 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.dzenc = o; o += pad4(B * L);
   w.dgenc = o; o += pad4(B * 6 * ENC_H);
   w.partial = o; o += pad4((B / 16) * 4);
+  w.adamc = o; o += 4;                              // Adam bias corrections of this step {1 - b1^t, 1 - b2^t, sqrt(1 - b2^t)} (signal 0's workspace)
   w.total = o;
   return w;
 }

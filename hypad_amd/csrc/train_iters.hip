@@ -282,7 +282,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* wst = smem + lp.wst;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   const uint32_t tick = (uint32_t)a.counters[3];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    // optimizer step number and its bias corrections (double-precision powers): once, here, for the dW + Adam launch
+    const int step = a.counters[a.opt] + 1;
+    a.counters[a.opt] = step;
+    const AdamCoef c0 = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
+    float* ac = a.ws + gw.adamc;
+    ac[0] = c0.bc1; ac[1] = c0.bc2; ac[2] = c0.sqrt_bc2;
+  }
   const int g0 = tile * 16;                 // first batch row of this tile
   const int pass = role;                    // decoder pass carried by this workgroup
   const int64_t prow0 = (int64_t)pass * B + g0;          // its first operand row in the pass-major workspace arrays
@@ -571,14 +578,24 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
   const int step = a.counters[a.opt];          // already incremented by the iteration's first kernel
-  const AdamCoef co = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
+  AdamCoef co;
+  if (tab.finalize == 1) {                     // generator: the first kernel left the bias corrections in the workspace
+    const float* ac = a.ws + gen_ws(a.B, a.S, a.L).adamc;
+    co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize;
+    co.step = step; co.bc1 = ac[0]; co.bc2 = ac[1]; co.sqrt_bc2 = ac[2];
+  } else {
+    co = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
+  }
   float* Pn[4] = {a.P.enc + (int64_t)sig * a.pe, a.P.dec + (int64_t)sig * a.pd, a.P.cx + (int64_t)sig * a.pcx, a.P.cz + (int64_t)sig * a.pcz};
   float* Mn[4] = {a.M.enc + (int64_t)sig * a.pe, a.M.dec + (int64_t)sig * a.pd, a.M.cx + (int64_t)sig * a.pcx, a.M.cz + (int64_t)sig * a.pcz};
   float* Vn[4] = {a.V.enc + (int64_t)sig * a.pe, a.V.dec + (int64_t)sig * a.pd, a.V.cx + (int64_t)sig * a.pcx, a.V.cz + (int64_t)sig * a.pcz};
   const int nwaves = gridDim.x * (THREADS / 64);
   for (int item = blockIdx.x * (THREADS / 64) + wave; item < tab.total_items; item += nwaves) {
-    int di = 0;
-    while (di + 1 < tab.n && tab.d[di + 1].begin <= item) ++di;
+    int di = 0;                                  // last descriptor with begin <= item: binary search (6 dependent scalar loads, not 60)
+    for (int step2 = 32; step2 > 0; step2 >>= 1) {
+      const int cand = di + step2;
+      if (cand < tab.n && tab.d[cand].begin <= item) di = cand;
+    }
     const DwDesc& d = tab.d[di];
     const int local = item - d.begin;
     float* P = Pn[d.net]; float* M = Mn[d.net]; float* V = Vn[d.net];
@@ -591,6 +608,16 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       const float* right = ws + d.right_off + kj;
       const int rlast = d.red_rows - 1;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // the optimiser state of this lane's four elements travels with the operand loads (one round trip, not two)
+      int64_t po[4]; float pp[4], pm[4], pvv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * q + r, k = k0 + j;
+        const bool ok = n < d.nrows && k < d.ncols;
+        po[r] = ok ? d.p_off + (int64_t)n * d.p_ld + k : -1;
+        const int64_t oc = ok ? po[r] : d.p_off;
+        pp[r] = P[oc]; pm[r] = M[oc]; pvv[r] = V[oc];
+      }
       for (int rc = 0; rc < d.red_rows; rc += 192) {       // 48 k-steps per chunk: B <= 64 -> one memory round trip
         float la[48], rb[48];
 #pragma unroll
@@ -608,13 +635,9 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 4 * q + r, k = k0 + j;
-        if (n < d.nrows && k < d.ncols) {
-          const int64_t o = d.p_off + (int64_t)n * d.p_ld + k;
-          float p = P[o], m = M[o], v = V[o];
-          adam_update(p, m, v, acc[r], co);
-          P[o] = p; M[o] = m; V[o] = v;
-        }
+        float p = pp[r], m = pm[r], v = pvv[r];
+        adam_update(p, m, v, acc[r], co);
+        if (po[r] >= 0) { P[po[r]] = p; M[po[r]] = m; V[po[r]] = v; }
       }
     } else if (d.kind == DW_BIAS) {
       // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
