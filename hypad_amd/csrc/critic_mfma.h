@@ -98,11 +98,11 @@ HD int critic_tile_floats(const CriticPad& cp, int nh) { return 16 * cp.ldin + (
 
 // Forward of 16 rows and the gradient of sum_r dout * out[r] with respect to the input rows.
 //   Xs [16][ldx]: input rows (in_dim columns);  W: padded weights (stage_critic_padded);  scratch: critic_tile_floats
-//   drop(li, r, c): dropout keep-scale;  dX [16][lddx] <- d / d input;  returns (thread 0 only) sum of the 16 outputs.
-// Starts and ends with a workgroup barrier.
-template <class Drop>
+//   drop(li, r, c4) -> float4 / drop1(li, r, c) -> float: dropout keep-scales;  dX [16][lddx] <- d / d input;
+//   returns the sum of the 16 outputs.  Starts and ends with a workgroup barrier.
+template <class Drop, class Drop1>
 __device__ __forceinline__ float critic_tile_fwd_bwd(const float* Xs, int ldx, const float* W, const CriticLayout& cl, int L, const CriticPad& cp,
-                                                     float* scratch, float dout, Drop drop, float* dX, int lddx) {
+                                                     float* scratch, float dout, Drop drop, Drop1 drop1, float* dX, int lddx) {
   const int in_dim = cl.in_dim, nh = cl.nh, ldin = cp.ldin, LQ = cp.LQ;
   float* in = scratch; float* act = in + 16 * ldin; float* dm = act + nh * 16 * LQ; float* dl = dm + nh * 16 * LQ;
   const float* w0 = W + cp.w0; const float* wh = W + cp.wh; const float* wl = W + cp.wl;
@@ -115,9 +115,17 @@ __device__ __forceinline__ float critic_tile_fwd_bwd(const float* Xs, int ldx, c
   for (int i = threadIdx.x; i < (nh + 2) * 16 * LQ; i += blockDim.x) {      // act | (dm) | dl: padding must be zero
     if (i < nh * 16 * LQ) act[i] = 0.f; else dl[i - nh * 16 * LQ] = 0.f;
   }
-  for (int i = threadIdx.x; i < nh * 16 * L; i += blockDim.x) {
-    const int li = i / (16 * L), rem = i - li * 16 * L, r = rem / L, c = rem - r * L;
-    dm[(li * 16 + r) * LQ + c] = drop(li, r, c);
+  if ((L & 3) == 0) {                       // four columns per thread: drop(li, r, c4) -> float4 (one Philox evaluation)
+    const int L4 = L >> 2;
+    for (int i = threadIdx.x; i < nh * 16 * L4; i += blockDim.x) {
+      const int li = i / (16 * L4), rem = i - li * 16 * L4, r = rem / L4, c = 4 * (rem - r * L4);
+      *reinterpret_cast<float4*>(dm + (li * 16 + r) * LQ + c) = drop(li, r, c);
+    }
+  } else {
+    for (int i = threadIdx.x; i < nh * 16 * L; i += blockDim.x) {
+      const int li = i / (16 * L), rem = i - li * 16 * L, r = rem / L, c = rem - r * L;
+      dm[(li * 16 + r) * LQ + c] = drop1(li, r, c);
+    }
   }
   __syncthreads();
   for (int li = 0; li < nh; ++li) {

@@ -24,6 +24,17 @@ struct DropSrc {
     if (mode == 1) return ptr[((size_t)layer * batch + grow) * ncols + c];
     return rng_dropout(seed, tick, stream + layer, sig, (uint32_t)(grow * ncols + c), p);
   }
+  // keep-scales of columns c4 .. c4+3 (c4 % 4 == 0, ncols % 4 == 0): the same numbers as four get() calls, from one
+  // Philox evaluation in the device-RNG mode
+  __device__ __forceinline__ float4 get4(int layer, int grow, int c4, int ncols) const {
+    if (mode == 0) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mode == 1) return *reinterpret_cast<const float4*>(ptr + ((size_t)layer * batch + grow) * ncols + c4);
+    Philox ph(seed);
+    const uint4 r = ph((uint32_t)(grow * ncols + c4) >> 2, stream + layer, tick, sig);
+    const float keep = 1.0f / (1.0f - p);
+    return make_float4(u32_to_unit(r.x) >= p ? keep : 0.f, u32_to_unit(r.y) >= p ? keep : 0.f,
+                       u32_to_unit(r.z) >= p ? keep : 0.f, u32_to_unit(r.w) >= p ? keep : 0.f);
+  }
 };
 __device__ __forceinline__ DropSrc no_drop() { return DropSrc{0, nullptr, 0, 0, 0, 0, 0, 0.f}; }
 
@@ -223,11 +234,15 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
   lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g0, valid, sv.ps);
   __syncthreads();
   if (drop.mode != 0) {
-    tile_for(rows, 2 * DEC_H, [&](int r, int c) {
-      const float m = drop.get(0, grow(r), c, 2 * DEC_H);
-      bufB[r * ldH + c] *= m;
-      if (sv.mask && r < valid) sv.mask[prow(r, sv.ps) * 2 * DEC_H + c] = m;
-    });
+    for (int i = threadIdx.x; i < rows * (2 * DEC_H / 4); i += blockDim.x) {       // four columns per thread: one Philox evaluation
+      const int r = i / (2 * DEC_H / 4), c = 4 * (i - r * (2 * DEC_H / 4));
+      const float4 m = drop.get4(0, grow(r), c, 2 * DEC_H);
+      float4* h = reinterpret_cast<float4*>(bufB + r * ldH + c);
+      float4 hv = *h;
+      hv.x *= m.x; hv.y *= m.y; hv.z *= m.z; hv.w *= m.w;
+      *h = hv;
+      if (sv.mask && r < valid) *reinterpret_cast<float4*>(sv.mask + prow(r, sv.ps) * 2 * DEC_H + c) = m;
+    }
     __syncthreads();
   }
   if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);

@@ -96,9 +96,20 @@ __device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, 
 __device__ __forceinline__ void load_z(const IterArgs& a, int sig, int tile, uint32_t tick, float* zs /* [16][LP] */) {
   const float* zinj = a.z ? a.z + ((int64_t)sig * a.B + tile * 16) * a.L : nullptr;
   const int L = a.L;
-  tile_for(16, L, [&](int r, int c) {
-    zs[r * LP + c] = zinj ? zinj[r * L + c] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * L + c));
-  });
+  if (zinj || (L & 1)) {
+    tile_for(16, L, [&](int r, int c) {
+      zs[r * LP + c] = zinj ? zinj[r * L + c] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * L + c));
+    });
+  } else {                                  // two normals per Philox evaluation: the same numbers as rng_normal per element
+    for (int i = threadIdx.x; i < 16 * (L >> 1); i += blockDim.x) {
+      const int r = i / (L >> 1), c = 2 * (i - r * (L >> 1));
+      const uint32_t idx = (uint32_t)((tile * 16 + r) * L + c);
+      Philox ph(a.seed);
+      const uint4 rr = ph(idx >> 1, RS_Z, tick, (uint32_t)sig);
+      zs[r * LP + c] = sqrtf(-2.0f * __logf(u32_to_unit_open(rr.x))) * __cosf(6.28318530717958647692f * u32_to_unit(rr.y));
+      zs[r * LP + c + 1] = sqrtf(-2.0f * __logf(u32_to_unit_open(rr.z))) * __cosf(6.28318530717958647692f * u32_to_unit(rr.w));
+    }
+  }
 }
 
 // ---- critic_x pass (train.py:18-81)
@@ -334,7 +345,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
                      ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, wst);
     GEN_STAMP(1);
     const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
-    sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
+    sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
+                                   [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
   }
   GEN_STAMP(2);
   // ---- decoder trunk on this role's pass
@@ -382,6 +394,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     const CriticLayout clx = cx_layout(S, L);
     const DropSrc dx = drop_src(a, sig, mbase ? mbase + 2 * BL : nullptr, RS_DROP_CRITIC + 8 * 1, tick, clx.p_drop);
     sum_crit = critic_tile_fwd_bwd(R, ldS, cw, clx, L, critic_pad(S, L, 4), ct, -1.f / B,
+                                   [&](int li, int r, int c) { return dx.get4(li, g0 + r, c, L); },
                                    [&](int li, int r, int c) { return dx.get(li, g0 + r, c, L); }, dR, ldS);
   }
   GEN_STAMP(5);
