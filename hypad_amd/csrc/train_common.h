@@ -135,18 +135,21 @@ struct AdamCoef {
   float lr, b1, b2, eps, wd, bc1, bc2, sqrt_bc2;
   int riemannian, step, stabilize;
 };
+// Division and square root through v_rcp_f32 / v_sqrt_f32 (1 ulp each): the update differs from IEEE division by at most
+// a few ulp of a step that is itself <= lr -- 1e-10 absolute, far below anything the parity tests (or fp32 training)
+// resolve -- and the update sits on the critical path of every iteration (4x fewer instructions).
 __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, const AdamCoef& c) {
   if (c.riemannian) {     // oracle/radam.py, Euclidean branch
     g += c.wd * p;
     m = c.b1 * m + (1.f - c.b1) * g;
     v = c.b2 * v + (1.f - c.b2) * g * g;
-    float den = sqrtf(v / c.bc2) + c.eps;
-    p -= c.lr * (m / c.bc1) / den;
+    const float den = __builtin_amdgcn_sqrtf(v * __builtin_amdgcn_rcpf(c.bc2)) + c.eps;
+    p -= c.lr * (m * __builtin_amdgcn_rcpf(c.bc1)) * __builtin_amdgcn_rcpf(den);
   } else {                // torch.optim.Adam (single-tensor rule)
     m = c.b1 * m + (1.f - c.b1) * g;
     v = c.b2 * v + (1.f - c.b2) * g * g;
-    float denom = sqrtf(v) / c.sqrt_bc2 + c.eps;
-    p -= (c.lr / c.bc1) * (m / denom);
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(c.sqrt_bc2) + c.eps;
+    p -= (c.lr * __builtin_amdgcn_rcpf(c.bc1)) * (m * __builtin_amdgcn_rcpf(denom));
   }
 }
 __device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, float wd, int riem, int stab, int step) {
