@@ -399,6 +399,8 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   int sk = 3;
 
   // ---- forward, 48 rows.  The last hidden layer's epilogue also starts the backward chain.
+  // (A wave-local variant -- wave p carrying pass p through the 20-wide layers without workgroup barriers -- was measured
+  // slower: one wave needs ~1.9 k cycles per layer, six waves sharing the tiles of a layer ~1.5 k including the barrier.)
   const float* dout = dl + nh * 48 * LQ;
   for (int li = 0; li < nh; ++li) {
     const float* A = li == 0 ? in0 : act + (li - 1) * 48 * LQ;
@@ -419,7 +421,6 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     STAMP(sk++);
   }
   // ---- critic outputs (loss terms) on the last wave, which owns no tile of the next products
-  float osum = 0.f;
   if (wave == NW - 1) {
     float o = 0.f;
     if (lane < 32) {
@@ -428,7 +429,8 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
-    osum = o;                                      // lane 0: sum over the real rows, lane 16: over the fake rows
+    if (lane == 0) red[32] = o;                    // sum over the real rows
+    if (lane == 16) red[33] = o;                   // sum over the fake rows
   }
   // ---- first-order backward chain, all 48 rows, every layer's delta kept
   for (int li = nh - 2; li >= 0; --li) {
@@ -478,21 +480,38 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     }
   };
   // ---- unscaled second-order chain: ep_0 = (g W_0^T) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
-  // (ones column cleared: the GP rows carry no bias term).  Only two tiles per step: the other waves fill the time with
-  // the real / fake part of their weight-gradient tiles, which is complete after the first backward.
-#pragma unroll
-  for (int li = 0; li < nh; ++li) {
-    const float* A = li == 0 ? in0 + 32 * ldin : act + ((li - 1) * 48 + 32) * LQ;
-    const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
-    float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
-    lds_gemm_nt(A, li == 0 ? ldin : LQ, 1, W, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? Kin : Lp, NW - 1 - wave, lane,
+  // (ones column cleared: the GP rows carry no bias term).  ep_0 is two K = in_dim tiles on waves 6 and 7; the 20-wide
+  // rest of the chain stays on wave 7 alone (wave-local).  Meanwhile the other waves do the real / fake part of their
+  // weight-gradient tiles, which has been complete since the first backward.
+  {
+    float* eo = act + 32 * LQ; const float* dmo = dm + 32 * LQ;
+    lds_gemm_nt(in0 + 32 * ldin, ldin, 1, w0, ldin, L, L + 1, Kin, NW - 1 - wave, lane,
                 [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; else if (c == L) eo[r * LQ + c] = 0.f; });
-    dw_tile(li, true, false);
-    __syncthreads();
-    STAMP(sk++);
+    if (wave < NW - 2) dw_tile(0, true, false);
   }
+  __syncthreads();
+  STAMP(sk++);
+  if (wave == NW - 1) {
+    for (int li = 1; li < nh; ++li) {
+      float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
+      wave_gemm_nt(act + ((li - 1) * 48 + 32) * LQ, LQ, wh + (li - 1) * L * LQ, LQ, L, L + 1, Lp, lane,
+                   [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; else if (c == L) eo[r * LQ + c] = 0.f; });
+      wave_lds_fence();
+    }
+  } else {
+    if (wave == NW - 2) dw_tile(0, true, false);
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) dw_tile(i, i >= nh, true);
+    for (int i = 1; i < MAXT; ++i) dw_tile(i, true, false);
+  }
+  __syncthreads();
+  STAMP(sk++);
+  if (wave == NW - 1) {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, true);
+  } else {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) dw_tile(i, false, true);
+  }
   STAMP(sk++);
 
   // ---- publish the chunk's shares: accumulator images + {sum g^2, sum real out, sum fake out}
@@ -507,7 +526,6 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   }
   const float tot = wave_sum(gsq);
   if (lane == 0) red[wave] = tot;
-  if (wave == NW - 1) { if (lane == 0) red[32] = osum; if (lane == 16) red[33] = osum; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float gs = 0.f;

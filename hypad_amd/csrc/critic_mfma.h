@@ -68,6 +68,78 @@ __device__ __forceinline__ void lds_gemm_nn(const float* A, int lda, int RT, con
 }
 
 
+// ---- one wave, one 16-row tile, all column tiles: the wave-local forms (no workgroup barrier between dependent layers;
+// the caller separates a layer's LDS writes from the next layer's reads with wave_lds_fence()).  Column tiles go in
+// pairs so that two independent accumulator chains share the MFMA pipe.
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS instructions of one wave execute in order; this only stops the compiler from moving a lane's reads above
+  // other lanes' writes of the same wave (which its per-thread alias analysis cannot see)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class Epi>
+__device__ __forceinline__ void wave_gemm_nt(const float* A, int lda, const float* W, int ldw, int Nrows, int Ncols, int Kp, int lane, Epi epi) {
+  const int j = lane & 15, q = lane >> 4, CT = (Ncols + 15) >> 4;
+  const float* a = A + j * lda + 4 * q;
+  for (int ct = 0; ct < CT; ct += 2) {
+    int n0 = ct * 16 + j, n1 = n0 + 16;
+    n0 = n0 < Nrows ? n0 : Nrows - 1; n1 = n1 < Nrows ? n1 : Nrows - 1;
+    const float* b0 = W + n0 * ldw + 4 * q;
+    const float* b1 = W + n1 * ldw + 4 * q;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int g = 0; g < Kp; g += 16) {
+      const float4 av = *reinterpret_cast<const float4*>(a + g);
+      const float4 v0 = *reinterpret_cast<const float4*>(b0 + g), v1 = *reinterpret_cast<const float4*>(b1 + g);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, v0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, v1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, v0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, v1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, v0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, v1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, v0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, v1.w, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      epi(4 * q + r, ct * 16 + j, acc0[r]);
+      if (ct + 1 < CT) epi(4 * q + r, (ct + 1) * 16 + j, acc1[r]);
+    }
+  }
+}
+template <class Epi>
+__device__ __forceinline__ void wave_gemm_nn(const float* A, int lda, const float* W, int ldw, int No, int Cvalid, int Ccols, int Kp, int lane,
+                                             Epi epi) {
+  const int j = lane & 15, q = lane >> 4, CT = (Ccols + 15) >> 4;
+  const float* a = A + j * lda + 4 * q;
+  for (int ct = 0; ct < CT; ct += 2) {
+    int c0 = ct * 16 + j, c1 = c0 + 16;
+    c0 = c0 < Cvalid ? c0 : Cvalid - 1; c1 = c1 < Cvalid ? c1 : Cvalid - 1;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int g = 0; g < Kp; g += 16) {
+      const int o = g + 4 * q;
+      const int o0 = (o < No ? o : No - 1) * ldw, o1 = (o + 1 < No ? o + 1 : No - 1) * ldw;
+      const int o2 = (o + 2 < No ? o + 2 : No - 1) * ldw, o3 = (o + 3 < No ? o + 3 : No - 1) * ldw;
+      const float4 av = *reinterpret_cast<const float4*>(a + g);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, W[o0 + c0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, W[o0 + c1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, W[o1 + c0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, W[o1 + c1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, W[o2 + c0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, W[o2 + c1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, W[o3 + c0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, W[o3 + c1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      epi(4 * q + r, ct * 16 + j, acc0[r]);
+      if (ct + 1 < CT) epi(4 * q + r, (ct + 1) * 16 + j, acc1[r]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------- frozen critic, one 16-row tile
 // (decoder_iteration, train.py:205-217: the critics only pass a gradient back to the generator)
 struct CriticPad {            // padded LDS image of a critic's weights: bias of every layer in column K of its rows
