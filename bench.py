@@ -185,6 +185,18 @@ def main():
     flop = 2.0 * MAC_PER_WINDOW[dom] * B * spg
     achieved = flop / (kern_ms[dom] * 1e-3) / 1e12
 
+    # memory-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run, so this is the
+    # figure of the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_traffic.json, with the
+    # gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); null when the profile does not cover the kernel / config
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        key = {"gen": "gen_kernel", "dw_gen": "dw_adam_kernel", "critic_iteration": "critic_iteration_kernel"}.get(dom)
+        if key in pm and hyperbolic and spg == 1:
+            traffic = pm[key]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         windows = world * spg * N_BATCHES * B * args.steps
         out = {
@@ -206,7 +218,7 @@ def main():
                        "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,
                        "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "kernel_ms": kern_ms, "epoch_share_ms": share, "flop_per_launch": flop},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
