@@ -2,8 +2,9 @@
 
 Same function names and argument meaning as the reference for the numerics on the hot path
 (SURVEY.md §8a rows S1-S6); inputs may be NumPy arrays (as the reference passes) or device tensors, results
-come back as NumPy arrays like the reference's.  File caches, plotting and interval extraction are outside
-the path and are not part of this module.
+come back as NumPy arrays like the reference's.  Interval extraction and the overlap-segment metrics
+ are host-side NumPy in ``hypad_amd.utils.intervals`` and re-exported here under the reference's
+names; file caches and plotting are not part of this module.
 """
 import math
 
@@ -12,6 +13,8 @@ import torch
 
 from .. import _C
 from ..hyperspace import gmath
+from .intervals import (_find_sequences, _find_threshold, _fixed_threshold, _merge_sequences, _overlap, _prune_anomalies,  # noqa: F401
+                        compute_metrics, contextual_confusion_matrix, find_anomalies)
 
 
 def _dev():
@@ -201,3 +204,33 @@ def hyperbolic_scores(recons_signal, true_signal, critic_score, signal_shape, co
     if combination in ("mult", "uncertainty", "sum", "sum_uncertainty", "critic", "critic_uncertainty"):
         critic_scores = final_critic_scores(critic_score, np.asarray(true_signal).reshape(len(true_signal), -1))[: rec.shape[0]]
     return combine_scores(combination, critic_scores, rec, recons_signal)
+
+
+def univariate_anomaly_detection(recons_signal, true_signal, params, combination, critic_score, path=None, read_path=None,
+                                 rec_error_type="euclidean", true_index=None, known_anomalies=None, signal=None,
+                                 signal_shape=None):
+    """:21-127 end to end: window scores on the device, interval extraction and overlap-segment counts on the host.
+
+    Differences from the reference, all outside the numerics: nothing is written (``path`` / ``params.save_result`` /
+    ``read_path`` are accepted and ignored -- the CSV is only read there for its timestamp range, which the overlap
+    form does not use), and the result is returned instead of printed:
+        dict(final_scores, intervals (n, 3) [start, end, score], confusion [tn, fp, fn, tp] or [0, 0, 0, 0] when no
+        interval was predicted (the reference's except branch), metrics or None)
+    """
+    if not params.hyperbolic:
+        final_scores, true_index, _, _ = score_anomalies(true_signal, recons_signal, critic_score, true_index,
+                                                         rec_error_type=rec_error_type, comb=combination, path=path)
+    else:
+        final_scores = hyperbolic_scores(recons_signal, true_signal, critic_score, params.signal_shape, combination)
+    final_scores = np.asarray(final_scores, dtype=np.float64).reshape(-1)
+    if true_index is None:
+        true_index = np.arange(final_scores.size)
+    intervals = find_anomalies(final_scores, true_index, window_size_portion=0.33, window_step_size_portion=0.1,
+                               fixed_threshold=True)
+    out = dict(final_scores=final_scores, intervals=np.asarray(intervals, dtype=np.float64).reshape(-1, 3), confusion=[0, 0, 0, 0],
+               metrics=None)
+    if known_anomalies is not None and out["intervals"].shape[0] > 0:
+        pred = [(r[0], r[1]) for r in out["intervals"]]
+        out["confusion"] = list(contextual_confusion_matrix(known_anomalies, pred, weighted=False))
+        out["metrics"] = compute_metrics(known_anomalies, pred, verbose=False)
+    return out

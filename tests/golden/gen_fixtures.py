@@ -291,15 +291,99 @@ def gen_scoring(N=300, S=100):
     np.savez(os.path.join(HERE, "score.npz"), **out)
 
 
+# ------------------------------------------------------------------------------ interval extraction + metrics
+def gen_intervals():
+    """find_anomalies (:1363-1472) and its helpers, contextual_confusion_matrix (:606-655, weighted=False)."""
+    import pandas as pd
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = []
+
+    def series(n, spikes, width, seed, plateau=False):
+        r = np.random.default_rng(seed)
+        e = 1.0 + 0.1 * np.abs(r.standard_normal(n))
+        for k in range(spikes):
+            c = int(r.integers(0, n))
+            w = int(r.integers(1, width + 1))
+            e[c: c + w] += r.uniform(0.8, 3.0) if not plateau else 2.0
+        return e
+
+    specs = [  # name, errors, kwargs
+        ("uni", series(2015, 3, 30, 1), dict(window_size_portion=0.33, window_step_size_portion=0.1, fixed_threshold=True)),
+        ("uni_edge", series(700, 4, 10, 2), dict(window_size_portion=0.33, window_step_size_portion=0.1, fixed_threshold=True)),
+        ("whole", series(900, 2, 40, 3), dict(fixed_threshold=True)),
+        ("nopad", series(900, 5, 5, 4), dict(window_size=300, window_step_size=100, fixed_threshold=True, anomaly_padding=0)),
+        ("pad5_lower", series(1200, 4, 20, 5), dict(window_size=400, window_step_size=150, fixed_threshold=True, anomaly_padding=5,
+                                                  lower_threshold=True, min_percent=0.05)),
+        ("plateau", series(1000, 6, 15, 6, plateau=True), dict(window_size_portion=0.5, window_step_size_portion=0.25, fixed_threshold=True,
+                                                             anomaly_padding=10)),
+        ("flat", np.ones(400), dict(window_size_portion=0.33, window_step_size_portion=0.1, fixed_threshold=True)),
+        ("startspike", np.concatenate([np.full(8, 9.0), series(600, 1, 10, 7)]), dict(window_size=200, window_step_size=50,
+                                                                                      fixed_threshold=True, anomaly_padding=3)),
+        ("dynamic", series(600, 3, 12, 8), dict(window_size=300, window_step_size=150, fixed_threshold=False, anomaly_padding=10)),
+    ]
+    for name, e, kw in specs:
+        idx = np.arange(1000, 1000 + 7 * len(e), 7, dtype=np.int64)        # a non-trivial index (timestamps)
+        raised = ""
+        try:
+            res = ref_adu.find_anomalies(e.copy(), idx, **kw)
+        except ZeroDivisionError as ex:       # np.average over zero-length sequences (:1302): the reference raises
+            res, raised = [], type(ex).__name__
+        out[f"fa_{name}_errors"] = e
+        out[f"fa_{name}_index"] = idx
+        out[f"fa_{name}_out"] = np.asarray(res, dtype=np.float64).reshape(-1, 3) if len(res) else np.zeros((0, 3))
+        cases.append(dict(name=name, kwargs=kw, raises=raised))
+    out["fa_cases"] = np.array(json.dumps(cases))
+    # helpers on one window
+    e = series(500, 3, 15, 21)
+    thr = ref_adu._fixed_threshold(e)
+    seqs, max_below = ref_adu._find_sequences(e, thr, 7)
+    me = ref_adu._get_max_errors(e, seqs, max_below)
+    pr = ref_adu._prune_anomalies(me, 0.1)
+    out.update(h_errors=e, h_threshold=np.float64(thr), h_sequences=np.asarray(seqs, dtype=np.int64), h_max_below=np.float64(max_below),
+               h_max_errors=me[["start", "stop", "max_error"]].values.astype(np.float64), h_pruned=np.asarray(pr, dtype=np.float64),
+               h_scores=np.asarray(ref_adu._compute_scores(pr, e, thr, 40), dtype=np.float64))
+    out["h_dyn_threshold"] = np.float64(ref_adu._find_threshold(e, (0, 10)))
+    out["h_zcost"] = np.array([ref_adu.z_cost(z, e, e.mean(), e.std()) for z in (0.5, 2.0, 4.0, 50.0)])
+    merged_in = [[10, 20, 1.0], [21, 30, 3.0], [5, 8, 0.5], [100, 140, 2.0], [120, 130, 4.0], [141, 141, 7.0], [300, 310, 1.5]]
+    out["merge_in"] = np.asarray(merged_in, dtype=np.float64)
+    out["merge_out"] = np.asarray(ref_adu._merge_sequences([list(m) for m in merged_in]), dtype=np.float64)
+    # confusion matrix, overlap-segment form
+    cm_cases = [
+        ([(10, 20), (50, 60), (100, 110)], [(15, 18), (19, 55), (200, 210), (300, 305)]),
+        ([(10, 20)], []),
+        ([], [(1, 2), (5, 9)]),
+        ([(0, 5), (6, 9)], [(5, 6)]),
+        ([(100, 200)], [(90, 100), (200, 210), (150, 160)]),
+    ]
+    for k, (ex, ob) in enumerate(cm_cases):
+        out[f"cm_{k}_expected"] = np.asarray(ex, dtype=np.int64).reshape(-1, 2)
+        out[f"cm_{k}_observed"] = np.asarray(ob, dtype=np.int64).reshape(-1, 2)
+        r = ref_adu.contextual_confusion_matrix([tuple(x) for x in ex], [tuple(x) for x in ob], weighted=False)
+        out[f"cm_{k}_out"] = np.array([-1 if v is None else v for v in r], dtype=np.int64)
+    # DataFrame inputs, as univariate_anomaly_detection passes them (:101-108)
+    kn = pd.DataFrame({"start": [1400, 5000], "end": [1900, 5600]})
+    pa = pd.DataFrame(out["fa_uni_out"], columns=["start", "end", "score"])
+    r = ref_adu.contextual_confusion_matrix(kn, pa, data=pd.DataFrame({"timestamp": out["fa_uni_index"]}), weighted=False)
+    out["cm_df_known"] = kn.values.astype(np.int64)
+    out["cm_df_out"] = np.array([-1 if v is None else v for v in r], dtype=np.int64)
+    np.savez(os.path.join(HERE, "intervals.npz"), **out)
+
+
 if __name__ == "__main__":
     import pandas
     import scipy
+    if len(sys.argv) > 1 and sys.argv[1] == "intervals":
+        gen_intervals()
+        print("intervals.npz written")
+        sys.exit(0)
     gen_forward(100, 64, "S100_B64")
     gen_forward(150, 256, "S150_B256")
     gen_ops()
     gen_iters(100, 64, True, "hyper_S100")
     gen_iters(100, 64, False, "eucl_S100")
     gen_scoring()
+    gen_intervals()
     with open(os.path.join(HERE, "versions.json"), "w") as f:
         json.dump(dict(torch=torch.__version__, numpy=np.__version__, scipy=scipy.__version__,
                        pandas=pandas.__version__, python=sys.version.split()[0],

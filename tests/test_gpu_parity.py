@@ -696,3 +696,33 @@ def test_scoring_properties_at_scale(dev):
     assert float((summ[:, 2] - med.double()).abs().max()) < 1e-6        # p50 == median
     # last timestep has exactly one contributor
     assert float(med[-1]) == float(yh[-1, -1]) and float(med[0]) == float(yh[0, 0])
+
+
+def test_univariate_anomaly_detection_end_to_end(dev):
+    """utils/anomaly_detection_utils.py:21-127: device scores -> host interval extraction -> overlap-segment counts; the
+    intervals are those the reference's own final scores give (score.npz)."""
+    from types import SimpleNamespace
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    from hypad_amd.utils import intervals as iv
+    fx = load("score.npz")
+    known = [(100, 125), (250, 260)]
+    for hyper, comb, ref_key in ((True, "mult", "comb_mult"), (True, "rec", "comb_rec"), (False, "mult", "eucl_mult")):
+        P = SimpleNamespace(hyperbolic=hyper, signal_shape=100)
+        if hyper:
+            out = adu.univariate_anomaly_detection(fx["ball_recons"], fx["ball_real"], P, comb, fx["critic"], known_anomalies=known)
+        else:
+            out = adu.univariate_anomaly_detection(fx["y_hat"], fx["y"], P, comb, fx["critic"], rec_error_type="point",
+                                                   known_anomalies=known)
+        ref_scores = fx[ref_key].reshape(-1)
+        assert out["final_scores"].shape == ref_scores.shape
+        np.testing.assert_allclose(out["final_scores"], ref_scores, rtol=2e-4, atol=2e-5)
+        ref_iv = iv.find_anomalies(ref_scores, np.arange(ref_scores.size), window_size_portion=0.33, window_step_size_portion=0.1,
+                                   fixed_threshold=True)
+        ref_iv = np.asarray(ref_iv, dtype=np.float64).reshape(-1, 3)
+        np.testing.assert_array_equal(out["intervals"][:, :2], ref_iv[:, :2])
+        np.testing.assert_allclose(out["intervals"][:, 2], ref_iv[:, 2], rtol=1e-3, atol=1e-5)
+        if ref_iv.shape[0]:
+            assert out["confusion"] == list(iv.contextual_confusion_matrix(known, [(r[0], r[1]) for r in ref_iv], weighted=False))
+            assert out["metrics"] is not None
+        else:
+            assert out["confusion"] == [0, 0, 0, 0]
