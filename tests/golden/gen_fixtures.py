@@ -370,9 +370,82 @@ def gen_intervals():
     np.savez(os.path.join(HERE, "intervals.npz"), **out)
 
 
+# ------------------------------------------------------------------------------ data pipeline
+def synth_signal_csv(path, n, seed, step=300, gaps=True, yahoo=False):
+    """A NAB-style CSV (timestamp,value): irregular sampling, missing stretches, a NaN or two."""
+    import pandas as pd
+    r = np.random.default_rng(seed)
+    if yahoo:
+        ts = np.arange(1, n + 1)
+        val = 0.01 * ts + np.sin(ts / 24.0) + 0.1 * r.standard_normal(n)
+        anom = np.zeros(n, dtype=np.int64)
+        anom[n // 3: n // 3 + 7] = 1
+        anom[n - 40: n - 35] = 1
+        val[anom == 1] += 3
+        pd.DataFrame({"timestamp": ts, "value": val, "is_anomaly": anom}).to_csv(path, index=False)
+        return
+    ts = 1_400_000_000 + step * np.arange(n) + r.integers(0, step // 3, n)
+    val = 50 + 20 * np.sin(np.arange(n) / 40.0) + r.standard_normal(n)
+    keep = np.ones(n, dtype=bool)
+    if gaps:
+        keep[n // 4: n // 4 + 30] = False            # a missing stretch: empty buckets -> NaN -> imputed
+        keep[n // 2: n // 2 + 3] = False
+        val[n // 5] = np.nan
+    order = r.permutation(int(keep.sum()))             # unsorted rows: the reference sorts by time stamp
+    pd.DataFrame({"timestamp": ts[keep][order], "value": val[keep][order]}).to_csv(path, index=False)
+
+
+def gen_dataloader():
+    """utils/dataloader.py:61-232 on synthetic CSVs written to a temporary directory."""
+    import tempfile
+    import utils.dataloader as ref_dl
+    out, cases = {}, []
+    with tempfile.TemporaryDirectory() as tmp:
+        specs = [("nab600", dict(n=1500, seed=1, step=300), dict(interval=600, windows_size=100)),
+                 ("nab1800", dict(n=2000, seed=2, step=300), dict(interval=1800, windows_size=50)),
+                 ("dense", dict(n=900, seed=3, step=300, gaps=False), dict(interval=300, windows_size=100)),
+                 ("coarse", dict(n=4000, seed=4, step=60), dict(interval=3600, windows_size=30)),
+                 ("yahoo", dict(n=700, seed=5, yahoo=True), dict(interval=1, windows_size=100, yahoo=True))]
+        for name, ckw, dkw in specs:
+            path = os.path.join(tmp, f"{name}.csv")
+            synth_signal_csv(path, **ckw)
+            ds = ref_dl.SignalDataset(path, test=True, **dkw)
+            out[f"dl_{name}_csv"] = np.array(open(path).read())
+            out[f"dl_{name}_index"] = np.asarray(ds.index)
+            out[f"dl_{name}_series"] = np.concatenate([ds.X[0, :, 0], ds.X[1:, -1, 0]])      # the scaled series the windows slide over
+            out[f"dl_{name}_Xshape"] = np.asarray(ds.X.shape)
+            out[f"dl_{name}_Xrows"] = ds.X[::max(1, len(ds.X) // 7)]
+            out[f"dl_{name}_y"] = ds.y
+            out[f"dl_{name}_X_index"] = ds.X_index
+            out[f"dl_{name}_y_index"] = ds.y_index
+            if dkw.get("yahoo"):
+                import pandas as pd
+                out[f"dl_{name}_known"] = pd.read_csv(path[:-4] + "_known_anomalies.csv")[["start", "end"]].values
+            cases.append(dict(name=name, dataset=dkw))
+        out["dl_cases"] = np.array(json.dumps(cases))
+        # the two building blocks on their own, with the arguments the reference never exercises
+        Xa = np.column_stack([np.arange(0, 400, 7), np.random.default_rng(0).standard_normal(58), np.arange(58) % 5.0])
+        ds0 = ref_dl.SignalDataset.__new__(ref_dl.SignalDataset)
+        v, i = ds0.time_segments_aggregate(Xa, 50, 0, method=["mean", "max"])
+        out.update(tsa_in=Xa, tsa_values=v, tsa_index=i)
+        Xr = np.random.default_rng(1).standard_normal((60, 2))
+        Xr[17, 0] = np.nan
+        Xr[41, 1] = np.nan
+        for tag, kw in (("plain", dict(window_size=8, target_size=2, step_size=3, target_column=1, offset=1)),
+                        ("drop", dict(window_size=8, target_size=1, step_size=2, target_column=0, drop=float("nan"), drop_windows=True))):
+            a, b, c, d = ds0.rolling_window_sequences(Xr, np.arange(100, 160), **kw)
+            out.update({f"rws_{tag}_X": a, f"rws_{tag}_y": b, f"rws_{tag}_Xi": c, f"rws_{tag}_yi": d})
+        out["rws_in"] = Xr
+    np.savez_compressed(os.path.join(HERE, "dataloader.npz"), **out)
+
+
 if __name__ == "__main__":
     import pandas
     import scipy
+    if len(sys.argv) > 1 and sys.argv[1] == "dataloader":
+        gen_dataloader()
+        print("dataloader.npz written")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "intervals":
         gen_intervals()
         print("intervals.npz written")
@@ -384,6 +457,7 @@ if __name__ == "__main__":
     gen_iters(100, 64, False, "eucl_S100")
     gen_scoring()
     gen_intervals()
+    gen_dataloader()
     with open(os.path.join(HERE, "versions.json"), "w") as f:
         json.dump(dict(torch=torch.__version__, numpy=np.__version__, scipy=scipy.__version__,
                        pandas=pandas.__version__, python=sys.version.split()[0],
