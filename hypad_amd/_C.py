@@ -52,12 +52,12 @@ class TrainState(Structure):
 
 
 class IterIO(Structure):
-    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("row_index", c_void_p), ("z", c_void_p), ("alpha", c_void_p),
+    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("z", c_void_p), ("alpha", c_void_p),
                 ("drop", Dropout), ("losses", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
 class EpochIO(Structure):
-    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
+    _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 

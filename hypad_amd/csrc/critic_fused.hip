@@ -179,7 +179,7 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
     float* bc = ph.bias_corr + ((int64_t)role * (ph.n_iters + 1) + it + 1) * 2;
     bc[0] = co.bc1; bc[1] = co.sqrt_bc2;
   }
-  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, S, ph.row_index ? ph.row_index + (int64_t)it * B : nullptr, g0, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ph.row_index ? ph.row_index + (int64_t)it * B : nullptr, g0, 16, S, 16);
   if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
     const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
     const float* PD = ax.P.dec + (int64_t)sig * ax.pd;

@@ -73,7 +73,7 @@ struct IterArgs {
   hypad_nets P, M, V;
   int pe, pd, pcx, pcz;            // floats per signal in each arena
   int32_t* counters;
-  const float* x; int64_t x_sig_stride; const int32_t* row_index;
+  const float* x; int64_t x_sig_stride; int64_t x_ld; const int32_t* row_index;   // x_ld: floats between window rows (S, or 1 = series view)
   const float* z; const float* alpha;
   int drop_mode;                   // 0 eval, 1 injected, 2 Philox
   const float* masks; int64_t mask_sig_stride;

@@ -129,7 +129,7 @@ __device__ __forceinline__ void cx_pass_body(const IterArgs& a, float* smem) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
   if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
-  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);
   __syncthreads();
   // decoder (frozen, train-mode dropout): x_ = decoder(z)
@@ -169,7 +169,7 @@ __device__ __forceinline__ void cz_pass_body(const IterArgs& a, float* smem) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
   if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
-  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, S, a.row_index, tile * 16, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);                       // real = z ~ N(0,1)
   __syncthreads();
   float* zenc = zs + 16 * LP;                           // fake = encoder(x)
@@ -337,7 +337,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     const CriticLayout clz = cz_layout(L);
     const CriticPad cpz = critic_pad(L, L, 2);
     stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
-    tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, S, a.row_index, g0, 16, S, 16);
+    tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
     __syncthreads();
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
     zin = zs + 16 * LP;
@@ -835,7 +835,7 @@ hipError_t allow_lds(const void* fn, size_t bytes) {
 long long* g_gen_stamps = nullptr;
 
 struct IterCall {
-  const float* x; int64_t x_sig_stride; const int32_t* row_index;
+  const float* x; int64_t x_sig_stride; int64_t x_row_stride; const int32_t* row_index;
   const float* z; const float* alpha;
   int train_mode; const float* masks; uint64_t seed;
   float* losses; int64_t loss_sig_stride;
@@ -855,7 +855,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.pe = enc_layout(a.S, a.L).total; a.pd = dec_layout(a.S, a.L, a.hyperbolic).total;
   a.pcx = cx_layout(a.S, a.L).total; a.pcz = cz_layout(a.L).total;
   a.counters = st->counters;
-  a.x = io.x; a.x_sig_stride = io.x_sig_stride; a.row_index = io.row_index;
+  a.x = io.x; a.x_sig_stride = io.x_sig_stride; a.x_ld = io.x_row_stride > 0 ? io.x_row_stride : d->signal_shape; a.row_index = io.row_index;
   a.z = io.z; a.alpha = io.alpha;
   a.drop_mode = io.train_mode ? (io.masks ? 1 : 2) : 0;
   a.masks = io.masks; a.seed = io.seed;
@@ -1004,7 +1004,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
 
 IterCall from_io(const hypad_iter_io* io) {
   IterCall c;
-  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.row_index = io->row_index; c.z = io->z; c.alpha = io->alpha;
+  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.x_row_stride = io->x_row_stride; c.row_index = io->row_index; c.z = io->z; c.alpha = io->alpha;
   c.train_mode = io->drop.train_mode; c.masks = io->drop.masks; c.seed = io->drop.seed;
   c.losses = io->losses; c.loss_sig_stride = 4; c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
   return c;
@@ -1112,7 +1112,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   int rc = check_dims(d);
   if (rc) return rc;
   IterCall c;
-  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.z = nullptr; c.alpha = nullptr;
+  c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.x_row_stride = io->x_row_stride; c.z = nullptr; c.alpha = nullptr;
   c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
   c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
   const int iters = (2 * io->n_critics + 1) * io->n_batches;

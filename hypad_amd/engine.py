@@ -78,8 +78,16 @@ class Engine:
         return _C.TrainState(self._nets(self.params), self._nets(self.exp_avg), self._nets(self.exp_avg_sq),
                              self.counters.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.gen_wd, self.gen_stab)
 
-    def _check_x(self, x):
+    def _check_x(self, x, x_row_stride=0):
+        """x: (n_signals, n_windows, S) window matrices, or -- with x_row_stride=1 -- (n_signals, T) scaled series whose
+        windows are the overlapping rows x[n : n + S] (SignalDataset.window_view: nothing is materialised)."""
         _C.require_cuda(x, "x")
+        if x_row_stride:
+            if x.dim() == 1:
+                x = x.unsqueeze(0)
+            if x.dim() != 2 or x.shape[0] not in (1, self.n) or x.shape[1] < self.S or not x.is_contiguous():
+                raise _C.HypadError(f"a series view must be a contiguous (n_signals, T >= {self.S}) tensor")
+            return x, (0 if (x.shape[0] == 1 and self.n > 1) else x.shape[1])
         if x.dim() == 2:
             x = x.unsqueeze(0)
         if x.shape[0] not in (1, self.n) or x.shape[2] != self.S:
@@ -87,25 +95,25 @@ class Engine:
         stride = 0 if (x.shape[0] == 1 and self.n > 1) else x.shape[1] * x.shape[2]
         return x, stride
 
-    def _iter(self, fn, x, row_index, z, alpha, train_mode, masks):
-        x, stride = self._check_x(x)
+    def _iter(self, fn, x, row_index, z, alpha, train_mode, masks, x_row_stride=0):
+        x, stride = self._check_x(x, x_row_stride)
         losses = torch.empty(self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None if masks is None else masks.data_ptr(), self.seed, 0)
-        io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(),
+        io = _C.IterIO(x.data_ptr(), stride, int(x_row_stride), None if row_index is None else row_index.data_ptr(),
                        None if z is None else z.data_ptr(), None if alpha is None else alpha.data_ptr(), drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
         st = self._state()
         _C.check(fn(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), fn.__name__)
         return losses
 
-    def critic_x_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None):
-        return self._iter(_C.lib.hypad_critic_x_iteration, x, row_index, z, alpha, train_mode, masks)
+    def critic_x_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None, x_row_stride=0):
+        return self._iter(_C.lib.hypad_critic_x_iteration, x, row_index, z, alpha, train_mode, masks, x_row_stride)
 
-    def critic_z_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None):
-        return self._iter(_C.lib.hypad_critic_z_iteration, x, row_index, z, alpha, train_mode, masks)
+    def critic_z_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None, x_row_stride=0):
+        return self._iter(_C.lib.hypad_critic_z_iteration, x, row_index, z, alpha, train_mode, masks, x_row_stride)
 
-    def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None):
-        return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks)
+    def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None, x_row_stride=0):
+        return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks, x_row_stride)
 
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
@@ -115,7 +123,7 @@ class Engine:
             self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 2, 1))
         losses = torch.empty(4 * self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None, self.seed, 0)
-        io = _C.IterIO(x.data_ptr(), stride, None if row_index is None else row_index.data_ptr(), None, None, drop,
+        io = _C.IterIO(x.data_ptr(), stride, 0, None if row_index is None else row_index.data_ptr(), None, None, drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
         st = self._state()
         out = (ctypes.c_float * 3)()
@@ -123,16 +131,17 @@ class Engine:
                                                 _C.stream()), "profile_iteration")
         return list(out)[: 2 if kind == 2 else 3]
 
-    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True):
+    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
-        hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks)."""
-        x, stride = self._check_x(x)
+        hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks).
+        x_row_stride=1: x is the scaled series (SignalDataset.window_view), not a window matrix."""
+        x, stride = self._check_x(x, x_row_stride)
         if hoist:
             self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
         iters = (2 * n_critics + 1) * n_batches
         if losses is None:
             losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
-        io = _C.EpochIO(x.data_ptr(), stride, row_index.data_ptr(), n_batches, n_critics, int(train_mode), self.seed,
+        io = _C.EpochIO(x.data_ptr(), stride, int(x_row_stride), row_index.data_ptr(), n_batches, n_critics, int(train_mode), self.seed,
                         losses.data_ptr(), self.workspace.data_ptr(),
                         self._ws_bytes if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)))
         st = self._state()

@@ -180,6 +180,9 @@ typedef struct hypad_train_state {
 typedef struct hypad_iter_io {
   const float* x;            /* window matrix resident in HBM: (n_signals, n_windows, S) fp32 */
   int64_t x_signal_stride;   /* floats between signals */
+  int64_t x_row_stride;      /* floats between consecutive window rows of x: 0 or signal_shape = a dense (n_windows,
+                                signal_shape) matrix; 1 = x is the scaled series itself and window n is x[n .. n + signal_shape)
+                                (utils/dataloader.py:139-222 materialises exactly that sliding view) */
   const int32_t* row_index;  /* (batch) rows of x forming this minibatch (shared by all signals); NULL = 0..batch-1 */
   const float* z;            /* injected N(0,1) latent draw (n_signals, batch, L) or NULL = device Philox (train.py:24,118,205) */
   const float* alpha;        /* injected U(0,1) interpolation weights (n_signals, batch, S or L) or NULL (train.py:64,149) */
@@ -202,6 +205,7 @@ int hypad_decoder_iteration(const hypad_dims* dims, const hypad_train_state* st,
  * (2 * n_critics + 1) * n_batches, 4) in launch order. */
 typedef struct hypad_epoch_io {
   const float* x; int64_t x_signal_stride;
+  int64_t x_row_stride;      /* as in hypad_iter_io */
   const int32_t* row_index;
   int n_batches, n_critics;
   int train_mode; uint64_t seed;

@@ -726,3 +726,38 @@ def test_univariate_anomaly_detection_end_to_end(dev):
             assert out["metrics"] is not None
         else:
             assert out["confusion"] == [0, 0, 0, 0]
+
+
+def test_series_view_equals_window_matrix(dev, tmp_path):
+    """x_row_stride = 1 (hypad.h): the kernels read window n as series[n : n + S] -- the sliding view that
+    utils/dataloader.py:139-222 materialises -- and train bit-identically to the materialised (N, S) matrix."""
+    import os
+    from hypad_amd.utils import dataloader as dl
+    fxd = load("dataloader.npz")
+    path = os.path.join(tmp_path, "s.csv")
+    with open(path, "w") as f:
+        f.write(str(fxd["dl_nab600_csv"]))
+    ds = dl.SignalDataset(path, interval=600, windows_size=100)
+    series, n_windows, stride = ds.window_view("cuda")
+    assert stride == 1 and n_windows == len(ds) and series.shape[0] == len(ds) + 100
+    xm = torch.as_tensor(ds.X[:, :, 0], dtype=torch.float32).cuda().contiguous().unsqueeze(0)
+    fx = load("iters_hyper_S100.npz")
+    nb, nc = 3, 2
+    perm = torch.stack([torch.randperm(n_windows, generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+    res = []
+    for view in (False, True):
+        eng = _engine_from(fx, True)
+        eng.seed = 77
+        if view:
+            l0 = eng.critic_x_iteration(series, perm[0, :64].contiguous(), train_mode=False, x_row_stride=1)
+            l1 = eng.train_epoch(series, perm, nb, nc, True, x_row_stride=1)
+        else:
+            l0 = eng.critic_x_iteration(xm, perm[0, :64].contiguous(), train_mode=False)
+            l1 = eng.train_epoch(xm, perm, nb, nc, True)
+        torch.cuda.synchronize()
+        res.append((l0.clone(), l1.clone(), {k: eng.params[k].clone() for k in ("enc", "dec", "cx", "cz")}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in ("enc", "dec", "cx", "cz"):
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    with pytest.raises(Exception):
+        _engine_from(fx, True).train_epoch(series[:50], perm, nb, nc, True, x_row_stride=1)
