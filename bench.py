@@ -109,6 +109,60 @@ def cpu_baseline(hyperbolic, budget_s=24.0):
     return best
 
 
+def bench_scoring(device, n=125_000, reps=5):
+    """BASELINE.json's second metric, anomaly-score windows/s, on this GPU's share of configs[4] (10^6 windows over 8
+    GPUs): the test-loop forward with the hyperbolic row distance (anomaly_detection.py:67-113), then un-roll median +
+    point and DTW errors + rolling mean + z-score (utils/anomaly_detection_utils.py:866-962, 516-524); and the HBM
+    rate of the row-wise Poincare-ball kernels (algorithmic bytes per row)."""
+    from hypad_amd import _C
+    from hypad_amd.hyperspace import gmath
+    from hypad_amd.models import tadgan
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    torch.manual_seed(0)
+    enc, dec, cx = tadgan.Encoder(S, L).to(device).eval(), tadgan.Decoder(S, L, True).to(device).eval(), tadgan.CriticX(S, L).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(3)
+    x = (torch.rand(n, S, device=device, generator=g) * 2 - 1).contiguous()
+    new = lambda *shape: torch.empty(*shape, device=device, dtype=torch.float32)
+    hyper, eucl, hreal, critic, dist = new(n, S), new(n, S), new(n, S), new(n), new(n)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def forward():
+        _C.check(_C.lib.hypad_score_forward(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(x), _C.ptr(hyper),
+                                            _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L, 1, _C.stream()), "score_forward")
+
+    def numerics():
+        true = adu.unroll_true(x)
+        pred, _ = adu.unroll_predictions(eucl, False)
+        e1 = adu.rolling_mean(adu._point_wise_error(true, pred), 200)
+        e2 = adu.rolling_mean(adu._dtw_error(true, pred, 10), 200)
+        return adu.zscore_clip(e1), adu.zscore_clip(e2)
+
+    t_fwd, t_num = timed(forward), timed(numerics)
+    # row-wise ball kernels on 2 * 10^6 rows (0.8 GB per operand: well past the 256 MB Infinity Cache, so the rate is HBM's)
+    m = 2_000_000
+    xb = (torch.rand(m, S, device=device, generator=g) * 2 - 1).contiguous()
+    ball = gmath.expmap0(0.03 * torch.randn(m, S, device=device, generator=g))
+    other = gmath.expmap0(0.03 * torch.randn(m, S, device=device, generator=g))
+    ops = {"expmap0": (lambda: gmath.expmap0(xb), 8 * S), "logmap0": (lambda: gmath.logmap0(ball), 8 * S),
+           "project": (lambda: gmath.project(xb), 8 * S), "mobius_add": (lambda: gmath.mobius_add(ball, other), 12 * S),
+           "poincare_rowdist": (lambda: gmath.poincare_rowdist(ball, other), 8 * S + 4)}
+    gbps = {k: m * b / timed(f) / 1e9 for k, (f, b) in ops.items()}
+    return {"windows": n, "value": n / (t_fwd + t_num), "unit": "windows/s",
+            "forward_windows_per_s": n / t_fwd, "forward_tflops": n * 340312 / t_fwd / 1e12,
+            "numerics_windows_per_s": n / t_num,
+            "numerics": "un-roll median, point + DTW(11) errors, rolling mean(200), z-score",
+            "hyperbolic_ops_GBps": gbps, "hyperbolic_ops_rows": m, "hbm_peak_GBps": 8000.0,
+            "note": "row-wise ball ops: algorithmic bytes (800-1204 B/row at S=100) / time; includes the output allocation of the torch-facing wrappers"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +171,7 @@ def main():
     ap.add_argument("--signals-per-gpu", type=int, default=1, help="independent signals (models) trained side by side on each GPU")
     ap.add_argument("--euclidean", action="store_true", help="configs[0]-style hyperbolic=False instead of configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +277,8 @@ def main():
                          "kernel_ms": kern_ms, "epoch_share_ms": share, "flop_per_launch": flop},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
+        if not args.no_scoring:
+            out["scoring"] = bench_scoring(device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hyperbolic)
         print(json.dumps(out))
