@@ -14,7 +14,7 @@ constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / 64;
 
 inline int row_grid(int64_t rows) {
-  int64_t blocks = (rows + WAVES - 1) / WAVES;
+  int64_t blocks = (rows + WAVES * 4 - 1) / (WAVES * 4);
   if (blocks > 4096) blocks = 4096;   // >> 256 CUs; the rest grid-strides
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -22,37 +22,114 @@ inline int row_grid(int64_t rows) {
 
 enum UnaryOp { OP_EXPMAP0, OP_EXPMAP0_BWD, OP_LOGMAP0, OP_LOGMAP0_BWD, OP_PROJECT, OP_PROJECT_BWD };
 
+// Rows per wave and iteration: a row is only 4*dim bytes, so each wave keeps RPW consecutive rows in flight (all loads
+// issued before the first reduction, branch-free, clamped row index) -- the kernels are HBM-bound and one 400-byte row
+// per wave leaves the memory pipeline mostly empty.
+constexpr int RPW = 4;
+
+// RPW consecutive rows are RPW*dim contiguous floats starting on a 16-byte boundary (r % 4 == 0): they move between HBM and
+// a wave-private LDS slab as `dim` float4s (16 B per lane per instruction, the shape that reaches HBM rate) and between the
+// slab and the row registers with the usual lane + 64 e pattern.  LDS instructions of a wave execute in order; the fence
+// only keeps the compiler from reordering a lane's accesses around other lanes' accesses of the same wave.
+__device__ __forceinline__ void slab_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void slab_in(float* slab, const float* __restrict__ src, int dim, int lane) {
+  for (int k = lane; k < dim; k += 64) reinterpret_cast<float4*>(slab)[k] = reinterpret_cast<const float4*>(src)[k];
+}
+__device__ __forceinline__ void slab_out(float* __restrict__ dst, const float* slab, int dim, int lane) {
+  for (int k = lane; k < dim; k += 64) reinterpret_cast<float4*>(dst)[k] = reinterpret_cast<const float4*>(slab)[k];
+}
+inline size_t slab_bytes(int dim, int nbuf) { return (size_t)WAVES * nbuf * RPW * dim * sizeof(float); }
+
 template <int OP>
 __global__ __launch_bounds__(THREADS) void unary_rows(const float* __restrict__ a, const float* __restrict__ g,
                                                        float* __restrict__ out, int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
+  const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr bool BWD = OP == OP_EXPMAP0_BWD || OP == OP_LOGMAP0_BWD || OP == OP_PROJECT_BWD;
+  float* sa = smem + (threadIdx.x >> 6) * 3 * RPW * dim;
+  float* sg = sa + RPW * dim;
+  float* so = sg + RPW * dim;
+  const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) | (BWD ? reinterpret_cast<uintptr_t>(g) : 0)) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec x = row_load(a + r * dim, dim, lane);
-    RowVec o;
-    if (OP == OP_EXPMAP0) o = expmap0_row(x);
-    else if (OP == OP_LOGMAP0) o = logmap0_row(x);
-    else if (OP == OP_PROJECT) o = project_row(x);
-    else {
-      RowVec go = row_load(g + r * dim, dim, lane);
-      if (OP == OP_EXPMAP0_BWD) o = expmap0_row_bwd(x, go);
-      else if (OP == OP_LOGMAP0_BWD) o = logmap0_row_bwd(x, go);
-      else o = project_row_bwd(x, go);
+    RowVec x[RPW], go[RPW], o[RPW];
+    const bool full = al && r + RPW <= rows;
+    if (full) {
+      slab_in(sa, a + r * dim, dim, lane);
+      if (BWD) slab_in(sg, g + r * dim, dim, lane);
+      slab_fence();
     }
-    row_store(out + r * dim, o, dim, lane);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int64_t rr = r + i < rows ? r + i : rows - 1;
+      x[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(a + rr * dim, dim, lane);
+      if (BWD) go[i] = full ? row_load(sg + i * dim, dim, lane) : row_load(g + rr * dim, dim, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      if (OP == OP_EXPMAP0) o[i] = expmap0_row(x[i]);
+      else if (OP == OP_LOGMAP0) o[i] = logmap0_row(x[i]);
+      else if (OP == OP_PROJECT) o[i] = project_row(x[i]);
+      else if (OP == OP_EXPMAP0_BWD) o[i] = expmap0_row_bwd(x[i], go[i]);
+      else if (OP == OP_LOGMAP0_BWD) o[i] = logmap0_row_bwd(x[i], go[i]);
+      else o[i] = project_row_bwd(x[i], go[i]);
+    }
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, o[i], dim, lane);
+      slab_fence();
+      slab_out(out + r * dim, so, dim, lane);
+      slab_fence();
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        if (r + i < rows) row_store(out + (r + i) * dim, o[i], dim, lane);
+    }
   }
 }
 
 __global__ __launch_bounds__(THREADS) void mobius_add_rows(const float* __restrict__ x, const float* __restrict__ y,
                                                             float* __restrict__ out, int64_t rows, int dim, int ybc) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
+  const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sa = smem + (threadIdx.x >> 6) * 3 * RPW * dim;
+  float* sb = sa + RPW * dim;
+  float* so = sb + RPW * dim;
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | (ybc ? 0 : reinterpret_cast<uintptr_t>(y))) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec a = row_load(x + r * dim, dim, lane);
-    RowVec b = row_load(y + (ybc ? 0 : r * dim), dim, lane);
-    row_store(out + r * dim, mobius_add_row(a, b), dim, lane);
+    RowVec a[RPW], b[RPW], o[RPW];
+    const bool full = al && r + RPW <= rows;
+    if (full) {
+      slab_in(sa, x + r * dim, dim, lane);
+      if (!ybc) slab_in(sb, y + r * dim, dim, lane);
+      slab_fence();
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int64_t rr = r + i < rows ? r + i : rows - 1;
+      a[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(x + rr * dim, dim, lane);
+      b[i] = (full && !ybc) ? row_load(sb + i * dim, dim, lane) : row_load(y + (ybc ? 0 : rr * dim), dim, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) o[i] = mobius_add_row(a[i], b[i]);
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, o[i], dim, lane);
+      slab_fence();
+      slab_out(out + r * dim, so, dim, lane);
+      slab_fence();
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        if (r + i < rows) row_store(out + (r + i) * dim, o[i], dim, lane);
+    }
   }
 }
 __global__ __launch_bounds__(THREADS) void mobius_add_rows_bwd(const float* __restrict__ x, const float* __restrict__ y,
@@ -75,11 +152,34 @@ __global__ __launch_bounds__(THREADS) void mobius_add_rows_bwd(const float* __re
 __global__ __launch_bounds__(THREADS) void head_rows(const float* __restrict__ u, const float* __restrict__ bias,
                                                       float* __restrict__ out, int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
+  const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
   const RowVec b = row_load(bias, dim, lane);
-  for (int64_t r = wave0; r < rows; r += stride)
-    row_store(out + r * dim, head_row(row_load(u + r * dim, dim, lane), b), dim, lane);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sa = smem + (threadIdx.x >> 6) * 2 * RPW * dim;
+  float* so = sa + RPW * dim;
+  const bool al = ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  for (int64_t r = wave0; r < rows; r += stride) {
+    RowVec x[RPW];
+    const bool full = al && r + RPW <= rows;
+    if (full) { slab_in(sa, u + r * dim, dim, lane); slab_fence(); }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+      x[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(u + (r + i < rows ? r + i : rows - 1) * dim, dim, lane);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) x[i] = head_row(x[i], b);
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, x[i], dim, lane);
+      slab_fence();
+      slab_out(out + r * dim, so, dim, lane);
+      slab_fence();
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i)
+        if (r + i < rows) row_store(out + (r + i) * dim, x[i], dim, lane);
+    }
+  }
 }
 __global__ __launch_bounds__(THREADS) void head_rows_bwd(const float* __restrict__ u, const float* __restrict__ bias,
                                                           const float* __restrict__ go, float* __restrict__ gu,
@@ -99,11 +199,31 @@ __global__ __launch_bounds__(THREADS) void head_rows_bwd(const float* __restrict
 __global__ __launch_bounds__(THREADS) void rowdist_rows(const float* __restrict__ u, const float* __restrict__ v,
                                                          float* __restrict__ dist, int64_t rows, int dim) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
+  const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sa = smem + (threadIdx.x >> 6) * 2 * RPW * dim;
+  float* sb = sa + RPW * dim;
+  const bool al = ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    float d = rowdist_row(row_load(u + r * dim, dim, lane), row_load(v + r * dim, dim, lane));
-    if (lane == 0) dist[r] = d;
+    RowVec a[RPW], b[RPW];
+    float d[RPW];
+    const bool full = al && r + RPW <= rows;
+    if (full) {
+      slab_in(sa, u + r * dim, dim, lane);
+      slab_in(sb, v + r * dim, dim, lane);
+      slab_fence();
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int64_t rr = r + i < rows ? r + i : rows - 1;
+      a[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(u + rr * dim, dim, lane);
+      b[i] = full ? row_load(sb + i * dim, dim, lane) : row_load(v + rr * dim, dim, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) d[i] = rowdist_row(a[i], b[i]);
+    if (lane < RPW && r + lane < rows) dist[r + lane] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+    slab_fence();
   }
 }
 // gd_scalar used when gd == nullptr (hyperbolic loss: every row gets grad_loss / batch)
@@ -212,7 +332,7 @@ int launch_unary(const float* a, const float* g, float* out, int64_t rows, int d
   int rc = check_rows(a, out, rows, dim);
   if (rc) return rc;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(unary_rows<OP>, dim3(row_grid(rows)), dim3(THREADS), 0, (hipStream_t)stream, a, g, out, rows, dim);
+  hipLaunchKernelGGL(unary_rows<OP>, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)stream, a, g, out, rows, dim);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -248,7 +368,7 @@ int hypad_mobius_add_fwd(const float* x, const float* y, float* out, int64_t row
   if (rc) return rc;
   if (!y || (y_rows != 1 && y_rows != rows)) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(mobius_add_rows, dim3(row_grid(rows)), dim3(THREADS), 0, (hipStream_t)s, x, y, out, rows, dim,
+  hipLaunchKernelGGL(mobius_add_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)s, x, y, out, rows, dim,
                      (int)(y_rows == 1 && rows != 1));
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
@@ -270,7 +390,7 @@ int hypad_mobius_head_fwd(const float* u, const float* bias, float* out, int64_t
   if (rc) return rc;
   if (!bias) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(head_rows, dim3(row_grid(rows)), dim3(THREADS), 0, (hipStream_t)s, u, bias, out, rows, dim);
+  hipLaunchKernelGGL(head_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, bias, out, rows, dim);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -290,7 +410,7 @@ int hypad_poincare_rowdist_fwd(const float* u, const float* v, float* dist, int6
   if (rc) return rc;
   if (!dist) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(rowdist_rows, dim3(row_grid(rows)), dim3(THREADS), 0, (hipStream_t)s, u, v, dist, rows, dim);
+  hipLaunchKernelGGL(rowdist_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, v, dist, rows, dim);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
