@@ -30,6 +30,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (a + b) + (c + d);
 }
+// Sum over each aligned group of 16 lanes (one DPP row), result in every lane of the group: the first four steps above.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move_<0xB1>(v);
+  v += dpp_move_<0x4E>(v);
+  v += dpp_move_<0x141>(v);
+  v += dpp_move_<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);

@@ -43,11 +43,20 @@ __device__ __forceinline__ void slab_out(float* __restrict__ dst, const float* s
   for (int k = lane; k < dim; k += 64) reinterpret_cast<float4*>(dst)[k] = reinterpret_cast<const float4*>(slab)[k];
 }
 inline size_t slab_bytes(int dim, int nbuf) { return (size_t)WAVES * nbuf * RPW * dim * sizeof(float); }
+// elements per lane of the 16-lanes-per-row layout, by row length
+#define HYPAD_EPL_DISPATCH(dim, ...)                        \
+  do {                                                      \
+    if ((dim) <= 64) { constexpr int EPL = 4; __VA_ARGS__; }        \
+    else if ((dim) <= 128) { constexpr int EPL = 8; __VA_ARGS__; }  \
+    else { constexpr int EPL = 16; __VA_ARGS__; }           \
+  } while (0)
 
-template <int OP>
+// Four rows per wave, one per DPP row of 16 lanes (RowT<16, EPL>, rowops.h).  Row r0 + (lane >> 4) belongs to the lane.
+template <int OP, int EPL>
 __global__ __launch_bounds__(THREADS) void unary_rows(const float* __restrict__ a, const float* __restrict__ g,
                                                        float* __restrict__ out, int64_t rows, int dim) {
-  const int lane = threadIdx.x & 63;
+  using R = RowT<16, EPL>;
+  const int lane = threadIdx.x & 63, sub = lane >> 4;
   const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
   const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -57,45 +66,41 @@ __global__ __launch_bounds__(THREADS) void unary_rows(const float* __restrict__ 
   float* so = sg + RPW * dim;
   const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) | (BWD ? reinterpret_cast<uintptr_t>(g) : 0)) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec x[RPW], go[RPW], o[RPW];
     const bool full = al && r + RPW <= rows;
+    const int64_t rr = r + sub < rows ? r + sub : rows - 1;
+    R x, go, o;
     if (full) {
       slab_in(sa, a + r * dim, dim, lane);
       if (BWD) slab_in(sg, g + r * dim, dim, lane);
       slab_fence();
+      x = row_load<R>(sa + sub * dim, dim, lane);
+      if (BWD) go = row_load<R>(sg + sub * dim, dim, lane);
+    } else {
+      x = row_load<R>(a + rr * dim, dim, lane);
+      if (BWD) go = row_load<R>(g + rr * dim, dim, lane);
     }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int64_t rr = r + i < rows ? r + i : rows - 1;
-      x[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(a + rr * dim, dim, lane);
-      if (BWD) go[i] = full ? row_load(sg + i * dim, dim, lane) : row_load(g + rr * dim, dim, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      if (OP == OP_EXPMAP0) o[i] = expmap0_row(x[i]);
-      else if (OP == OP_LOGMAP0) o[i] = logmap0_row(x[i]);
-      else if (OP == OP_PROJECT) o[i] = project_row(x[i]);
-      else if (OP == OP_EXPMAP0_BWD) o[i] = expmap0_row_bwd(x[i], go[i]);
-      else if (OP == OP_LOGMAP0_BWD) o[i] = logmap0_row_bwd(x[i], go[i]);
-      else o[i] = project_row_bwd(x[i], go[i]);
-    }
+    if (OP == OP_EXPMAP0) o = expmap0_row(x);
+    else if (OP == OP_LOGMAP0) o = logmap0_row(x);
+    else if (OP == OP_PROJECT) o = project_row(x);
+    else if (OP == OP_EXPMAP0_BWD) o = expmap0_row_bwd(x, go);
+    else if (OP == OP_LOGMAP0_BWD) o = logmap0_row_bwd(x, go);
+    else o = project_row_bwd(x, go);
     if (full) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, o[i], dim, lane);
+      row_store(so + sub * dim, o, dim, lane);
       slab_fence();
       slab_out(out + r * dim, so, dim, lane);
       slab_fence();
-    } else {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i)
-        if (r + i < rows) row_store(out + (r + i) * dim, o[i], dim, lane);
+    } else if (r + sub < rows) {
+      row_store(out + (r + sub) * dim, o, dim, lane);
     }
   }
 }
 
+template <int EPL>
 __global__ __launch_bounds__(THREADS) void mobius_add_rows(const float* __restrict__ x, const float* __restrict__ y,
                                                             float* __restrict__ out, int64_t rows, int dim, int ybc) {
-  const int lane = threadIdx.x & 63;
+  using R = RowT<16, EPL>;
+  const int lane = threadIdx.x & 63, sub = lane >> 4;
   const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
   const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -104,31 +109,27 @@ __global__ __launch_bounds__(THREADS) void mobius_add_rows(const float* __restri
   float* so = sb + RPW * dim;
   const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | (ybc ? 0 : reinterpret_cast<uintptr_t>(y))) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec a[RPW], b[RPW], o[RPW];
     const bool full = al && r + RPW <= rows;
+    const int64_t rr = r + sub < rows ? r + sub : rows - 1;
+    R a, b;
     if (full) {
       slab_in(sa, x + r * dim, dim, lane);
       if (!ybc) slab_in(sb, y + r * dim, dim, lane);
       slab_fence();
+      a = row_load<R>(sa + sub * dim, dim, lane);
+      b = ybc ? row_load<R>(y, dim, lane) : row_load<R>(sb + sub * dim, dim, lane);
+    } else {
+      a = row_load<R>(x + rr * dim, dim, lane);
+      b = row_load<R>(y + (ybc ? 0 : rr * dim), dim, lane);
     }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int64_t rr = r + i < rows ? r + i : rows - 1;
-      a[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(x + rr * dim, dim, lane);
-      b[i] = (full && !ybc) ? row_load(sb + i * dim, dim, lane) : row_load(y + (ybc ? 0 : rr * dim), dim, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) o[i] = mobius_add_row(a[i], b[i]);
+    const R o = mobius_add_row(a, b);
     if (full) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, o[i], dim, lane);
+      row_store(so + sub * dim, o, dim, lane);
       slab_fence();
       slab_out(out + r * dim, so, dim, lane);
       slab_fence();
-    } else {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i)
-        if (r + i < rows) row_store(out + (r + i) * dim, o[i], dim, lane);
+    } else if (r + sub < rows) {
+      row_store(out + (r + sub) * dim, o, dim, lane);
     }
   }
 }
@@ -149,35 +150,31 @@ __global__ __launch_bounds__(THREADS) void mobius_add_rows_bwd(const float* __re
   }
 }
 
+template <int EPL>
 __global__ __launch_bounds__(THREADS) void head_rows(const float* __restrict__ u, const float* __restrict__ bias,
                                                       float* __restrict__ out, int64_t rows, int dim) {
-  const int lane = threadIdx.x & 63;
+  using R = RowT<16, EPL>;
+  const int lane = threadIdx.x & 63, sub = lane >> 4;
   const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
   const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
-  const RowVec b = row_load(bias, dim, lane);
+  const R b = row_load<R>(bias, dim, lane);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sa = smem + (threadIdx.x >> 6) * 2 * RPW * dim;
   float* so = sa + RPW * dim;
   const bool al = ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec x[RPW];
     const bool full = al && r + RPW <= rows;
-    if (full) { slab_in(sa, u + r * dim, dim, lane); slab_fence(); }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-      x[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(u + (r + i < rows ? r + i : rows - 1) * dim, dim, lane);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) x[i] = head_row(x[i], b);
+    R x;
+    if (full) { slab_in(sa, u + r * dim, dim, lane); slab_fence(); x = row_load<R>(sa + sub * dim, dim, lane); }
+    else x = row_load<R>(u + (r + sub < rows ? r + sub : rows - 1) * dim, dim, lane);
+    x = head_row(x, b);
     if (full) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) row_store(so + i * dim, x[i], dim, lane);
+      row_store(so + sub * dim, x, dim, lane);
       slab_fence();
       slab_out(out + r * dim, so, dim, lane);
       slab_fence();
-    } else {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i)
-        if (r + i < rows) row_store(out + (r + i) * dim, x[i], dim, lane);
+    } else if (r + sub < rows) {
+      row_store(out + (r + sub) * dim, x, dim, lane);
     }
   }
 }
@@ -196,9 +193,11 @@ __global__ __launch_bounds__(THREADS) void head_rows_bwd(const float* __restrict
   }
 }
 
+template <int EPL>
 __global__ __launch_bounds__(THREADS) void rowdist_rows(const float* __restrict__ u, const float* __restrict__ v,
                                                          float* __restrict__ dist, int64_t rows, int dim) {
-  const int lane = threadIdx.x & 63;
+  using R = RowT<16, EPL>;
+  const int lane = threadIdx.x & 63, sub = lane >> 4;
   const int64_t wave0 = ((int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * RPW;
   const int64_t stride = (int64_t)gridDim.x * WAVES * RPW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -206,23 +205,21 @@ __global__ __launch_bounds__(THREADS) void rowdist_rows(const float* __restrict_
   float* sb = sa + RPW * dim;
   const bool al = ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   for (int64_t r = wave0; r < rows; r += stride) {
-    RowVec a[RPW], b[RPW];
-    float d[RPW];
     const bool full = al && r + RPW <= rows;
+    const int64_t rr = r + sub < rows ? r + sub : rows - 1;
+    R a, b;
     if (full) {
       slab_in(sa, u + r * dim, dim, lane);
       slab_in(sb, v + r * dim, dim, lane);
       slab_fence();
+      a = row_load<R>(sa + sub * dim, dim, lane);
+      b = row_load<R>(sb + sub * dim, dim, lane);
+    } else {
+      a = row_load<R>(u + rr * dim, dim, lane);
+      b = row_load<R>(v + rr * dim, dim, lane);
     }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int64_t rr = r + i < rows ? r + i : rows - 1;
-      a[i] = full ? row_load(sa + i * dim, dim, lane) : row_load(u + rr * dim, dim, lane);
-      b[i] = full ? row_load(sb + i * dim, dim, lane) : row_load(v + rr * dim, dim, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) d[i] = rowdist_row(a[i], b[i]);
-    if (lane < RPW && r + lane < rows) dist[r + lane] = lane == 0 ? d[0] : lane == 1 ? d[1] : lane == 2 ? d[2] : d[3];
+    const float d = rowdist_row(a, b);
+    if ((lane & 15) == 0 && r + sub < rows) dist[r + sub] = d;
     slab_fence();
   }
 }
@@ -332,7 +329,7 @@ int launch_unary(const float* a, const float* g, float* out, int64_t rows, int d
   int rc = check_rows(a, out, rows, dim);
   if (rc) return rc;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(unary_rows<OP>, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)stream, a, g, out, rows, dim);
+  HYPAD_EPL_DISPATCH(dim, hipLaunchKernelGGL((unary_rows<OP, EPL>), dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)stream, a, g, out, rows, dim));
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -368,8 +365,8 @@ int hypad_mobius_add_fwd(const float* x, const float* y, float* out, int64_t row
   if (rc) return rc;
   if (!y || (y_rows != 1 && y_rows != rows)) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(mobius_add_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)s, x, y, out, rows, dim,
-                     (int)(y_rows == 1 && rows != 1));
+  HYPAD_EPL_DISPATCH(dim, hipLaunchKernelGGL((mobius_add_rows<EPL>), dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 3), (hipStream_t)s, x, y, out, rows, dim,
+                     (int)(y_rows == 1 && rows != 1)));
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -390,7 +387,7 @@ int hypad_mobius_head_fwd(const float* u, const float* bias, float* out, int64_t
   if (rc) return rc;
   if (!bias) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(head_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, bias, out, rows, dim);
+  HYPAD_EPL_DISPATCH(dim, hipLaunchKernelGGL((head_rows<EPL>), dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, bias, out, rows, dim));
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -410,7 +407,7 @@ int hypad_poincare_rowdist_fwd(const float* u, const float* v, float* dist, int6
   if (rc) return rc;
   if (!dist) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(rowdist_rows, dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, v, dist, rows, dim);
+  HYPAD_EPL_DISPATCH(dim, hipLaunchKernelGGL((rowdist_rows<EPL>), dim3(row_grid(rows)), dim3(THREADS), slab_bytes(dim, 2), (hipStream_t)s, u, v, dist, rows, dim));
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
