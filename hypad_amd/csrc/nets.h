@@ -260,25 +260,20 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
 }
 
 // Moebius head on LDS rows: Us[rows][ld] (u = e W_h^T) -> in place r = project(mobius_add(expmap0(u), bias)).
-// A row is a chain of ~5 dependent wave reductions: RPW rows per wave are carried through it together (branch-free,
-// fully unrolled) so their chains overlap.
-template <int RPW>
-__device__ __forceinline__ void head_rows_group(float* Us, int ld, int rows, int S, const RowVec& b, int r0, int rstep, int lane) {
-  RowVec u[RPW];
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) { const int r = r0 + rstep * i; u[i] = row_load(Us + (r < rows ? r : rows - 1) * ld, S, lane); }
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) u[i] = head_row(u[i], b);
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) { const int r = r0 + rstep * i; if (r < rows) row_store(Us + r * ld, u[i], S, lane); }
-}
+// Four rows per wave, one per 16-lane DPP row (RowT<16, EPL>): the chain's per-row scalars cost one instruction for four
+// rows and its ~5 reductions are 4 DPP steps each.
 __device__ __forceinline__ void head_rows_tile(float* Us, int ld, int rows, int S, const float* bias_g) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const RowVec b = row_load(bias_g, S, lane);
-  int r = wave;
-  for (; r + 3 * nw < rows; r += 4 * nw) head_rows_group<4>(Us, ld, rows, S, b, r, nw, lane);
-  for (; r + nw < rows; r += 2 * nw) head_rows_group<2>(Us, ld, rows, S, b, r, nw, lane);
-  for (; r < rows; r += nw) head_rows_group<1>(Us, ld, rows, S, b, r, nw, lane);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, sub = lane >> 4;
+  epl16_dispatch(S, [&](auto tag) {
+    using R = RowT<16, decltype(tag)::value>;
+    const R b = row_load<R>(bias_g, S, lane);
+    for (int r0 = wave * 4; r0 < rows; r0 += nw * 4) {
+      const int r = r0 + sub;
+      const R u = row_load<R>(Us + (r < rows ? r : rows - 1) * ld, S, lane);
+      const R o = head_row(u, b);
+      if (r < rows) row_store(Us + r * ld, o, S, lane);
+    }
+  });
 }
 
 // copy n floats (n % 4 == 0, 16-byte aligned) global -> LDS: the weights of a small network, whole workgroup

@@ -7,6 +7,8 @@
 // Formulas and clamp constants: /root/reference/math_.py (see oracle/gmath.py, oracle/manual.py which these
 // transcribe line by line).
 #pragma once
+#include <type_traits>
+
 #include "device_utils.h"
 
 namespace hypad {
@@ -199,6 +201,14 @@ __device__ __forceinline__ float rowdist_row_bwd(const R& u, const R& v, float g
     dv.v[e] = -dsq * 2.f * d.v[e] + dvn * 2.f * v.v[e];
   }
   return acoshf(xt);
+}
+
+// f(integral_constant<int, EPL>) with the 16-lanes-per-row EPL that fits `dim` (wave-uniform branch)
+template <class F>
+__device__ __forceinline__ void epl16_dispatch(int dim, F f) {
+  if (dim <= 64) f(std::integral_constant<int, 4>{});
+  else if (dim <= 128) f(std::integral_constant<int, 8>{});
+  else f(std::integral_constant<int, 16>{});
 }
 
 }  // namespace hypad

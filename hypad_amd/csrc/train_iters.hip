@@ -402,14 +402,18 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     if (role == 1) {
       // ---- hyperbolic reconstruction loss 10 * sum(dist)/B (train.py:226-234) and its gradients
       float part = 0.f;
-      {                                               // 16 rows over 8 waves: both rows of a wave together (overlapped chains)
-        RowVec du[2], dv[2], ru[2], rv[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int r = (wave & 7) + 8 * i; ru[i] = row_load(R + r * ldS, S, lane); rv[i] = row_load(R + (16 + r) * ldS, S, lane); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) part += rowdist_row_bwd(ru[i], rv[i], 10.f / B, du[i], dv[i]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int r = (wave & 7) + 8 * i; row_store(dR + r * ldS, du[i], S, lane); row_store(dR + (16 + r) * ldS, dv[i], S, lane); }
+      if (wave < 4) {                                 // 16 row pairs: four per wave, one per 16-lane DPP row
+        epl16_dispatch(S, [&](auto tag) {
+          using R16 = RowT<16, decltype(tag)::value>;
+          const int r = wave * 4 + (lane >> 4);
+          R16 du, dv;
+          const float d = rowdist_row_bwd(row_load<R16>(R + r * ldS, S, lane), row_load<R16>(R + (16 + r) * ldS, S, lane), 10.f / B, du, dv);
+          row_store(dR + r * ldS, du, S, lane);
+          row_store(dR + (16 + r) * ldS, dv, S, lane);
+          const float d0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 0)), d1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 16));
+          const float d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 32)), d3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 48));
+          part = (d0 + d1) + (d2 + d3);
+        });
       }
       if (lane == 0) red[16 + wave] = part;
       __syncthreads();
@@ -417,36 +421,23 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     }
     GEN_STAMP(23);
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
-    const RowVec hb = row_load(PD + dl.head_b, S, lane);
-    RowVec dbacc;
-#pragma unroll
-    for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] = 0.f;
-    auto head_bwd_rows = [&](auto rpw_tag) __attribute__((always_inline)) {
-      constexpr int RPW = decltype(rpw_tag)::value;   // rows per wave, carried through the chain together
-      RowVec u[RPW], g[RPW], du[RPW], db[RPW];
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int r = wave + 8 * i;
-        u[i] = row_load(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane);
-        g[i] = row_load(dR + r * ldS, S, lane);
+    // (four rows per wave, one per 16-lane DPP row; the row's bias gradient goes to its own row of R: the head outputs are dead)
+    epl16_dispatch(S, [&](auto tag) {
+      using R16 = RowT<16, decltype(tag)::value>;
+      const R16 hb = row_load<R16>(PD + dl.head_b, S, lane);
+      const int r = wave * 4 + (lane >> 4);
+      if (wave * 4 < hrows) {
+        R16 du, db;
+        head_row_bwd(row_load<R16>(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane), hb, row_load<R16>(dR + r * ldS, S, lane), du, db);
+        row_store(dR + r * ldS, du, S, lane);
+        row_store(R + r * ldS, db, S, lane);
       }
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) head_row_bwd(u[i], hb, g[i], du[i], db[i]);
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        row_store(dR + (wave + 8 * i) * ldS, du[i], S, lane);
-#pragma unroll
-        for (int e = 0; e < MAX_EPL; ++e) dbacc.v[e] += db[i].v[e];
-      }
-    };
-    if (hrows == 32) head_bwd_rows(std::integral_constant<int, 4>{}); else head_bwd_rows(std::integral_constant<int, 2>{});
-    __syncthreads();                                    // R (the head outputs) is dead: reuse as [nw][ldS] scratch
-    GEN_STAMP(24);
-    row_store(R + wave * ldS, dbacc, S, lane);
+    });
     __syncthreads();
+    GEN_STAMP(24);
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
       float s = 0.f;
-      for (int w = 0; w < nw; ++w) s += R[w * ldS + c];
+      for (int r = 0; r < hrows; ++r) s += R[r * ldS + c];
       ws[gw.ballpart + ((int64_t)role * (B / 16) + tile) * S + c] = s;
     }
     tile_store_p(ws + gw.du + prow0 * S, S, B, dR, ldS, hrows, S, hrows);
