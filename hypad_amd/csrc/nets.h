@@ -76,7 +76,7 @@ template <int MT>
 __device__ __forceinline__ void lstm_gates_tile(const float* As, int lda, int K, const float* P, const LstmDir& d0,
                                                 const LstmDir& d1, int H, float* Gs, int ldg, float* wst) {
   gemm_nt<MT>(As, lda, P + d0.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d0.b_ih, P + d0.b_hh, Gs, ldg, 0, wst);
-  gemm_nt<MT>(As, lda, P + d1.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d1.b_ih, P + d1.b_hh, Gs, ldg, 3 * H, wst);
+  gemm_nt<MT>(As, lda, P + d1.w_ih, K, K, 3 * H, lstm_gate_map(H), P + d1.b_ih, P + d1.b_hh, Gs, ldg, 3 * H, wst, (3 * H + 15) >> 4);
 }
 // cell: c = sig(i)*tanh(g), h = sig(o)*tanh(c).  Hs[rows][ldh] <- [h_fwd | h_rev].
 // gates_save (global, may be null): row r at gates_save + prow(r)*8H, layout [dir][i,g,o,tanh c][H].

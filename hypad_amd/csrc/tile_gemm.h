@@ -154,13 +154,15 @@ __device__ __forceinline__ void nt_tile_scalar(const float* __restrict__ Xs, int
 template <int MT>
 __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, const float* __restrict__ W, int ldw, int K, int N,
                         RowMap map, const float* __restrict__ bias0, const float* __restrict__ bias1,
-                        float* __restrict__ Ys, int ldy, int ycol0, float* __restrict__ wstage) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+                        float* __restrict__ Ys, int ldy, int ycol0, float* __restrict__ wstage, int wave_rot = 0) {
+  // wave_rot: tile t goes to wave (t + wave_rot) mod nwaves -- back-to-back calls without a barrier between them (the two
+  // directions of an LSTM layer) rotate the deal so the same waves do not get the odd tile every time
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4;
   const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
   const int vw = (((K | ldw) & 3) == 0 && (wa & 15) == 0) ? 4 : (((K | ldw) & 1) == 0 && (wa & 7) == 0) ? 2 : 1;
-  float* stage = wstage + wave * WSTAGE_FLOATS;
+  float* stage = wstage + (threadIdx.x >> 6) * WSTAGE_FLOATS;
   for (int t = wave; t < ntiles; t += nwaves) {
     const int n = t * 16 + j;
     const bool nv = n < N;
