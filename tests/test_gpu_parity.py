@@ -761,3 +761,53 @@ def test_series_view_equals_window_matrix(dev, tmp_path):
         assert torch.equal(res[0][2][k], res[1][2][k]), k
     with pytest.raises(Exception):
         _engine_from(fx, True).train_epoch(series[:50], perm, nb, nc, True, x_row_stride=1)
+
+
+@pytest.mark.parametrize("S,B,hyper", [(150, 256, True), (123, 64, True), (51, 32, False), (100, 16, True)])
+def test_hoisted_critic_phase_other_shapes(dev, S, B, hyper):
+    """The hoisted critic phase on the multivariate shape (configs[3]: S=150, B=256 = 16 chunks per critic), the odd window
+    sizes (unaligned weight rows, records padded to 16) and single-chunk batches: first-step losses and gradients equal the
+    per-minibatch path's; a longer run stays finite and deterministic."""
+    from hypad_amd import _C
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    torch.manual_seed(S + B)
+    mods = dict(enc=ot.Encoder(S, 20), dec=ot.Decoder(S, 20, hyper), cx=ot.CriticX(S, 20), cz=ot.CriticZ(20))
+    n_win = 4 * B
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(1, n_win, S, generator=g) * 2 - 1).cuda().contiguous()
+
+    def engine():
+        e = Engine(S, 20, B, hyper, lr=5e-4, seed=11)
+        for k, m in mods.items():
+            e.load_state_dict(k, m.state_dict())
+        return e
+
+    assert _C.lib.hypad_epoch_workspace_bytes(ctypes_byref(engine().dims), 2, 2) > _C.lib.hypad_train_workspace_bytes(ctypes_byref(engine().dims))
+    perm1 = torch.randperm(n_win, generator=g)[:B].to(torch.int32).cuda().reshape(1, B).repeat(2, 1).contiguous()
+    res = []
+    for hoist in (True, False):
+        e = engine()
+        l = e.train_epoch(x, perm1, 1, 1, True, hoist=hoist)
+        torch.cuda.synchronize()
+        res.append((l.clone(), {k: e.exp_avg[k].clone() for k in ("cx", "cz")}))
+    np.testing.assert_allclose(res[0][0][:, :2].cpu().numpy(), res[1][0][:, :2].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    for k in ("cx", "cz"):
+        d = (res[0][1][k] - res[1][1][k]).abs().max().item()
+        scale = res[1][1][k].abs().max().item()
+        assert scale > 0 and d <= 2e-4 * scale, (k, d, scale)
+    nb, nc = 3, 2
+    perm = torch.stack([torch.randperm(n_win, generator=torch.Generator().manual_seed(i))[: nb * B] for i in range(nc + 1)]).to(torch.int32).cuda()
+    outs = []
+    for rep in range(2):
+        e = engine()
+        l = e.train_epoch(x, perm, nb, nc, True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(l).all()) and e.counters.cpu().tolist() == [nb * nc, nb * nc, nb, nb * nc + nb]
+        outs.append((l.clone(), e.params["cx"].clone(), e.params["dec"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def ctypes_byref(obj):
+    import ctypes
+    return ctypes.byref(obj)
