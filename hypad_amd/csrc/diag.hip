@@ -62,7 +62,66 @@ __global__ void diag_decoder_kernel(const float* __restrict__ P, const float* __
   }
 }
 
+// the same decoder forward with MFMA-native packed weights (gemm_nt_packed): pk = packed arena, off[] = float offsets of
+// {d1 W, d1 b, l0d0 W, l0d0 b, l0d1 W, l0d1 b, l1d0 W, l1d0 b, l1d1 W, l1d1 b, d2 W, d2 b, head W}
+struct PackedOffs { int o[13]; };
+__global__ void diag_decoder_packed_kernel(const float* __restrict__ pk, PackedOffs po, const float* __restrict__ head_b,
+                                           const float* __restrict__ z, float* __restrict__ hyper, int64_t rows, int S, int L,
+                                           long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int R = 16;
+  const int ldS = pad4(S) + 4;
+  const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
+  float* zs = smem;
+  float* bufA = zs + R * LP;
+  float* bufB = bufA + R * per_row;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int valid = (int)min((int64_t)R, rows - r0);
+  long long* st = stamps + (size_t)blockIdx.x * 64;
+  int k = 0;
+  constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
+  for (int rep = 0; rep < 2; ++rep) {
+  stamp(st, k);
+  tile_load(zs, LP, z + r0 * L, L, R, L, valid);
+  stamp(st, k);
+  gemm_nt_packed<1>(zs, LP, L, DEC_D1, pk + po.o[0], pk + po.o[1], bufB, ldA0, 0);
+  stamp(st, k);
+  gemm_nt_packed<1>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + po.o[2], pk + po.o[3], bufA, ldG, 0);
+  gemm_nt_packed<1>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + po.o[4], pk + po.o[5], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
+  stamp(st, k);
+  lstm_cell_tile(bufA, ldG, DEC_H, R, bufB, ldH, nullptr, valid, 16);
+  stamp(st, k);
+  gemm_nt_packed<1>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + po.o[6], pk + po.o[7], bufA, ldG, 0);
+  gemm_nt_packed<1>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + po.o[8], pk + po.o[9], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
+  stamp(st, k);
+  lstm_cell_tile(bufA, ldG, DEC_H, R, bufB, ldH, nullptr, valid, 16);
+  stamp(st, k);
+  gemm_nt_packed<1>(bufB, ldH, 2 * DEC_H, S, pk + po.o[10], pk + po.o[11], bufA, ldS, 0);
+  stamp(st, k);
+  tile_for(R, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
+  stamp(st, k);
+  gemm_nt_packed<1>(bufA, ldS, S, S, pk + po.o[12], nullptr, bufB, ldS, 0);
+  stamp(st, k);
+  head_rows_tile(bufB, ldS, R, S, head_b);
+  stamp(st, k);
+  tile_store(hyper + r0 * S, S, bufB, ldS, R, S, valid);
+  stamp(st, k);
+  }
+}
+
 }  // namespace
+
+extern "C" int hypad_diag_decoder_packed(const float* pk, const int* offs, const float* head_b, const float* z, float* hyper, int64_t rows,
+                                         int S, int L, long long* stamps, void* stream) {
+  PackedOffs po;
+  for (int i = 0; i < 13; ++i) po.o[i] = offs[i];
+  const int ldS = pad4(S) + 4;
+  const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
+  const size_t lds = (size_t)(16 * LP + 2 * 16 * per_row) * sizeof(float);
+  const int nblk = (int)((rows + 15) / 16);
+  hipLaunchKernelGGL(diag_decoder_packed_kernel, dim3(nblk), dim3(512), lds, (hipStream_t)stream, pk, po, head_b, z, hyper, rows, S, L, stamps);
+  return (int)hipGetLastError();
+}
 
 extern "C" int hypad_diag_decoder_timeline(const float* P, const float* z, float* hyper, int64_t rows, int S, int L, int mt,
                                            int threads, long long* stamps, hypad_stream_t s) {

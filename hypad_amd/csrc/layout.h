@@ -69,6 +69,52 @@ HD DecLayout dec_layout(int S, int L, int hyperbolic) {
   return d;
 }
 
+// ---- MFMA-native packed copies of the generator's weights (tile_gemm.h gemm_nt_packed): a matrix of N output rows and K
+// reduction columns is stored as blocks [ceil(N/16)][ceil(K/16)][64 lanes][4], lane (j, q) of block (tn, g) holding
+// M[16 tn + j][16 g + 4 q .. + 3], zero padded.  Forward products use M = W with the LSTM gate rows compacted to [i|g|o];
+// backward-data products use M = W^T (for an LSTM layer both directions stacked along the reduction), so that both are
+// "NT" products against fully coalesced 1 KB blocks.  The copies live in the training workspace and are rebuilt / updated
+// by the library (pack kernel, dW + Adam kernel); the parameter arena stays the PyTorch layout.
+HD int packed_floats(int N, int K) { return ((N + 15) >> 4) * ((K + 15) >> 4) * 256; }
+struct GenPack {
+  // forward: W blocks, then summed biases (padded to 16)
+  int enc_g[2], enc_gb[2];       // encoder gates, direction d: (3 ENC_H, S)
+  int enc_d, enc_db;             // encoder dense (L, 2 ENC_H)
+  int d1, d1b;                   // decoder dense1 (DEC_D1, L)
+  int l_g[2][2], l_gb[2][2];     // decoder layer l, direction d gates (3 DEC_H, in_l)
+  int d2, d2b;                   // decoder dense2 (S, 2 DEC_H)
+  int head;                      // hyperbolic_linear.weight (S, S), hyperbolic only (else -1)
+  // backward data: W^T blocks
+  int enc_d_t;                   // (2 ENC_H out, L red)
+  int head_t;                    // (S, S)
+  int d2_t;                      // (2 DEC_H out, S red)
+  int l_t[2];                    // layer l: (in_l out, 6 DEC_H red)
+  int d1_t;                      // (L out, DEC_D1 red)
+  int total;
+};
+HD GenPack gen_pack(int S, int L, int hyperbolic) {
+  GenPack g; int o = 0;
+  auto vec = [](int n) { return (n + 15) & ~15; };
+  for (int d = 0; d < 2; ++d) { g.enc_g[d] = o; o += packed_floats(3 * ENC_H, S); g.enc_gb[d] = o; o += vec(3 * ENC_H); }
+  g.enc_d = o; o += packed_floats(L, 2 * ENC_H); g.enc_db = o; o += vec(L);
+  g.d1 = o; o += packed_floats(DEC_D1, L); g.d1b = o; o += vec(DEC_D1);
+  for (int l = 0; l < 2; ++l) {
+    const int in = l == 0 ? DEC_D1 : 2 * DEC_H;
+    for (int d = 0; d < 2; ++d) { g.l_g[l][d] = o; o += packed_floats(3 * DEC_H, in); g.l_gb[l][d] = o; o += vec(3 * DEC_H); }
+  }
+  g.d2 = o; o += packed_floats(S, 2 * DEC_H); g.d2b = o; o += vec(S);
+  g.head = -1;
+  if (hyperbolic) { g.head = o; o += packed_floats(S, S); }
+  g.enc_d_t = o; o += packed_floats(2 * ENC_H, L);
+  g.head_t = -1;
+  if (hyperbolic) { g.head_t = o; o += packed_floats(S, S); }
+  g.d2_t = o; o += packed_floats(2 * DEC_H, S);
+  for (int l = 0; l < 2; ++l) { g.l_t[l] = o; o += packed_floats(l == 0 ? DEC_D1 : 2 * DEC_H, 6 * DEC_H); }
+  g.d1_t = o; o += packed_floats(L, DEC_D1);
+  g.total = o;
+  return g;
+}
+
 // Critics: nh hidden Linear(.,L)+LeakyReLU+Dropout blocks, then Linear(L,1).
 struct CriticLayout {
   int nh;              // 4 (CriticX) or 2 (CriticZ)

@@ -259,6 +259,59 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------- packed-weight forms (training)
+// The same encoder / decoder trunk against the MFMA-native copies of the weights (layout.h GenPack, gemm_nt_packed).
+__device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx, int S, int L, const float* pk, const GenPack& gp,
+                                                        float* bufG, int ldg, float* bufH, int ldh, float* Zs,
+                                                        float* gates_save, float* h_save, int valid) {
+  gemm_nt_packed<1>(Xs, ldx, S, 3 * ENC_H, pk + gp.enc_g[0], pk + gp.enc_gb[0], bufG, ldg, 0);
+  gemm_nt_packed<1>(Xs, ldx, S, 3 * ENC_H, pk + gp.enc_g[1], pk + gp.enc_gb[1], bufG, ldg, 3 * ENC_H, (3 * ENC_H + 15) >> 4);
+  __syncthreads();
+  lstm_cell_tile(bufG, ldg, ENC_H, 16, bufH, ldh, gates_save, valid);
+  __syncthreads();
+  if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
+  gemm_nt_packed<1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0);
+  __syncthreads();
+}
+template <int MT, class RowFn>
+__device__ __forceinline__ void decoder_trunk_fwd_tile_packed(const float* Zs, int L, int S, const float* pk, const GenPack& gp,
+                                                              float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
+                                                              const DecSave& sv, int valid) {
+  constexpr int rows = MT * 16;
+  constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
+  gemm_nt_packed<MT>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0);
+  __syncthreads();
+  if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
+  gemm_nt_packed<MT>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], bufA, ldG, 0);
+  gemm_nt_packed<MT>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + gp.l_g[0][1], pk + gp.l_gb[0][1], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
+  __syncthreads();
+  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g0, valid, sv.ps);
+  __syncthreads();
+  if (drop.mode != 0) {
+    for (int i = threadIdx.x; i < rows * (2 * DEC_H / 4); i += blockDim.x) {
+      const int r = i / (2 * DEC_H / 4), c = 4 * (i - r * (2 * DEC_H / 4));
+      const float4 m = drop.get4(0, grow(r), c, 2 * DEC_H);
+      float4* h = reinterpret_cast<float4*>(bufB + r * ldH + c);
+      float4 hv = *h;
+      hv.x *= m.x; hv.y *= m.y; hv.z *= m.z; hv.w *= m.w;
+      *h = hv;
+      if (sv.mask && r < valid) *reinterpret_cast<float4*>(sv.mask + prow(r, sv.ps) * 2 * DEC_H + c) = m;
+    }
+    __syncthreads();
+  }
+  if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
+  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], bufA, ldG, 0);
+  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + gp.l_g[1][1], pk + gp.l_gb[1][1], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
+  __syncthreads();
+  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g1, valid, sv.ps);
+  __syncthreads();
+  if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
+  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0);
+  __syncthreads();
+  tile_for(rows, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
+  __syncthreads();
+}
+
 // Moebius head on LDS rows: Us[rows][ld] (u = e W_h^T) -> in place r = project(mobius_add(expmap0(u), bias)).
 // Four rows per wave, one per 16-lane DPP row (RowT<16, EPL>): the chain's per-row scalars cost one instruction for four
 // rows and its ~5 reductions are 4 DPP steps each.

@@ -185,6 +185,54 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- gemm_nt_packed
+// Forward product against a weight stored in MFMA-native blocks: block (tn, g) = 64 lanes x float4, lane (j, q) holding
+// W[16 tn + j][16 g + 4 q .. + 3] (rows past N / columns past K are zeros; LSTM gate rows already compacted to [i|g|o]).
+// A tile's weights are then `kg` fully coalesced 1 KB loads straight into the B operand registers: no LDS re-shape.
+// Wp: blocks of tile tn at Wp + tn * kg * 256 floats; bsum[n]: summed biases (may be null).
+template <int MT>
+__device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
+                                               const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0) {
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
+  const int j = lane & 15, q = lane >> 4;
+  const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)t * kg * 64 + lane;
+    const int n = t * 16 + j;
+    const float bs = (bsum && n < N) ? bsum[n] : 0.f;
+    f32x4 acc[MT], acc2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int g0 = 0; g0 < kg; g0 += 8) {               // 8 k-groups (128 k) of weights in flight per lane
+      float4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (g0 + u < kg) {                             // wave-uniform
+          const int k0 = 16 * (g0 + u) + 4 * q;
+          const int ka = k0 < ldx - 4 ? k0 : ldx - 4;  // stay inside the activation row (the weights are zero past K)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(Xs + (m * 16 + j) * ldx + ka);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 < K ? a.x : 0.f, w[u].x, acc[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 1 < K ? a.y : 0.f, w[u].y, acc2[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 2 < K ? a.z : 0.f, w[u].z, acc[m], 0, 0, 0);
+            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 3 < K ? a.w : 0.f, w[u].w, acc2[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (n < N) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = acc[m][r] + acc2[m][r] + bs;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- gemm_nn
 // Y (LDS) [MT*16][ldy] columns 0..C-1  (+)= D (LDS) [MT*16][ldd] columns dcol0..dcol0+Nred-1  times  W rows wrow(n).
 // Contains __syncthreads(): every wave of the workgroup must call it.  The caller needs no barrier between two

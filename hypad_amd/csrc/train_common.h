@@ -61,10 +61,14 @@ HD GenWs gen_ws(int B, int S, int L) {
 // critic_x and critic_z iterations of one minibatch may run side by side (train.py:320-327 touch disjoint weights):
 // their workspaces are disjoint, the generator's overlays both.
 inline int64_t ws_cz_offset(const hypad_dims& d) { return crit_ws(d.batch, d.signal_shape, d.latent_dim, 4).total; }
-inline int64_t ws_floats_per_signal(const hypad_dims& d) {
+// the MFMA-native packed copies of the generator's weights (layout.h GenPack) follow the iteration scratch
+inline int64_t ws_pack_offset(const hypad_dims& d) {
   int64_t a = ws_cz_offset(d) + crit_ws(d.batch, d.latent_dim, d.latent_dim, 2).total;
   int64_t c = gen_ws(d.batch, d.signal_shape, d.latent_dim).total;
-  return a > c ? a : c;
+  return ((a > c ? a : c) + 63) & ~(int64_t)63;
+}
+inline int64_t ws_floats_per_signal(const hypad_dims& d) {
+  return ws_pack_offset(d) + gen_pack(d.signal_shape, d.latent_dim, d.hyperbolic).total;
 }
 
 // ------------------------------------------------------------------------------------------------ kernel arguments
@@ -80,6 +84,7 @@ struct IterArgs {
   uint64_t seed;
   float* losses; int64_t loss_sig_stride;
   float* ws; int64_t ws_sig_stride;
+  int64_t pk_off;                  // packed generator weights of signal s at ws + s * ws_sig_stride + pk_off
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)

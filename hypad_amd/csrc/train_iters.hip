@@ -285,6 +285,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const float* PE = a.P.enc + (int64_t)sig * a.pe;
   const float* PD = a.P.dec + (int64_t)sig * a.pd;
   float* ws = a.ws + sig * a.ws_sig_stride;
+  const float* pk = ws + a.pk_off;          // MFMA-native copies of the generator weights (pack_generator_kernel / dW kernel)
+  const GenPack gp = gen_pack(S, L, HYPER ? 1 : 0);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* small = smem + lp.small;
   float* dzc = small;                       // [16][LP] gradient of -mean(critic_z) w.r.t. encoder output
@@ -341,8 +343,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     __syncthreads();
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
     zin = zs + 16 * LP;
-    encoder_fwd_tile(xs, ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
-                     ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, wst);
+    encoder_fwd_tile_packed(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
+                            ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16);
     GEN_STAMP(1);
     const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
     sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
@@ -363,7 +365,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
   const int growp = pass * B + g0;
-  decoder_trunk_fwd_tile<1>(zin, L, S, PD, dl, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16, wst);
+  decoder_trunk_fwd_tile_packed<1>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16);
   GEN_STAMP(3);
   // E = tanh output in bufA[0..15]
   const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
@@ -374,8 +376,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     }
     tile_store_p(ws + gw.ecat + prow0 * S, S, B, bufA, ldS, hrows, S, hrows);
     GEN_STAMP(20);
-    if (role == 1) gemm_nt<2>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
-    else gemm_nt<1>(bufA, ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, ldS, 0, wst);
+    if (role == 1) gemm_nt_packed<2>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0);
+    else gemm_nt_packed<1>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0);
     __syncthreads();
     GEN_STAMP(21);
     tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
@@ -444,7 +446,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     __syncthreads();
     GEN_STAMP(25);
     // dE = dU W_h for the decoder pass
-    gemm_nn<1>(dR, ldS, 0, PD + dl.head_w, S, S, identity_map(), S, R, ldS, false);
+    gemm_nt_packed<1>(dR, ldS, S, S, pk + gp.head_t, nullptr, R, ldS, 0);
     __syncthreads();
     GEN_STAMP(26);
     // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
@@ -476,14 +478,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(6);
   tile_store(ws + gw.dpre2 + prow0 * S, S, dP, ldS, 16, S, 16);
   // dH1 = dpre W2
-  gemm_nn<1>(dP, ldS, 0, PD + dl.d2_w, 2 * DEC_H, S, identity_map(), 2 * DEC_H, oth, ldH, false);
+  gemm_nt_packed<1>(dP, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, oth, ldH, 0);
   __syncthreads();
   GEN_STAMP(7);
   // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
   tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
-  lstm_bwd_data_tile<1>(dP, ldG, PD, dl.l[1][0], dl.l[1][1], DEC_H, 2 * DEC_H, oth, ldH);
+  gemm_nt_packed<1>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0);     // both directions: one stacked reduction
   __syncthreads();
   if (a.drop_mode != 0) {
     tile_for(16, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow0 + r) * 2 * DEC_H + c]; });
@@ -494,7 +496,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
   tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
-  lstm_bwd_data_tile<1>(dP, ldG, PD, dl.l[0][0], dl.l[0][1], DEC_H, DEC_D1, oth, ldA0);
+  gemm_nt_packed<1>(dP, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, oth, ldA0, 0);
   __syncthreads();
   tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, oth, ldA0, 16, DEC_D1, 16);
   GEN_STAMP(9);
@@ -506,14 +508,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     return;
   }
   // dZ = dA0 W1: the gradient reaching the encoder's output
-  gemm_nn<1>(oth, ldA0, 0, PD + dl.d1_w, L, DEC_D1, identity_map(), L, dP, LP, false);
+  gemm_nt_packed<1>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0);
   __syncthreads();
   tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c] + dzc[r * LP + c]; });
   __syncthreads();
   tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
   GEN_STAMP(10);
   // ---- encoder backward
-  gemm_nn<1>(dzs, LP, 0, PE + el.dense_w, 2 * ENC_H, L, identity_map(), 2 * ENC_H, oth, 2 * ENC_H + 4, false);
+  gemm_nt_packed<1>(dzs, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0);
   __syncthreads();
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
@@ -823,6 +825,99 @@ hipError_t allow_lds(const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// ------------------------------------------------------------------------------------------------ packed generator weights
+// Builds the MFMA-native copies (layout.h GenPack) from the parameter arenas: one thread per float4 of a packed block.
+struct PackDesc {
+  int kind;            // 0 W, 1 W with LSTM gate rows compacted, 2 W^T, 3 [W_fwd; W_rev]^T with compacted gate rows, 4 summed biases
+  int net;             // HYPAD_NET_ENCODER / HYPAD_NET_DECODER
+  int dst, nout, kred; // packed matrix: nout output rows, kred reduction columns
+  int src0, src1, ld, H;
+};
+struct PackTable { int n; int max_units; PackDesc d[32]; };
+__global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab) {
+  const PackDesc d = tab.d[blockIdx.y];
+  const int sig = blockIdx.z;
+  const float* P = d.net == HYPAD_NET_ENCODER ? a.P.enc + (int64_t)sig * a.pe : a.P.dec + (int64_t)sig * a.pd;
+  float* pk = a.ws + sig * a.ws_sig_stride + a.pk_off + d.dst;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  auto gate_row = [&](int n) { return n < d.H ? n : n + d.H; };           // compact [i|g|o] -> PyTorch [i,f,g,o] row
+  if (d.kind == 4) {
+    if (u < ((d.nout + 15) & ~15)) {
+      float v = 0.f;
+      if (u < d.nout) {
+        const int r = d.H > 0 ? gate_row(u) : u;
+        v = P[d.src0 + r] + (d.src1 >= 0 ? P[d.src1 + r] : 0.f);
+      }
+      pk[u] = v;
+    }
+    return;
+  }
+  const int kg = (d.kred + 15) >> 4, units = ((d.nout + 15) >> 4) * kg * 64;
+  if (u >= units) return;
+  const int blk = u >> 6, lane = u & 63, tn = blk / kg, g = blk - tn * kg;
+  const int n = 16 * tn + (lane & 15), k0 = 16 * g + 4 * (lane >> 4);
+  float v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = k0 + c;
+    float x = 0.f;
+    if (n < d.nout && k < d.kred) {
+      if (d.kind == 0) x = P[d.src0 + n * d.ld + k];
+      else if (d.kind == 1) x = P[d.src0 + gate_row(n) * d.ld + k];
+      else if (d.kind == 2) x = P[d.src0 + k * d.ld + n];
+      else { const int dir = k >= 3 * d.H ? 1 : 0, kc = k - dir * 3 * d.H; x = P[(dir ? d.src1 : d.src0) + gate_row(kc) * d.ld + n]; }
+    }
+    v[c] = x;
+  }
+  reinterpret_cast<float4*>(pk)[u] = make_float4(v[0], v[1], v[2], v[3]);
+}
+PackTable pack_table(const hypad_dims& dm) {
+  const int S = dm.signal_shape, L = dm.latent_dim;
+  const EncLayout el = enc_layout(S, L);
+  const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
+  const GenPack gp = gen_pack(S, L, dm.hyperbolic);
+  PackTable t; t.n = 0; t.max_units = 0;
+  auto push = [&](int kind, int net, int dst, int nout, int kred, int src0, int src1, int ld, int H) {
+    PackDesc d{kind, net, dst, nout, kred, src0, src1, ld, H};
+    t.d[t.n++] = d;
+    const int units = kind == 4 ? ((nout + 15) & ~15) : ((nout + 15) >> 4) * ((kred + 15) >> 4) * 64;
+    if (units > t.max_units) t.max_units = units;
+  };
+  const int E = HYPAD_NET_ENCODER, D = HYPAD_NET_DECODER;
+  for (int d = 0; d < 2; ++d) {
+    push(1, E, gp.enc_g[d], 3 * ENC_H, S, el.dir[d].w_ih, -1, S, ENC_H);
+    push(4, E, gp.enc_gb[d], 3 * ENC_H, 0, el.dir[d].b_ih, el.dir[d].b_hh, 0, ENC_H);
+  }
+  push(0, E, gp.enc_d, L, 2 * ENC_H, el.dense_w, -1, 2 * ENC_H, 0);
+  push(4, E, gp.enc_db, L, 0, el.dense_b, -1, 0, 0);
+  push(0, D, gp.d1, DEC_D1, L, dl.d1_w, -1, L, 0);
+  push(4, D, gp.d1b, DEC_D1, 0, dl.d1_b, -1, 0, 0);
+  for (int l = 0; l < 2; ++l) {
+    const int in = l == 0 ? DEC_D1 : 2 * DEC_H;
+    for (int d = 0; d < 2; ++d) {
+      push(1, D, gp.l_g[l][d], 3 * DEC_H, in, dl.l[l][d].w_ih, -1, in, DEC_H);
+      push(4, D, gp.l_gb[l][d], 3 * DEC_H, 0, dl.l[l][d].b_ih, dl.l[l][d].b_hh, 0, DEC_H);
+    }
+    push(3, D, gp.l_t[l], in, 6 * DEC_H, dl.l[l][0].w_ih, dl.l[l][1].w_ih, in, DEC_H);
+  }
+  push(0, D, gp.d2, S, 2 * DEC_H, dl.d2_w, -1, 2 * DEC_H, 0);
+  push(4, D, gp.d2b, S, 0, dl.d2_b, -1, 0, 0);
+  if (dm.hyperbolic) {
+    push(0, D, gp.head, S, S, dl.head_w, -1, S, 0);
+    push(2, D, gp.head_t, S, S, dl.head_w, -1, S, 0);
+  }
+  push(2, E, gp.enc_d_t, 2 * ENC_H, L, el.dense_w, -1, 2 * ENC_H, 0);
+  push(2, D, gp.d2_t, 2 * DEC_H, S, dl.d2_w, -1, 2 * DEC_H, 0);
+  push(2, D, gp.d1_t, L, DEC_D1, dl.d1_w, -1, L, 0);
+  return t;
+}
+int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s) {
+  const PackTable t = pack_table(dm);
+  hipLaunchKernelGGL(pack_generator_kernel, dim3((t.max_units + 255) / 256, t.n, dm.n_signals), dim3(256), 0, s, a, t);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
 long long* g_gen_stamps = nullptr;
 
 struct IterCall {
@@ -853,6 +948,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.losses = io.losses; a.loss_sig_stride = io.loss_sig_stride;
   a.ws = (float*)io.workspace + (opt == 1 ? ws_cz_offset(*d) : 0);
   a.ws_sig_stride = per;
+  a.pk_off = ws_pack_offset(*d) - (opt == 1 ? ws_cz_offset(*d) : 0);       // a.ws is shifted for critic_z
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
   a.opt = opt; a.tick_owner = 1; a.stamps = g_gen_stamps;
   if (opt == 0) {
@@ -973,6 +1069,8 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
+  rc = launch_pack(a, *d, s);             // the workspace is scratch between calls: rebuild the packed weights
+  if (rc) return rc;
   HYPAD_MARK(ev, 0, s);
   const bool ref_cfg = a.S == 100 && a.L == 20 && a.B == 64;          // BASELINE.json configs[0..1]
 #define HYPAD_LAUNCH_GEN(...)                                                     \
