@@ -188,10 +188,12 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
     __syncthreads();
     DropSrc ddrop = drop_src(ax, sig, nullptr, RS_DROP_DEC0, tick, 0.2f);
     DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, lp.ldS, ddrop, [g0](int r) { return g0 + r; }, none, 16, wst);
+    const float* pk = ax.ws + sig * ax.ws_sig_stride + ax.pk_off;       // packed generator weights (hypad_train_epoch builds them first)
+    const GenPack gp = gen_pack(S, L, ax.hyperbolic);
+    decoder_trunk_fwd_tile_packed<1>(zs, L, S, pk, gp, bufA, bufB, lp.ldS, ddrop, [g0](int r) { return g0 + r; }, none, 16);
     float* gen = bufA;
     if (ax.hyperbolic) {
-      gemm_nt<1>(bufA, lp.ldS, PD + dl.head_w, S, S, S, identity_map(), nullptr, nullptr, bufB, lp.ldS, 0, wst);
+      gemm_nt_packed<1>(bufA, lp.ldS, S, S, pk + gp.head, nullptr, bufB, lp.ldS, 0);
       __syncthreads();
       head_rows_tile(bufB, lp.ldS, 16, S, PD + dl.head_b);
       __syncthreads();
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
     tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
     float* zenc = zs + 16 * LP;
-    encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16, wst);
+    const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
+    encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
     __syncthreads();
     const CritGeom g = cz_geom(L);
     emit_record<false>(az, g, ph.rec_z + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, zs, LP, zenc, LP, sig, g0, tick,

@@ -577,6 +577,51 @@ struct DwTableT {
 using DwTable = DwTableT<60>;                 // generator
 using DwTableS = DwTableT<12>;                // one critic
 
+// Where a generator weight block / bias vector lives in the packed copies (layout.h GenPack), found from its arena offset:
+// the dW + Adam kernel keeps the copies current so that an epoch never re-packs.
+struct ShadowRef {
+  int fwd, fwd_kg;       // forward copy: blocks of (compact rows, K), or -1
+  int nbase;             // compact row of the block's row 0 (LSTM: 0 for the i gate rows, H for the g|o rows)
+  int bwd, bwd_ng;       // backward-data copy (W^T), or -1; ng = k-groups of its reduction
+  int mbase;             // reduction index of compact row 0 in the backward copy (direction * 3H)
+  int bsum;              // summed-bias vector, or -1 (bias items)
+};
+__device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L, int hyper) {
+  ShadowRef r{-1, 0, 0, -1, 0, 0, -1};
+  const GenPack gp = gen_pack(S, L, hyper);
+  if (net == HYPAD_NET_ENCODER) {
+    const EncLayout el = enc_layout(S, L);
+    for (int d = 0; d < 2; ++d) {
+      const int w = el.dir[d].w_ih, wg = w + 2 * ENC_H * S;
+      if (p_off == w || p_off == wg) { r.fwd = gp.enc_g[d]; r.fwd_kg = (S + 15) >> 4; r.nbase = p_off == w ? 0 : ENC_H; }
+      const int b = el.dir[d].b_ih;
+      if (p_off == b || p_off == b + 2 * ENC_H) { r.bsum = gp.enc_gb[d]; r.nbase = p_off == b ? 0 : ENC_H; }
+    }
+    if (p_off == el.dense_w) { r.fwd = gp.enc_d; r.fwd_kg = (2 * ENC_H + 15) >> 4; r.bwd = gp.enc_d_t; r.bwd_ng = (L + 15) >> 4; }
+    if (p_off == el.dense_b) r.bsum = gp.enc_db;
+  } else if (net == HYPAD_NET_DECODER) {
+    const DecLayout dl = dec_layout(S, L, hyper);
+    if (p_off == dl.d1_w) { r.fwd = gp.d1; r.fwd_kg = (L + 15) >> 4; r.bwd = gp.d1_t; r.bwd_ng = (DEC_D1 + 15) >> 4; }
+    if (p_off == dl.d1_b) r.bsum = gp.d1b;
+    for (int l = 0; l < 2; ++l) {
+      const int in = l == 0 ? DEC_D1 : 2 * DEC_H;
+      for (int d = 0; d < 2; ++d) {
+        const int w = dl.l[l][d].w_ih, wg = w + 2 * DEC_H * in;
+        if (p_off == w || p_off == wg) {
+          r.fwd = gp.l_g[l][d]; r.fwd_kg = (in + 15) >> 4; r.nbase = p_off == w ? 0 : DEC_H;
+          r.bwd = gp.l_t[l]; r.bwd_ng = (6 * DEC_H) >> 4; r.mbase = d * 3 * DEC_H;
+        }
+        const int b = dl.l[l][d].b_ih;
+        if (p_off == b || p_off == b + 2 * DEC_H) { r.bsum = gp.l_gb[l][d]; r.nbase = p_off == b ? 0 : DEC_H; }
+      }
+    }
+    if (p_off == dl.d2_w) { r.fwd = gp.d2; r.fwd_kg = (2 * DEC_H + 15) >> 4; r.bwd = gp.d2_t; r.bwd_ng = (S + 15) >> 4; }
+    if (p_off == dl.d2_b) r.bsum = gp.d2b;
+    if (hyper && p_off == dl.head_w) { r.fwd = gp.head; r.fwd_kg = (S + 15) >> 4; r.bwd = gp.head_t; r.bwd_ng = (S + 15) >> 4; }
+  }
+  return r;
+}
+
 template <class Table>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
   const int sig = blockIdx.y;
@@ -639,11 +684,22 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
           if (rc + 4 * u < d.red_rows)             // wave-uniform
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
       }
+      ShadowRef sh{-1, 0, 0, -1, 0, 0, -1};
+      if (tab.finalize == 1) sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
+      float* pk = ws + a.pk_off;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p = pp[r], m = pm[r], v = pvv[r];
         adam_update(p, m, v, acc[r], co);
-        if (po[r] >= 0) { P[po[r]] = p; M[po[r]] = m; V[po[r]] = v; }
+        if (po[r] >= 0) {
+          P[po[r]] = p; M[po[r]] = m; V[po[r]] = v;
+          const int nc = sh.nbase + n0 + 4 * q + r, k = k0 + j;            // compact row, column
+          if (sh.fwd >= 0) pk[sh.fwd + (((nc >> 4) * sh.fwd_kg + (k >> 4)) * 64 + (nc & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
+          if (sh.bwd >= 0) {
+            const int mm = sh.mbase + nc;                                     // reduction index of the transposed copy
+            pk[sh.bwd + (((k >> 4) * sh.bwd_ng + (mm >> 4)) * 64 + (k & 15) + 16 * ((mm & 15) >> 2)) * 4 + (mm & 3)] = p;
+          }
+        }
       }
     } else if (d.kind == DW_BIAS) {
       // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
@@ -669,11 +725,17 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
         float p = P[o], m = M[o], v = V[o];
         adam_update(p, m, v, g, co);
         P[o] = p; M[o] = m; V[o] = v;
+        float bs = p;
         if (d.p_off2 >= 0) {
           o = d.p_off2 + n;
           p = P[o]; m = M[o]; v = V[o];
           adam_update(p, m, v, g, co);
           P[o] = p; M[o] = m; V[o] = v;
+          bs += p;
+        }
+        if (tab.finalize == 1) {
+          const ShadowRef sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
+          if (sh.bsum >= 0) ws[a.pk_off + sh.bsum + sh.nbase + n] = bs;
         }
       }
     } else if (d.kind == DW_DECAY) {
@@ -1061,7 +1123,7 @@ int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const Iter
   return HYPAD_OK;
 }
 
-int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr) {
+int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr, bool pack = true) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
@@ -1069,8 +1131,10 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
-  rc = launch_pack(a, *d, s);             // the workspace is scratch between calls: rebuild the packed weights
-  if (rc) return rc;
+  if (pack) {                             // the workspace is scratch between calls: rebuild the packed weights
+    rc = launch_pack(a, *d, s);           // (inside an epoch the dW + Adam kernel keeps them current)
+    if (rc) return rc;
+  }
   HYPAD_MARK(ev, 0, s);
   const bool ref_cfg = a.S == 100 && a.L == 20 && a.B == 64;          // BASELINE.json configs[0..1]
 #define HYPAD_LAUNCH_GEN(...)                                                     \
@@ -1131,6 +1195,27 @@ size_t hypad_train_workspace_bytes(const hypad_dims* d) {
   return (size_t)ws_floats_per_signal(*d) * d->n_signals * sizeof(float);
 }
 
+int hypad_pack_generator(const hypad_dims* d, const hypad_train_state* st, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!st || !st->params.enc || !st->params.dec || !workspace) return HYPAD_EINVAL;
+  const int64_t per = ws_floats_per_signal(*d);
+  if (workspace_bytes < (size_t)per * d->n_signals * sizeof(float)) return HYPAD_EWORKSPACE;
+  IterArgs a{};
+  a.S = d->signal_shape; a.L = d->latent_dim; a.B = d->batch; a.hyperbolic = d->hyperbolic;
+  a.P = st->params;
+  a.pe = enc_layout(a.S, a.L).total; a.pd = dec_layout(a.S, a.L, a.hyperbolic).total;
+  a.ws = (float*)workspace; a.ws_sig_stride = per; a.pk_off = ws_pack_offset(*d);
+  return launch_pack(a, *d, (hipStream_t)s);
+}
+int hypad_packed_region(const hypad_dims* d, int64_t* offset_floats, int64_t* signal_stride_floats, int64_t* count_floats) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (offset_floats) *offset_floats = ws_pack_offset(*d);
+  if (signal_stride_floats) *signal_stride_floats = ws_floats_per_signal(*d);
+  if (count_floats) *count_floats = gen_pack(d->signal_shape, d->latent_dim, d->hyperbolic).total;
+  return HYPAD_OK;
+}
 int hypad_critic_x_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
   if (!io) return HYPAD_EINVAL;
   return run_cx(d, st, from_io(io), (hipStream_t)s);
@@ -1172,6 +1257,7 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
     const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
     if (!rc && !critic_phase_supported(*d)) rc = HYPAD_EUNSUPPORTED;
     if (!rc && io->workspace_bytes < (base + critic_phase_fixed_floats(*d) + 2 * critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
+    if (!rc) rc = launch_pack(ax, *d, (hipStream_t)s);      // the precompute reads the packed generator weights
     if (!rc) rc = run_critic_phase(ax, az, nullptr, 2, io->losses, (float*)io->workspace + base,
                                    io->workspace_bytes / sizeof(float) - base, d->n_signals, (hipStream_t)s, ev);
   }
@@ -1210,6 +1296,13 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   const int64_t pass_rows = (int64_t)io->n_batches * d->batch;
   const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
   const size_t have = io->workspace_bytes / sizeof(float);
+  {                                                    // packed generator weights: built once, then kept current by the dW kernel
+    IterArgs ag;
+    c.row_index = io->row_index; c.losses = io->losses;
+    rc = fill_args(ag, d, st, c, 2);
+    if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s);
+    if (rc) return rc;
+  }
   const char* legacy = getenv("HYPAD_EPOCH_LEGACY");
   const bool hoisted = io->n_critics > 0 && critic_phase_supported(*d) &&
                        have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
@@ -1238,7 +1331,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   for (int b = 0; b < io->n_batches; ++b) {            // train.py:347-352
     c.row_index = io->row_index + io->n_critics * pass_rows + (int64_t)b * d->batch;
     c.losses = io->losses + (int64_t)(it++) * 4;
-    rc = run_gen(d, st, c, (hipStream_t)s);
+    rc = run_gen(d, st, c, (hipStream_t)s, nullptr, false);
     if (rc) return rc;
   }
   return HYPAD_OK;

@@ -195,6 +195,15 @@ typedef struct hypad_iter_io {
 } hypad_iter_io;
 
 size_t hypad_train_workspace_bytes(const hypad_dims* dims);
+/* The training workspace also holds MFMA-native packed copies of the generator's weights (blocks of 16 output rows x 16
+ * reduction columns laid out as the matrix cores consume them; forward and transposed).  The library builds them itself
+ * (every hypad_decoder_iteration call; once per hypad_train_epoch, whose dW + Adam kernel then keeps them current), so
+ * callers never need these two: hypad_pack_generator rebuilds the copies of every signal from the parameter arenas,
+ * hypad_packed_region reports where they are (floats from the start of a signal's workspace slice, slice stride and
+ * count) -- for tests and tools. */
+int hypad_pack_generator(const hypad_dims* dims, const hypad_train_state* st, void* workspace, size_t workspace_bytes,
+                         hypad_stream_t stream);
+int hypad_packed_region(const hypad_dims* dims, int64_t* offset_floats, int64_t* signal_stride_floats, int64_t* count_floats);
 int hypad_critic_x_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);
 int hypad_critic_z_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);
 int hypad_decoder_iteration(const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t stream);

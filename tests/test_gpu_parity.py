@@ -811,3 +811,37 @@ def test_hoisted_critic_phase_other_shapes(dev, S, B, hyper):
 def ctypes_byref(obj):
     import ctypes
     return ctypes.byref(obj)
+
+
+@pytest.mark.parametrize("S,B,hyper", [(100, 64, True), (100, 64, False), (150, 256, True), (51, 32, True)])
+def test_packed_weight_copies_stay_current(dev, S, B, hyper):
+    """The MFMA-native packed copies of the generator weights (workspace) are updated element by element by the dW + Adam
+    kernel during an epoch: afterwards they must equal, bit for bit, a fresh pack of the final arenas."""
+    import ctypes
+    from hypad_amd import _C
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    torch.manual_seed(S)
+    mods = dict(enc=ot.Encoder(S, 20), dec=ot.Decoder(S, 20, hyper), cx=ot.CriticX(S, 20), cz=ot.CriticZ(20))
+    e = Engine(S, 20, B, hyper, lr=5e-4, seed=3, n_signals=2)
+    for k, m in mods.items():
+        e.load_state_dict(k, m.state_dict(), 0)
+        e.load_state_dict(k, m.state_dict(), 1)
+    e.params["dec"][1].mul_(1.02)
+    n_win = 3 * B
+    x = (torch.rand(1, n_win, S, generator=torch.Generator().manual_seed(2)) * 2 - 1).cuda().contiguous()
+    nb, nc = 3, 1
+    perm = torch.stack([torch.randperm(n_win, generator=torch.Generator().manual_seed(i))[: nb * B] for i in range(nc + 1)]).to(torch.int32).cuda()
+    e.train_epoch(x, perm, nb, nc, True)
+    torch.cuda.synchronize()
+    off, stride, cnt = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _C.check(_C.lib.hypad_packed_region(ctypes.byref(e.dims), ctypes.byref(off), ctypes.byref(stride), ctypes.byref(cnt)))
+    region = lambda: torch.stack([e.workspace[s * stride.value + off.value: s * stride.value + off.value + cnt.value].clone() for s in range(2)])
+    kept = region()
+    st = e._state()
+    _C.check(_C.lib.hypad_pack_generator(ctypes.byref(e.dims), ctypes.byref(st), e.workspace.data_ptr(), e._ws_bytes, _C.stream()))
+    torch.cuda.synchronize()
+    fresh = region()
+    assert cnt.value > 0 and bool(torch.isfinite(fresh).all()) and float(fresh.abs().max()) > 0
+    assert torch.equal(kept, fresh), int((kept != fresh).sum())
+    assert not torch.equal(fresh[0], fresh[1])
