@@ -76,6 +76,10 @@ HD DecLayout dec_layout(int S, int L, int hyperbolic) {
 // "NT" products against fully coalesced 1 KB blocks.  The copies live in the training workspace and are rebuilt / updated
 // by the library (pack kernel, dW + Adam kernel); the parameter arena stays the PyTorch layout.
 HD int packed_floats(int N, int K) { return ((N + 15) >> 4) * ((K + 15) >> 4) * 256; }
+// In the packed gate matrices every gate owns a whole number of 16-row blocks: gate x of hidden unit u is packed row
+// x * up16(H) + u (rows H .. up16(H)-1 of a gate are zero).  A wave can then own the i, g and o tiles of the same 16
+// hidden units and apply the LSTM cell straight from its accumulators (nets.h lstm_layer_fwd_packed).
+HD int gate_rows(int H) { return 3 * ((H + 15) & ~15); }
 struct GenPack {
   // forward: W blocks, then summed biases (padded to 16)
   int enc_g[2], enc_gb[2];       // encoder gates, direction d: (3 ENC_H, S)
@@ -95,12 +99,12 @@ struct GenPack {
 HD GenPack gen_pack(int S, int L, int hyperbolic) {
   GenPack g; int o = 0;
   auto vec = [](int n) { return (n + 15) & ~15; };
-  for (int d = 0; d < 2; ++d) { g.enc_g[d] = o; o += packed_floats(3 * ENC_H, S); g.enc_gb[d] = o; o += vec(3 * ENC_H); }
+  for (int d = 0; d < 2; ++d) { g.enc_g[d] = o; o += packed_floats(gate_rows(ENC_H), S); g.enc_gb[d] = o; o += gate_rows(ENC_H); }
   g.enc_d = o; o += packed_floats(L, 2 * ENC_H); g.enc_db = o; o += vec(L);
   g.d1 = o; o += packed_floats(DEC_D1, L); g.d1b = o; o += vec(DEC_D1);
   for (int l = 0; l < 2; ++l) {
     const int in = l == 0 ? DEC_D1 : 2 * DEC_H;
-    for (int d = 0; d < 2; ++d) { g.l_g[l][d] = o; o += packed_floats(3 * DEC_H, in); g.l_gb[l][d] = o; o += vec(3 * DEC_H); }
+    for (int d = 0; d < 2; ++d) { g.l_g[l][d] = o; o += packed_floats(gate_rows(DEC_H), in); g.l_gb[l][d] = o; o += gate_rows(DEC_H); }
   }
   g.d2 = o; o += packed_floats(S, 2 * DEC_H); g.d2b = o; o += vec(S);
   g.head = -1;

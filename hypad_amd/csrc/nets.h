@@ -261,13 +261,87 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
 
 // ---------------------------------------------------------------------------------------- packed-weight forms (training)
 // The same encoder / decoder trunk against the MFMA-native copies of the weights (layout.h GenPack, gemm_nt_packed).
+// One LSTM layer at T = 1 from the packed gate matrices, cell included: wave w owns hidden units [16 ub, 16 ub + 16) of
+// direction d (w = nb d + ub, nb = up16(H) / 16 <= 4): it computes their i, g and o tiles -- same accumulator layout, so
+// the gates of one (row, unit) meet in one lane's registers -- and applies c = sig(i) tanh(g), h = sig(o) tanh(c) right
+// there.  No gate tile in LDS, no separate cell pass, no barrier in between.
+// Hs[rows][ldh] <- [h_fwd | h_rev]; gates_save as in lstm_cell_tile.  pb: summed biases, gate x of unit u at x up16(H) + u.
+template <int MT>
+__device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ As, int lda, int K, const float* __restrict__ pk0,
+                                                      const float* __restrict__ pb0, const float* __restrict__ pk1,
+                                                      const float* __restrict__ pb1, int H, float* __restrict__ Hs, int ldh,
+                                                      float* __restrict__ gates_save, int valid, int ps = 16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
+  for (int task = wave; task < 2 * nb; task += nwaves) {
+    const int d = task / nb, ub = task - d * nb;
+    const float4* wi = reinterpret_cast<const float4*>(d ? pk1 : pk0) + (size_t)ub * kg * 64 + lane;
+    const float4* wg = wi + (size_t)nb * kg * 64;
+    const float4* wo = wg + (size_t)nb * kg * 64;
+    const float* pb = d ? pb1 : pb0;
+    f32x4 ai[MT], ag[MT], ao[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { ai[m] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[m] = ai[m]; ao[m] = ai[m]; }
+    for (int g0 = 0; g0 < kg; g0 += 4) {
+      float4 bi[4], bg[4], bo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64;
+        bi[u] = wi[o]; bg[u] = wg[o]; bo[u] = wo[o];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (g0 + u < kg) {                             // wave-uniform
+          const int k0 = 16 * (g0 + u) + 4 * q;
+          const int ka = k0 < lda - 4 ? k0 : lda - 4;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float4 a = *reinterpret_cast<const float4*>(As + (m * 16 + j) * lda + ka);
+            const float a0 = k0 < K ? a.x : 0.f, a1 = k0 + 1 < K ? a.y : 0.f, a2 = k0 + 2 < K ? a.z : 0.f, a3 = k0 + 3 < K ? a.w : 0.f;
+            ai[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bi[u].x, ai[m], 0, 0, 0);
+            ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bg[u].x, ag[m], 0, 0, 0);
+            ao[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bo[u].x, ao[m], 0, 0, 0);
+            ai[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bi[u].y, ai[m], 0, 0, 0);
+            ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bg[u].y, ag[m], 0, 0, 0);
+            ao[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bo[u].y, ao[m], 0, 0, 0);
+            ai[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bi[u].z, ai[m], 0, 0, 0);
+            ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bg[u].z, ag[m], 0, 0, 0);
+            ao[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bo[u].z, ao[m], 0, 0, 0);
+            ai[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bi[u].w, ai[m], 0, 0, 0);
+            ag[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bg[u].w, ag[m], 0, 0, 0);
+            ao[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bo[u].w, ao[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int jj = 16 * ub + j;
+    if (jj < H) {
+      const float b_i = pb[jj], b_g = pb[Hp + jj], b_o = pb[2 * Hp + jj];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m * 16 + 4 * q + r;
+          const float gi = sigmoidf_(ai[m][r] + b_i), gg = tanhf_(ag[m][r] + b_g), go = sigmoidf_(ao[m][r] + b_o);
+          const float tc = tanhf_(gi * gg);
+          Hs[row * ldh + d * H + jj] = go * tc;
+          if (gates_save && row < valid) {
+            float* sv = gates_save + prow(row, ps) * 8 * H + d * 4 * H + jj;
+            sv[0] = gi; sv[H] = gg; sv[2 * H] = go; sv[3 * H] = tc;
+          }
+        }
+    }
+  }
+}
+
 __device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx, int S, int L, const float* pk, const GenPack& gp,
                                                         float* bufG, int ldg, float* bufH, int ldh, float* Zs,
                                                         float* gates_save, float* h_save, int valid) {
-  gemm_nt_packed<1>(Xs, ldx, S, 3 * ENC_H, pk + gp.enc_g[0], pk + gp.enc_gb[0], bufG, ldg, 0);
-  gemm_nt_packed<1>(Xs, ldx, S, 3 * ENC_H, pk + gp.enc_g[1], pk + gp.enc_gb[1], bufG, ldg, 3 * ENC_H, (3 * ENC_H + 15) >> 4);
-  __syncthreads();
-  lstm_cell_tile(bufG, ldg, ENC_H, 16, bufH, ldh, gates_save, valid);
+  (void)bufG; (void)ldg;
+  lstm_layer_fwd_packed<1>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
+                           gates_save, valid);
   __syncthreads();
   if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
   gemm_nt_packed<1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0);
@@ -278,20 +352,19 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile_packed(const float* Zs, i
                                                               float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
                                                               const DecSave& sv, int valid) {
   constexpr int rows = MT * 16;
-  constexpr int ldA0 = 52, ldG = 6 * DEC_H + 4, ldH = 2 * DEC_H + 4;
+  constexpr int ldA0 = 52, ldH = 2 * DEC_H + 4;
   gemm_nt_packed<MT>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0);
   __syncthreads();
   if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
-  gemm_nt_packed<MT>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], bufA, ldG, 0);
-  gemm_nt_packed<MT>(bufB, ldA0, DEC_D1, 3 * DEC_H, pk + gp.l_g[0][1], pk + gp.l_gb[0][1], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
-  __syncthreads();
-  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g0, valid, sv.ps);
+  // layer 0: input a0 in bufB [rows][ldA0] -> h0 in bufA [rows][ldH] (the cell runs in the gate product's epilogue)
+  lstm_layer_fwd_packed<MT>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA, ldH,
+                            sv.g0, valid, sv.ps);
   __syncthreads();
   if (drop.mode != 0) {
     for (int i = threadIdx.x; i < rows * (2 * DEC_H / 4); i += blockDim.x) {
       const int r = i / (2 * DEC_H / 4), c = 4 * (i - r * (2 * DEC_H / 4));
       const float4 m = drop.get4(0, grow(r), c, 2 * DEC_H);
-      float4* h = reinterpret_cast<float4*>(bufB + r * ldH + c);
+      float4* h = reinterpret_cast<float4*>(bufA + r * ldH + c);
       float4 hv = *h;
       hv.x *= m.x; hv.y *= m.y; hv.z *= m.z; hv.w *= m.w;
       *h = hv;
@@ -299,11 +372,10 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile_packed(const float* Zs, i
     }
     __syncthreads();
   }
-  if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
-  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], bufA, ldG, 0);
-  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, 3 * DEC_H, pk + gp.l_g[1][1], pk + gp.l_gb[1][1], bufA, ldG, 3 * DEC_H, (3 * DEC_H + 15) >> 4);
-  __syncthreads();
-  lstm_cell_tile(bufA, ldG, DEC_H, rows, bufB, ldH, sv.g1, valid, sv.ps);
+  if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufA, ldH, rows, 2 * DEC_H, valid);
+  // layer 1: h0 (dropped) in bufA -> h1 in bufB
+  lstm_layer_fwd_packed<MT>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB, ldH,
+                            sv.g1, valid, sv.ps);
   __syncthreads();
   if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
   gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0);

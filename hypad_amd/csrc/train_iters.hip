@@ -585,17 +585,18 @@ struct ShadowRef {
   int bwd, bwd_ng;       // backward-data copy (W^T), or -1; ng = k-groups of its reduction
   int mbase;             // reduction index of compact row 0 in the backward copy (direction * 3H)
   int bsum;              // summed-bias vector, or -1 (bias items)
+  int gate_H;            // LSTM gate matrices: hidden size (forward copy rows are x * up16(H) + u); 0 otherwise
 };
 __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L, int hyper) {
-  ShadowRef r{-1, 0, 0, -1, 0, 0, -1};
+  ShadowRef r{-1, 0, 0, -1, 0, 0, -1, 0};
   const GenPack gp = gen_pack(S, L, hyper);
   if (net == HYPAD_NET_ENCODER) {
     const EncLayout el = enc_layout(S, L);
     for (int d = 0; d < 2; ++d) {
       const int w = el.dir[d].w_ih, wg = w + 2 * ENC_H * S;
-      if (p_off == w || p_off == wg) { r.fwd = gp.enc_g[d]; r.fwd_kg = (S + 15) >> 4; r.nbase = p_off == w ? 0 : ENC_H; }
+      if (p_off == w || p_off == wg) { r.fwd = gp.enc_g[d]; r.fwd_kg = (S + 15) >> 4; r.nbase = p_off == w ? 0 : ENC_H; r.gate_H = ENC_H; }
       const int b = el.dir[d].b_ih;
-      if (p_off == b || p_off == b + 2 * ENC_H) { r.bsum = gp.enc_gb[d]; r.nbase = p_off == b ? 0 : ENC_H; }
+      if (p_off == b || p_off == b + 2 * ENC_H) { r.bsum = gp.enc_gb[d]; r.nbase = p_off == b ? 0 : ENC_H; r.gate_H = ENC_H; }
     }
     if (p_off == el.dense_w) { r.fwd = gp.enc_d; r.fwd_kg = (2 * ENC_H + 15) >> 4; r.bwd = gp.enc_d_t; r.bwd_ng = (L + 15) >> 4; }
     if (p_off == el.dense_b) r.bsum = gp.enc_db;
@@ -608,11 +609,11 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
       for (int d = 0; d < 2; ++d) {
         const int w = dl.l[l][d].w_ih, wg = w + 2 * DEC_H * in;
         if (p_off == w || p_off == wg) {
-          r.fwd = gp.l_g[l][d]; r.fwd_kg = (in + 15) >> 4; r.nbase = p_off == w ? 0 : DEC_H;
+          r.fwd = gp.l_g[l][d]; r.fwd_kg = (in + 15) >> 4; r.nbase = p_off == w ? 0 : DEC_H; r.gate_H = DEC_H;
           r.bwd = gp.l_t[l]; r.bwd_ng = (6 * DEC_H) >> 4; r.mbase = d * 3 * DEC_H;
         }
         const int b = dl.l[l][d].b_ih;
-        if (p_off == b || p_off == b + 2 * DEC_H) { r.bsum = gp.l_gb[l][d]; r.nbase = p_off == b ? 0 : DEC_H; }
+        if (p_off == b || p_off == b + 2 * DEC_H) { r.bsum = gp.l_gb[l][d]; r.nbase = p_off == b ? 0 : DEC_H; r.gate_H = DEC_H; }
       }
     }
     if (p_off == dl.d2_w) { r.fwd = gp.d2; r.fwd_kg = (2 * DEC_H + 15) >> 4; r.bwd = gp.d2_t; r.bwd_ng = (S + 15) >> 4; }
@@ -684,7 +685,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
           if (rc + 4 * u < d.red_rows)             // wave-uniform
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
       }
-      ShadowRef sh{-1, 0, 0, -1, 0, 0, -1};
+      ShadowRef sh{-1, 0, 0, -1, 0, 0, -1, 0};
       if (tab.finalize == 1) sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
       float* pk = ws + a.pk_off;
 #pragma unroll
@@ -694,7 +695,11 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
         if (po[r] >= 0) {
           P[po[r]] = p; M[po[r]] = m; V[po[r]] = v;
           const int nc = sh.nbase + n0 + 4 * q + r, k = k0 + j;            // compact row, column
-          if (sh.fwd >= 0) pk[sh.fwd + (((nc >> 4) * sh.fwd_kg + (k >> 4)) * 64 + (nc & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
+          if (sh.fwd >= 0) {
+            int nf = nc;                                                     // forward copy row: gates padded to 16-row blocks
+            if (sh.gate_H > 0) { const int x = nc / sh.gate_H; nf = x * ((sh.gate_H + 15) & ~15) + nc - x * sh.gate_H; }
+            pk[sh.fwd + (((nf >> 4) * sh.fwd_kg + (k >> 4)) * 64 + (nf & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
+          }
           if (sh.bwd >= 0) {
             const int mm = sh.mbase + nc;                                     // reduction index of the transposed copy
             pk[sh.bwd + (((k >> 4) * sh.bwd_ng + (mm >> 4)) * 64 + (k & 15) + 16 * ((mm & 15) >> 2)) * 4 + (mm & 3)] = p;
@@ -735,7 +740,11 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
         }
         if (tab.finalize == 1) {
           const ShadowRef sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
-          if (sh.bsum >= 0) ws[a.pk_off + sh.bsum + sh.nbase + n] = bs;
+          if (sh.bsum >= 0) {
+            int nf = sh.nbase + n;
+            if (sh.gate_H > 0) { const int x = nf / sh.gate_H; nf = x * ((sh.gate_H + 15) & ~15) + nf - x * sh.gate_H; }
+            ws[a.pk_off + sh.bsum + nf] = bs;
+          }
         }
       }
     } else if (d.kind == DW_DECAY) {
@@ -903,12 +912,15 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
   float* pk = a.ws + sig * a.ws_sig_stride + a.pk_off + d.dst;
   const int u = blockIdx.x * 256 + threadIdx.x;
   auto gate_row = [&](int n) { return n < d.H ? n : n + d.H; };           // compact [i|g|o] -> PyTorch [i,f,g,o] row
+  const int Hp = (d.H + 15) & ~15;
+  // forward gate matrices: packed row x * Hp + u (gate x of unit u; layout.h gate_rows) -> PyTorch row, or -1 for padding
+  auto padded_gate_row = [&](int n) { const int x = n / Hp, u = n - x * Hp; return u < d.H ? (x == 0 ? 0 : x == 1 ? 2 * d.H : 3 * d.H) + u : -1; };
   if (d.kind == 4) {
     if (u < ((d.nout + 15) & ~15)) {
       float v = 0.f;
       if (u < d.nout) {
-        const int r = d.H > 0 ? gate_row(u) : u;
-        v = P[d.src0 + r] + (d.src1 >= 0 ? P[d.src1 + r] : 0.f);
+        const int r = d.H > 0 ? padded_gate_row(u) : u;
+        if (r >= 0) v = P[d.src0 + r] + (d.src1 >= 0 ? P[d.src1 + r] : 0.f);
       }
       pk[u] = v;
     }
@@ -925,7 +937,7 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
     float x = 0.f;
     if (n < d.nout && k < d.kred) {
       if (d.kind == 0) x = P[d.src0 + n * d.ld + k];
-      else if (d.kind == 1) x = P[d.src0 + gate_row(n) * d.ld + k];
+      else if (d.kind == 1) { const int r = padded_gate_row(n); x = r >= 0 ? P[d.src0 + r * d.ld + k] : 0.f; }
       else if (d.kind == 2) x = P[d.src0 + k * d.ld + n];
       else { const int dir = k >= 3 * d.H ? 1 : 0, kc = k - dir * 3 * d.H; x = P[(dir ? d.src1 : d.src0) + gate_row(kc) * d.ld + n]; }
     }
@@ -947,8 +959,8 @@ PackTable pack_table(const hypad_dims& dm) {
   };
   const int E = HYPAD_NET_ENCODER, D = HYPAD_NET_DECODER;
   for (int d = 0; d < 2; ++d) {
-    push(1, E, gp.enc_g[d], 3 * ENC_H, S, el.dir[d].w_ih, -1, S, ENC_H);
-    push(4, E, gp.enc_gb[d], 3 * ENC_H, 0, el.dir[d].b_ih, el.dir[d].b_hh, 0, ENC_H);
+    push(1, E, gp.enc_g[d], gate_rows(ENC_H), S, el.dir[d].w_ih, -1, S, ENC_H);
+    push(4, E, gp.enc_gb[d], gate_rows(ENC_H), 0, el.dir[d].b_ih, el.dir[d].b_hh, 0, ENC_H);
   }
   push(0, E, gp.enc_d, L, 2 * ENC_H, el.dense_w, -1, 2 * ENC_H, 0);
   push(4, E, gp.enc_db, L, 0, el.dense_b, -1, 0, 0);
@@ -957,8 +969,8 @@ PackTable pack_table(const hypad_dims& dm) {
   for (int l = 0; l < 2; ++l) {
     const int in = l == 0 ? DEC_D1 : 2 * DEC_H;
     for (int d = 0; d < 2; ++d) {
-      push(1, D, gp.l_g[l][d], 3 * DEC_H, in, dl.l[l][d].w_ih, -1, in, DEC_H);
-      push(4, D, gp.l_gb[l][d], 3 * DEC_H, 0, dl.l[l][d].b_ih, dl.l[l][d].b_hh, 0, DEC_H);
+      push(1, D, gp.l_g[l][d], gate_rows(DEC_H), in, dl.l[l][d].w_ih, -1, in, DEC_H);
+      push(4, D, gp.l_gb[l][d], gate_rows(DEC_H), 0, dl.l[l][d].b_ih, dl.l[l][d].b_hh, 0, DEC_H);
     }
     push(3, D, gp.l_t[l], in, 6 * DEC_H, dl.l[l][0].w_ih, dl.l[l][1].w_ih, in, DEC_H);
   }
