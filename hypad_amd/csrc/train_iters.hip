@@ -263,7 +263,7 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
   p.bufA = o; o += bufFloats;
   p.bufB = o; o += bufFloats;
   p.small = o; o += 3 * 16 * LP + 64;             // dzc | dzs | spare, then 64 reduction slots
-  p.wst = o; o += (TB / 64) * WSTAGE_FLOATS;
+  p.wst = o;                                      // (no weight re-shape slabs: the generator products read packed weights)
   p.cw = o; o += cp.total;                        // the role's frozen critic, padded image (critic_mfma.h)
   p.ct = o; o += critic_tile_floats(cp, role == 0 ? 4 : 2);
   p.total = o;

@@ -763,11 +763,12 @@ def test_series_view_equals_window_matrix(dev, tmp_path):
         _engine_from(fx, True).train_epoch(series[:50], perm, nb, nc, True, x_row_stride=1)
 
 
-@pytest.mark.parametrize("S,B,hyper", [(150, 256, True), (123, 64, True), (51, 32, False), (100, 16, True)])
+@pytest.mark.parametrize("S,B,hyper", [(150, 256, True), (123, 64, True), (51, 32, False), (100, 16, True), (256, 32, True)])
 def test_hoisted_critic_phase_other_shapes(dev, S, B, hyper):
     """The hoisted critic phase on the multivariate shape (configs[3]: S=150, B=256 = 16 chunks per critic), the odd window
     sizes (unaligned weight rows, records padded to 16) and single-chunk batches: first-step losses and gradients equal the
-    per-minibatch path's; a longer run stays finite and deterministic."""
+    per-minibatch path's; a longer run stays finite and deterministic.  (S=256, the largest window: the critic does not
+    fit the hoisted kernel's LDS plan, hypad_train_epoch falls back to the per-minibatch launch groups on its own.)"""
     from hypad_amd import _C
     from hypad_amd.engine import Engine
     from oracle import tadgan as ot
@@ -783,7 +784,8 @@ def test_hoisted_critic_phase_other_shapes(dev, S, B, hyper):
             e.load_state_dict(k, m.state_dict())
         return e
 
-    assert _C.lib.hypad_epoch_workspace_bytes(ctypes_byref(engine().dims), 2, 2) > _C.lib.hypad_train_workspace_bytes(ctypes_byref(engine().dims))
+    ew, tw = _C.lib.hypad_epoch_workspace_bytes(ctypes_byref(engine().dims), 2, 2), _C.lib.hypad_train_workspace_bytes(ctypes_byref(engine().dims))
+    assert (ew > tw) if S <= 150 else (ew == tw)          # no hoisting scratch is asked for where the hoisted kernel cannot run
     perm1 = torch.randperm(n_win, generator=g)[:B].to(torch.int32).cuda().reshape(1, B).repeat(2, 1).contiguous()
     res = []
     for hoist in (True, False):
