@@ -14,7 +14,7 @@ import torch
 from .. import _C
 from ..hyperspace import gmath
 from .intervals import (_find_sequences, _find_threshold, _fixed_threshold, _merge_sequences, _overlap, _prune_anomalies,  # noqa: F401
-                        compute_metrics, contextual_confusion_matrix, find_anomalies)
+                        casas_anomalies, compute_metrics, contextual_confusion_matrix, find_anomalies)
 
 
 def _dev():
@@ -233,4 +233,36 @@ def univariate_anomaly_detection(recons_signal, true_signal, params, combination
         pred = [(r[0], r[1]) for r in out["intervals"]]
         out["confusion"] = list(contextual_confusion_matrix(known_anomalies, pred, weighted=False))
         out["metrics"] = compute_metrics(known_anomalies, pred, verbose=False)
+    return out
+
+
+def multivariate_anomaly_detection(recons_signal, true_signal, params, combination, critic_score, path=None, y=None, x_index=None):
+    """:129-222 with the ground truth passed in instead of loaded from the reference's data tree (``y``: the 0/1 label
+    tensor the reference torch.load()s, or None) and nothing written or plotted.  Reconstruction score: z-scored L2 norm
+    (Euclidean) or z-scored row-wise Poincare distance (hyperbolic), on the device; intervals with the multivariate
+    settings (window 0.2 T, step 0.1 window, padding 200).  Returns dict(final_scores, intervals, known_anomalies, metrics)."""
+    n = len(recons_signal)
+    if x_index is None:
+        from .dataloader import _yahoo_timestamps       # the reference's stand-in index: one time stamp per second (:133-137)
+        x_index = _yahoo_timestamps(n)
+    if not params.hyperbolic:
+        diff = _f32(np.asarray(true_signal, dtype=np.float32).reshape(n, -1) - np.asarray(recons_signal, dtype=np.float32).reshape(n, -1))
+        rec = row_norms(diff)
+    else:
+        rec = hyperbolic_rec_scores(recons_signal, true_signal, params.signal_shape)
+    rec = rec if isinstance(rec, torch.Tensor) else torch.as_tensor(np.asarray(rec, dtype=np.float64))
+    rec_scores = zscore_clip(rec.to(torch.float64)).cpu().numpy()
+    critic_scores = []
+    if combination in ("mult", "uncertainty", "sum", "sum_uncertainty", "critic", "critic_uncertainty"):
+        ts = np.asarray(true_signal)
+        critic_scores = final_critic_scores(critic_score, ts.reshape(len(ts), -1))[: rec_scores.shape[0]]
+    final_scores = np.asarray(combine_scores(combination, critic_scores, rec_scores, recons_signal), dtype=np.float64).reshape(-1)
+    intervals = find_anomalies(final_scores, x_index, window_size_portion=0.2, window_step_size_portion=0.1, fixed_threshold=True,
+                               anomaly_padding=200)
+    out = dict(final_scores=final_scores, intervals=np.asarray(intervals, dtype=np.float64).reshape(-1, 3), known_anomalies=None, metrics=None)
+    if y is not None:
+        known = casas_anomalies(y, np.asarray(x_index))
+        out["known_anomalies"] = known
+        if out["intervals"].shape[0] and len(known):
+            out["metrics"] = compute_metrics(known, [(r[0], r[1]) for r in out["intervals"]], verbose=False)
     return out

@@ -23,7 +23,7 @@ Pinned by tests/golden/intervals.npz (outputs of the reference's functions).
 import numpy as np
 
 __all__ = [
-    "find_anomalies", "contextual_confusion_matrix", "compute_metrics", "deltas", "count_above", "z_cost",
+    "find_anomalies", "contextual_confusion_matrix", "compute_metrics", "deltas", "count_above", "z_cost", "casas_anomalies",
 ]
 
 
@@ -246,3 +246,20 @@ def compute_metrics(known_anomalies, pred_anomalies, verbose=True):
         print("precision: {}, recall: {}".format(precision, recall))
         print("f1_score: {}, gmean: {}".format(f1, gmean))
     return dict(precision=precision, recall=recall, f1=f1, gmean=gmean, tp=tp, fp=fp, fn=fn)
+
+
+def casas_anomalies(y, x_index):
+    """Ground-truth intervals of a 0/1 label tensor y (batches, batch, ...) on the time stamps x_index
+    (utils/anomaly_detection_utils.py:279-298).  As in the reference: a run [a, b] of ones is reported as
+    (x_index[a], x_index[b - 1]) -- its last point is cut, a one-point run ends before it starts -- and a run that is
+    still open at the end of y is dropped.  Returns a DataFrame with columns start, end."""
+    import pandas as pd
+    x_index = np.asarray(x_index)
+    y = np.asarray(y)
+    y = y.reshape(y.shape[0] * y.shape[1], -1)[: x_index.shape[0]]
+    flag = (y[:, 0] == 1) if y.ndim > 1 else (y == 1)
+    prev = np.concatenate(([False], flag[:-1]))
+    starts = np.flatnonzero(flag & ~prev)
+    ends = np.flatnonzero(~flag & prev)              # first zero after a run: the run is [start, end - 1]
+    runs = [(x_index[s], x_index[e - 2]) for s, e in zip(starts, ends)]      # x_index[actual - 1] with actual = e - 1
+    return pd.DataFrame.from_records(runs, columns=["start", "end"])

@@ -367,6 +367,21 @@ def gen_intervals():
     r = ref_adu.contextual_confusion_matrix(kn, pa, data=pd.DataFrame({"timestamp": out["fa_uni_index"]}), weighted=False)
     out["cm_df_known"] = kn.values.astype(np.int64)
     out["cm_df_out"] = np.array([-1 if v is None else v for v in r], dtype=np.int64)
+    # casas_anomalies (:279-298): label runs -> ground-truth intervals, with its cut-the-last-point behaviour
+    r2 = np.random.default_rng(3)
+    for k in range(6):
+        nb, b = int(r2.integers(1, 6)), int(r2.integers(4, 40))
+        y = (r2.random((nb, b, 1)) < r2.uniform(0.05, 0.6)).astype(np.float32)
+        if k % 2 == 0:
+            y[-1, -3:] = 1          # a run still open at the end
+        if k % 3 == 0:
+            y[0, :2] = 1            # a run from the first point
+        if k == 5:
+            y[0, 0], y[0, 1] = 1, 0  # a one-point run at index 0: the reference's end index wraps
+        n = int(r2.integers(max(1, nb * b - 5), nb * b + 1))
+        x = 1000.0 + 3.0 * np.arange(n)
+        out[f"casas_{k}_y"], out[f"casas_{k}_x"] = y, x
+        out[f"casas_{k}_out"] = ref_adu.casas_anomalies(torch.from_numpy(y), x).values.astype(np.float64).reshape(-1, 2)
     np.savez(os.path.join(HERE, "intervals.npz"), **out)
 
 

@@ -847,3 +847,37 @@ def test_packed_weight_copies_stay_current(dev, S, B, hyper):
     assert cnt.value > 0 and bool(torch.isfinite(fresh).all()) and float(fresh.abs().max()) > 0
     assert torch.equal(kept, fresh), int((kept != fresh).sum())
     assert not torch.equal(fresh[0], fresh[1])
+
+
+def test_multivariate_anomaly_detection(dev):
+    """utils/anomaly_detection_utils.py:129-222 without its file I/O: z-scored L2 / Poincare reconstruction scores, critic
+    scores, combination, multivariate interval settings, CASAS-style ground truth -- against the oracle's composition of the
+    same (reference-pinned) pieces."""
+    from types import SimpleNamespace
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    from hypad_amd.utils import intervals as iv
+    from oracle import scoring as osc
+    fx = load("score.npz")
+    n = fx["ball_recons"].shape[0]
+    y = np.zeros((3, 100, 1), np.float32)
+    y[1, 10:40] = 1
+    for hyper in (True, False):
+        P = SimpleNamespace(hyperbolic=hyper, signal_shape=100)
+        rec_in = fx["ball_recons"].copy()
+        rec_in[120:135] *= 0.2                                     # a stretch the model "fails" to reconstruct
+        out = adu.multivariate_anomaly_detection(rec_in, fx["ball_real"], P, "mult", fx["critic"], y=y)
+        if hyper:
+            a, b = rec_in.astype(np.float64), fx["ball_real"].astype(np.float64)
+            sq = ((b - a) ** 2).sum(1)
+            rec = np.arccosh(1 + 2 * sq / ((1 - (b ** 2).sum(1)) * (1 - (a ** 2).sum(1))) + 1e-7)
+        else:
+            rec = np.linalg.norm(fx["ball_real"].astype(np.float64) - rec_in.astype(np.float64), axis=1)
+        rec_scores = osc.zscore_clip(rec)
+        crit = osc.final_critic_scores(fx["critic"], n, 100)[:n]
+        ref = np.asarray(osc.combine_scores("mult", crit, rec_scores, rec_in), dtype=np.float64).reshape(-1)
+        np.testing.assert_allclose(out["final_scores"], ref, rtol=3e-4, atol=3e-5)
+        from hypad_amd.utils.dataloader import _yahoo_timestamps
+        ref_iv = np.asarray(iv.find_anomalies(ref, _yahoo_timestamps(n), window_size_portion=0.2, window_step_size_portion=0.1,
+                                              fixed_threshold=True, anomaly_padding=200), dtype=np.float64).reshape(-1, 3)
+        np.testing.assert_array_equal(out["intervals"][:, :2], ref_iv[:, :2])
+        assert list(out["known_anomalies"].columns) == ["start", "end"] and len(out["known_anomalies"]) == 1
