@@ -1,0 +1,61 @@
+"""Command-line driver (reference: main.py:15-70): YAML config -> datasets -> training -> anomaly detection.
+
+    python -m hypad_amd.main --config configs/univariate.yaml [--data-dir ./data] [--drop-in]
+
+Default: the resident fast path (``train.train_resident``: one ``hypad_train_epoch`` per epoch, the signal trained
+from its scaled series in HBM).  ``--drop-in`` runs the reference-shaped loop instead (``train.train`` over a
+``DataLoader`` with host-side randomness, iteration by iteration).  Scoring is the same either way: fused test-loop
+forward, device scoring kernels, host interval extraction and overlap-segment metrics.  Prints the metrics and returns
+them from ``run``."""
+import argparse
+from types import SimpleNamespace
+
+import numpy as np
+
+
+def run(params, config_path=None, data_dir="./data", drop_in=False, log=print):
+    import pandas as pd
+    from torch.utils.data import DataLoader
+
+    from . import anomaly_detection
+    from . import train as ht
+    from .utils import anomaly_detection_utils as adu
+    from .utils import data as od
+
+    log("dataset: {}, signal: {}".format(params.dataset, params.signal))
+    train_dataset, test_dataset, read_path = od.dataset_selection(params, data_dir)
+    if drop_in:
+        train_loader = DataLoader(train_dataset, batch_size=params.batch_size, drop_last=True, shuffle=True, num_workers=0)
+        encoder, decoder, critic_x, _, path = ht.train(train_loader, params, config_path)
+    else:
+        encoder, decoder, critic_x, _, path, _ = ht.train_resident(train_dataset, params, config_path, log=log)
+    test_loader = DataLoader(test_dataset, batch_size=params.batch_size, drop_last=False, shuffle=False, num_workers=0)
+    recons_signal, true_signal, critic_score = anomaly_detection.test_tadgan(
+        test_loader, encoder, decoder, critic_x, read_path=read_path, signal=params.signal, path=path, signal_shape=params.signal_shape,
+        params=params)
+    if params.dataset in ("A1", "A2", "A3", "A4"):                       # anomaly_detection.py:32-37
+        known = pd.read_csv(read_path[:-4] + "_known_anomalies.csv")
+    else:
+        known = od.load_anomalies(params.signal, data_dir=data_dir)
+    out = adu.univariate_anomaly_detection(recons_signal, true_signal, params, params.combination, critic_score, path, read_path,
+                                           params.rec_error, np.asarray(test_dataset.X_index), known, params.signal, params.signal_shape)
+    log("predicted intervals:\n{}".format(out["intervals"]))
+    log("tn, fp, fn, tp: {}".format(out["confusion"]))
+    if out["metrics"]:
+        log("precision: {precision}, recall: {recall}\nf1_score: {f1}, gmean: {gmean}".format(**out["metrics"]))
+    return out
+
+
+def main(argv=None):
+    import yaml
+    ap = argparse.ArgumentParser(description="HypAD on MI355X")
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--data-dir", type=str, default="./data")
+    ap.add_argument("--drop-in", action="store_true", help="reference-shaped DataLoader loop with host-side randomness")
+    args = ap.parse_args(argv)
+    params = SimpleNamespace(**yaml.load(open(args.config), Loader=yaml.FullLoader))
+    return run(params, args.config, args.data_dir, args.drop_in)
+
+
+if __name__ == "__main__":
+    main()

@@ -250,3 +250,72 @@ def train(train_loader, params, config_path):
     torch.save(critic_x, PATH + "/critic_x.pt")
     torch.save(critic_z, PATH + "/critic_z.pt")
     return encoder, decoder, critic_x, critic_z, PATH
+
+
+# ------------------------------------------------------------------------------------------------ resident fast path
+def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epochs, params, path="", seed=None, log=print):
+    """train_tadgan (train.py:252-385) with everything on the device: the same epoch schedule -- 5 passes of
+    (critic_x_iteration, critic_z_iteration) over the shuffled minibatches, then one pass of decoder_iteration -- as one
+    ``hypad_train_epoch`` call per epoch (205 kernel launches, no host round trip inside).  ``dataset``: a
+    ``hypad_amd.utils.dataloader.SignalDataset`` (trained straight from its scaled series, no window matrix), or an
+    (N, signal_shape) array / tensor of windows.  Differences from the drop-in loop: latent noise, interpolation weights
+    and dropout masks come from the device Philox generator (seeded by ``seed`` / torch.initial_seed()) instead of
+    NumPy / torch CPU, and the DataLoader's shuffles are ``torch.randperm`` draws on the device (drop_last semantics:
+    n_batches = N // batch_size, a fresh permutation per pass).  Checkpoint cadence and file names as the reference."""
+    B, S = params.batch_size, params.signal_shape
+    dev = encoder.arena().device
+    eng = Engine(S, params.latent_space_dim, B, bool(params.hyperbolic), 1, dev, lr=params.lr,
+                 gen_weight_decay=1e-5 if params.hyperbolic else 0.0, gen_stabilize=10 if params.hyperbolic else 0,
+                 seed=torch.initial_seed() if seed is None else seed)
+    mods = {"enc": encoder, "dec": decoder, "cx": critic_x, "cz": critic_z}
+    eng.adopt({k: m.arena() for k, m in mods.items()})
+    if hasattr(dataset, "window_view"):
+        x, n_windows, stride = dataset.window_view(dev)
+    else:
+        x = torch.as_tensor(np.asarray(dataset), dtype=torch.float32).reshape(-1, S).to(dev).contiguous()
+        n_windows, stride = x.shape[0], 0
+    n_batches = n_windows // B
+    if n_batches < 1:
+        raise _C.HypadError(f"{n_windows} windows do not fill one batch of {B}")
+    n_critics = 5
+    gen = torch.Generator(device=dev).manual_seed(int(eng.seed) & 0x7FFFFFFF)
+    history = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[])
+    actual_epoch = 0
+    if getattr(params, "resume", False):
+        n_epochs = n_epochs - params.resume_epoch
+        actual_epoch = params.resume_epoch + 1
+    for epoch in range(n_epochs):
+        perm = torch.stack([torch.randperm(n_windows, device=dev, generator=gen)[: n_batches * B] for _ in range(n_critics + 1)])
+        losses = eng.train_epoch(x, perm.to(torch.int32).contiguous(), n_batches, n_critics, True, x_row_stride=stride)[0]
+        crit = losses[: 2 * n_critics * n_batches, 0].reshape(n_critics * n_batches, 2).mean(0)
+        gl = losses[2 * n_critics * n_batches:].mean(0)
+        history.cx.append(float(crit[0])); history.cz.append(float(crit[1])); history.dec.append(float(gl[0]))
+        (history.hyper if params.hyperbolic else history.mse).append(float(gl[1]))
+        if log:
+            log("epoch {}: critic x loss {:.3f} critic z loss {:.3f} decoder loss {:.3f} {} {:.5f}".format(
+                epoch, history.cx[-1], history.cz[-1], history.dec[-1], "hyperbolic loss" if params.hyperbolic else "mse", float(gl[1])))
+        actual_epoch += 1
+        if path and ((actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1))):      # train.py:381 (cadence kept as is)
+            for name, m in (("encoder", encoder), ("decoder", decoder), ("critic_x", critic_x), ("critic_z", critic_z)):
+                torch.save(m, path + "/{}_{}.pt".format(name, actual_epoch))
+    return history
+
+
+def train_resident(dataset, params, config_path=None, seed=None, log=print):
+    """train.train (train.py:409-466) on the resident fast path; returns (encoder, decoder, critic_x, critic_z, PATH)."""
+    params.latent_space_dim = 20
+    encoder = tadgan.Encoder(params.signal_shape, params.latent_space_dim).cuda().train()
+    decoder = tadgan.Decoder(params.signal_shape, params.latent_space_dim, params.hyperbolic).cuda().train()
+    critic_x = tadgan.CriticX(params.signal_shape, params.latent_space_dim).cuda().train()
+    critic_z = tadgan.CriticZ(params.latent_space_dim).cuda().train()
+    PATH = model_path(params)
+    os.makedirs(PATH, exist_ok=True)
+    if config_path and os.path.exists(config_path):
+        import shutil
+        shutil.copyfile(config_path, os.path.join(PATH, "config.yaml"))
+    if getattr(params, "resume", False):
+        encoder, decoder, critic_x, critic_z = resume_ckpt(params)
+    history = train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, params.epochs, params, PATH, seed, log)
+    for name, m in (("encoder", encoder), ("decoder", decoder), ("critic_x", critic_x), ("critic_z", critic_z)):
+        torch.save(m, PATH + "/{}.pt".format(name))
+    return encoder, decoder, critic_x, critic_z, PATH, history

@@ -881,3 +881,35 @@ def test_multivariate_anomaly_detection(dev):
                                               fixed_threshold=True, anomaly_padding=200), dtype=np.float64).reshape(-1, 3)
         np.testing.assert_array_equal(out["intervals"][:, :2], ref_iv[:, :2])
         assert list(out["known_anomalies"].columns) == ["start", "end"] and len(out["known_anomalies"]) == 1
+
+
+@pytest.mark.parametrize("hyper", [True, False])
+def test_cli_pipeline_end_to_end(dev, tmp_path, monkeypatch, hyper):
+    """main.py:15-70 on the resident fast path: CSV -> SignalDataset -> epochs on the device (series view) -> test loop ->
+    scoring kernels -> intervals and overlap-segment counts.  An integration check (the reference's end-to-end numbers
+    depend on its host RNG streams): everything finite, shapes right, checkpoints written, training moved the weights."""
+    import os
+    from types import SimpleNamespace
+    from hypad_amd import main as hmain
+    fxd = load("dataloader.npz")
+    d = str(tmp_path)
+    with open(os.path.join(d, "sig.csv"), "w") as f:
+        f.write(str(fxd["dl_nab600_csv"]))
+    ts = fxd["dl_nab600_index"]
+    with open(os.path.join(d, "anomalies.csv"), "w") as f:
+        f.write('signal,events\nsig,"[[%d, %d]]"\n' % (ts[200], ts[260]))
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(5)
+    P = SimpleNamespace(dataset="NAB", signal="sig", epochs=3, hyperbolic=hyper, signal_shape=100, lr=5e-4, batch_size=64,
+                        save_result=False, filename="", rec_error="dtw", combination="mult", interval=600, unique_dataset=True,
+                        resume=False, resume_epoch=0, load=False)
+    logs = []
+    out = hmain.run(P, None, d, log=logs.append)
+    n = int(fxd["dl_nab600_Xshape"][0])
+    assert out["final_scores"].shape[0] in (n, n + 99) and np.isfinite(out["final_scores"]).all()
+    assert out["intervals"].ndim == 2 and out["intervals"].shape[1] == 3 and len(out["confusion"]) == 4
+    model_dir = "./trained_models/models_{}_NAB_3_0.0005/NAB/sig".format("hyper" if hyper else "eucl")
+    assert os.path.exists(os.path.join(model_dir, "encoder.pt")) and os.path.exists(os.path.join(model_dir, "recons_signal.pt"))
+    assert sum("decoder loss" in str(l) for l in logs) == 3
+    enc = torch.load(os.path.join(model_dir, "encoder.pt"), weights_only=False)
+    assert {"lstm.weight_ih_l0", "dense.weight"} <= set(enc.state_dict().keys())
