@@ -134,9 +134,13 @@ def bench_scoring(device, n=125_000, reps=5):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 1)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
+
     def forward():
-        _C.check(_C.lib.hypad_score_forward(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(x), _C.ptr(hyper),
-                                            _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L, 1, _C.stream()), "score_forward")
+        _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(x), 0, _C.ptr(hyper),
+                                                   _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L, 1, ws.data_ptr(),
+                                                   ws_bytes, _C.stream()), "score_forward_packed")
 
     def numerics():
         true = adu.unroll_true(x)

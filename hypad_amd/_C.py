@@ -100,6 +100,9 @@ _SIGS = {
     "hypad_score_forward": (c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "hypad_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "hypad_epoch_workspace_bytes": (c_size_t, [POINTER(Dims), c_int, c_int]),
+    "hypad_score_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "hypad_score_forward_packed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "hypad_pack_generator": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, c_void_p]),
     "hypad_packed_region": (c_int, [POINTER(Dims), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "hypad_critic_x_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),

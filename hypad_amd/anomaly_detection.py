@@ -13,6 +13,8 @@ def score_batches(test_loader, encoder, decoder, critic_x, signal_shape):
     hyp = bool(decoder.hyperbolic)
     S, L = signal_shape, encoder.latent_space_dim
     outs = {k: [] for k in ("recons", "eucl", "hyper_real", "critic", "rowdist", "true")}
+    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, int(hyp))
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device="cuda")           # packed weight copies (built by the call)
     for batch in test_loader:
         sample = batch[0] if isinstance(batch, (list, tuple)) else batch
         x = sample.reshape(-1, S).to("cuda", torch.float32).contiguous()
@@ -20,9 +22,9 @@ def score_batches(test_loader, encoder, decoder, critic_x, signal_shape):
         new = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
         eucl, critic = new(n, S), new(n)
         hyper, hreal, dist = (new(n, S), new(n, S), new(n)) if hyp else (None, None, None)
-        _C.check(_C.lib.hypad_score_forward(_C.ptr(encoder.arena()), _C.ptr(decoder.arena()), _C.ptr(critic_x.arena()), _C.ptr(x),
-                                            _C.ptr(hyper), _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L,
-                                            int(hyp), _C.stream()), "score_forward")
+        _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(encoder.arena()), _C.ptr(decoder.arena()), _C.ptr(critic_x.arena()), _C.ptr(x), 0,
+                                                   _C.ptr(hyper), _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L,
+                                                   int(hyp), ws.data_ptr(), ws_bytes, _C.stream()), "score_forward_packed")
         outs["recons"].append(hyper if hyp else eucl)
         outs["eucl"].append(eucl)
         outs["critic"].append(critic)

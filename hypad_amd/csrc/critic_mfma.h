@@ -242,4 +242,38 @@ __device__ __forceinline__ float critic_tile_fwd_bwd(const float* Xs, int ldx, c
   return in[0];
 }
 
+// Forward only (eval mode, no dropout): out[r] for 16 rows, written to `outv` (LDS, 16 floats).  scratch: in [16][ldin] |
+// act [2][16][LQ] (ping-pong).  Starts and ends with a workgroup barrier.
+__device__ __forceinline__ void critic_tile_fwd(const float* Xs, int ldx, const float* W, const CriticLayout& cl, int L, const CriticPad& cp,
+                                                float* scratch, float* outv) {
+  const int in_dim = cl.in_dim, nh = cl.nh, ldin = cp.ldin, LQ = cp.LQ;
+  float* in = scratch; float* act = in + 16 * ldin;
+  const float* w0 = W + cp.w0; const float* wh = W + cp.wh; const float* wl = W + cp.wl;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * ldin; i += blockDim.x) {
+    const int r = i / ldin, c = i - r * ldin;
+    in[i] = c < in_dim ? Xs[r * ldx + c] : (c == in_dim ? 1.f : 0.f);
+  }
+  for (int i = threadIdx.x; i < 2 * 16 * LQ; i += blockDim.x) act[i] = 0.f;
+  __syncthreads();
+  for (int li = 0; li < nh; ++li) {
+    const float* A = li == 0 ? in : act + ((li - 1) & 1) * 16 * LQ;
+    const float* Wl = li == 0 ? w0 : wh + (li - 1) * L * LQ;
+    float* ao = act + (li & 1) * 16 * LQ;
+    lds_gemm_nt(A, li == 0 ? ldin : LQ, 1, Wl, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? cp.Kin : cp.Lp, wave, lane, [&](int r, int c, float pre) {
+      if (c < L) ao[r * LQ + c] = pre * leaky_slope(pre);
+      else if (c == L) ao[r * LQ + c] = 1.f;
+    });
+    __syncthreads();
+  }
+  if (threadIdx.x < 16) {
+    const float* x = act + ((nh - 1) & 1) * 16 * LQ + threadIdx.x * LQ;
+    float o = 0.f;
+    for (int c = 0; c <= L; ++c) o += x[c] * wl[c];
+    outv[threadIdx.x] = o;
+  }
+  __syncthreads();
+}
+
 }  // namespace hypad

@@ -993,6 +993,80 @@ int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s) {
   return HYPAD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ scoring forward, packed
+// The test-loop body (anomaly_detection.py:67-113, eval mode) on the training kernels' machinery: 512 threads per 16 rows,
+// packed weights (no LDS re-shape), LSTM cells in the gate products' epilogues, the critic as LDS-resident MFMA layers, the
+// row-wise ball math four rows per wave.  79 KB of LDS: two workgroups per CU.
+struct ScoreArgs {
+  const float* pk; const float* cx; const float* head_b; const float* x; int64_t x_ld;
+  float* hyper; float* eucl; float* hyper_real; float* critic; float* rowdist;
+  int64_t rows; int S, L, hyperbolic;
+};
+struct ScoreLds { int xs, zs, bufA, bufB, cw, small, total, ldS; };
+HD ScoreLds score_lds(int S, int L) {
+  ScoreLds p; int o = 0;
+  p.ldS = pad4(S) + 4;
+  const CriticPad cp = critic_pad(S, L, 4);
+  int buf = 16 * (2 * DEC_H + 4) > 32 * p.ldS ? 16 * (2 * DEC_H + 4) : 32 * p.ldS;       // h tiles / the 32-row head tile
+  const int crit = 16 * cp.ldin + 2 * 16 * cp.LQ;                                        // critic_tile_fwd scratch, over bufA | bufB
+  if (2 * buf < crit) buf = (crit + 1) / 2;
+  buf = (buf + 3) & ~3;
+  p.xs = o; o += 16 * p.ldS;
+  p.zs = o; o += 32 * LP;
+  p.bufA = o; o += buf;
+  p.bufB = o; o += buf;
+  p.cw = o; o += cp.total;
+  p.small = o; o += 16;
+  p.total = o;
+  return p;
+}
+template <int SC, int LC>
+__global__ __launch_bounds__(TB) void score_forward_packed_kernel(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = SC ? SC : a.S, L = LC ? LC : a.L;
+  const ScoreLds lp = score_lds(S, L);
+  const int ldS = lp.ldS;
+  const GenPack gp = gen_pack(S, L, a.hyperbolic);
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  float* cw = smem + lp.cw; float* outv = smem + lp.small;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)(a.rows - r0 < 16 ? a.rows - r0 : 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  tile_load(xs, ldS, a.x + r0 * a.x_ld, a.x_ld, 16, S, valid);
+  if (a.critic) {
+    const CriticLayout clx = cx_layout(S, L);
+    const CriticPad cpx = critic_pad(S, L, 4);
+    stage_critic_padded(cw, a.cx, clx, L, cpx);
+    critic_tile_fwd(xs, ldS, cw, clx, L, cpx, bufA, outv);
+    if (threadIdx.x < valid) a.critic[r0 + threadIdx.x] = outv[threadIdx.x];
+  } else {
+    __syncthreads();
+  }
+  encoder_fwd_tile_packed(xs, ldS, S, L, a.pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid);
+  DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  decoder_trunk_fwd_tile_packed<1>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
+  if (a.eucl) tile_store(a.eucl + r0 * S, S, bufA, ldS, 16, S, valid);
+  if (a.hyperbolic) {
+    for (int i = threadIdx.x; i < 16 * ldS; i += TB) bufA[16 * ldS + i] = xs[i];      // rows 16-31: the real windows
+    __syncthreads();
+    gemm_nt_packed<2>(bufA, ldS, S, S, a.pk + gp.head, nullptr, bufB, ldS, 0);
+    __syncthreads();
+    head_rows_tile(bufB, ldS, 32, S, a.head_b);
+    __syncthreads();
+    if (a.hyper) tile_store(a.hyper + r0 * S, S, bufB, ldS, 16, S, valid);
+    if (a.hyper_real) tile_store(a.hyper_real + r0 * S, S, bufB + 16 * ldS, ldS, 16, S, valid);
+    if (a.rowdist && wave < 4) {
+      // (pred = real window on the ball, true = reconstruction): anomaly_detection_utils.py:58-65; four rows per wave
+      epl16_dispatch(S, [&](auto tag) {
+        using R16 = RowT<16, decltype(tag)::value>;
+        const int r = wave * 4 + (lane >> 4);
+        const float d = rowdist_row(row_load<R16>(bufB + (16 + r) * ldS, S, lane), row_load<R16>(bufB + r * ldS, S, lane));
+        if ((lane & 15) == 0 && r < valid) a.rowdist[r0 + r] = d;
+      });
+    }
+  }
+}
+
 long long* g_gen_stamps = nullptr;
 
 struct IterCall {
@@ -1220,6 +1294,46 @@ int hypad_pack_generator(const hypad_dims* d, const hypad_train_state* st, void*
   a.pe = enc_layout(a.S, a.L).total; a.pd = dec_layout(a.S, a.L, a.hyperbolic).total;
   a.ws = (float*)workspace; a.ws_sig_stride = per; a.pk_off = ws_pack_offset(*d);
   return launch_pack(a, *d, (hipStream_t)s);
+}
+size_t hypad_score_workspace_bytes(int S, int L, int hyperbolic) {
+  if (S < 1 || S > MAX_S || L < 1 || L > MAX_L) return 0;
+  return (size_t)gen_pack(S, L, hyperbolic).total * sizeof(float);
+}
+int hypad_score_forward_packed(const float* enc, const float* dec, const float* cx, const float* x, int64_t x_row_stride, float* hyper,
+                               float* eucl, float* hyper_real, float* critic, float* rowdist, int64_t rows, int S, int L,
+                               int hyperbolic, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  if (S < 1 || S > MAX_S || L < 1 || L > MAX_L) return HYPAD_EUNSUPPORTED;
+  if (!enc || !dec || !x || rows < 0 || (critic && !cx)) return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < hypad_score_workspace_bytes(S, L, hyperbolic)) return HYPAD_EWORKSPACE;
+  if (rows == 0) return HYPAD_OK;
+  hypad_dims d; d.signal_shape = S; d.latent_dim = L; d.batch = 16; d.hyperbolic = hyperbolic; d.n_signals = 1;
+  IterArgs pa{};
+  pa.S = S; pa.L = L; pa.B = 16; pa.hyperbolic = hyperbolic;
+  pa.P.enc = const_cast<float*>(enc); pa.P.dec = const_cast<float*>(dec);
+  pa.pe = enc_layout(S, L).total; pa.pd = dec_layout(S, L, hyperbolic).total;
+  pa.ws = (float*)workspace; pa.ws_sig_stride = 0; pa.pk_off = 0;
+  int rc = launch_pack(pa, d, (hipStream_t)s);
+  if (rc) return rc;
+  ScoreArgs a;
+  a.pk = (const float*)workspace; a.cx = cx; a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
+  a.x = x; a.x_ld = x_row_stride > 0 ? x_row_stride : S;
+  a.hyper = hyper; a.eucl = eucl; a.hyper_real = hyper_real; a.critic = critic; a.rowdist = rowdist;
+  a.rows = rows; a.S = S; a.L = L; a.hyperbolic = hyperbolic;
+  const size_t lds = (size_t)score_lds(S, L).total * sizeof(float);
+  if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
+  const int64_t tiles = (rows + 15) / 16;
+  if (tiles > 0x7fffffff) return HYPAD_EINVAL;
+  if (S == 100 && L == 20) {
+    hipError_t e = allow_lds((const void*)score_forward_packed_kernel<100, 20>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((score_forward_packed_kernel<100, 20>), dim3((unsigned)tiles), dim3(TB), lds, (hipStream_t)s, a);
+  } else {
+    hipError_t e = allow_lds((const void*)score_forward_packed_kernel<0, 0>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((score_forward_packed_kernel<0, 0>), dim3((unsigned)tiles), dim3(TB), lds, (hipStream_t)s, a);
+  }
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
 }
 int hypad_packed_region(const hypad_dims* d, int64_t* offset_floats, int64_t* signal_stride_floats, int64_t* count_floats) {
   int rc = check_dims(d);

@@ -149,6 +149,15 @@ int hypad_critic_z_fwd(const float* params, const float* z, float* out, int64_t 
  *   lat = Encoder(x); (hyper, eucl) = Decoder(lat); hyper_real = hyperbolic_linear(x); critic = CriticX(x);
  *   rowdist = poincare distance(hyper_real, hyper)  (utils/anomaly_detection_utils.py:58-66).
  * Any output pointer may be NULL (that output is then not written).  Euclidean mode: recon = eucl only. */
+/* The same on the training kernels' machinery (MFMA-native packed weights built into `workspace` by the call, LSTM cells in
+ * the gate products' epilogues, 512 threads per 16 windows): ~4x the rate of hypad_score_forward at large `rows`.
+ * x_row_stride: 0 / S = window matrix, 1 = x is the scaled series and window n is x[n .. n+S) (no matrix at all).
+ * workspace: hypad_score_workspace_bytes(S, L, hyperbolic). */
+size_t hypad_score_workspace_bytes(int signal_shape, int latent_dim, int hyperbolic);
+int hypad_score_forward_packed(const float* enc, const float* dec, const float* cx, const float* x, int64_t x_row_stride,
+                               float* hyper, float* eucl, float* hyper_real, float* critic, float* rowdist, int64_t rows,
+                               int signal_shape, int latent_dim, int hyperbolic, void* workspace, size_t workspace_bytes,
+                               hypad_stream_t stream);
 int hypad_score_forward(const float* enc, const float* dec, const float* cx, const float* x,
                         float* hyper, float* eucl, float* hyper_real, float* critic, float* rowdist,
                         int64_t rows, int signal_shape, int latent_dim, int hyperbolic, hypad_stream_t stream);

@@ -913,3 +913,39 @@ def test_cli_pipeline_end_to_end(dev, tmp_path, monkeypatch, hyper):
     assert sum("decoder loss" in str(l) for l in logs) == 3
     enc = torch.load(os.path.join(model_dir, "encoder.pt"), weights_only=False)
     assert {"lstm.weight_ih_l0", "dense.weight"} <= set(enc.state_dict().keys())
+
+
+@pytest.mark.parametrize("S,hyper", [(100, True), (100, False), (150, True), (51, True)])
+def test_score_forward_packed_matches_streamed_kernel(dev, S, hyper):
+    """hypad_score_forward_packed (packed weights, fused LSTM layers, LDS-MFMA critic, series view) against
+    hypad_score_forward (the reference-fixture-checked kernel): every output, ragged row counts, and the x_row_stride=1 view."""
+    from hypad_amd import _C
+    from hypad_amd.models import tadgan
+    torch.manual_seed(S)
+    enc, dec, cx = tadgan.Encoder(S, 20).cuda().eval(), tadgan.Decoder(S, 20, hyper).cuda().eval(), tadgan.CriticX(S, 20).cuda().eval()
+    if hyper:
+        with torch.no_grad():
+            dec.hyperbolic_linear.weight.mul_(30)
+    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, 20, int(hyper))
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    for n in (1, 16, 37, 1000):
+        series = (torch.rand(n + S - 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n)) * 2 - 1).contiguous()
+        x = series.unfold(0, S, 1).contiguous()
+        assert x.shape == (n, S)
+        new = lambda *s: torch.full(s, float("nan"), device="cuda")
+        ref = [new(n, S), new(n, S), new(n, S), new(n), new(n)]
+        _C.check(_C.lib.hypad_score_forward(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(x), _C.ptr(ref[0] if hyper else None),
+                                            _C.ptr(ref[1]), _C.ptr(ref[2] if hyper else None), _C.ptr(ref[3]), _C.ptr(ref[4] if hyper else None),
+                                            n, S, 20, int(hyper), _C.stream()))
+        for src, stride in ((x, 0), (series, 1)):
+            got = [new(n, S), new(n, S), new(n, S), new(n), new(n)]
+            _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(src), stride,
+                                                       _C.ptr(got[0] if hyper else None), _C.ptr(got[1]), _C.ptr(got[2] if hyper else None),
+                                                       _C.ptr(got[3]), _C.ptr(got[4] if hyper else None), n, S, 20, int(hyper), ws.data_ptr(),
+                                                       ws_bytes, _C.stream()))
+            torch.cuda.synchronize()
+            for k, (g, r) in enumerate(zip(got, ref)):
+                if not hyper and k in (0, 2, 4):
+                    continue
+                assert bool(torch.isfinite(g).all()), (n, k)
+                assert float((g - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max())), (n, stride, k, float((g - r).abs().max()))
