@@ -30,9 +30,12 @@ __device__ __forceinline__ float np_lerp(float a, float b, float t) {
   if (t >= 0.5f) r = b - diff * (1.0f - t);
   return r;
 }
+// EPL: anti-diagonal values per lane (window <= 64 EPL); the rank-by-counting loop is the kernel's cost (window^2 / 64
+// compares per timestep and lane), so it is instantiated for the window class and reads the broadcast values four at a time.
+template <int EPL>
 __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
                                                                  double* __restrict__ summary, int64_t n, int W) {
-  __shared__ float vals[THREADS / 64][MAX_WINDOW];
+  __shared__ __attribute__((aligned(16))) float vals[THREADS / 64][MAX_WINDOW];
   __shared__ float sorted[THREADS / 64][MAX_WINDOW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t T = n + W - 1;
@@ -42,9 +45,9 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
     const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
     const int j1 = (int)(t + 1 < W ? t + 1 : W);
     const int cnt = j1 - j0;
-    float mine[4];
+    float mine[EPL];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < EPL; ++e) {
       int i = lane + 64 * e;
       mine[e] = 0.f;
       if (i < cnt) {
@@ -55,17 +58,43 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave landed
-    int rank[4] = {0, 0, 0, 0};
-    for (int k = 0; k < cnt; ++k) {
-      const float vk = v[k];
+    // pad the slab to a multiple of 4 with +inf (never below or equal to a finite value)
+    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) v[cnt + lane] = __int_as_float(0x7f800000);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" and "equal" (two compare + add-carry
+    // pairs per value); only when some value occurs twice in this anti-diagonal is the ordered tie count needed.
+    int rank[EPL], same[EPL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = lane + 64 * e;
-        rank[e] += (vk < mine[e]) || (vk == mine[e] && k < i);
+    for (int e = 0; e < EPL; ++e) { rank[e] = 0; same[e] = 0; }
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(v + k0);
+      const float vk[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          rank[e] += vk[u] < mine[e] ? 1 : 0;
+          same[e] += vk[u] == mine[e] ? 1 : 0;
+        }
+    }
+    bool ties = false;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) ties |= (lane + 64 * e < cnt) && same[e] > 1;
+    if (__any(ties)) {                               // wave-uniform
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) rank[e] = 0;
+      for (int k = 0; k < cnt; ++k) {
+        const float vk = v[k];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int i = lane + 64 * e;
+          rank[e] += (vk < mine[e]) || (vk == mine[e] && k < i);
+        }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < EPL; ++e)
       if (lane + 64 * e < cnt) s[rank[e]] = mine[e];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -356,7 +385,9 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   if (!y_hat || !median || n <= 0 || window <= 0) return HYPAD_EINVAL;
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
   const int64_t T = n + window - 1;
-  hipLaunchKernelGGL(unroll_median_kernel, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
+  if (window <= 64) hipLaunchKernelGGL(unroll_median_kernel<1>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
+  else if (window <= 128) hipLaunchKernelGGL(unroll_median_kernel<2>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
+  else hipLaunchKernelGGL(unroll_median_kernel<4>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
