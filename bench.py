@@ -224,8 +224,9 @@ def main():
     assert all(np.isfinite(last)), "training diverged"
 
     # ---- per-kernel durations, HIP events on the launch stream (same workload, after the timed region)
-    # kind 4 = two iterations of the critic phase exactly as train_epoch launches them (precompute of their records, the
-    # first critic_x || critic_z iteration launch, a steady-state one); kind 2 = decoder_iteration
+    # kind 4 = nine iterations of the critic phase exactly as train_epoch launches them (precompute of their records, the
+    # first critic_x || critic_z iteration launch, the mean of eight steady-state launches back to back -- event overhead
+    # amortised); kind 2 = decoder_iteration
     names = {4: ["critic_precompute", "critic_iteration_first", "critic_iteration"], 2: ["gen", "dw_gen"]}
     acc = {n: [] for v in names.values() for n in v}
     idx = torch.arange(B, device=device, dtype=torch.int32)
@@ -236,7 +237,7 @@ def main():
                 for n, v in zip(names[kind], ms):
                     acc[n].append(v)
     kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_iteration_first"}
-    # the precompute runs ONCE per epoch for all 145 iterations; profiled here for two iterations' rows (a lower bound
+    # the precompute runs ONCE per epoch for all 145 iterations; profiled here for nine iterations' rows (a lower bound
     # on its efficiency), so its epoch share is not extrapolated from this number
     launches = {"gen": N_BATCHES, "dw_gen": N_BATCHES, "critic_iteration": N_CRITICS * N_BATCHES + 1, "critic_precompute": 1}
     share = {n: kern_ms[n] * launches[n] for n in kern_ms}

@@ -582,8 +582,8 @@ size_t critic_phase_floats_per_iter(const hypad_dims& d) {
 // iterations.  ax / az: arguments of the two iterations (loss_sig_stride set; row_index and losses are taken from the
 // arguments here).  extra: `extra_floats` floats of scratch; the phase is cut into chunks of as many iterations as fit.
 // losses: iteration `it` writes rows 2*it (critic_x) and 2*it+1 (critic_z) of each signal's loss table.  ev (optional,
-// 4 events, profiling, n_iters == 2): recorded before the precompute, after it, after the first iteration launch (no
-// Adam prologue) and after the second (steady state).
+// 4 events, profiling): recorded before the precompute, after it, after the first iteration launch (no Adam prologue)
+// and after the last one (n_iters - 1 steady-state launches back to back: event overhead amortised).
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
@@ -637,7 +637,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
       if (ref_cfg) hipLaunchKernelGGL((critic_iteration_kernel<100, 20, 64>), grid, dim3(FT), lds, s, ax, az, ph);
       else hipLaunchKernelGGL((critic_iteration_kernel<0, 0, 0>), grid, dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
-      if (ev && it < 2) (void)hipEventRecord(ev[2 + it], s);
+      if (ev && (it == 0 || it == n - 1)) (void)hipEventRecord(ev[it == 0 ? 2 : 3], s);
     }
     hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
     HYPAD_CHECK_LAUNCH();

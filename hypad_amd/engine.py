@@ -117,11 +117,11 @@ class Engine:
 
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
-        4 two iterations of train_epoch's hoisted critic phase: precompute, first launch, steady-state launch), HIP events on the current stream."""
+        4 nine iterations of train_epoch's hoisted critic phase: precompute, first launch, mean steady-state launch), HIP events on the current stream."""
         x, stride = self._check_x(x)
         if kind == 4:
-            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 2, 1))
-        losses = torch.empty(4 * self.n, 4, dtype=torch.float32, device=self.device)
+            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 9, 1))
+        losses = torch.empty(18 * self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None, self.seed, 0)
         io = _C.IterIO(x.data_ptr(), stride, 0, None if row_index is None else row_index.data_ptr(), None, None, drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)

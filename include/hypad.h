@@ -239,12 +239,13 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
 /* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder, 3 = the critic_x ||
- * critic_z pair of the per-iteration path) or, kind 4, TWO iterations of the hoisted critic phase of hypad_train_epoch
+ * critic_z pair of the per-iteration path) or, kind 4, NINE iterations of the hoisted critic phase of hypad_train_epoch
  * over rows 0 .. batch-1 (row_index is ignored), with HIP events recorded on `stream` between the kernels; synchronise;
  * return the per-kernel durations in ms: critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam};
- * decoder -> {generator kernel, dW+Adam}; kind 4 -> {precompute kernel (two iterations' records), first iteration
- * launch (no Adam in its prologue), second iteration launch (steady state)}.  losses: room for 2 * n_signals * 4 floats
- * (kind 3) / 4 * n_signals * 4 floats (kind 4); workspace for kind 4: hypad_epoch_workspace_bytes(dims, 2, 1).
+ * decoder -> {generator kernel, dW+Adam}; kind 4 -> {precompute kernel (nine iterations' records), first iteration
+ * launch (no Adam in its prologue), mean of the eight steady-state launches that follow back to back}.  losses: room for
+ * 2 * n_signals * 4 floats (kind 3) / 18 * n_signals * 4 floats (kind 4); workspace for kind 4:
+ * hypad_epoch_workspace_bytes(dims, 9, 1).
  * Not capturable into a graph. */
 int hypad_profile_iteration(int kind, const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io,
                             float* ms_out, int n_out, hypad_stream_t stream);
