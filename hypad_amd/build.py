@@ -16,11 +16,29 @@ def _newest_source():
     return max(os.path.getmtime(f) for f in files)
 
 
+def _fresh():
+    return os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source()
+
+
 def build(force=False, verbose=False):
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
+    if not force and _fresh():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
+    # one builder at a time (bench.py runs one process per GPU and every rank calls build()): the others wait on the lock
+    # and then find the library fresh
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _fresh():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SOURCES:
@@ -36,7 +54,9 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
+    os.replace(tmp, LIB)                       # atomic: a concurrent importer never maps a half-written library
     return LIB
 
 
