@@ -398,6 +398,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
   }
   if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
+  if (threadIdx.x < 2) reinterpret_cast<int*>(red + 48)[threadIdx.x] = 0;      // pair flags of the second-order chain
   __syncthreads();
   STAMP(2);
   int sk = 3;
@@ -495,23 +496,44 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   }
   __syncthreads();
   STAMP(sk++);
-  if (wave == NW - 1) {
+  if (wave >= NW - 2) {
+    // waves 6 and 7 carry the 20-wide rest of the chain, one column tile each, meeting after every layer through a pair of
+    // LDS flags (no workgroup barrier: the other six waves are busy with weight-gradient tiles)
+    const int ct = NW - 1 - wave;                                   // my column tile; the partner has 1 - ct
+    const int jj = lane & 15, qq = lane >> 4;
+    int* flag = reinterpret_cast<int*>(red + 48);
+    const int CTn = (L + 1 + 15) >> 4;                              // column tiles of a layer (1 or 2)
     for (int li = 1; li < nh; ++li) {
       float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
-      wave_gemm_nt(act + ((li - 1) * 48 + 32) * LQ, LQ, wh + (li - 1) * L * LQ, LQ, L, L + 1, Lp, lane,
-                   [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; else if (c == L) eo[r * LQ + c] = 0.f; });
-      wave_lds_fence();
+      if (ct < CTn) {
+        int n = ct * 16 + jj; n = n < L ? n : L - 1;
+        const float* ap = act + ((li - 1) * 48 + 32 + jj) * LQ + 4 * qq;
+        const float* bp = wh + ((li - 1) * L + n) * LQ + 4 * qq;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int g16 = 0; g16 < Lp; g16 += 16)
+          acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
+        const int c = ct * 16 + jj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * qq + r;
+          if (c < L) eo[row * LQ + c] = acc[r] * dmo[row * LQ + c];
+          else if (c == L) eo[row * LQ + c] = 0.f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&flag[ct], li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   } else {
-    if (wave == NW - 2) dw_tile(0, true, false);
 #pragma unroll
     for (int i = 1; i < MAXT; ++i) dw_tile(i, true, false);
   }
   __syncthreads();
   STAMP(sk++);
-  if (wave == NW - 1) {
+  if (wave >= NW - 2) {
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, true);
+    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, true);          // the chain's two waves do both parts of their tiles now
   } else {
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) dw_tile(i, false, true);

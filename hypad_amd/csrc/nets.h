@@ -51,10 +51,19 @@ __device__ __forceinline__ void tile_load(float* __restrict__ dst, int ld, const
 __device__ __forceinline__ void tile_load_rows(float* __restrict__ dst, int ld, const float* __restrict__ base, int64_t gld,
                                                const int32_t* __restrict__ row_index, int row0, int rows, int cols, int valid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int r = wave; r < rows; r += nw) {
-    const bool ok = r < valid;
+  // a gathered row is two dependent memory round trips (index, then row): a wave takes its rows two at a time so that
+  // the round trips of the pair overlap
+  for (int r = wave; r < rows; r += 2 * nw) {
+    const int r2 = r + nw;
+    const bool ok = r < valid, ok2 = r2 < rows && r2 < valid;
     const int64_t gr = ok ? (row_index ? (int64_t)row_index[row0 + r] : (int64_t)(row0 + r)) : 0;
-    for (int c = lane; c < cols; c += 64) dst[r * ld + c] = ok ? base[gr * gld + c] : 0.f;
+    const int64_t gr2 = ok2 ? (row_index ? (int64_t)row_index[row0 + r2] : (int64_t)(row0 + r2)) : 0;
+    for (int c = lane; c < cols; c += 64) {
+      const float a = ok ? base[gr * gld + c] : 0.f;
+      const float b = ok2 ? base[gr2 * gld + c] : 0.f;
+      dst[r * ld + c] = a;
+      if (r2 < rows) dst[r2 * ld + c] = b;
+    }
   }
 }
 __device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t gld, const float* __restrict__ src, int ld,

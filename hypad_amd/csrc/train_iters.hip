@@ -337,8 +337,11 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // ---- encoder(x), critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
     const CriticLayout clz = cz_layout(L);
     const CriticPad cpz = critic_pad(L, L, 2);
-    stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
+    // the window gather is two dependent memory round trips (row index, then the row): issue it first, stage the critic behind it
+    GEN_STAMP(14);
     tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+    GEN_STAMP(15);
+    stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
     GEN_STAMP(12);
     __syncthreads();
     GEN_STAMP(13);

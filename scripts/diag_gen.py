@@ -22,5 +22,5 @@ for role, nm in ((0, "G"), (1, "R")):
     print(f"role {nm}: total {r[11] - r[0]} cycles = {(r[11] - r[0]) / 2400.0:.1f} us")
     ks = [k for k in range(12) if r[k] > 0]
     print("   " + ", ".join(f"{names[k1]} {r[k2] - r[k1]}" for k1, k2 in zip(ks[:-1], ks[1:])))
-    sub = {"crit stage + x gather issue": (0, 12), "x gather wait": (12, 13), "enc layer+dense": (13, 1), "ecat store": (3, 20), "head gemm": (20, 21), "u store": (21, 22), "head rows": (22, 4), "rowdist": (5, 23), "head bwd rows": (23, 24), "ballpart+du store": (24, 25), "dE gemm": (25, 26), "tanh'": (26, 6)}
+    sub = {"setup+warm": (0, 14), "x gather": (14, 15), "critic stage": (15, 12), "x gather wait": (12, 13), "enc layer+dense": (13, 1), "ecat store": (3, 20), "head gemm": (20, 21), "u store": (21, 22), "head rows": (22, 4), "rowdist": (5, 23), "head bwd rows": (23, 24), "ballpart+du store": (24, 25), "dE gemm": (25, 26), "tanh'": (26, 6)}
     print("   sub: " + ", ".join(f"{k} {r[b] - r[a]}" for k, (a, b) in sub.items() if r[a] > 0 and r[b] > 0))
