@@ -949,3 +949,49 @@ def test_score_forward_packed_matches_streamed_kernel(dev, S, hyper):
                     continue
                 assert bool(torch.isfinite(g).all()), (n, k)
                 assert float((g - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max())), (n, stride, k, float((g - r).abs().max()))
+
+
+@pytest.mark.parametrize("S,L,B,hyper", [(100, 8, 64, True), (100, 32, 64, True), (60, 12, 32, False), (100, 10, 64, True)])
+def test_other_latent_dims(dev, S, L, B, hyper):
+    """The ABI admits latent_dim <= 32 (the reference fixes 20, train.py:412): the three iterations against the oracle and
+    the hoisted epoch against the per-minibatch path at other widths, incl. one that is not a multiple of 4 and one (32)
+    whose critic does not fit the hoisted kernel's tables."""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    from oracle import train_iters as oi
+    torch.manual_seed(1)
+    mods = dict(enc=ot.Encoder(S, L).eval(), dec=ot.Decoder(S, L, hyper).eval(), cx=ot.CriticX(S, L).eval(), cz=ot.CriticZ(L).eval())
+    eng = Engine(S, L, B, hyper, lr=5e-4)
+    for k, m in mods.items():
+        eng.load_state_dict(k, m.state_dict())
+    P = params_ns(B, S, hyper)
+    P.latent_space_dim = L
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(B, S, 1))
+    xs = cu(x[:, :, 0]).reshape(1, B, S)
+    z = rng.standard_normal((B, L)).astype(np.float32)
+    ax, az = rng.uniform(size=(B, S)).astype(np.float32), rng.uniform(size=(B, L)).astype(np.float32)
+    o = oi.make_optimizers(mods["enc"], mods["dec"], mods["cx"], mods["cz"], P)
+    sample = torch.from_numpy(x)
+    r1 = float(oi.critic_x_iteration(sample, mods["dec"], mods["cx"], o[0], P, z=z, alpha=ax))
+    g1 = float(eng.critic_x_iteration(xs, None, cu(z), cu(ax), train_mode=False)[0, 0])
+    r2 = float(oi.critic_z_iteration(sample, mods["enc"], mods["cz"], o[1], P, z=z, alpha=az))
+    g2 = float(eng.critic_z_iteration(xs, None, cu(z), cu(az), train_mode=False)[0, 0])
+    for k in ("cx", "cz"):
+        mods[k].load_state_dict({n: v.cpu() for n, v in eng.state_dict(k).items()})
+    r3 = oi.decoder_iteration(sample, mods["enc"], mods["dec"], mods["cx"], mods["cz"], o[2], P, z=z)
+    g3 = eng.decoder_iteration(xs, None, cu(z), train_mode=False)
+    assert abs(r1 - g1) < TOL * max(1, abs(r1)) and abs(r2 - g2) < TOL * max(1, abs(r2))
+    assert abs(float(r3[0]) - float(g3[0, 0])) < 2 * TOL * max(1, abs(float(r3[0])))
+    nw = 4 * B
+    xx = (torch.rand(1, nw, S, generator=torch.Generator().manual_seed(2)) * 2 - 1).cuda().contiguous()
+    perm = torch.randperm(nw, generator=torch.Generator().manual_seed(3))[:B].to(torch.int32).cuda().reshape(1, B).repeat(2, 1).contiguous()
+    outs = []
+    for hoist in (True, False):
+        e = Engine(S, L, B, hyper, lr=5e-4, seed=5)
+        for k, m in mods.items():
+            e.load_state_dict(k, m.state_dict())
+        outs.append(e.train_epoch(xx, perm, 1, 1, True, hoist=hoist).clone())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    np.testing.assert_allclose(outs[0].cpu().numpy(), outs[1].cpu().numpy(), rtol=5e-5, atol=5e-5)
