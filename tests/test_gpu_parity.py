@@ -995,3 +995,62 @@ def test_other_latent_dims(dev, S, L, B, hyper):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(outs[0]).all())
     np.testing.assert_allclose(outs[0].cpu().numpy(), outs[1].cpu().numpy(), rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("hyper", [True, False])
+def test_training_trajectory_tracks_the_cpu_path(dev, hyper):
+    """Beyond per-step parity: 8 epochs of the full schedule (5 critic passes + 1 generator pass over 6 minibatches, train-mode
+    dropout) from the same initial weights on the device (device RNG) and on the CPU oracle (reference-structured loop, NumPy
+    / torch RNG).  The random streams differ, so the comparison is statistical: the reconstruction objective must fall on both
+    and end within a band of each other, and the evaluated reconstruction error of the two trained generators must agree."""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    from oracle import train_iters as oi
+    S, L, B, nb, epochs = 100, 20, 64, 6, 8
+    torch.manual_seed(3)
+    mods = dict(enc=ot.Encoder(S, L), dec=ot.Decoder(S, L, hyper), cx=ot.CriticX(S, L), cz=ot.CriticZ(L))
+    t = np.arange(nb * B + S)
+    series = np.clip(np.sin(2 * np.pi * t / 57.0) * 0.8 + 0.05 * np.random.default_rng(0).standard_normal(t.size), -1, 1)
+    win = np.stack([series[i:i + S] for i in range(nb * B)])                               # (384, 100)
+    eng = Engine(S, L, B, hyper, lr=5e-4, gen_weight_decay=1e-5 if hyper else 0.0, gen_stabilize=10 if hyper else 0, seed=17)
+    for k, m in mods.items():
+        eng.load_state_dict(k, m.state_dict())
+    x = cu(win).reshape(1, -1, S)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    aux_dev = []
+    for ep in range(epochs):
+        perm = torch.stack([torch.randperm(nb * B, device="cuda", generator=gen) for _ in range(6)]).to(torch.int32).contiguous()
+        l = eng.train_epoch(x, perm, nb, 5, True)[0]
+        aux_dev.append(float(l[2 * 5 * nb:, 1].mean()))
+    # CPU: the oracle's epoch over shuffled minibatches
+    P = params_ns(B, S, hyper)
+    for m in mods.values():
+        m.train()
+    opt = oi.make_optimizers(mods["enc"], mods["dec"], mods["cx"], mods["cz"], P)
+    np.random.seed(0); torch.manual_seed(0)
+    rng = np.random.default_rng(5)
+    aux_cpu = []
+    data = torch.from_numpy(win[:, :, None])
+    for ep in range(epochs):
+        order = rng.permutation(nb * B)
+        batches = [data[order[i * B:(i + 1) * B]] for i in range(nb)]
+        out = oi.train_epoch(batches, mods["enc"], mods["dec"], mods["cx"], mods["cz"], opt, P)
+        aux_cpu.append(float(out[1] if hyper else out[2]))
+    print("reconstruction objective per epoch, device:", [round(v, 4) for v in aux_dev], "cpu:", [round(v, 4) for v in aux_cpu])
+    assert aux_dev[-1] < 0.85 * aux_dev[0] and aux_cpu[-1] < 0.85 * aux_cpu[0], (aux_dev, aux_cpu)
+    assert 0.6 < aux_dev[-1] / aux_cpu[-1] < 1.6, (aux_dev, aux_cpu)
+    # evaluated reconstruction error of both trained generators on the same windows
+    for m in mods.values():
+        m.eval()
+    with torch.no_grad():
+        xt = torch.from_numpy(win).float()
+        rec_cpu = mods["dec"](mods["enc"](xt.view(1, -1, S)))
+        rec_cpu = (rec_cpu[1] if hyper else rec_cpu).reshape(-1, S)
+    from hypad_amd.models import tadgan
+    henc, hdec = tadgan.Encoder(S, L).cuda().eval(), tadgan.Decoder(S, L, hyper).cuda().eval()
+    henc.load_state_dict(eng.state_dict("enc")); hdec.load_state_dict(eng.state_dict("dec"))
+    rec_dev = hdec(henc(cu(win).view(1, -1, S)))
+    rec_dev = (rec_dev[1] if hyper else rec_dev).reshape(-1, S).cpu()
+    e_cpu, e_dev = float(((rec_cpu - xt) ** 2).mean()), float(((rec_dev - xt) ** 2).mean())
+    print("evaluated reconstruction mse, device:", e_dev, "cpu:", e_cpu)
+    assert 0.5 < e_dev / e_cpu < 2.0, (e_dev, e_cpu)
