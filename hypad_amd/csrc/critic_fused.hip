@@ -121,6 +121,21 @@ __device__ __forceinline__ float4 rng_uniform4(uint64_t seed, uint32_t tick, uin
 }
 
 // ---------------------------------------------------------------------------------------------- precompute
+// LDS of a precompute workgroup: the window rows, the latent rows and two layer buffers -- 28 KB at S = 100, so the
+// register file, not LDS, bounds the workgroups per CU (the kernel is one wide launch of 1 160 workgroups per epoch).
+struct PreLds { int xs, zs, bufA, bufB, total, ldS; };
+HD PreLds pre_lds(int S) {
+  PreLds p; int o = 0;
+  p.ldS = pad4(S) + 4;
+  const int a = 16 * (2 * DEC_H + 4), b = 16 * p.ldS;      // h tiles (the gate tiles never reach LDS: fused LSTM layers)
+  const int buf = a > b ? a : b;
+  p.xs = o; o += 16 * p.ldS;
+  p.zs = o; o += 32 * LP;
+  p.bufA = o; o += buf;
+  p.bufB = o; o += buf;
+  p.total = o;
+  return p;
+}
 // Writes one record: rows real | fake | interpolated ([48][Kin], ones column at in_dim, zeros after) and the dropout
 // scales [nh][48][L4] (pass order real, fake, interpolated).  real / fake: LDS tiles of 16 rows.
 template <bool IS_X>
@@ -169,9 +184,8 @@ __global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sig = blockIdx.y, tile = blockIdx.x, S = ax.S, L = ax.L, B = ax.B;
   const int it = blockIdx.z >> 1, role = blockIdx.z & 1;
-  const LdsPlan lp = lds_plan(S, 16, 16, 0);
+  const PreLds lp = pre_lds(S);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
-  float* wst = smem + lp.wst;
   const uint32_t tick = (uint32_t)ax.counters[3] + (uint32_t)it;
   const int g0 = tile * 16, nchunks = B / 16;
   if (tile == 0 && sig == 0 && threadIdx.x == 0) {   // Adam bias corrections of the step that launch it + 1 applies (train.py:274-281)
@@ -618,7 +632,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   const int nchunks = ax.B / 16;
   // the generator-side randomness (z, decoder dropout) keeps the critic_x seed; critic_z draws from its own
   az.seed = ax.seed ^ 0x5851F42D4C957F2DULL;
-  const size_t lds_pre = (size_t)lds_plan(ax.S, 16, 16, 0).total * sizeof(float);
+  const size_t lds_pre = (size_t)pre_lds(ax.S).total * sizeof(float);
   if (lds_pre > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)critic_phase_precompute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
     if (e != hipSuccess) return (int)e;
