@@ -272,7 +272,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("configs[1]: univariate synthetic (sine+noise+jump), hyperbolic=%s, batch=64, window=100, "
+            "config": {"workload": (("configs[1]" if hyperbolic else "configs[0] on the GPU") + ": univariate synthetic (sine+noise+jump), hyperbolic=%s, batch=64, window=100, "
                                     "latent=20, 1916 windows/signal, %d signal(s) per GPU; step = 1 epoch = 29 x "
                                     "(5 critic_x + 5 critic_z + 1 decoder) iterations") % (hyperbolic, spg),
                        "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,

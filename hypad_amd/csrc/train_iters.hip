@@ -1,13 +1,22 @@
 // The three WGAN-GP minibatch steps of train.py (critic_x_iteration :18-104, critic_z_iteration :107-186,
 // decoder_iteration :189-249) with the optimizer step fused in.
 //
-// Launch structure per iteration (every kernel: grid = (work, n_signals), one model per blockIdx.y):
-//   critic_x / critic_z :  pass kernel  (row tiles: 3 critic passes, first GP backward, partial norms)
+// Launch structure (every kernel: one model per blockIdx.y):
+//   hypad_critic_{x,z}_iteration (per-iteration entry points; also hypad_train_epoch's fallback for shapes that
+//   critic_fused.hip cannot take):
+//                          pass kernel  (row tiles: frozen generator forward, 3 critic passes, first GP backward, partial norms)
 //                          gp kernel    (row tiles: whole-batch norm -> second-order chain)
 //                          dw_adam      (16x16 weight tiles: dW = left^T right on MFMA, Adam in registers)
-//   decoder_iteration   :  gen kernel   (row tiles: full forward + backward-data of encoder/decoder through the
-//                                        frozen critics, every (delta, activation) pair written for dw_adam)
-//                          dw_adam      (Adam or Riemannian Adam)
+//   hypad_decoder_iteration:
+//                          pack kernel  (MFMA-native copies of the generator weights into the workspace; inside an epoch the
+//                                        dW kernel keeps them current instead)
+//                          gen kernel   (one workgroup per (row tile, chain): G = z -> decoder -> critic_x and back,
+//                                        R = x -> encoder -> critic_z, decoder, reconstruction loss and back; every
+//                                        (delta, activation) pair written for dw_adam)
+//                          dw_adam      (Adam or Riemannian Adam; writes arena + packed copies)
+//   hypad_train_epoch:     pack once -> critic phase (critic_fused.hip: precompute + one launch per critic_x || critic_z
+//                          iteration) -> n_batches x (gen, dw_adam)
+//   hypad_score_forward_packed: pack + the test-loop body on the same building blocks.
 // No gradient buffer exists: a weight's gradient tile lives in MFMA accumulators and is consumed by the update.
 // Formulas: oracle/manual.py (CPU derivation sheet, validated against autograd and the reference fixtures).
 #include <hip/hip_runtime.h>
@@ -248,7 +257,7 @@ HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) 
 // One workgroup per (16-row tile, role): blockIdx.z = role.  Operand rows in the workspace are pass-major as before:
 // pass 0 = decoder(z), pass 1 = decoder(encoder(x)), pass 2 (hyperbolic only) = hyperbolic_linear(x).
 struct GenLds {
-  int xs, zs, bufA, bufB, small, wst, cw, ct, total, ldS;
+  int xs, zs, bufA, bufB, small, cw, ct, total, ldS;
 };
 HD GenLds gen_lds(int S, int L, int hyper, int role) {
   GenLds p;
@@ -263,7 +272,6 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
   p.bufA = o; o += bufFloats;
   p.bufB = o; o += bufFloats;
   p.small = o; o += 3 * 16 * LP + 64;             // dzc | dzs | spare, then 64 reduction slots
-  p.wst = o;                                      // (no weight re-shape slabs: the generator products read packed weights)
   p.cw = o; o += cp.total;                        // the role's frozen critic, padded image (critic_mfma.h)
   p.ct = o; o += critic_tile_floats(cp, role == 0 ? 4 : 2);
   p.total = o;
@@ -292,7 +300,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* dzc = small;                       // [16][LP] gradient of -mean(critic_z) w.r.t. encoder output
   float* dzs = small + 16 * LP;             // [16][LP] total gradient of the encoder output
   float* red = small + 3 * 16 * LP;
-  float* wst = smem + lp.wst;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   const uint32_t tick = (uint32_t)a.counters[3];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
