@@ -200,7 +200,8 @@ def main():
 
     def step():
         # the DataLoader's shuffles: a fresh permutation for each of the 5 critic passes and the generator pass
-        perm = torch.stack([torch.randperm(N_WINDOWS, device=device, generator=gen)[: N_BATCHES * B] for _ in range(N_CRITICS + 1)])
+        # (argsort of uniform keys: six independent uniform permutations from one batched sort instead of six randperm calls)
+        perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
         eng.train_epoch(x, perm.to(torch.int32).contiguous(), N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
 
     def barrier():
