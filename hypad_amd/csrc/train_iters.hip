@@ -579,14 +579,18 @@ struct DwDesc {
   int32_t p_off2;                             // second destination with the same gradient (b_hh), or -1
   int32_t begin;                              // first work item
 };
-template <int CAP>
+template <int CAP, int BLK>
 struct DwTableT {
-  int n, total_items;
+  static constexpr int cap = CAP, blk = BLK;
+  int n, total_items;                         // n < 0: the table did not fit (host check)
   int finalize;                               // 0 none, 1 generator losses
+  // Work items are dealt four to a workgroup (one per wave) and every descriptor starts on a workgroup boundary, so a
+  // workgroup finds its descriptor with one byte lookup instead of a search (byte b of word b / 4).
+  uint32_t block_desc[BLK / 4];
   DwDesc d[CAP];
 };
-using DwTable = DwTableT<60>;                 // generator
-using DwTableS = DwTableT<12>;                // one critic
+using DwTable = DwTableT<60, 512>;            // generator (S = MAX_S needs ~470 workgroups)
+using DwTableS = DwTableT<12, 64>;            // one critic
 
 // Where a generator weight block / bias vector lives in the packed copies (layout.h GenPack), found from its arena offset:
 // the dW + Adam kernel keeps the copies current so that an epoch never re-packs.
@@ -634,81 +638,96 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
   return r;
 }
 
-template <class Table>
+// SC / LC / BC: compile-time dims of the reference configuration (0 = run-time), which fold the layout arithmetic of
+// shadow_ref() and gen_ws() into constants.
+template <class Table, int SC = 0, int LC = 0, int BC = 0>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
+  const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
-  const int step = a.counters[a.opt];          // already incremented by the iteration's first kernel
+  const int item = blockIdx.x * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
+  // Every scalar fetch that hangs off the kernel arguments leaves in one batch -- the workgroup's descriptor, the step
+  // counter, the generator's bias corrections -- instead of one memory round trip each.
+  const int di = (tab.block_desc[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xff;
+  const DwDesc d = tab.d[di];                    // by value: one load group, not one load per field
+  const int step = a.counters[a.opt];            // already incremented by the iteration's first kernel
+  const float* ac = a.ws + (tab.finalize == 1 ? gen_ws(B_, S_, L_).adamc : 0);
+  const float ac0 = ac[0], ac1 = ac[1], ac2 = ac[2];
   AdamCoef co;
   if (tab.finalize == 1) {                     // generator: the first kernel left the bias corrections in the workspace
-    const float* ac = a.ws + gen_ws(a.B, a.S, a.L).adamc;
     co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize;
-    co.step = step; co.bc1 = ac[0]; co.bc2 = ac[1]; co.sqrt_bc2 = ac[2];
+    co.step = step; co.bc1 = ac0; co.bc2 = ac1; co.sqrt_bc2 = ac2;
   } else {
     co = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
   }
-  float* Pn[4] = {a.P.enc + (int64_t)sig * a.pe, a.P.dec + (int64_t)sig * a.pd, a.P.cx + (int64_t)sig * a.pcx, a.P.cz + (int64_t)sig * a.pcz};
-  float* Mn[4] = {a.M.enc + (int64_t)sig * a.pe, a.M.dec + (int64_t)sig * a.pd, a.M.cx + (int64_t)sig * a.pcx, a.M.cz + (int64_t)sig * a.pcz};
-  float* Vn[4] = {a.V.enc + (int64_t)sig * a.pe, a.V.dec + (int64_t)sig * a.pd, a.V.cx + (int64_t)sig * a.pcx, a.V.cz + (int64_t)sig * a.pcz};
-  const int nwaves = gridDim.x * (THREADS / 64);
-  for (int item = blockIdx.x * (THREADS / 64) + wave; item < tab.total_items; item += nwaves) {
-    int di = 0;                                  // last descriptor with begin <= item: binary search (6 dependent scalar loads, not 60)
-    for (int step2 = 32; step2 > 0; step2 >>= 1) {
-      const int cand = di + step2;
-      if (cand < tab.n && tab.d[cand].begin <= item) di = cand;
-    }
-    const DwDesc& d = tab.d[di];
-    const int local = item - d.begin;
-    float* P = Pn[d.net]; float* M = Mn[d.net]; float* V = Vn[d.net];
-    if (d.kind == DW_WEIGHT) {
+  const int64_t arena = d.net == HYPAD_NET_ENCODER ? a.pe : d.net == HYPAD_NET_DECODER ? a.pd : d.net == HYPAD_NET_CRITIC_X ? a.pcx : a.pcz;
+  auto pick = [&](const hypad_nets& n) __attribute__((always_inline)) {
+    float* base = d.net == HYPAD_NET_ENCODER ? n.enc : d.net == HYPAD_NET_DECODER ? n.dec : d.net == HYPAD_NET_CRITIC_X ? n.cx : n.cz;
+    return base + sig * arena;
+  };
+  if (item < tab.total_items) {
+    const long long dbg_t0 = a.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const int local = item - d.begin;            // may lie in the padding behind the descriptor's last item (checked per kind)
+    float* P = pick(a.P); float* M = pick(a.M); float* V = pick(a.V);
+    if (d.kind == DW_WEIGHT && local < ((d.nrows + 15) >> 4) * ((d.ncols + 15) >> 4)) {
       const int tk = (d.ncols + 15) >> 4;
       const int n0 = (local / tk) * 16, k0 = (local % tk) * 16;
       // out-of-range columns are clamped (their results are dropped below); rows past red_rows contribute zeros
       const int nj = n0 + j < d.nrows ? n0 + j : d.nrows - 1, kj = k0 + j < d.ncols ? k0 + j : d.ncols - 1;
-      const float* left = ws + d.left_off + nj;
-      const float* right = ws + d.right_off + kj;
-      const int rlast = d.red_rows - 1;
+      // Operands through buffer loads: one per-lane byte offset (row q, column nj / kj) plus a scalar row offset per load,
+      // so the ~100 loads of an item cost no vector address arithmetic (with flat addressing that arithmetic took longer
+      // than the memory round trip).  Row offsets are clamped on the scalar side; masked rows contribute zeros below.
+      const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.left_off), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.right_off), 0, 0x7fffffff, 0x00020000);
+      // red_rows is a multiple of 16 (whole batches of B = 16 m rows): the reduction runs in groups of four k-steps, each
+      // entirely in range, so nothing is clamped or masked.
+      const int lvo = (q * d.left_ld + nj) * 4, rvo = (q * d.right_ld + kj) * 4;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       // the optimiser state of this lane's four elements travels with the operand loads (one round trip, not two)
-      int64_t po[4]; float pp[4], pm[4], pvv[4];
+      int po[4]; float pp[4], pm[4], pvv[4];
+      float* Pb = P + d.p_off; float* Mb = M + d.p_off; float* Vb = V + d.p_off;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + 4 * q + r, k = k0 + j;
         const bool ok = n < d.nrows && k < d.ncols;
-        po[r] = ok ? d.p_off + (int64_t)n * d.p_ld + k : -1;
-        const int64_t oc = ok ? po[r] : d.p_off;
-        pp[r] = P[oc]; pm[r] = M[oc]; pvv[r] = V[oc];
+        po[r] = ok ? n * d.p_ld + k : -1;
+        const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
+        pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
       }
-      for (int rc = 0; rc < d.red_rows; rc += 192) {       // 48 k-steps per chunk: B <= 64 -> one memory round trip
+      for (int rc = 0; rc < d.red_rows; rc += 192) {       // up to 48 k-steps in flight: B <= 64 -> one memory round trip
         float la[48], rb[48];
 #pragma unroll
-        for (int u = 0; u < 48; ++u) {
-          const int r = rc + 4 * u + q;
-          const int rr = r < rlast ? r : rlast;
-          la[u] = left[(int64_t)rr * d.left_ld];
-          rb[u] = right[(int64_t)rr * d.right_ld];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < 12; ++c)
+          if (rc + 16 * c < d.red_rows) {                  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 48; ++u)
-          if (rc + 4 * u < d.red_rows)             // wave-uniform
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rc + 4 * u + q < d.red_rows ? la[u] : 0.f, rb[u], acc, 0, 0, 0);
+            for (int u = 4 * c; u < 4 * c + 4; ++u) {
+              la[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, lvo, (rc + 4 * u) * d.left_ld * 4, 0));
+              rb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, (rc + 4 * u) * d.right_ld * 4, 0));
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < 12; ++c)
+          if (rc + 16 * c < d.red_rows) {
+#pragma unroll
+            for (int u = 4 * c; u < 4 * c + 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc, 0, 0, 0);
+          }
       }
       ShadowRef sh{-1, 0, 0, -1, 0, 0, -1, 0};
-      if (tab.finalize == 1) sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
+      if (tab.finalize == 1) sh = shadow_ref(d.net, d.p_off, S_, L_, a.hyperbolic);
       float* pk = ws + a.pk_off;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p = pp[r], m = pm[r], v = pvv[r];
         adam_update(p, m, v, acc[r], co);
         if (po[r] >= 0) {
-          P[po[r]] = p; M[po[r]] = m; V[po[r]] = v;
+          const uint32_t o = (uint32_t)po[r];
+          Pb[o] = p; Mb[o] = m; Vb[o] = v;
           const int nc = sh.nbase + n0 + 4 * q + r, k = k0 + j;            // compact row, column
           if (sh.fwd >= 0) {
             int nf = nc;                                                     // forward copy row: gates padded to 16-row blocks
-            if (sh.gate_H > 0) { const int x = nc / sh.gate_H; nf = x * ((sh.gate_H + 15) & ~15) + nc - x * sh.gate_H; }
+            if (sh.gate_H > 0) nf += ((nc >= sh.gate_H) + (nc >= 2 * sh.gate_H)) * (((sh.gate_H + 15) & ~15) - sh.gate_H);   // nc < 3H
             pk[sh.fwd + (((nf >> 4) * sh.fwd_kg + (k >> 4)) * 64 + (nf & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
           }
           if (sh.bwd >= 0) {
@@ -724,15 +743,15 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
       const int rlast = d.red_rows - 1;
       float g = 0.f;
-      for (int rc = 0; rc < d.red_rows; rc += 64) {
-        float t[16];
+      for (int rc = 0; rc < d.red_rows; rc += 192) {       // 48 rows per lane in flight: B <= 64 -> one memory round trip
+        float t[48];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 48; ++u) {
           const int r = rc + 4 * u + q;
           t[u] = left[(int64_t)(r < rlast ? r : rlast) * d.left_ld];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
+        for (int u = 0; u < 48; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
       }
       g += __shfl_xor(g, 16, WAVE);
       g += __shfl_xor(g, 32, WAVE);
@@ -750,7 +769,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
           bs += p;
         }
         if (tab.finalize == 1) {
-          const ShadowRef sh = shadow_ref(d.net, d.p_off, a.S, a.L, a.hyperbolic);
+          const ShadowRef sh = shadow_ref(d.net, d.p_off, S_, L_, a.hyperbolic);
           if (sh.bsum >= 0) {
             int nf = sh.nbase + n;
             if (sh.gate_H > 0) { const int x = nf / sh.gate_H; nf = x * ((sh.gate_H + 15) & ~15) + nf - x * sh.gate_H; }
@@ -769,26 +788,39 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
           P[o] = p; M[o] = m; V[o] = v;
         }
       }
-    } else {   // DW_BALL: hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
+    } else if (d.kind == DW_BALL && local == 0) {   // hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
       const float* left = ws + d.left_off;
       RowVec g;
 #pragma unroll
       for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
-      for (int r = 0; r < d.red_rows; ++r) {
+      for (int r0 = 0; r0 < d.red_rows; r0 += 8) {           // eight partial rows in flight per round trip (fixed order)
+        float t[8][MAX_EPL];
 #pragma unroll
-        for (int e = 0; e < MAX_EPL; ++e) {
-          int c = lane + 64 * e;
-          if (c < d.nrows) g.v[e] += left[(int64_t)r * d.left_ld + c];
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u < d.red_rows ? r0 + u : d.red_rows - 1;
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) {
+            const int c = lane + 64 * e;
+            t[u][e] = c < d.nrows ? left[(int64_t)r * d.left_ld + c] : 0.f;
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
       }
       radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
+    }
+    if (a.stamps && tab.finalize == 1 && lane == 0 && blockIdx.y == 0 && item < 2000) {   // development aid: per-item kind, start, duration
+      long long* o = a.stamps + 64 + (int64_t)item * 4;
+      o[0] = tab.d[di].kind; o[1] = 0; o[2] = dbg_t0; o[3] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (tab.finalize == 1) {        // generator losses (train.py:232-234, 243-244)
-      const GenWs gw = gen_ws(a.B, a.S, a.L);
+      const GenWs gw = gen_ws(B_, S_, L_);
       float aux = 0.f, fx = 0.f, fz = 0.f;
-      for (int t = 0; t < a.B / 16; ++t) {
+      for (int t = 0; t < B_ / 16; ++t) {
         const float* part = ws + gw.partial + t * 4;
         aux += part[0]; fx += part[1]; fz += part[2];
       }
@@ -800,7 +832,8 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     if (blockIdx.y == 0 && a.tick_owner) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body(a, tab); }
+template <int SC, int LC, int BC>
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body<DwTable, SC, LC, BC>(a, tab); }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
 __global__ __launch_bounds__(THREADS) void dw_adam_pair_kernel(IterArgs ax, DwTableS tx, IterArgs az, DwTableS tz) {
   if (blockIdx.z == 0) dw_adam_body(ax, tx); else dw_adam_body(az, tz);
@@ -810,13 +843,19 @@ __global__ __launch_bounds__(THREADS) void dw_adam_pair_kernel(IterArgs ax, DwTa
 template <class Table>
 struct TableBuilder {
   Table t;
-  TableBuilder() { t.n = 0; t.total_items = 0; t.finalize = 0; }
+  bool overflow = false;
+  TableBuilder() { t.n = 0; t.total_items = 0; t.finalize = 0; for (int i = 0; i < Table::blk / 4; ++i) t.block_desc[i] = 0; }
   void push(DwDesc d, int items) {
     if (items <= 0) return;
-    d.begin = t.total_items;
+    const int start = (t.total_items + 3) & ~3;          // descriptors start on a workgroup boundary
+    const int b0 = start / 4, b1 = (start + items + 3) / 4;
+    if (t.n >= Table::cap || b1 > Table::blk) { overflow = true; return; }
+    d.begin = start;
+    for (int b = b0; b < b1; ++b) t.block_desc[b >> 2] |= (uint32_t)t.n << (8 * (b & 3));
     t.d[t.n++] = d;
-    t.total_items += items;
+    t.total_items = start + items;
   }
+  Table done() { if (overflow) t.n = -1; return t; }
   void weight(int net, int p_off, int p_ld, int nrows, int ncols, int left_off, int left_ld, int right_off, int right_ld, int red) {
     DwDesc d{};
     d.kind = DW_WEIGHT; d.net = (int16_t)net; d.p_off = p_off; d.p_ld = p_ld; d.nrows = nrows; d.ncols = ncols;
@@ -864,7 +903,7 @@ DwTableS critic_table(int net, const CriticLayout& cl, const CritWs& cw, int B, 
     tb.weight(net, cl.w[li], k, n, k, cw.left[li], n, right, k, 3 * B);
     tb.bias(net, cl.b[li], -1, n, cw.left[li], n, 2 * B);      // the GP rows carry no bias gradient
   }
-  return tb.t;
+  return tb.done();
 }
 
 DwTable gen_table(const hypad_dims& dm) {
@@ -891,7 +930,7 @@ DwTable gen_table(const hypad_dims& dm) {
     tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
     tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, 2 * (B / 16));      // per (role, tile) partial column sums
   }
-  return tb.t;
+  return tb.done();
 }
 
 // ------------------------------------------------------------------------------------------------ host: launches
@@ -899,6 +938,7 @@ int check_dims(const hypad_dims* d) {
   if (!d || d->signal_shape <= 0 || d->latent_dim <= 0 || d->batch <= 0 || d->n_signals <= 0) return HYPAD_EINVAL;
   if (d->batch % 16 != 0) return HYPAD_EINVAL;
   if (d->signal_shape > MAX_S || d->latent_dim > MAX_L) return HYPAD_EUNSUPPORTED;
+  if (gen_table(*d).n < 0) return HYPAD_EUNSUPPORTED;      // cannot happen within MAX_S / MAX_L; the critic tables are far smaller
   return HYPAD_OK;
 }
 
@@ -1246,7 +1286,8 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
   const DwTable tab = gen_table(*d);
-  hipLaunchKernelGGL(dw_adam_kernel, dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64>), dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0>), dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
   return HYPAD_OK;
