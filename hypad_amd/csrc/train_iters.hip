@@ -668,7 +668,6 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     return base + sig * arena;
   };
   if (item < tab.total_items) {
-    const long long dbg_t0 = a.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int local = item - d.begin;            // may lie in the padding behind the descriptor's last item (checked per kind)
     float* P = pick(a.P); float* M = pick(a.M); float* V = pick(a.V);
     if (d.kind == DW_WEIGHT && local < ((d.nrows + 15) >> 4) * ((d.ncols + 15) >> 4)) {
@@ -810,10 +809,6 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
           for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
       }
       radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
-    }
-    if (a.stamps && tab.finalize == 1 && lane == 0 && blockIdx.y == 0 && item < 2000) {   // development aid: per-item kind, start, duration
-      long long* o = a.stamps + 64 + (int64_t)item * 4;
-      o[0] = tab.d[di].kind; o[1] = 0; o[2] = dbg_t0; o[3] = (long long)__builtin_amdgcn_s_memtime() - dbg_t0;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
