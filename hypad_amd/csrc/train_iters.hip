@@ -640,7 +640,10 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 
 // SC / LC / BC: compile-time dims of the reference configuration (0 = run-time), which fold the layout arithmetic of
 // shadow_ref() and gen_ws() into constants.
-template <class Table, int SC = 0, int LC = 0, int BC = 0>
+// KS: k-steps (groups of four reduction rows) a weight item keeps in flight: 48 covers B <= 64 in one memory round trip.
+// (16 halves the registers and doubles the waves per SIMD; measured with 8 and 32 signals per GPU it changes nothing --
+// with many signals the launch moves ~9 MB per signal and sits at ~3.5 TB/s of HBM traffic.)
+template <class Table, int SC = 0, int LC = 0, int BC = 0, int KS = 48>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = blockIdx.y;
@@ -695,10 +698,10 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
         const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
         pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
       }
-      for (int rc = 0; rc < d.red_rows; rc += 192) {       // up to 48 k-steps in flight: B <= 64 -> one memory round trip
-        float la[48], rb[48];
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // up to KS k-steps in flight
+        float la[KS], rb[KS];
 #pragma unroll
-        for (int c = 0; c < 12; ++c)
+        for (int c = 0; c < KS / 4; ++c)
           if (rc + 16 * c < d.red_rows) {                  // wave-uniform
 #pragma unroll
             for (int u = 4 * c; u < 4 * c + 4; ++u) {
@@ -707,7 +710,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
             }
           }
 #pragma unroll
-        for (int c = 0; c < 12; ++c)
+        for (int c = 0; c < KS / 4; ++c)
           if (rc + 16 * c < d.red_rows) {
 #pragma unroll
             for (int u = 4 * c; u < 4 * c + 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc, 0, 0, 0);
@@ -742,15 +745,15 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
       const int rlast = d.red_rows - 1;
       float g = 0.f;
-      for (int rc = 0; rc < d.red_rows; rc += 192) {       // 48 rows per lane in flight: B <= 64 -> one memory round trip
-        float t[48];
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // KS rows per lane in flight
+        float t[KS];
 #pragma unroll
-        for (int u = 0; u < 48; ++u) {
+        for (int u = 0; u < KS; ++u) {
           const int r = rc + 4 * u + q;
           t[u] = left[(int64_t)(r < rlast ? r : rlast) * d.left_ld];
         }
 #pragma unroll
-        for (int u = 0; u < 48; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
+        for (int u = 0; u < KS; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
       }
       g += __shfl_xor(g, 16, WAVE);
       g += __shfl_xor(g, 32, WAVE);
@@ -827,8 +830,8 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     if (blockIdx.y == 0 && a.tick_owner) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
-template <int SC, int LC, int BC>
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body<DwTable, SC, LC, BC>(a, tab); }
+template <int SC, int LC, int BC, int KS>
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab); }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
 __global__ __launch_bounds__(THREADS) void dw_adam_pair_kernel(IterArgs ax, DwTableS tx, IterArgs az, DwTableS tz) {
   if (blockIdx.z == 0) dw_adam_body(ax, tx); else dw_adam_body(az, tz);
@@ -1268,21 +1271,24 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
     if (rc) return rc;
   }
   HYPAD_MARK(ev, 0, s);
-  const bool ref_cfg = a.S == 100 && a.L == 20 && a.B == 64;          // BASELINE.json configs[0..1]
+  const bool ref_cfg = a.S == 100 && a.L == 20 && a.B == 64;          // BASELINE.json configs[0..2]
+  const bool mv_cfg = a.S == 150 && a.L == 20 && a.B == 256;          // configs[3]: 5 channels x 30, batch 256
 #define HYPAD_LAUNCH_GEN(...)                                                     \
   do {                                                                           \
     hipError_t e = allow_lds((const void*)gen_kernel<__VA_ARGS__>, lds);         \
     if (e != hipSuccess) return (int)e;                                          \
     hipLaunchKernelGGL((gen_kernel<__VA_ARGS__>), grid, dim3(TB), lds, s, a);    \
   } while (0)
-  if (a.hyperbolic) { if (ref_cfg) HYPAD_LAUNCH_GEN(true, 100, 20, 64); else HYPAD_LAUNCH_GEN(true, 0, 0, 0); }
+  if (a.hyperbolic) { if (ref_cfg) HYPAD_LAUNCH_GEN(true, 100, 20, 64); else if (mv_cfg) HYPAD_LAUNCH_GEN(true, 150, 20, 256); else HYPAD_LAUNCH_GEN(true, 0, 0, 0); }
   else { if (ref_cfg) HYPAD_LAUNCH_GEN(false, 100, 20, 64); else HYPAD_LAUNCH_GEN(false, 0, 0, 0); }
 #undef HYPAD_LAUNCH_GEN
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
   const DwTable tab = gen_table(*d);
-  if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64>), dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
-  else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0>), dim3(dw_blocks(tab.total_items), d->n_signals), dim3(THREADS), 0, s, a, tab);
+  const dim3 dgrid(dw_blocks(tab.total_items), d->n_signals);
+  if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+  else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+  else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
   return HYPAD_OK;
