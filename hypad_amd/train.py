@@ -142,6 +142,13 @@ def decoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_dec, p
     return losses[0, 0].clone(), 0, losses[0, 1].clone()
 
 
+def encoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_enc, params, err_loss=None, z=None, dropout_masks=None):
+    """The name BASELINE.json's north_star uses for the generator step.  The reference has no live function of this name
+    (its call is commented out at train.py:348): ``decoder_iteration`` updates the encoder *and* the decoder
+    with one optimizer, and this is that function under the other name."""
+    return decoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_enc, params, err_loss, z, dropout_masks)
+
+
 def _set_requires_grad(modules, flag):
     for m in modules:
         for p in m.parameters():
