@@ -167,6 +167,28 @@ def bench_scoring(device, n=125_000, reps=5):
             "note": "row-wise ball ops: algorithmic bytes (800-1204 B/row at S=100) / time; includes the output allocation of the torch-facing wrappers"}
 
 
+def bench_scoring_sharded(device, world, per_gpu=125_000, reps=3):
+    """configs[4] across the ranks (opt-in: --sharded-scoring): 125 000 windows per GPU of one long series, every rank scoring
+    its window range (+ halo) and all-gathering the per-window / per-timestep vectors (hypad_amd/parallel.py).  All ranks call this."""
+    from hypad_amd import parallel as par
+    from hypad_amd.models import tadgan
+    torch.manual_seed(0)                                                  # the same weights on every rank
+    enc, dec, cx = tadgan.Encoder(S, L).to(device).eval(), tadgan.Decoder(S, L, True).to(device).eval(), tadgan.CriticX(S, L).to(device).eval()
+    n = per_gpu * world
+    g = torch.Generator(device=device).manual_seed(3)
+    series = (torch.rand(n + S - 1, device=device, generator=g) * 2 - 1).contiguous()
+    par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scores = par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert scores.shape == (n,) and np.isfinite(scores).all()
+    return {"windows": n, "value": n / dt, "unit": "windows/s", "what": "forward + row-wise Poincare distance + KDE critic modes sharded by window "
+            "range; all-gather; quantile z-score, rolling mean, combination 'mult' on the full vectors (every rank)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +198,7 @@ def main():
     ap.add_argument("--euclidean", action="store_true", help="configs[0]-style hyperbolic=False instead of configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
+    ap.add_argument("--sharded-scoring", action="store_true", help="also time configs[4]-style scoring sharded over all ranks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,6 +281,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    sharded = bench_scoring_sharded(device, world) if args.sharded_scoring else None
     if rank == 0:
         windows = world * spg * N_BATCHES * B * args.steps
         out = {
@@ -285,6 +309,8 @@ def main():
         }
         if not args.no_scoring:
             out["scoring"] = bench_scoring(device)
+        if sharded is not None:
+            out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hyperbolic)
         print(json.dumps(out))

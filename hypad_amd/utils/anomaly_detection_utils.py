@@ -128,14 +128,16 @@ def row_norms(x):
     return out
 
 
-def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[]):
-    """:336-362."""
+def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[], norms=None):
+    """:336-362.  ``norms``: the row norms of ``recons_signal`` when the caller already has them (sharded scoring)."""
     if combination not in ("sum", "mult", "uncertainty", "critic", "critic_uncertainty", "sum_uncertainty", "rec", "rec_uncertainty"):
         raise ValueError(combination)
     c = _f64(critic_scores) if len(critic_scores) else None
     r = _f64(rec_scores) if len(rec_scores) else None
     n = (r if r is not None else c).numel()
-    u = row_norms(recons_signal)[:n].contiguous() if "uncertainty" in combination else None
+    u = None
+    if "uncertainty" in combination:
+        u = (_f64(norms) if norms is not None else row_norms(recons_signal))[:n].contiguous()
     if c is not None:
         c = c[:n].contiguous()
     out = torch.empty(n, device=_dev(), dtype=torch.float64)

@@ -61,3 +61,48 @@ def test_partition_helpers_cover_everything_once():
         assert max(e - b for b, e in ranges) - min(e - b for b, e in ranges) <= 1
         owned = sorted(s for r in range(w) for s in par.signals_of_rank(n if n < 100 else 64, w, r))
         assert owned == list(range(n if n < 100 else 64))
+
+
+def _score_worker(rank, world, port, n_windows, window, combination, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import math
+        from oracle import scoring
+        rng = np.random.default_rng(1)                                     # the same "model outputs" on every rank
+        rowdist_all, critic_all = rng.random(n_windows), rng.standard_normal(n_windows)
+        recons_all = rng.standard_normal((n_windows, window))
+        calls = []
+
+        def evaluate(lo, hi):
+            calls.append((lo, hi))
+            return {"rowdist": torch.from_numpy(rowdist_all[lo:hi]), "critic": torch.from_numpy(critic_all[lo:hi]),
+                    "norms": torch.from_numpy(np.linalg.norm(recons_all[lo:hi], axis=1))}
+
+        def kde_modes(critic, w):
+            ext = np.repeat(critic.numpy().reshape(-1, 1), w, axis=1)
+            return torch.tensor([scoring.kde_mode(scoring.antidiagonal(ext, i)) for i in range(len(ext) + w - 1)], dtype=torch.float64)
+
+        def finish(rowdist, modes, norms):
+            crit = scoring.compute_critic_score(modes.numpy(), math.trunc(n_windows * 0.01))[:n_windows]
+            fake = np.zeros((n_windows, 1)) if norms is None else norms.numpy().reshape(-1, 1)     # ||row|| == |value|
+            return scoring.combine_scores(combination, crit, rowdist.numpy(), np.abs(fake))
+
+        got = par.sharded_hyperbolic_scores(n_windows, window, evaluate, kde_modes, finish, "uncertainty" in combination)
+        want = scoring.combine_scores(combination, scoring.final_critic_scores(critic_all, n_windows, window)[:n_windows], rowdist_all,
+                                      recons_all)
+        assert np.array_equal(got, want), "sharded scores differ from the unsharded ones"
+        b, e = par.window_range(n_windows, world, rank)
+        assert calls == [(max(0, b - window + 1), e)]                      # own range + halo, evaluated once
+        ret[rank] = float(got.sum())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_hyperbolic_scores_equal_unsharded():
+    """BASELINE.json configs[4] partitioning: window ranges + re-computed halo + all-gather; bit-equal to one rank."""
+    for combination in ("mult", "sum_uncertainty"):
+        port = _free_port()
+        ret = mp.Manager().dict()
+        mp.spawn(_score_worker, args=(2, port, 157, 20, combination, ret), nprocs=2, join=True)
+        assert ret[0] == ret[1]

@@ -1054,3 +1054,36 @@ def test_training_trajectory_tracks_the_cpu_path(dev, hyper):
     e_cpu, e_dev = float(((rec_cpu - xt) ** 2).mean()), float(((rec_dev - xt) ** 2).mean())
     print("evaluated reconstruction mse, device:", e_dev, "cpu:", e_cpu)
     assert 0.5 < e_dev / e_cpu < 2.0, (e_dev, e_cpu)
+
+
+@pytest.mark.gpu
+def test_score_windows_sharded_equals_unsharded_pipeline(dev):
+    """parallel.score_windows_sharded (window ranges + halo + all-gather; here one rank) returns what test_tadgan ->
+    hyperbolic_scores returns on the same windows, from the window matrix and from the series view; a two-"rank"
+    evaluation stitched by hand (the ranges the ranks would take) reproduces it bit for bit."""
+    from hypad_amd import anomaly_detection as had, parallel as par
+    from hypad_amd.models import tadgan
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    S, n = 100, 517
+    torch.manual_seed(5)
+    enc, dec, cx = tadgan.Encoder(S, 20).cuda().eval(), tadgan.Decoder(S, 20, True).cuda().eval(), tadgan.CriticX(S, 20).cuda().eval()
+    with torch.no_grad():
+        dec.hyperbolic_linear.weight.mul_(30)
+    series = (torch.rand(n + S - 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 2 - 1).contiguous()
+    x = series.unfold(0, S, 1).contiguous()
+    loader = [x[i:i + 64].cpu().double().unsqueeze(-1) for i in range(0, n, 64)]
+    recons, true_hyper, critic = had.test_tadgan(loader, enc, dec, cx, signal_shape=S)
+    for comb in ("mult", "sum_uncertainty"):
+        want = adu.hyperbolic_scores(recons, true_hyper, critic, S, comb)
+        got_m = par.score_windows_sharded(x, enc, dec, cx, S, comb)
+        got_s = par.score_windows_sharded(series, enc, dec, cx, S, comb, x_row_stride=1)
+        assert got_m.shape == (n,) and np.array_equal(got_m, got_s)
+        np.testing.assert_allclose(got_m, want, rtol=1e-6, atol=1e-9)
+    # what two ranks would evaluate: [0, e0) and [b1 - 99, n); stitched, the per-window and per-timestep vectors are the one-rank ones
+    full = adu.kde_modes(torch.as_tensor(np.asarray(critic)), S)
+    for rank in range(2):
+        b, e = par.window_range(n, 2, rank)
+        hb, he = par.window_range_with_halo(n, 2, rank, S)
+        tb, te = par.timestep_range(n, 2, rank, S)
+        local = adu.kde_modes(torch.as_tensor(np.asarray(critic[hb:he])), S)
+        assert torch.equal(local[tb - hb: te - hb], full[tb:te])
