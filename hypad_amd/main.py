@@ -24,15 +24,26 @@ def run(params, config_path=None, data_dir="./data", drop_in=False, log=print):
 
     log("dataset: {}, signal: {}".format(params.dataset, params.signal))
     train_dataset, test_dataset, read_path = od.dataset_selection(params, data_dir)
+    multivariate = hasattr(train_dataset, "device_windows")            # utils/dataloader_multivariate.py datasets
     if drop_in:
         train_loader = DataLoader(train_dataset, batch_size=params.batch_size, drop_last=True, shuffle=True, num_workers=0)
         encoder, decoder, critic_x, _, path = ht.train(train_loader, params, config_path)
     else:
-        encoder, decoder, critic_x, _, path, _ = ht.train_resident(train_dataset, params, config_path, log=log)
+        resident = train_dataset.device_windows("cpu") if multivariate else train_dataset
+        encoder, decoder, critic_x, _, path, _ = ht.train_resident(resident, params, config_path, log=log)
     test_loader = DataLoader(test_dataset, batch_size=params.batch_size, drop_last=False, shuffle=False, num_workers=0)
     recons_signal, true_signal, critic_score = anomaly_detection.test_tadgan(
         test_loader, encoder, decoder, critic_x, read_path=read_path, signal=params.signal, path=path, signal_shape=params.signal_shape,
         params=params)
+    if params.signal == "multivariate" or multivariate:                 # anomaly_detection.py:137-140
+        # the reference torch.load()s the labels from its data tree (utils/anomaly_detection_utils.py:143-151); the test
+        # dataset already holds that tensor
+        y = test_dataset.y if len(getattr(test_dataset, "y", [])) else None
+        out = adu.multivariate_anomaly_detection(recons_signal, true_signal, params, params.combination, critic_score, path, y=y)
+        log("predicted intervals:\n{}".format(out["intervals"]))
+        if out.get("metrics"):
+            log("precision: {precision}, recall: {recall}\nf1_score: {f1}, gmean: {gmean}".format(**out["metrics"]))
+        return out
     if params.dataset in ("A1", "A2", "A3", "A4"):                       # anomaly_detection.py:32-37
         known = pd.read_csv(read_path[:-4] + "_known_anomalies.csv")
     else:

@@ -3,13 +3,17 @@
 ``load_anomalies`` (:227-249) and ``dataset_selection`` (:252-379) with the reference's file layout under ``data_dir``
 (default ``./data``: ``<signal>.csv``, ``<signal>-train.csv`` / ``<signal>-test.csv``, ``YAHOO/<A?>Benchmark/<signal>.csv``,
 ``anomalies.csv``).  The S3 download fallback of the reference (:200-224) is not reproduced -- files must be local -- and
-the multivariate branches (CASAS / SWAT / WADI tensors that are not part of the reference tree) raise."""
+the multivariate branches take the reference's relative file layout from ``data_dir`` too (``DATASETS/<name>/...``, ``SWAT/``,
+``WADI_downsampled/``; the tensors themselves are not part of the reference tree).  ``CASAS_`` / ``new_CASAS`` carry the
+placeholder roots ``path_to_CASAS`` / ``path_to_new_CASAS`` in the reference (:260,276): here the root is
+``params.casas_root`` when given, else that same placeholder."""
 import json
 import os
 
 import numpy as np
 
 from .dataloader import SignalDataset
+from .dataloader_multivariate import MultivariateDataset
 
 __all__ = ["load_csv", "load_anomalies", "dataset_selection"]
 
@@ -38,9 +42,31 @@ def load_anomalies(signal, edges=False, data_dir="./data"):
 
 
 def dataset_selection(params, data_dir="./data"):
-    """(train_dataset, test_dataset, read_path) for the univariate branches of utils/data.py:252-379."""
-    if params.dataset in ("CASAS_", "new_CASAS", "SWAT", "WADI", "CASAS", "ELINUS", "eHealth"):
-        raise NotImplementedError(f"dataset {params.dataset!r}: multivariate tensors are not part of the reference tree")
+    """(train_dataset, test_dataset, read_path), utils/data.py:252-379."""
+    ds = params.dataset
+    if ds == "CASAS_":                                                  # original CASAS, test == train (:259-271)
+        root = getattr(params, "casas_root", "path_to_CASAS")
+        seq, gt = root + "sequences_2week_{}.pt".format(params.signal), root + "ground_truth_2week_{}.pt".format(params.signal)
+        return (MultivariateDataset(seq_path=seq, gt_path=gt, split=params.split, dataset="CASAS_"),
+                MultivariateDataset(seq_path=seq, gt_path=gt, test=True, dataset="CASAS_"), "")
+    if ds == "new_CASAS":                                               # :274-287
+        root = getattr(params, "casas_root", "path_to_new_CASAS") + params.signal
+        return (MultivariateDataset(seq_path=root, gt_path=root, split=params.split, dataset=ds),
+                MultivariateDataset(seq_path=root, gt_path=root, test=True, dataset=ds), "")
+    if ds in ("SWAT", "WADI"):                                          # :289-297
+        return MultivariateDataset(dataset=ds, data_dir=data_dir), MultivariateDataset(test=True, dataset=ds, data_dir=data_dir), ""
+    if ds in ("CASAS", "ELINUS", "eHealth"):                            # :299-327
+        base = os.path.join(data_dir, "DATASETS", ds)
+        if not params.new_features:
+            seq = os.path.join(base, "normal_sequences.pt")
+            seq_test = os.path.join(base, "POINTS", params.signal, "{}_sequences_id{}.pt".format(params.signal, params.id))
+            gt = os.path.join(base, "POINTS", params.signal, "{}_groundtruth_id{}.pt".format(params.signal, params.id))
+        else:
+            seq = os.path.join(base, "normal_sequences_newfeatures.pt")
+            seq_test = os.path.join(base, "POINTS_NEWFEATURES", "{}_sequences_newfeatures.pt".format(params.signal))
+            gt = os.path.join(base, "POINTS_NEWFEATURES", "{}_groundtruth_newfeatures.pt".format(params.signal))
+        return (MultivariateDataset(seq_path=seq, gt_path=gt, split=params.split, dataset=ds),
+                MultivariateDataset(seq_path=seq_test, gt_path=gt, test=True, dataset=ds), "")
     if getattr(params, "unique_dataset", False):                       # train == test
         read_path = os.path.join(data_dir, "{}.csv".format(params.signal))
         return (SignalDataset(path=read_path, interval=params.interval),

@@ -454,9 +454,79 @@ def gen_dataloader():
     np.savez_compressed(os.path.join(HERE, "dataloader.npz"), **out)
 
 
+def gen_multivariate():
+    """utils/dataloader_multivariate.py:16-121 on synthetic tensors / CSVs written to a temporary directory (the reference
+    reads the SWaT / WADI files relative to the working directory, so it is run from there)."""
+    import tempfile
+    import pandas as pd
+    import utils.dataloader_multivariate as ref_mv
+    rng = np.random.default_rng(11)
+    out = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            # CASAS / ELINUS / eHealth: (n, 5, 30) sequences -> (n, 150), MinMax per column; one constant column
+            seq = rng.standard_normal((97, 5, 30)).astype(np.float32) * 3 + 1
+            seq[:, 2, 7] = 0.25
+            gt = (rng.random(97) < 0.1).astype(np.int64)
+            torch.save(torch.from_numpy(seq), "seq.pt"); torch.save(torch.from_numpy(gt), "gt.pt")
+            for test in (False, True):
+                ds = ref_mv.MultivariateDataset(seq_path="seq.pt", gt_path="gt.pt", test=test, dataset="CASAS")
+                out[f"mv_casas_X_{int(test)}"] = np.asarray(ds.X)
+            out.update(mv_casas_seq=seq, mv_casas_gt=gt)
+            # new_CASAS: directory with x_train / y_train / x_test / y_test
+            os.makedirs("nc")
+            for part, n in (("train", 64), ("test", 41)):
+                xx = rng.uniform(-5, 9, (n, 150)).astype(np.float32)
+                yy = (rng.random(n) < 0.2).astype(np.int64)
+                torch.save(torch.from_numpy(xx), f"nc/x_{part}"); torch.save(torch.from_numpy(yy), f"nc/y_{part}")
+                ds = ref_mv.MultivariateDataset(seq_path="nc", gt_path="nc", test=(part == "test"), dataset="new_CASAS")
+                out.update({f"mv_nc_x_{part}": xx, f"mv_nc_y_{part}": yy, f"mv_nc_X_{part}": np.asarray(ds.X)})
+            # CASAS_: (a, b, 5) rows, first 4500 dropped, train = rows before (first anomaly - 1000), test = +-1000 around them
+            X = rng.standard_normal((80, 100, 5)).astype(np.float32)
+            y = np.zeros((80, 100, 1), dtype=np.int64)
+            y.reshape(-1)[6520:6621] = 1
+            torch.save(torch.from_numpy(X), "cX.pt"); torch.save(torch.from_numpy(y), "cy.pt")
+            for test in (False, True):
+                ds = ref_mv.MultivariateDataset(seq_path="cX.pt", gt_path="cy.pt", test=test, dataset="CASAS_")
+                out[f"mv_casas__X_{int(test)}"] = np.asarray(ds.X)
+                out[f"mv_casas__y_{int(test)}"] = np.asarray(ds.y)
+            out.update(mv_casas__seq=X, mv_casas__gt=y)
+            # SWaT / WADI CSVs with gaps
+            os.makedirs("data/SWAT"); os.makedirs("data/WADI_downsampled")
+            def frame(n, k, seed):
+                r = np.random.default_rng(seed)
+                a = r.standard_normal((n, k)) * r.uniform(0.5, 20, k) + r.uniform(-3, 3, k)
+                a[r.random((n, k)) < 0.03] = np.nan
+                a[:, 1] = 4.0
+                return pd.DataFrame(a, columns=[f"f{i}" for i in range(k)])
+            tr, te = frame(120, 6, 1), frame(90, 6, 2)
+            tr.insert(0, "Timestamp", np.arange(120)); tr["Normal/Attack"] = "Normal"
+            te.insert(0, "Timestamp", np.arange(90)); te["Normal/Attack"] = "Attack"; te["label"] = 1
+            tr.to_csv("data/SWAT/SWaT_train_mine.csv"); te.to_csv("data/SWAT/SWaT_test_mine.csv")
+            wtr, wte = frame(110, 7, 3), frame(70, 7, 4)
+            wte.insert(0, "Time", np.arange(70)); wte["label"] = 0
+            wtr.to_csv("data/WADI_downsampled/WADI_train.csv", index=False); wte.to_csv("data/WADI_downsampled/WADI_test_mine.csv", index=False)
+            for name in ("SWAT", "WADI"):
+                for test in (False, True):
+                    ds = ref_mv.MultivariateDataset(test=test, dataset=name)
+                    out[f"mv_{name}_X_{int(test)}"] = np.asarray(ds.X)
+            for rel in ("data/SWAT/SWaT_train_mine.csv", "data/SWAT/SWaT_test_mine.csv", "data/WADI_downsampled/WADI_train.csv",
+                        "data/WADI_downsampled/WADI_test_mine.csv"):
+                out["mv_csv_" + os.path.basename(rel)[:-4]] = np.array(open(rel).read())
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "multivariate.npz"), **out)
+
+
 if __name__ == "__main__":
     import pandas
     import scipy
+    if len(sys.argv) > 1 and sys.argv[1] == "multivariate":
+        gen_multivariate()
+        print("multivariate.npz written")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "dataloader":
         gen_dataloader()
         print("dataloader.npz written")
