@@ -44,49 +44,49 @@ def _load(path):
     return t
 
 
+# CSV-backed sets: sub-directory, (train file, test file), read_csv keywords, (columns dropped for train, for test)  (:72-108)
+_CSV_SETS = {
+    "SWAT": ("SWAT", ("SWaT_train_mine.csv", "SWaT_test_mine.csv"), {"index_col": 0},
+             (["Timestamp", "Normal/Attack"], ["Timestamp", "Normal/Attack", "label"])),
+    "WADI": ("WADI_downsampled", ("WADI_train.csv", "WADI_test_mine.csv"), {}, ([], ["Time", "label"])),
+}
+_TENSOR_SETS = ("CASAS", "ELINUS", "eHealth")           # one tensor of windows + one of labels, test == train (:65-69)
+
+
+def _windows(t, width=150):
+    """Tensor of samples -> (n, 150) float64 array: 5 channels x 30 samples per window (:66)."""
+    return np.asarray(t.reshape(-1, width))
+
+
 class MultivariateDataset:
     """utils/dataloader_multivariate.py:16-121."""
 
     def __init__(self, seq_path=None, gt_path=None, test=False, split=1, dataset="CASAS", data_dir="./data"):
-        import pandas as pd
-        self.test = test
-        if dataset == "CASAS_":
-            self.X = _load(seq_path)
-            self.y = _load(gt_path)
-            self.X = self.X.reshape(self.X.shape[0] * self.X.shape[1], -1)[4500:]
-            self.y = self.y.reshape(self.y.shape[0] * self.y.shape[1], -1)[4500:]
-            ynp = np.asarray(self.y)
-            init = np.where(ynp == 1)[0][0] - 1000
-            end = np.where(ynp == 1)[0][-1] + 1000
-            if self.test:
-                print("total length: {}, test length: {}, train length: {}".format(self.y.shape[0], end - init,
-                                                                                   self.y.shape[0] - (end - init)))
-                self.y = self.y[init:end]
-                self.X = self.X[init:end].reshape(-1, 150)
-            else:
-                self.y = self.y[:init]
-                self.X = self.X[:init].reshape(-1, 150)
-        elif dataset == "new_CASAS":
-            part = "test" if self.test else "train"
-            self.X = _minmax_m11(np.asarray(_load(os.path.join(seq_path, "x_" + part)).reshape(-1, 150)))
+        self.test = bool(test)
+        which = int(self.test)
+        if dataset in _TENSOR_SETS:
+            self.X, self.y = _minmax_m11(_windows(_load(seq_path))), _load(gt_path)
+        elif dataset == "new_CASAS":                                     # a directory holding x_/y_ train and test (:52-63)
+            part = ("train", "test")[which]
+            self.X = _minmax_m11(_windows(_load(os.path.join(seq_path, "x_" + part))))
             self.y = _load(os.path.join(seq_path, "y_" + part))
-        elif dataset in ("CASAS", "ELINUS", "eHealth"):                  # test == train
-            self.X = _minmax_m11(np.asarray(_load(seq_path).reshape(-1, 150)))
-            self.y = _load(gt_path)
-        elif dataset == "SWAT":
-            self.y = []        # the reference never sets y in the SWaT / WADI branches, so its test items raise AttributeError
-            if not self.test:
-                X = pd.read_csv(os.path.join(data_dir, "SWAT", "SWaT_train_mine.csv"), index_col=0).drop(["Timestamp", "Normal/Attack"], axis=1)
-            else:
-                X = pd.read_csv(os.path.join(data_dir, "SWAT", "SWaT_test_mine.csv"), index_col=0).drop(["Timestamp", "Normal/Attack", "label"], axis=1)
-            self.X = _minmax_m11(_impute_mean(X.values))
-        elif dataset == "WADI":
-            self.y = []
-            if not self.test:
-                X = pd.read_csv(os.path.join(data_dir, "WADI_downsampled", "WADI_train.csv"))
-            else:
-                X = pd.read_csv(os.path.join(data_dir, "WADI_downsampled", "WADI_test_mine.csv")).drop(["Time", "label"], axis=1)
-            self.X = _minmax_m11(_impute_mean(X.values))
+        elif dataset in _CSV_SETS:
+            import pandas as pd
+            sub, files, kw, drops = _CSV_SETS[dataset]
+            frame = pd.read_csv(os.path.join(data_dir, sub, files[which]), **kw).drop(drops[which], axis=1)
+            self.X = _minmax_m11(_impute_mean(frame.values))
+            self.y = []        # the reference never sets y in these branches, so its test items raise AttributeError
+        elif dataset == "CASAS_":
+            # legacy two-week recordings (:27-50): rows flattened, the first 4 500 dropped; training = everything up to 1 000
+            # rows before the first labelled anomaly, test = from there to 1 000 rows past the last one.  Not rescaled.
+            rows = lambda t: t.reshape(t.shape[0] * t.shape[1], -1)[4500:]
+            X, y = rows(_load(seq_path)), rows(_load(gt_path))
+            hits = np.where(np.asarray(y) == 1)[0]
+            lo, hi = hits[0] - 1000, hits[-1] + 1000
+            if self.test:
+                print("total length: {}, test length: {}, train length: {}".format(y.shape[0], hi - lo, y.shape[0] - (hi - lo)))
+            span = slice(lo, hi) if self.test else slice(None, lo)
+            self.X, self.y = X[span].reshape(-1, 150), y[span]
         else:
             print("Dataset not supported")
             sys.exit(0)
