@@ -224,6 +224,7 @@ struct DecSave {           // global workspace rows for this tile (null = do not
   float* mask;             // [rows][2*DEC_H]   dropout keep-scale
   float* g1;               // [rows][8*DEC_H]
   float* h1;               // [rows][2*DEC_H]
+  long long* stamps = nullptr;   // development aid
 };
 // Zs [rows][LP] -> tanh output E in bufA [rows][ldS].  bufA/bufB: LDS, each >= rows * max(ldS, 6*DEC_H + 4).
 // drop: inter-layer dropout (p = 0.2, models/tadgan.py:37); grow(r) = batch row of tile row r for the mask.
@@ -275,15 +276,37 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
 // the gates of one (row, unit) meet in one lane's registers -- and applies c = sig(i) tanh(g), h = sig(o) tanh(c) right
 // there.  No gate tile in LDS, no separate cell pass, no barrier in between.
 // Hs[rows][ldh] <- [h_fwd | h_rev]; gates_save as in lstm_cell_tile.  pb: summed biases, gate x of unit u at x up16(H) + u.
-template <int MT>
+// The first batch of weights of a wave's first task, requested ahead of time (weights do not depend on activations): the
+// caller issues lstm_layer_prefetch() before the previous stage's epilogue / barrier and the layer starts with its
+// operands already in registers instead of an L2 round trip.
+struct LstmPre { float4 bi[4], bg[4], bo[4]; };
+__device__ __forceinline__ LstmPre lstm_layer_prefetch(const float* __restrict__ pk0, const float* __restrict__ pk1, int H, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
+  const int task = wave < 2 * nb ? wave : 0;
+  const int d = task / nb, ub = task - d * nb;
+  const float4* wi = reinterpret_cast<const float4*>(d ? pk1 : pk0) + (size_t)ub * kg * 64 + lane;
+  const float4* wg = wi + (size_t)nb * kg * 64;
+  const float4* wo = wg + (size_t)nb * kg * 64;
+  LstmPre p;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t o = (size_t)(u < kg ? u : kg - 1) * 64;
+    p.bi[u] = wi[o]; p.bg[u] = wg[o]; p.bo[u] = wo[o];
+  }
+  return p;
+}
+template <int MT, bool PRE = false>
 __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ As, int lda, int K, const float* __restrict__ pk0,
                                                       const float* __restrict__ pb0, const float* __restrict__ pk1,
                                                       const float* __restrict__ pb1, int H, float* __restrict__ Hs, int ldh,
-                                                      float* __restrict__ gates_save, int valid, int ps = 16) {
+                                                      float* __restrict__ gates_save, int valid, int ps = 16,
+                                                      const LstmPre& pre = LstmPre{}) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
-  for (int task = wave; task < 2 * nb; task += nwaves) {
+  // one task = 16 units of one direction: the i, g, o gate tiles side by side, the cell in the epilogue
+  auto run = [&](int task, auto first_from_pre) __attribute__((always_inline)) {
     const int d = task / nb, ub = task - d * nb;
     const float4* wi = reinterpret_cast<const float4*>(d ? pk1 : pk0) + (size_t)ub * kg * 64 + lane;
     const float4* wg = wi + (size_t)nb * kg * 64;
@@ -292,14 +315,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     f32x4 ai[MT], ag[MT], ao[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { ai[m] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[m] = ai[m]; ao[m] = ai[m]; }
-    for (int g0 = 0; g0 < kg; g0 += 4) {
-      float4 bi[4], bg[4], bo[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const size_t o = (size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64;
-        bi[u] = wi[o]; bg[u] = wg[o]; bo[u] = wo[o];
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    auto consume = [&](const float4 (&bi)[4], const float4 (&bg)[4], const float4 (&bo)[4], int g0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (g0 + u < kg) {                             // wave-uniform
@@ -324,6 +340,36 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           }
         }
       }
+    };
+    auto fetch = [&](float4 (&bi)[4], float4 (&bg)[4], float4 (&bo)[4], int g0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64;
+        bi[u] = wi[o]; bg[u] = wg[o]; bo[u] = wo[o];
+      }
+    };
+    if constexpr (decltype(first_from_pre)::value) {
+      // latency-chain callers: the first batch is already in registers (lstm_layer_prefetch), and two batches of four
+      // k-groups stay in flight -- the next one is requested before the current one is consumed
+      float4 xi[4], xg[4], xo[4], yi[4], yg[4], yo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { xi[u] = pre.bi[u]; xg[u] = pre.bg[u]; xo[u] = pre.bo[u]; }
+      for (int g0 = 0; g0 < kg; g0 += 8) {
+        if (g0 + 4 < kg) fetch(yi, yg, yo, g0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(xi, xg, xo, g0);
+        if (g0 + 8 < kg) fetch(xi, xg, xo, g0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g0 + 4 < kg) consume(yi, yg, yo, g0 + 4);
+      }
+    } else {
+      // throughput callers (many workgroups per CU hide the latency): one batch in flight, half the registers
+      for (int g0 = 0; g0 < kg; g0 += 4) {
+        float4 bi[4], bg[4], bo[4];
+        fetch(bi, bg, bo, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(bi, bg, bo, g0);
+      }
     }
     const int jj = 16 * ub + j;
     if (jj < H) {
@@ -342,33 +388,54 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           }
         }
     }
-  }
+  };
+  if (wave < 2 * nb) run(wave, std::integral_constant<bool, PRE>{});
+  for (int task = wave + nwaves; task < 2 * nb; task += nwaves) run(task, std::false_type{});
 }
 
+// PRE: the caller requested the layer's first weights earlier (lstm_layer_prefetch on gp.enc_g) and passes them in.
+template <bool PRE = false>
 __device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx, int S, int L, const float* pk, const GenPack& gp,
                                                         float* bufG, int ldg, float* bufH, int ldh, float* Zs,
-                                                        float* gates_save, float* h_save, int valid) {
+                                                        float* gates_save, float* h_save, int valid, const LstmPre& pre = LstmPre{}) {
   (void)bufG; (void)ldg;
-  lstm_layer_fwd_packed<1>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
-                           gates_save, valid);
+  PackedPre pred{};
+  if constexpr (PRE) pred = gemm_nt_prefetch(pk + gp.enc_d, 2 * ENC_H, L);        // the dense layer's weights, one stage ahead
+  lstm_layer_fwd_packed<1, PRE>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
+                                gates_save, valid, 16, pre);
   __syncthreads();
   if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
-  gemm_nt_packed<1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0);
+  gemm_nt_packed<1, PRE>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
   __syncthreads();
 }
-template <int MT, class RowFn>
-__device__ __forceinline__ void decoder_trunk_fwd_tile_packed(const float* Zs, int L, int S, const float* pk, const GenPack& gp,
-                                                              float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
-                                                              const DecSave& sv, int valid) {
+// PRE: the caller requested d1's first weights earlier (gemm_nt_prefetch on gp.d1) and passes them in.  next_W (may be
+// null): packed weights of the product that follows the trunk; their first batch is requested before the last product
+// here and returned.
+template <int MT, bool PRE = false, class RowFn>
+__device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* Zs, int L, int S, const float* pk, const GenPack& gp,
+                                                                   float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
+                                                                   const DecSave& sv, int valid, const PackedPre& pred1 = PackedPre{},
+                                                                   const float* next_W = nullptr, int next_K = 0, int next_N = 0) {
   constexpr int rows = MT * 16;
   constexpr int ldA0 = 52, ldH = 2 * DEC_H + 4;
-  gemm_nt_packed<MT>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0);
+#define TSTAMP(k) do { if (sv.stamps && (threadIdx.x & 63) == 0) sv.stamps[(k) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+  TSTAMP(16);
+  // PRE (latency-chain callers): every product's first weights are requested one stage ahead -- they do not depend on the
+  // activations.  Throughput callers (scoring, the critic phase's precompute) keep the registers for occupancy instead.
+  LstmPre pre0{}, pre1{};
+  PackedPre pre2{};
+  if constexpr (PRE) pre0 = lstm_layer_prefetch(pk + gp.l_g[0][0], pk + gp.l_g[0][1], DEC_H, DEC_D1);
+  gemm_nt_packed<MT, PRE>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0, 0, pred1);
+  TSTAMP(17);
   __syncthreads();
   if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
   // layer 0: input a0 in bufB [rows][ldA0] -> h0 in bufA [rows][ldH] (the cell runs in the gate product's epilogue)
-  lstm_layer_fwd_packed<MT>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA, ldH,
-                            sv.g0, valid, sv.ps);
+  if constexpr (PRE) pre1 = lstm_layer_prefetch(pk + gp.l_g[1][0], pk + gp.l_g[1][1], DEC_H, 2 * DEC_H);
+  lstm_layer_fwd_packed<MT, PRE>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA,
+                                  ldH, sv.g0, valid, sv.ps, pre0);
+  TSTAMP(18);
   __syncthreads();
+  TSTAMP(19);
   if (drop.mode != 0) {
     for (int i = threadIdx.x; i < rows * (2 * DEC_H / 4); i += blockDim.x) {
       const int r = i / (2 * DEC_H / 4), c = 4 * (i - r * (2 * DEC_H / 4));
@@ -381,16 +448,25 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile_packed(const float* Zs, i
     }
     __syncthreads();
   }
+  TSTAMP(27);
   if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufA, ldH, rows, 2 * DEC_H, valid);
+  TSTAMP(28);
   // layer 1: h0 (dropped) in bufA -> h1 in bufB
-  lstm_layer_fwd_packed<MT>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB, ldH,
-                            sv.g1, valid, sv.ps);
+  if constexpr (PRE) pre2 = gemm_nt_prefetch(pk + gp.d2, 2 * DEC_H, S);
+  lstm_layer_fwd_packed<MT, PRE>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB,
+                                  ldH, sv.g1, valid, sv.ps, pre1);
+  TSTAMP(29);
   __syncthreads();
   if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
-  gemm_nt_packed<MT>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0);
+  TSTAMP(30);
+  PackedPre nxt{};
+  if (next_W) nxt = gemm_nt_prefetch(next_W, next_K, next_N);
+  gemm_nt_packed<MT, PRE>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0, 0, pre2);
+  TSTAMP(31);
   __syncthreads();
   tile_for(rows, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
   __syncthreads();
+  return nxt;
 }
 
 // Moebius head on LDS rows: Us[rows][ld] (u = e W_h^T) -> in place r = project(mobius_add(expmap0(u), bias)).

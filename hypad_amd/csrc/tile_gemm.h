@@ -25,6 +25,7 @@
 // The reduction index may be permuted freely as long as A and B agree: a float4 per lane feeds four consecutive
 // MFMAs (lane (.,q) carries k = k0 + 4q + i at step i).
 #pragma once
+#include <type_traits>
 #include "device_utils.h"
 
 namespace hypad {
@@ -190,24 +191,34 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
 // W[16 tn + j][16 g + 4 q .. + 3] (rows past N / columns past K are zeros; LSTM gate rows already compacted to [i|g|o]).
 // A tile's weights are then `kg` fully coalesced 1 KB loads straight into the B operand registers: no LDS re-shape.
 // Wp: blocks of tile tn at Wp + tn * kg * 256 floats; bsum[n]: summed biases (may be null).
-template <int MT>
+// The first batch of a wave's first tile can be requested ahead of time (weights do not depend on activations): issue
+// gemm_nt_prefetch() before the previous stage's work and pass the result with PRE = true; the product then starts with its
+// B operands in registers instead of an L2 round trip (~2 k cycles on a chain that runs every product once).
+struct PackedPre { float4 w[8]; };
+__device__ __forceinline__ PackedPre gemm_nt_prefetch(const float* __restrict__ Wp, int K, int N, int wave_rot = 0) {
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
+  const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
+  const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)(wave < ntiles ? wave : 0) * kg * 64 + lane;
+  PackedPre p;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p.w[u] = wp[(size_t)(u < kg ? u : kg - 1) * 64];
+  return p;
+}
+template <int MT, bool PRE = false>
 __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
-                                               const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0) {
+                                               const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
+                                               const PackedPre& pre = PackedPre{}) {
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
-  for (int t = wave; t < ntiles; t += nwaves) {
+  auto run = [&](int t, auto first_from_pre) __attribute__((always_inline)) {
     const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)t * kg * 64 + lane;
     const int n = t * 16 + j;
     const float bs = (bsum && n < N) ? bsum[n] : 0.f;
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int g0 = 0; g0 < kg; g0 += 8) {               // 8 k-groups (128 k) of weights in flight per lane
-      float4 w[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64];
-      __builtin_amdgcn_sched_barrier(0);
+    auto consume = [&](const float4 (&w)[8], int g0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (g0 + u < kg) {                             // wave-uniform
@@ -223,6 +234,18 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
           }
         }
       }
+    };
+    int gbeg = 0;
+    if constexpr (decltype(first_from_pre)::value) {
+      consume(pre.w, 0);
+      gbeg = 8;
+    }
+    for (int g0 = gbeg; g0 < kg; g0 += 8) {            // 8 k-groups (128 k) of weights in flight per lane
+      float4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      consume(w, g0);
     }
     if (n < N) {
 #pragma unroll
@@ -230,7 +253,9 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = acc[m][r] + acc2[m][r] + bs;
     }
-  }
+  };
+  if (wave < ntiles) run(wave, std::integral_constant<bool, PRE>{});
+  for (int t = wave + nwaves; t < ntiles; t += nwaves) run(t, std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------- gemm_nn

@@ -334,7 +334,9 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   }
 
   float* zin;                               // decoder input rows [16][LP]
+  PackedPre pre_d1;                         // first weights of the decoder's first layer, requested a stage ahead
   if (role == 0) {
+    pre_d1 = gemm_nt_prefetch(pk + gp.d1, L, DEC_D1);
     const CriticLayout clx = cx_layout(S, L);
     stage_critic_padded(cw, a.P.cx + (int64_t)sig * a.pcx, clx, L, critic_pad(S, L, 4));
     load_z(a, sig, tile, tick, zs);
@@ -346,6 +348,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     const CriticPad cpz = critic_pad(L, L, 2);
     // the window gather is two dependent memory round trips (row index, then the row): issue it first, stage the critic behind it
     GEN_STAMP(14);
+    const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
     tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
     GEN_STAMP(15);
     stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
@@ -354,9 +357,10 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     GEN_STAMP(13);
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
     zin = zs + 16 * LP;
-    encoder_fwd_tile_packed(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
-                            ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16);
+    encoder_fwd_tile_packed<true>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
+                                  ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, pre_enc);
     GEN_STAMP(1);
+    pre_d1 = gemm_nt_prefetch(pk + gp.d1, L, DEC_D1);
     const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
     sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
                                    [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
@@ -372,11 +376,13 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   sv.mask = ws + gw.mask + prow0 * 2 * DEC_H;
   sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
+  sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 32 * 8 : nullptr;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
   const int growp = pass * B + g0;
-  decoder_trunk_fwd_tile_packed<1>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16);
+  const PackedPre pre_head = decoder_trunk_fwd_tile_packed<1, true>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16,
+                                                                    pre_d1, HYPER ? pk + gp.head : nullptr, S, S);
   GEN_STAMP(3);
   // E = tanh output in bufA[0..15]
   const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
@@ -387,8 +393,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     }
     tile_store_p(ws + gw.ecat + prow0 * S, S, B, bufA, ldS, hrows, S, hrows);
     GEN_STAMP(20);
-    if (role == 1) gemm_nt_packed<2>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0);
-    else gemm_nt_packed<1>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0);
+    if (role == 1) gemm_nt_packed<2, true>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    else gemm_nt_packed<1, true>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
     __syncthreads();
     GEN_STAMP(21);
     tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
@@ -433,6 +439,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
       for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
     }
     GEN_STAMP(23);
+    const PackedPre pre_ht = gemm_nt_prefetch(pk + gp.head_t, S, S);        // the backward products' weights, each a stage ahead
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     // (four rows per wave, one per 16-lane DPP row; the row's bias gradient goes to its own row of R: the head outputs are dead)
     epl16_dispatch(S, [&](auto tag) {
@@ -457,7 +464,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     __syncthreads();
     GEN_STAMP(25);
     // dE = dU W_h for the decoder pass
-    gemm_nt_packed<1>(dR, ldS, S, S, pk + gp.head_t, nullptr, R, ldS, 0);
+    gemm_nt_packed<1, true>(dR, ldS, S, S, pk + gp.head_t, nullptr, R, ldS, 0, 0, pre_ht);
     __syncthreads();
     GEN_STAMP(26);
     // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
@@ -487,16 +494,19 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* dP = HYPER ? R : dR;               // d(pre-tanh) [16][ldS]
   float* oth = HYPER ? dR : R;
   GEN_STAMP(6);
+  const PackedPre pre_d2t = gemm_nt_prefetch(pk + gp.d2_t, S, 2 * DEC_H);
   tile_store(ws + gw.dpre2 + prow0 * S, S, dP, ldS, 16, S, 16);
+  const PackedPre pre_l1t = gemm_nt_prefetch(pk + gp.l_t[1], 6 * DEC_H, 2 * DEC_H);
   // dH1 = dpre W2
-  gemm_nt_packed<1>(dP, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, oth, ldH, 0);
+  gemm_nt_packed<1, true>(dP, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, oth, ldH, 0, 0, pre_d2t);
   __syncthreads();
   GEN_STAMP(7);
   // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
   tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
-  gemm_nt_packed<1>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0);     // both directions: one stacked reduction
+  const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
+  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0, 0, pre_l1t);     // both directions: one stacked reduction
   __syncthreads();
   if (a.drop_mode != 0) {
     tile_for(16, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow0 + r) * 2 * DEC_H + c]; });
@@ -507,7 +517,9 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   __syncthreads();
   tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
-  gemm_nt_packed<1>(dP, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, oth, ldA0, 0);
+  PackedPre pre_d1t{};
+  if (role == 1) pre_d1t = gemm_nt_prefetch(pk + gp.d1_t, DEC_D1, L);
+  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, oth, ldA0, 0, 0, pre_l0t);
   __syncthreads();
   tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, oth, ldA0, 16, DEC_D1, 16);
   GEN_STAMP(9);
@@ -519,14 +531,15 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     return;
   }
   // dZ = dA0 W1: the gradient reaching the encoder's output
-  gemm_nt_packed<1>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0);
+  const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
+  gemm_nt_packed<1, true>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0, 0, pre_d1t);
   __syncthreads();
   tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c] + dzc[r * LP + c]; });
   __syncthreads();
   tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
   GEN_STAMP(10);
   // ---- encoder backward
-  gemm_nt_packed<1>(dzs, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0);
+  gemm_nt_packed<1, true>(dzs, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
   __syncthreads();
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
@@ -1069,7 +1082,7 @@ HD ScoreLds score_lds(int S, int L) {
   return p;
 }
 template <int SC, int LC>
-__global__ __launch_bounds__(TB) void score_forward_packed_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void score_forward_packed_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = SC ? SC : a.S, L = LC ? LC : a.L;
   const ScoreLds lp = score_lds(S, L);
