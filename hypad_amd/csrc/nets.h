@@ -418,6 +418,7 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
                                                                    const float* next_W = nullptr, int next_K = 0, int next_N = 0) {
   constexpr int rows = MT * 16;
   constexpr int ldA0 = 52, ldH = 2 * DEC_H + 4;
+// development aid (scripts/diag_gen.py): per-wave shader-clock marks 16-19, 27-31 of the generator kernel's timeline
 #define TSTAMP(k) do { if (sv.stamps && (threadIdx.x & 63) == 0) sv.stamps[(k) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
   TSTAMP(16);
   // PRE (latency-chain callers): every product's first weights are requested one stage ahead -- they do not depend on the
@@ -467,6 +468,7 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   tile_for(rows, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
   __syncthreads();
   return nxt;
+#undef TSTAMP
 }
 
 // Moebius head on LDS rows: Us[rows][ld] (u = e W_h^T) -> in place r = project(mobius_add(expmap0(u), bias)).
