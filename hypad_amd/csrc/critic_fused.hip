@@ -79,6 +79,7 @@ struct IterLds {
   int w0;       // [L][ldin]      weights of layer 0, bias in column in_dim
   int wh;       // [nh-1][L][LQ]  hidden layers, bias in column L
   int wl;       // [LQ]           output layer, bias at index L
+  int gram;     // [Lp][LQ]     G0 = W0 W0^T over the input columns (bias column excluded), zero-padded
   int red;      // [64]
   int total;
 };
@@ -91,6 +92,7 @@ HD IterLds iter_lds(const CritGeom& g) {
   f.w0 = o; o += g.L * g.ldin;
   f.wh = o; o += (g.nh - 1) * g.L * g.LQ;
   f.wl = o; o += g.LQ;
+  f.gram = o; o += g.Lp * g.LQ;
   f.red = o; o += 64;
   f.total = o;
   return f;
@@ -246,6 +248,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   const int in_dim = g.in_dim, ldin = g.ldin, LQ = g.LQ, Kin = g.Kin, Lp = g.Lp;
   float* in0 = smem + fl.in0; float* act = smem + fl.act; float* dm = smem + fl.dm; float* dl = smem + fl.dl;
   float* w0 = smem + fl.w0; float* wh = smem + fl.wh; float* wl = smem + fl.wl; float* red = smem + fl.red;
+  float* gram = smem + fl.gram;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int it = ph.it;
@@ -440,7 +443,35 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   // (A wave-local variant -- wave p carrying pass p through the 20-wide layers without workgroup barriers -- was measured
   // slower: one wave needs ~1.9 k cycles per layer, six waves sharing the tiles of a layer ~1.5 k including the barrier.)
   const float* dout = dl + nh * 48 * LQ;
+  // Meanwhile (a layer has six tiles for eight waves) the two spare waves form G0 = W0 W0^T over the input columns, a few
+  // tiles per forward stage: the
+  // second-order chain starts with ep_0 = ((delta_0 W0) W0^T) * dm_0 = (delta_0 G0) * dm_0, a 20-wide product that does not
+  // wait for g = delta_0 W0 -- g leaves the critical path (it is still needed, for its norm and as a dW operand).
+  const int CTg = Lp >> 4, gram_per = 2 * ((CTg * CTg + 2 * nh - 1) / (2 * nh));   // Gram tiles per side; tiles per forward stage (both spare waves busy)
+  auto gram_tiles = [&](int li) __attribute__((always_inline)) {   // the spare waves' share during forward stage li
+    const int tend = (li + 1) * gram_per < CTg * CTg ? (li + 1) * gram_per : CTg * CTg;
+    for (int t = li * gram_per + (wave - (NW - 2)); t < tend; t += 2) {
+      const int mt = t / CTg, nt = t - mt * CTg;
+      const int m = mt * 16 + j, n = nt * 16 + j;
+      const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
+      const float* bp = w0 + (n < L ? n : L - 1) * ldin + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int g16 = 0; g16 < Kin; g16 += 16) {
+        float4 av = *reinterpret_cast<const float4*>(ap + g16);
+        const float4 bv = *reinterpret_cast<const float4*>(bp + g16);
+        const int k = g16 + 4 * q;                                  // the bias sits in column in_dim: not part of W0
+        av.x = k == in_dim ? 0.f : av.x; av.y = k + 1 == in_dim ? 0.f : av.y; av.z = k + 2 == in_dim ? 0.f : av.z; av.w = k + 3 == in_dim ? 0.f : av.w;
+        acc = mfma4(av, bv, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = mt * 16 + 4 * q + r;
+        gram[mm * LQ + n] = (mm < L && n < L) ? acc[r] : 0.f;
+      }
+    }
+  };
   for (int li = 0; li < nh; ++li) {
+    if (wave >= NW - 2) gram_tiles(li);
     const float* A = li == 0 ? in0 : act + (li - 1) * 48 * LQ;
     const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
     float* ao = act + li * 48 * LQ; float* dmo = dm + li * 48 * LQ;
@@ -478,15 +509,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     __syncthreads();
     STAMP(sk++);
   }
-  // ---- g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47 (ones column cleared), sum of squares
   float gsq = 0.f;
-  lds_gemm_nn(dl + 32 * LQ, LQ, 1, w0, ldin, L, in_dim, in_dim + 1, Lp, wave, lane, [&](int r, int c, float v) {
-    if (c < in_dim) { in0[(32 + r) * ldin + c] = v; gsq += v * v; }
-    else if (c == in_dim) in0[(32 + r) * ldin + c] = 0.f;
-  });
-  __syncthreads();
-  STAMP(sk++);
-
   // ---- weight-gradient tiles: dW += left^T right over the chunk's rows; rows 0-31 (real, fake) -> acc_rf, GP rows -> acc_gp
   f32x4 acc_rf[MAXT], acc_gp[MAXT];
 #pragma unroll
@@ -517,50 +540,64 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       }
     }
   };
-  // ---- unscaled second-order chain: ep_0 = (g W_0^T) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
-  // (ones column cleared: the GP rows carry no bias term).  ep_0 is two K = in_dim tiles on waves 6 and 7; the 20-wide
-  // rest of the chain stays on wave 7 alone (wave-local).  Meanwhile the other waves do the real / fake part of their
-  // weight-gradient tiles, which has been complete since the first backward.
-  {
-    float* eo = act + 32 * LQ; const float* dmo = dm + 32 * LQ;
-    lds_gemm_nt(in0 + 32 * ldin, ldin, 1, w0, ldin, L, L + 1, Kin, NW - 1 - wave, lane,
-                [&](int r, int c, float v) { if (c < L) eo[r * LQ + c] = v * dmo[r * LQ + c]; else if (c == L) eo[r * LQ + c] = 0.f; });
-    if (wave < NW - 2) dw_tile(0, true, false);
-  }
-  __syncthreads();
-  STAMP(sk++);
+  // ---- unscaled second-order chain: ep_0 = (delta_0 G0) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
+  // (ones column cleared: the GP rows carry no bias term).  Waves 6 and 7 carry the whole chain, one 16-column tile each,
+  // meeting after every layer through a pair of LDS flags (no workgroup barrier).  Meanwhile the other six waves compute
+  // g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47 (ones column cleared) with its sum of squares,
+  // then the real / fake part of their weight-gradient tiles, which has been complete since the first backward.
   if (wave >= NW - 2) {
-    // waves 6 and 7 carry the 20-wide rest of the chain, one column tile each, meeting after every layer through a pair of
-    // LDS flags (no workgroup barrier: the other six waves are busy with weight-gradient tiles)
     const int ct = NW - 1 - wave;                                   // my column tile; the partner has 1 - ct
-    const int jj = lane & 15, qq = lane >> 4;
     int* flag = reinterpret_cast<int*>(red + 48);
     const int CTn = (L + 1 + 15) >> 4;                              // column tiles of a layer (1 or 2)
-    for (int li = 1; li < nh; ++li) {
+    for (int li = 0; li < nh; ++li) {
       float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
       if (ct < CTn) {
-        int n = ct * 16 + jj; n = n < L ? n : L - 1;
-        const float* ap = act + ((li - 1) * 48 + 32 + jj) * LQ + 4 * qq;
-        const float* bp = wh + ((li - 1) * L + n) * LQ + 4 * qq;
+        int n = ct * 16 + j; n = n < L ? n : L - 1;
+        const float* ap = (li == 0 ? dl + (32 + j) * LQ : act + ((li - 1) * 48 + 32 + j) * LQ) + 4 * q;
+        const float* bp = (li == 0 ? gram + n * LQ : wh + ((li - 1) * L + n) * LQ) + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int g16 = 0; g16 < Lp; g16 += 16)
           acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
-        const int c = ct * 16 + jj;
+        const int c = ct * 16 + j;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 4 * qq + r;
+          const int row = 4 * q + r;
           if (c < L) eo[row * LQ + c] = acc[r] * dmo[row * LQ + c];
           else if (c == L) eo[row * LQ + c] = 0.f;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(&flag[ct], li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li) __builtin_amdgcn_s_sleep(1);
+      if (lane == 0) __hip_atomic_store(&flag[ct], li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li + 1) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   } else {
+    // g's column tiles over six waves
+    const int CT = (in_dim + 1 + 15) >> 4;
+    const float* a = dl + (32 + j) * LQ + 4 * q;
+    for (int ct = wave; ct < CT; ct += NW - 2) {
+      int c = ct * 16 + j; c = c < in_dim ? c : in_dim - 1;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int g16 = 0; g16 < Lp; g16 += 16) {
+        const int o = g16 + 4 * q;
+        float4 bv;
+        bv.x = w0[(o < L ? o : L - 1) * ldin + c];
+        bv.y = w0[(o + 1 < L ? o + 1 : L - 1) * ldin + c];
+        bv.z = w0[(o + 2 < L ? o + 2 : L - 1) * ldin + c];
+        bv.w = w0[(o + 3 < L ? o + 3 : L - 1) * ldin + c];
+        acc = mfma4(*reinterpret_cast<const float4*>(a + g16), bv, acc);
+      }
+      const int cc = ct * 16 + j;
 #pragma unroll
-    for (int i = 1; i < MAXT; ++i) dw_tile(i, true, false);
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        if (cc < in_dim) { in0[(32 + row) * ldin + cc] = acc[r]; gsq += acc[r] * acc[r]; }
+        else if (cc == in_dim) in0[(32 + row) * ldin + cc] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, false);
   }
   __syncthreads();
   STAMP(sk++);
