@@ -64,7 +64,7 @@ HD CritGeom cx_geom(int S, int L) { return crit_geom(S, L, 4, cx_layout(S, L).to
 HD CritGeom cz_geom(int L) { return crit_geom(L, L, 2, cz_layout(L).total); }
 HD bool geom_supported(const CritGeom& g) {
   const int Q = (g.L + 3) >> 2;
-  const int nitems = (g.tk0 + (g.nh - 1) * g.tkh) * 16 * Q + g.tkh * 16;
+  const int nitems = Q * (g.in_dim + 1) + (g.nh - 1) * Q * (g.L + 1) + g.L + 1;      // valid quads (critic_iteration_body)
   return g.ntiles <= MAXT * NW && g.rec_rows4 <= MAX_ROW4 * FT && g.rec_mask4 <= MAX_MASK4 * FT && nitems <= NITEM * FT;
 }
 
@@ -303,17 +303,27 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     t -= (li - 1) * g.tilesh;
     n0 = (t / g.tkh) * 16; k0 = (t % g.tkh) * 16;
   };
-  // Reduction + Adam over *valid accumulator quads* (a lane's 4 rows of one weight tile that hold real parameters),
-  // dealt round-robin to the 512 threads; every load is issued before the first use (one HBM round trip for the
-  // previous launch's slabs and the optimiser state together): clamped indices instead of branches around the loads.
+  // Reduction + Adam over *valid accumulator quads* -- a lane's 4 rows of one weight tile at a column that holds real
+  // parameters (weight columns and the bias column; the tiles' padding columns are not visited: 841 quads instead of 1072
+  // at S = 100, L = 20, two rounds of the 512 threads instead of three) -- dealt round-robin to the threads; every load is
+  // issued before the first use (one HBM round trip for the previous launch's slabs and the optimiser state together):
+  // clamped indices instead of branches around the loads, rounds beyond the last quad skipped block-wide.
   const int Q = (L + 3) >> 2;                              // valid quad rows of an L-row layer
-  const int I0 = g.tk0 * 16 * Q, Ih = g.tkh * 16 * Q, nitems = I0 + (nh - 1) * Ih + g.tkh * 16;
+  const int C0 = in_dim + 1, Ch = L + 1;                   // valid columns of layer 0 / of a hidden layer, bias column included
+  const int I0 = Q * C0, Ih = Q * Ch, nitems = I0 + (nh - 1) * Ih + Ch;
   float4 sx[NITEM][4], sy[NITEM][4];
   float pv[NITEM][4], mv[NITEM][4], vv[NITEM][4];
   int off[NITEM][4], i_li[NITEM], i_n[NITEM], i_k[NITEM], i_so[NITEM];
   const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
+  // the weight tiles' padding columns (beyond the bias column) are read by the products: zero them once, here
+  for (int i = threadIdx.x; i < L * (ldin - C0); i += FT) { const int n = i / (ldin - C0), c = i - n * (ldin - C0); w0[n * ldin + C0 + c] = 0.f; }
+  for (int i = threadIdx.x; i < ((nh - 1) * L + 1) * (LQ - Ch); i += FT) {
+    const int n = i / (LQ - Ch), c = i - n * (LQ - Ch);
+    wh[n * LQ + Ch + c] = 0.f;                             // wl follows wh: row (nh - 1) L of this loop is wl
+  }
 #pragma unroll
   for (int u = 0; u < NITEM; ++u) {            // straight-line code: selects, no branches, so all loads leave together
+    if (u * FT >= nitems) continue;            // block-uniform
     const int e0 = threadIdx.x + u * FT;
     const bool live = e0 < nitems;
     const int e = live ? e0 : 0;
@@ -323,14 +333,14 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     const bool last = !first && lh >= nh - 1;
     const int li = first ? 0 : (last ? nh : 1 + lh);
     const int er = first ? e : (last ? e1 - (nh - 1) * Ih : e1 - lh * Ih);
-    const int tk = first ? g.tk0 : g.tkh;
+    const int tk = first ? g.tk0 : g.tkh, cols = first ? C0 : Ch;
     const int base = first ? 0 : g.tiles0 + (last ? nh - 1 : lh) * g.tilesh;
-    const int kt = last ? er >> 4 : er / (16 * Q);
-    const int rem = er - kt * (last ? 16 : 16 * Q), qq = rem >> 4, jj = rem & 15;
+    const int qq = last ? 0 : er / cols, k = er - qq * cols;               // quad row, column (k == K: the bias)
+    const int kt = k >> 4, jj = k & 15;
     const int t = base + (qq >> 2) * tk + kt;
     const int so = t * 512 + ((qq & 3) * 16 + jj) * 4;
     const int N = last ? 1 : L, K = first ? in_dim : L;                   // K = index of the bias column
-    const int n = 4 * qq, k = 16 * kt + jj;
+    const int n = 4 * qq;
     int wof = cw_[0], bof = cb_[0];
 #pragma unroll
     for (int x = 1; x <= nh; ++x) { wof = li == x ? cw_[x] : wof; bof = li == x ? cb_[x] : bof; }
@@ -342,7 +352,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = live && n + r < N && k <= K;
+      const bool ok = live && n + r < N;
       const int o = k < K ? wof + (n + r) * K + k : bof + n + r;
       off[u][r] = ok ? o : -1;
       const int oc = ok ? o : 0;
@@ -373,6 +383,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
   for (int u = 0; u < NITEM; ++u) {
     grf_[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ggp_[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (u * FT >= nitems) continue;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float on = w < nchunks ? 1.f : 0.f;
@@ -386,6 +397,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     for (int u = 0; u < NITEM; ++u)
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+        if (u * FT >= nitems) continue;
         const float* sl = prev + (int64_t)(w0 + w < nchunks ? w0 + w : 0) * g.slab_floats + i_so[u];
         x[u][w] = *reinterpret_cast<const float4*>(sl); y[u][w] = *reinterpret_cast<const float4*>(sl + 256);
       }
@@ -393,6 +405,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     for (int u = 0; u < NITEM; ++u)
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+        if (u * FT >= nitems) continue;
         const float on = w0 + w < nchunks ? 1.f : 0.f;
         grf_[u][0] += on * x[u][w].x; grf_[u][1] += on * x[u][w].y; grf_[u][2] += on * x[u][w].z; grf_[u][3] += on * x[u][w].w;
         ggp_[u][0] += on * y[u][w].x; ggp_[u][1] += on * y[u][w].y; ggp_[u][2] += on * y[u][w].z; ggp_[u][3] += on * y[u][w].w;
@@ -400,6 +413,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   }
 #pragma unroll
   for (int u = 0; u < NITEM; ++u) {
+    if (u * FT >= nitems) continue;
     const int li = i_li[u];
     const f32x4 grf = grf_[u], ggp = ggp_[u];
     const int N = li == nh ? 1 : L;
