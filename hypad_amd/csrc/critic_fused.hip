@@ -569,20 +569,27 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         int n = ct * 16 + j; n = n < L ? n : L - 1;
         const float* ap = (li == 0 ? dl + (32 + j) * LQ : act + ((li - 1) * 48 + 32 + j) * LQ) + 4 * q;
         const float* bp = (li == 0 ? gram + n * LQ : wh + ((li - 1) * L + n) * LQ) + 4 * q;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int g16 = 0; g16 < Lp; g16 += 16)
+        const int c = ct * 16 + j, cm = c < L ? c : 0;
+        // the epilogue's scales do not depend on the chain: fetched with the operands, ahead of the dependent MFMAs
+        float dmv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dmv[r] = dmo[(4 * q + r) * LQ + cm];
+        // k-groups go to alternating accumulators: two dependent MFMA chains of half the length share the pipe
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        for (int g16 = 0; g16 < Lp; g16 += 32) {
           acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
-        const int c = ct * 16 + j;
+          if (g16 + 16 < Lp) acc2 = mfma4(*reinterpret_cast<const float4*>(ap + g16 + 16), *reinterpret_cast<const float4*>(bp + g16 + 16), acc2);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 4 * q + r;
-          if (c < L) eo[row * LQ + c] = acc[r] * dmo[row * LQ + c];
+          if (c < L) eo[row * LQ + c] = (acc[r] + acc2[r]) * dmv[r];
           else if (c == L) eo[row * LQ + c] = 0.f;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_store(&flag[ct], li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li + 1) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li + 1) {}
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
   } else {
