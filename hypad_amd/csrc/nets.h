@@ -103,24 +103,48 @@ __device__ __forceinline__ void lstm_cell_tile(const float* Gs, int ldg, int H, 
     }
   });
 }
-// backward of the cell: dHs[rows][ldh] -> dGs[rows][ldg] compact [dir][di|dg|do] (oracle/manual.py lstm_dir_bwd)
+// backward of the cell: dHs[rows][ldh] -> dGs[rows][ldg] compact [dir][di|dg|do] (oracle/manual.py lstm_dir_bwd).
+// The saved gates come from the global workspace: a thread's (up to) four elements -- rows wave, wave + nw, ...; columns
+// lane, lane + 64, ... -- have all their 16 gate values requested before the first is used (one memory round trip; an
+// element-at-a-time loop paid one per element on a chain that runs this once per layer).
 __device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, const float* gates_saved, int H, int rows,
                                                    float* dGs, int ldg, int valid, int ps = 16) {
-  tile_for(rows, 2 * H, [&](int r, int c) {
-    const int d = c >= H ? 1 : 0, jj = c - d * H;
-    float di = 0.f, dg = 0.f, dov = 0.f;
-    if (r < valid) {
-      const float* s = gates_saved + prow(r, ps) * 8 * H + d * 4 * H + jj;
-      const float gi = s[0], gg = s[H], go = s[2 * H], tc = s[3 * H];
-      const float dh = dHs[r * ldh + c];
-      dov = dh * tc * go * (1.f - go);
-      const float dc = dh * go * (1.f - tc * tc);
-      di = dc * gg * gi * (1.f - gi);
-      dg = dc * gi * (1.f - gg * gg);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  constexpr int RB = 2, CB = 2;                         // rows x column steps per batch (16 rows on 8 waves, 2H <= 128: one batch)
+  for (int r0 = wave; r0 < rows; r0 += RB * nw)
+    for (int c0 = lane; c0 < 2 * H; c0 += CB * 64) {
+      float gi[RB][CB], gg[RB][CB], go[RB][CB], tc[RB][CB], dh[RB][CB];
+#pragma unroll
+      for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+          const int r = r0 + a * nw, c = c0 + b * 64;
+          const bool ok = r < rows && r < valid && c < 2 * H;
+          const int rr = ok ? r : 0, cc = ok ? c : 0;
+          const int d = cc >= H ? 1 : 0, jj = cc - d * H;
+          const float* s = gates_saved + prow(rr, ps) * 8 * H + d * 4 * H + jj;
+          gi[a][b] = s[0]; gg[a][b] = s[H]; go[a][b] = s[2 * H]; tc[a][b] = s[3 * H];
+          dh[a][b] = dHs[(r < rows ? r : 0) * ldh + cc];
+        }
+#pragma unroll
+      for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+          const int r = r0 + a * nw, c = c0 + b * 64;
+          if (r < rows && c < 2 * H) {
+            const int d = c >= H ? 1 : 0, jj = c - d * H;
+            float di = 0.f, dg = 0.f, dov = 0.f;
+            if (r < valid) {
+              dov = dh[a][b] * tc[a][b] * go[a][b] * (1.f - go[a][b]);
+              const float dc = dh[a][b] * go[a][b] * (1.f - tc[a][b] * tc[a][b]);
+              di = dc * gg[a][b] * gi[a][b] * (1.f - gi[a][b]);
+              dg = dc * gi[a][b] * (1.f - gg[a][b] * gg[a][b]);
+            }
+            float* o = dGs + r * ldg + d * 3 * H;
+            o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
+          }
+        }
     }
-    float* o = dGs + r * ldg + d * 3 * H;
-    o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
-  });
 }
 // dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)
 template <int MT>
