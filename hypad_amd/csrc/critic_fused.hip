@@ -182,7 +182,7 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
   }
 }
 
-__global__ __launch_bounds__(TB) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int sig = blockIdx.y, tile = blockIdx.x, S = ax.S, L = ax.L, B = ax.B;
   const int it = blockIdx.z >> 1, role = blockIdx.z & 1;
