@@ -29,13 +29,16 @@ HD CritWs crit_ws(int B, int in_dim, int L, int nh) {
   return w;
 }
 struct GenWs {
-  int xg, enc_g, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, adamc, total;
+  int xg, enc_g, enc_g2, enc_h, zcat, a0, g0, h0d, mask, g1, h1, ecat, u, du, ballpart, dpre2, dg1, dg0, da0, dzenc, dgenc, partial, adamc, total;
 };
 HD GenWs gen_ws(int B, int S, int L) {
   GenWs w; int o = 0;
-  w.xg = o; o += pad4(B * S);
+  // the encoder's operand rows come twice: rows [0, B) from chain R (gradient arriving through the decoder), rows [B, 2B)
+  // from chain Z (gradient arriving through critic_z); the weight-gradient reduction runs over all 2B rows
+  w.xg = o; o += pad4(2 * B * S);
   w.enc_g = o; o += pad4(B * 8 * ENC_H);
-  w.enc_h = o; o += pad4(B * 2 * ENC_H);
+  w.enc_g2 = o; o += pad4(B * 8 * ENC_H);            // chain Z's own copy of the encoder gates
+  w.enc_h = o; o += pad4(2 * B * 2 * ENC_H);
   w.zcat = o; o += pad4(2 * B * L);
   w.a0 = o; o += pad4(2 * B * DEC_D1);
   w.g0 = o; o += pad4(2 * B * 8 * DEC_H);
@@ -51,8 +54,8 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.dg1 = o; o += pad4(2 * B * 6 * DEC_H);
   w.dg0 = o; o += pad4(2 * B * 6 * DEC_H);
   w.da0 = o; o += pad4(2 * B * DEC_D1);
-  w.dzenc = o; o += pad4(B * L);
-  w.dgenc = o; o += pad4(B * 6 * ENC_H);
+  w.dzenc = o; o += pad4(2 * B * L);
+  w.dgenc = o; o += pad4(2 * B * 6 * ENC_H);
   w.partial = o; o += pad4((B / 16) * 4);
   w.adamc = o; o += 4;                              // Adam bias corrections of this step {1 - b1^t, 1 - b2^t, sqrt(1 - b2^t)} (signal 0's workspace)
   w.total = o;

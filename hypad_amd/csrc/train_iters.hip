@@ -249,11 +249,16 @@ __device__ __forceinline__ void gp_body(const IterArgs& a, float* smem) {
 HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) + 4) + 2 * 16 * LP + critic_floats; }
 
 // ------------------------------------------------------------------------------------------------ generator body
-// decoder_iteration (train.py:189-249).  Its two chains are independent until the weight gradients are summed:
+// decoder_iteration (train.py:189-249).  Its three chains are independent until the weight gradients are summed:
 //   role 0 (G):  z ~ N(0,1) -> decoder -> critic_x -> -mean(fake_x)                      and back through the decoder;
-//   role 1 (R):  x -> encoder -> critic_z -> -mean(fake_z);  encoder(x) -> decoder -> reconstruction loss against x
-//                (hyperbolic: Poincare distance between the Moebius heads of x_rec and of x) and back through decoder
-//                and encoder.
+//   role 1 (R):  x -> encoder -> decoder -> reconstruction loss against x (hyperbolic: Poincare distance between the
+//                Moebius heads of x_rec and of x) and back through decoder and encoder;
+//   role 2 (Z):  x -> encoder -> critic_z -> -mean(fake_z) and back through the encoder (gen_role_z).  The encoder's
+//                backward is linear in the gradient of its output, so the two contributions (through the decoder, chain R;
+//                through critic_z, chain Z) are propagated separately and meet in the weight-gradient reduction, which runs
+//                over both chains' operand rows (train_common.h GenWs).  Chain Z repeats the encoder forward of its 16 rows
+//                -- 13 k cycles on its own CU -- and takes critic_z (7 k cycles, five barrier-separated 20-wide stages) off
+//                chain R, the longest of the three.
 // One workgroup per (16-row tile, role): blockIdx.z = role.  Operand rows in the workspace are pass-major as before:
 // pass 0 = decoder(z), pass 1 = decoder(encoder(x)), pass 2 (hyperbolic only) = hyperbolic_linear(x).
 struct GenLds {
@@ -262,12 +267,12 @@ struct GenLds {
 HD GenLds gen_lds(int S, int L, int hyper, int role) {
   GenLds p;
   p.ldS = pad4(S) + 4;
-  const CriticPad cp = role == 0 ? critic_pad(S, L, 4) : critic_pad(L, L, 2);
+  const CriticPad cp = role == 0 ? critic_pad(S, L, 4) : critic_pad(L, L, 2);      // (chain R stages no critic; same plan as Z)
   const int rows_head = (role == 1 && hyper) ? 32 : 16;
   const int a = 16 * (6 * DEC_H + 4), b = rows_head * p.ldS;
   const int bufFloats = a > b ? a : b;
   int o = 0;
-  p.xs = o; o += role == 1 ? 16 * p.ldS : 0;     // the real windows: role R only
+  p.xs = o; o += role >= 1 ? 16 * p.ldS : 0;     // the real windows: roles R and Z
   p.zs = o; o += 32 * LP;
   p.bufA = o; o += bufFloats;
   p.bufB = o; o += bufFloats;
@@ -278,6 +283,64 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
   return p;
 }
 
+// Chain Z of the generator step (see above): encoder forward of the tile's windows, critic_z forward / backward, encoder
+// backward of that gradient; operand rows into the second halves of xg / enc_h / dzenc / dgenc.
+template <int SC, int LC, int BC>
+__device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
+  const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
+  const int sig = blockIdx.y, tile = blockIdx.x >> 3;
+  const GenLds lp = gen_lds(S, L, a.hyperbolic, 2);
+  const int ldS = lp.ldS;
+  const GenWs gw = gen_ws(B, S, L);
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  const float* pk = ws + a.pk_off;
+  const GenPack gp = gen_pack(S, L, a.hyperbolic);
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  float* dzc = smem + lp.small;             // [16][LP] gradient of -mean(critic_z) w.r.t. the encoder output
+  float* cw = smem + lp.cw; float* ct = smem + lp.ct;
+  const uint32_t tick = (uint32_t)a.counters[3];
+  const int g0 = tile * 16;
+  const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
+  // this workgroup's share of the L2 warm-up of the packed weights (see gen_body)
+  float warm[3] = {0.f, 0.f, 0.f};
+  {
+    const int nwg = 3 * (B / 16), w = 2 * (B / 16) + tile;
+    const int lines = gp.total / 32;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int line = (u * nwg + w) * TB + threadIdx.x;
+      if (line < lines) warm[u] = pk[line * 32];
+    }
+  }
+  const CriticLayout clz = cz_layout(L);
+  const CriticPad cpz = critic_pad(L, L, 2);
+  const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
+  tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+  stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
+  __syncthreads();
+  tile_store(ws + gw.xg + (int64_t)(B + g0) * S, S, xs, ldS, 16, S, 16);
+  float* zin = zs + 16 * LP;
+  float* gates = ws + gw.enc_g2 + (int64_t)g0 * 8 * ENC_H;
+  encoder_fwd_tile_packed<true>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin, gates,
+                                ws + gw.enc_h + (int64_t)(B + g0) * 2 * ENC_H, 16, pre_enc);
+  const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
+  // critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
+  const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
+  const float sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
+                                             [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
+  tile_store(ws + gw.dzenc + (int64_t)(B + g0) * L, L, dzc, LP, 16, L, 16);
+  // encoder backward of that gradient
+  float* oth = bufB; float* dP = bufA;
+  gemm_nt_packed<1, true>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
+  __syncthreads();
+  lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, gates, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
+  __syncthreads();
+  tile_store(ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
+  float* part_out = ws + gw.partial + tile * 4;
+  if (threadIdx.x == 0) part_out[2] = sum_crit;
+  if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
+}
+
 // SC / LC / BC: window length, latent width, batch as compile-time constants (0 = from the arguments); see
 // critic_fused.hip: every layer of the chain runs once per launch, so index arithmetic is never amortised.
 static_assert(TB == 512, "gen_body deals rows over 8 waves");
@@ -285,6 +348,7 @@ template <bool HYPER, int SC, int LC, int BC>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
   const int sig = blockIdx.y, tile = blockIdx.x >> 3, role = blockIdx.z;
+  if (role == 2) { gen_role_z<SC, LC, BC>(a, smem); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
@@ -297,7 +361,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const GenPack gp = gen_pack(S, L, HYPER ? 1 : 0);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* small = smem + lp.small;
-  float* dzc = small;                       // [16][LP] gradient of -mean(critic_z) w.r.t. encoder output
   float* dzs = small + 16 * LP;             // [16][LP] total gradient of the encoder output
   float* red = small + 3 * 16 * LP;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
@@ -324,7 +387,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   // they touch every 128-byte line once, now, and the layers find the weights in L2 when they get there.
   float warm[3] = {0.f, 0.f, 0.f};
   {
-    const int nwg = 2 * (B / 16), w = role * (B / 16) + tile;
+    const int nwg = 3 * (B / 16), w = role * (B / 16) + tile;
     const int lines = gp.total / 32;
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -343,15 +406,12 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     zin = zs;
     __syncthreads();
   } else {
-    // ---- encoder(x), critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
-    const CriticLayout clz = cz_layout(L);
-    const CriticPad cpz = critic_pad(L, L, 2);
-    // the window gather is two dependent memory round trips (row index, then the row): issue it first, stage the critic behind it
+    // ---- encoder(x)  (critic_z(encoder(x)) and its way back through the encoder: chain Z)
+    // the window gather is two dependent memory round trips (row index, then the row)
     GEN_STAMP(14);
     const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
     tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
     GEN_STAMP(15);
-    stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
     GEN_STAMP(12);
     __syncthreads();
     GEN_STAMP(13);
@@ -361,9 +421,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
                                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, pre_enc);
     GEN_STAMP(1);
     pre_d1 = gemm_nt_prefetch(pk + gp.d1, L, DEC_D1);
-    const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
-    sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
-                                   [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
   }
   GEN_STAMP(2);
   // ---- decoder trunk on this role's pass
@@ -534,7 +591,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
   gemm_nt_packed<1, true>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0, 0, pre_d1t);
   __syncthreads();
-  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c] + dzc[r * LP + c]; });
+  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c]; });        // (the critic_z part of dZ: chain Z)
   __syncthreads();
   tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
   GEN_STAMP(10);
@@ -544,7 +601,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
   tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
-  if (threadIdx.x == 0) { part_out[0] = sum_aux; part_out[2] = sum_crit; }
+  if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
   GEN_STAMP(11);
 }
@@ -926,9 +983,9 @@ DwTable gen_table(const hypad_dims& dm) {
   TableBuilder<DwTable> tb;
   tb.t.finalize = 1;
   for (int d = 0; d < 2; ++d)
-    tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, B, hyp);
-  tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, B);
-  tb.bias(HYPAD_NET_ENCODER, el.dense_b, -1, L, gw.dzenc, L, B);
+    tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, 2 * B, hyp);     // chains R and Z
+  tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, 2 * B);
+  tb.bias(HYPAD_NET_ENCODER, el.dense_b, -1, L, gw.dzenc, L, 2 * B);
   tb.weight(HYPAD_NET_DECODER, dl.d1_w, L, DEC_D1, L, gw.da0, DEC_D1, gw.zcat, L, 2 * B);
   tb.bias(HYPAD_NET_DECODER, dl.d1_b, -1, DEC_D1, gw.da0, DEC_D1, 2 * B);
   for (int d = 0; d < 2; ++d) {
@@ -1275,7 +1332,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
-  dim3 grid(8 * (a.B / 16), d->n_signals, 2);            // blockIdx.x >> 3: tile (see gen_kernel); blockIdx.z: role G / role R
+  dim3 grid(8 * (a.B / 16), d->n_signals, 3);            // blockIdx.x >> 3: tile (see gen_kernel); blockIdx.z: role G / R / Z
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
