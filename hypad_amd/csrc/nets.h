@@ -66,12 +66,29 @@ __device__ __forceinline__ void tile_load_rows(float* __restrict__ dst, int ld, 
     }
   }
 }
+// LDS [rows][ld] -> global (row stride gld): 16 bytes per lane when the shapes allow it (a scalar sweep is one dependent
+// LDS read -> store per element and thread, 12 in a row for a 16 x 384 tile)
+__device__ __forceinline__ bool tile_vec4_ok(const float* g, int64_t gld, int ld, int cols) {
+  return ((cols | ld | (int)gld) & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+}
 __device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t gld, const float* __restrict__ src, int ld,
                                            int rows, int cols, int valid) {
+  if (tile_vec4_ok(dst, gld, ld, cols)) {
+    tile_for(rows, cols >> 2, [&](int r, int c4) {
+      if (r < valid) *reinterpret_cast<float4*>(dst + (int64_t)r * gld + 4 * c4) = *reinterpret_cast<const float4*>(src + r * ld + 4 * c4);
+    });
+    return;
+  }
   tile_for(rows, cols, [&](int r, int c) { if (r < valid) dst[(int64_t)r * gld + c] = src[r * ld + c]; });
 }
 __device__ __forceinline__ void tile_store_p(float* __restrict__ dst, int64_t gld, int ps, const float* __restrict__ src, int ld,
                                              int rows, int cols, int valid) {
+  if (tile_vec4_ok(dst, gld, ld, cols)) {
+    tile_for(rows, cols >> 2, [&](int r, int c4) {
+      if (r < valid) *reinterpret_cast<float4*>(dst + prow(r, ps) * gld + 4 * c4) = *reinterpret_cast<const float4*>(src + r * ld + 4 * c4);
+    });
+    return;
+  }
   tile_for(rows, cols, [&](int r, int c) { if (r < valid) dst[prow(r, ps) * gld + c] = src[r * ld + c]; });
 }
 __device__ __forceinline__ void tile_load_p(float* __restrict__ dst, int ld, const float* __restrict__ src, int64_t gld, int ps,

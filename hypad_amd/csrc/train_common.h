@@ -91,9 +91,9 @@ struct IterArgs {
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
-  long long* stamps;               // development aid: shader-clock stamps [role][32 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null
+  long long* stamps;               // development aid: shader-clock stamps [role][48 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null
 };
-#define GEN_STAMP(k) do { if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[(blockIdx.z * 32 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define GEN_STAMP(k) do { if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[(blockIdx.z * 48 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
 struct LdsPlan {
   int xs, zs, bufA, bufB, crit, small, wst, cparams, total, ldS, bufFloats;

@@ -433,7 +433,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   sv.mask = ws + gw.mask + prow0 * 2 * DEC_H;
   sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
-  sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 32 * 8 : nullptr;
+  sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
@@ -560,11 +560,16 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(7);
   // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
+  GEN_STAMP(32);
   __syncthreads();
+  GEN_STAMP(33);
   tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
   const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
+  GEN_STAMP(34);
   gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0, 0, pre_l1t);     // both directions: one stacked reduction
+  GEN_STAMP(35);
   __syncthreads();
+  GEN_STAMP(36);
   if (a.drop_mode != 0) {
     tile_for(16, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow0 + r) * 2 * DEC_H + c]; });
     __syncthreads();
@@ -572,11 +577,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(8);
   // layer 0
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
+  GEN_STAMP(37);
   __syncthreads();
   tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
   PackedPre pre_d1t{};
   if (role == 1) pre_d1t = gemm_nt_prefetch(pk + gp.d1_t, DEC_D1, L);
+  GEN_STAMP(38);
   gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, oth, ldA0, 0, 0, pre_l0t);
+  GEN_STAMP(39);
   __syncthreads();
   tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, oth, ldA0, 16, DEC_D1, 16);
   GEN_STAMP(9);

@@ -7,7 +7,7 @@ from hypad_amd import _C
 
 dev = torch.device("cuda", 0)
 eng, x = bench.build_engine(1, 0, True, dev)
-st = torch.zeros(2 * 32 * 8, dtype=torch.int64, device=dev)
+st = torch.zeros(3 * 48 * 8, dtype=torch.int64, device=dev)
 fn = _C.lib.hypad_diag_set_gen_stamps
 fn.restype = None; fn.argtypes = [ctypes.c_void_p]
 fn(st.data_ptr())
@@ -15,7 +15,7 @@ idx = torch.arange(bench.B, device=dev, dtype=torch.int32)
 for _ in range(5):
     eng.decoder_iteration(x, idx, None, True)
 torch.cuda.synchronize()
-tw = st.cpu().numpy().reshape(2, 32, 8)        # [role][mark][wave]
+tw = st.cpu().numpy().reshape(3, 48, 8)        # [role][mark][wave]
 t = tw[:, :, 0]
 names = ["start/enc fwd", "critic_z", "(z store)", "trunk", "head fwd", "critic_x", "loss+head bwd+dE+tanh'", "dH1", "l1 bwd", "l0 bwd", "dZ", "enc bwd"]
 for role, nm in ((0, "G"), (1, "R")):
@@ -27,7 +27,7 @@ for role, nm in ((0, "G"), (1, "R")):
     print("   sub: " + ", ".join(f"{k} {r[b] - r[a]}" for k, (a, b) in sub.items() if r[a] > 0 and r[b] > 0))
 
 # per-wave arrival at every mark, relative to wave 0's start: who is late for the barrier that follows
-order = [0, 14, 15, 12, 13, 1, 2, 16, 17, 18, 19, 27, 28, 29, 30, 31, 3, 20, 21, 22, 4, 5, 23, 24, 25, 26, 6, 7, 8, 9, 10, 11]
+order = [0, 14, 15, 12, 13, 1, 2, 16, 17, 18, 19, 27, 28, 29, 30, 31, 3, 20, 21, 22, 4, 5, 23, 24, 25, 26, 6, 7, 32, 33, 34, 35, 36, 8, 37, 38, 39, 9, 10, 11]
 for role, nm in ((0, "G"), (1, "R")):
     print(f"role {nm}: mark: arrival of waves 0..7 (cycles since start), spread")
     base = tw[role, 0, 0]
