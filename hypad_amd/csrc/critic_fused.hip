@@ -321,6 +321,14 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     const int n = i / (LQ - Ch), c = i - n * (LQ - Ch);
     wh[n * LQ + Ch + c] = 0.f;                             // wl follows wh: row (nh - 1) L of this loop is wl
   }
+  // the chunks' scalars {sum g^2, sum real out, sum fake out} are requested first: loads return in order, and the penalty
+  // coefficient they give is needed by the first quad's update, which can then start while the later quads are still in flight
+  float gsum = 0.f, sreal = 0.f, sfake = 0.f;
+#pragma unroll 4
+  for (int w = 0; w < nchunks; ++w) {                   // fixed order: every workgroup gets the same bits
+    const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
+    gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
+  }
 #pragma unroll
   for (int u = 0; u < NITEM; ++u) {            // straight-line code: selects, no branches, so all loads leave together
     if (u * FT >= nitems) continue;            // block-uniform
@@ -359,12 +367,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       pv[u][r] = src_p[oc]; mv[u][r] = src_m[oc]; vv[u][r] = src_v[oc];
     }
   }
-  float coef = 0.f, gsum = 0.f, sreal = 0.f, sfake = 0.f;
-#pragma unroll 4
-  for (int w = 0; w < nchunks; ++w) {                   // fixed order: every workgroup gets the same bits
-    const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
-    gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
-  }
+  float coef = 0.f;
   {
     const float nrm = sqrtf(gsum + 1e-12f);             // train.py:90, whole batch
     const float gp = (nrm - 1.f) * (nrm - 1.f);
