@@ -80,6 +80,7 @@ struct IterLds {
   int wh;       // [nh-1][L][LQ]  hidden layers, bias in column L
   int wl;       // [LQ]           output layer, bias at index L
   int gram;     // [Lp][LQ]     G0 = W0 W0^T over the input columns (bias column excluded), zero-padded
+  int whT;      // [nh-1][Lp][LQ] hidden weights transposed ([in feature][out feature], no bias), zero-padded: backward chain
   int red;      // [64]
   int total;
 };
@@ -93,6 +94,7 @@ HD IterLds iter_lds(const CritGeom& g) {
   f.wh = o; o += (g.nh - 1) * g.L * g.LQ;
   f.wl = o; o += g.LQ;
   f.gram = o; o += g.Lp * g.LQ;
+  f.whT = o; o += (g.nh - 1) * g.Lp * g.LQ;
   f.red = o; o += 64;
   f.total = o;
   return f;
@@ -248,7 +250,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   const int in_dim = g.in_dim, ldin = g.ldin, LQ = g.LQ, Kin = g.Kin, Lp = g.Lp;
   float* in0 = smem + fl.in0; float* act = smem + fl.act; float* dm = smem + fl.dm; float* dl = smem + fl.dl;
   float* w0 = smem + fl.w0; float* wh = smem + fl.wh; float* wl = smem + fl.wl; float* red = smem + fl.red;
-  float* gram = smem + fl.gram;
+  float* gram = smem + fl.gram; float* whT = smem + fl.whT;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, q = lane >> 4;
   const int it = ph.it;
@@ -317,6 +319,10 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
   // the weight tiles' padding columns (beyond the bias column) are read by the products: zero them once, here
   for (int i = threadIdx.x; i < L * (ldin - C0); i += FT) { const int n = i / (ldin - C0), c = i - n * (ldin - C0); w0[n * ldin + C0 + c] = 0.f; }
+  for (int i = threadIdx.x; i < (nh - 1) * Lp * LQ; i += FT) {          // everything outside the L x L blocks
+    const int rr = i / LQ, k = i - rr * LQ, m = rr % Lp;
+    if (m >= L || k >= L) whT[i] = 0.f;
+  }
   for (int i = threadIdx.x; i < ((nh - 1) * L + 1) * (LQ - Ch); i += FT) {
     const int n = i / (LQ - Ch), c = i - n * (LQ - Ch);
     wh[n * LQ + Ch + c] = 0.f;                             // wl follows wh: row (nh - 1) L of this loop is wl
@@ -433,13 +439,14 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         const float pw = o >= 0 ? p : 0.f;
         float* wdst = li == 0 ? w0 + (n + r) * ldin + k : (li < nh ? wh + ((li - 1) * L + n + r) * LQ + k : wl + k);
         *wdst = pw;
+        if (li > 0 && li < nh && k < L) whT[((li - 1) * Lp + k) * LQ + n + r] = pw;
       }
     }
   }
   if (fin) return;
   STAMP(1);
 
-  // ---- record -> LDS; constant d loss / d out
+  // ---- record -> LDS; constant d loss / d out (column 0 of dl[nh]: the left operand of the output layer's weight gradient)
 #pragma unroll
   for (int u = 0; u < MAX_ROW4; ++u) {
     const int i = threadIdx.x + u * FT;
@@ -451,23 +458,137 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
   }
   if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
-  if (threadIdx.x < 2) reinterpret_cast<int*>(red + 48)[threadIdx.x] = 0;      // pair flags of the second-order chain
   __syncthreads();
   STAMP(2);
   int sk = 3;
 
-  // ---- forward, 48 rows.  The last hidden layer's epilogue also starts the backward chain.
-  // (A wave-local variant -- wave p carrying pass p through the 20-wide layers without workgroup barriers -- was measured
-  // slower: one wave needs ~1.9 k cycles per layer, six waves sharing the tiles of a layer ~1.5 k including the barrier.)
-  const float* dout = dl + nh * 48 * LQ;
-  // Meanwhile (a layer has six tiles for eight waves) the two spare waves form G0 = W0 W0^T over the input columns, a few
-  // tiles per forward stage: the
-  // second-order chain starts with ep_0 = ((delta_0 W0) W0^T) * dm_0 = (delta_0 G0) * dm_0, a 20-wide product that does not
-  // wait for g = delta_0 W0 -- g leaves the critical path (it is still needed, for its norm and as a dW operand).
-  const int CTg = Lp >> 4, gram_per = 2 * ((CTg * CTg + 2 * nh - 1) / (2 * nh));   // Gram tiles per side; tiles per forward stage (both spare waves busy)
-  auto gram_tiles = [&](int li) __attribute__((always_inline)) {   // the spare waves' share during forward stage li
-    const int tend = (li + 1) * gram_per < CTg * CTg ? (li + 1) * gram_per : CTg * CTg;
-    for (int t = li * gram_per + (wave - (NW - 2)); t < tend; t += 2) {
+  // ---- forward and first backward, 48 rows: three register-resident chains.  Wave p (0 real, 1 fake, 2 interpolated) carries
+  // its 16 rows through every layer in the *transposed* form out^T = W in^T: the MFMA A operand is a weight row block
+  // (ds_read_b128 from LDS, independent of the data), the B operand is the previous layer's output -- and the accumulator
+  // layout of v_mfma_f32_16x16x4 (lane (j, q), register r = out^T[feature 4 q + r][row j]) is exactly the B layout the next
+  // product wants for k = 16 g + 4 q + s.  So a layer's result never leaves the registers: no LDS round trip, no barrier, no
+  // flag between dependent layers; activations, scales and deltas are written to LDS on the side, for the weight-gradient
+  // tiles.  A 20-wide layer is 16 MFMAs (two feature tiles x two k-groups), ~0.6 k cycles; it was ~1.5 k as a block-wide stage.
+  // Meanwhile waves 3 and 4 form G0 = W0 W0^T over the input columns: the second-order chain starts with
+  // ep_0 = ((delta_0 W0) W0^T) * dm_0 = (delta_0 G0) * dm_0, a 20-wide product that does not wait for g = delta_0 W0 -- g is
+  // still needed, for its norm and as a dW operand, but not on the critical path.
+  constexpr int MF = 3, MAXNH = 4;                               // feature tiles of a layer (Lp <= 48), hidden layers
+  const int NT = Lp >> 4;
+  f32x4 DD[MAXNH][MF], DL[MF];                                   // leaky' * dropout scale of every layer; current delta^T
+  const int myrow = 16 * wave + j;                               // the chain waves' batch row (of 48)
+  auto as4 = [](const f32x4& v) __attribute__((always_inline)) { return make_float4(v[0], v[1], v[2], v[3]); };
+  if (wave < 3) {
+    f32x4 T[MF];                                                 // current activation^T tiles
+#pragma unroll
+    for (int li = 0; li < MAXNH; ++li)
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        DD[li][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (li < nh && t < NT) { const float4 v = *reinterpret_cast<const float4*>(dm + (li * 48 + myrow) * LQ + 16 * t + 4 * q); DD[li][t] = f32x4{v.x, v.y, v.z, v.w}; }
+      }
+    auto epilogue = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        if (t >= NT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = 16 * t + 4 * q + r;
+          const float pre = T[t][r];
+          const float dd = f < L ? leaky_slope(pre) * DD[li][t][r] : 0.f;
+          DD[li][t][r] = dd;
+          T[t][r] = f < L ? pre * dd : (f == L ? 1.f : 0.f);     // feature L: the ones row that carries the next layer's bias
+        }
+        *reinterpret_cast<float4*>(act + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(T[t]);
+      }
+    };
+    // layer 0: the input rows come from LDS
+#pragma unroll
+    for (int t = 0; t < MF; ++t) {
+      if (t >= NT) continue;
+      const int m = 16 * t + j;
+      const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
+      const float* bp = in0 + myrow * ldin + 4 * q;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+      for (int g16 = 0; g16 < Kin; g16 += 32) {
+        acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
+        if (g16 + 16 < Kin) acc2 = mfma4(*reinterpret_cast<const float4*>(ap + g16 + 16), *reinterpret_cast<const float4*>(bp + g16 + 16), acc2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[t][r] = acc[r] + acc2[r];
+    }
+    epilogue(0);
+    for (int li = 1; li < nh; ++li) {
+      f32x4 N[MF];
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        if (t >= NT) continue;
+        const int m = 16 * t + j;
+        const float* ap = wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg = 0; gg < MF; ++gg)
+          if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), as4(T[gg]), acc);
+        N[t] = acc;
+      }
+#pragma unroll
+      for (int t = 0; t < MF; ++t) T[t] = N[t];
+#pragma unroll
+      for (int x = 0; x < MAXNH; ++x) if (x == li) epilogue(x);   // (keeps DD's first index a compile-time constant)
+    }
+    // critic outputs (loss terms) and the top delta: d loss / d out = -1/B (real), +1/B (fake), 1 (interpolated: the penalty's
+    // gradient is taken of the plain output)
+    const float doutp = wave == 0 ? -invB : (wave == 1 ? invB : 1.f);
+    float o = 0.f;
+#pragma unroll
+    for (int t = 0; t < MF; ++t) {
+      DL[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t >= NT) continue;
+      const float4 wv = *reinterpret_cast<const float4*>(wl + 16 * t + 4 * q);
+      const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o += T[t][r] * wq[r];                                      // features past L are zero, feature L is 1 x bias
+        float ddtop = 0.f;
+#pragma unroll
+        for (int x = 0; x < MAXNH; ++x) ddtop = x == nh - 1 ? DD[x][t][r] : ddtop;
+        DL[t][r] = doutp * wq[r] * ddtop;                          // zero past L (ddtop is)
+      }
+      *reinterpret_cast<float4*>(dl + ((nh - 1) * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
+    }
+    o += __shfl_xor(o, 16, 64);
+    o += __shfl_xor(o, 32, 64);                                    // row j's output, in every lane of column j
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+    if (wave < 2 && lane == 0) red[32 + wave] = o;                 // sum over the real / the fake rows
+    // first-order backward chain: delta_li^T = dm_li * (W_{li+1}^T delta_{li+1}^T), A operand from the transposed copies
+    for (int li = nh - 2; li >= 0; --li) {
+      f32x4 N[MF];
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        N[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t >= NT) continue;
+        const float* ap = whT + (li * Lp + 16 * t + j) * LQ + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg = 0; gg < MF; ++gg)
+          if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), as4(DL[gg]), acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float ddl = 0.f;
+#pragma unroll
+          for (int x = 0; x < MAXNH; ++x) ddl = x == li ? DD[x][t][r] : ddl;
+          N[t][r] = acc[r] * ddl;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        DL[t] = N[t];
+        if (t < NT) *reinterpret_cast<float4*>(dl + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
+      }
+    }
+  } else if (wave < 5) {
+    const int CTg = Lp >> 4;                                       // Gram tiles per side
+    for (int t = wave - 3; t < CTg * CTg; t += 2) {
       const int mt = t / CTg, nt = t - mt * CTg;
       const int m = mt * 16 + j, n = nt * 16 + j;
       const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
@@ -486,46 +607,9 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         gram[mm * LQ + n] = (mm < L && n < L) ? acc[r] : 0.f;
       }
     }
-  };
-  for (int li = 0; li < nh; ++li) {
-    if (wave >= NW - 2) gram_tiles(li);
-    const float* A = li == 0 ? in0 : act + (li - 1) * 48 * LQ;
-    const float* W = li == 0 ? w0 : wh + (li - 1) * L * LQ;
-    float* ao = act + li * 48 * LQ; float* dmo = dm + li * 48 * LQ;
-    float* dtop = dl + (nh - 1) * 48 * LQ;
-    lds_gemm_nt(A, li == 0 ? ldin : LQ, 3, W, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? Kin : Lp, wave, lane, [&](int r, int c, float pre) {
-      if (c < L) {
-        const float dd = leaky_slope(pre) * dmo[r * LQ + c];
-        dmo[r * LQ + c] = dd;
-        ao[r * LQ + c] = pre * dd;
-        if (li == nh - 1) dtop[r * LQ + c] = dout[r * LQ] * wl[c] * dd;
-      } else if (c == L) {
-        ao[r * LQ + c] = 1.f;                      // ones column: carries the next layer's bias
-      }
-    });
-    __syncthreads();
-    STAMP(sk++);
   }
-  // ---- critic outputs (loss terms) on the last wave, which owns no tile of the next products
-  if (wave == NW - 1) {
-    float o = 0.f;
-    if (lane < 32) {
-      const float* x = act + ((nh - 1) * 48 + lane) * LQ;
-      for (int c = 0; c <= L; ++c) o += x[c] * wl[c];
-    }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
-    if (lane == 0) red[32] = o;                    // sum over the real rows
-    if (lane == 16) red[33] = o;                   // sum over the fake rows
-  }
-  // ---- first-order backward chain, all 48 rows, every layer's delta kept
-  for (int li = nh - 2; li >= 0; --li) {
-    float* dst = dl + li * 48 * LQ; const float* dmo = dm + li * 48 * LQ;
-    lds_gemm_nn(dl + (li + 1) * 48 * LQ, LQ, 3, wh + li * L * LQ, LQ, L, L, L, Lp, wave, lane,
-                [&](int r, int c, float v) { if (c < L) dst[r * LQ + c] = v * dmo[r * LQ + c]; });
-    __syncthreads();
-    STAMP(sk++);
-  }
+  __syncthreads();
+  STAMP(sk++);
   float gsq = 0.f;
   // ---- weight-gradient tiles: dW += left^T right over the chunk's rows; rows 0-31 (real, fake) -> acc_rf, GP rows -> acc_gp
   f32x4 acc_rf[MAXT], acc_gp[MAXT];
@@ -557,49 +641,43 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       }
     }
   };
-  // ---- unscaled second-order chain: ep_0 = (delta_0 G0) * dm_0, ep_li = (ep_{li-1} W_li^T) * dm_li  -> act rows 32-47
-  // (ones column cleared: the GP rows carry no bias term).  Waves 6 and 7 carry the whole chain, one 16-column tile each,
-  // meeting after every layer through a pair of LDS flags (no workgroup barrier).  Meanwhile the other six waves compute
-  // g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47 (ones column cleared) with its sum of squares,
-  // then the real / fake part of their weight-gradient tiles, which has been complete since the first backward.
-  if (wave >= NW - 2) {
-    const int ct = NW - 1 - wave;                                   // my column tile; the partner has 1 - ct
-    int* flag = reinterpret_cast<int*>(red + 48);
-    const int CTn = (L + 1 + 15) >> 4;                              // column tiles of a layer (1 or 2)
+  // ---- unscaled second-order chain on the interpolated rows' wave, still in registers: ep_0^T = dm_0 * (G0 delta_0^T),
+  // ep_li^T = dm_li * (W_li ep_{li-1}^T)  -> act rows 32-47 (feature L stays zero: the GP rows carry no bias term).  Meanwhile
+  // the other seven waves compute g = delta_0 W_0 on the interpolated rows (unscaled) -> in0 rows 32-47 (ones column cleared)
+  // with its sum of squares, then the real / fake part of their weight-gradient tiles.
+  if (wave == 2) {
+    f32x4 E[MF];
     for (int li = 0; li < nh; ++li) {
-      float* eo = act + (li * 48 + 32) * LQ; const float* dmo = dm + (li * 48 + 32) * LQ;
-      if (ct < CTn) {
-        int n = ct * 16 + j; n = n < L ? n : L - 1;
-        const float* ap = (li == 0 ? dl + (32 + j) * LQ : act + ((li - 1) * 48 + 32 + j) * LQ) + 4 * q;
-        const float* bp = (li == 0 ? gram + n * LQ : wh + ((li - 1) * L + n) * LQ) + 4 * q;
-        const int c = ct * 16 + j, cm = c < L ? c : 0;
-        // the epilogue's scales do not depend on the chain: fetched with the operands, ahead of the dependent MFMAs
-        float dmv[4];
+      f32x4 N[MF];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dmv[r] = dmo[(4 * q + r) * LQ + cm];
-        // k-groups go to alternating accumulators: two dependent MFMA chains of half the length share the pipe
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        for (int g16 = 0; g16 < Lp; g16 += 32) {
-          acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
-          if (g16 + 16 < Lp) acc2 = mfma4(*reinterpret_cast<const float4*>(ap + g16 + 16), *reinterpret_cast<const float4*>(bp + g16 + 16), acc2);
-        }
+      for (int t = 0; t < MF; ++t) {
+        N[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t >= NT) continue;
+        const int m = 16 * t + j;
+        const float* ap = (li == 0 ? gram + m * LQ : wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ) + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg = 0; gg < MF; ++gg)
+          if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), li == 0 ? as4(DL[gg]) : as4(E[gg]), acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 4 * q + r;
-          if (c < L) eo[row * LQ + c] = (acc[r] + acc2[r]) * dmv[r];
-          else if (c == L) eo[row * LQ + c] = 0.f;
+          float ddl = 0.f;
+#pragma unroll
+          for (int x = 0; x < MAXNH; ++x) ddl = x == li ? DD[x][t][r] : ddl;
+          N[t][r] = acc[r] * ddl;                                  // zero from feature L on
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(&flag[ct], li + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(&flag[1 - ct], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < li + 1) {}
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        E[t] = N[t];
+        if (t < NT) *reinterpret_cast<float4*>(act + (li * 48 + 32 + j) * LQ + 16 * t + 4 * q) = as4(E[t]);
+      }
     }
   } else {
-    // g's column tiles over six waves
-    const int CT = (in_dim + 1 + 15) >> 4;
+    // g's column tiles over the seven other waves
+    const int CT = (in_dim + 1 + 15) >> 4, slot = wave < 2 ? wave : wave - 1;
     const float* a = dl + (32 + j) * LQ + 4 * q;
-    for (int ct = wave; ct < CT; ct += NW - 2) {
+    for (int ct = slot; ct < CT; ct += NW - 1) {
       int c = ct * 16 + j; c = c < in_dim ? c : in_dim - 1;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
@@ -625,9 +703,9 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   }
   __syncthreads();
   STAMP(sk++);
-  if (wave >= NW - 2) {
+  if (wave == 2) {
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, true);          // the chain's two waves do both parts of their tiles now
+    for (int i = 0; i < MAXT; ++i) dw_tile(i, true, true);          // the chain's wave does both parts of its tiles now
   } else {
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) dw_tile(i, false, true);

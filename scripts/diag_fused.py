@@ -20,7 +20,8 @@ s = st.cpu().numpy().reshape(2, 64)
 print("events ms", ms)
 for z, nm in ((0, "critic_x"), (1, "critic_z")):
     nh = 4 if z == 0 else 2
-    names = ["prologue (record loads, reduce+Adam)", "record->LDS", ] + [f"fwd{l}" for l in range(nh)] + [f"bwd{l}" for l in range(nh - 2, -1, -1)] + ["ep chain (waves 6,7) | g + dWrf", "dW gp (+rf of waves 6,7)", "publish"]
+    names = ["prologue (record loads, reduce+Adam)", "record->LDS", "fwd + bwd chains in registers (waves 0-2) | Gram (waves 3,4)",
+             "ep chain (wave 2) | g + dWrf", "dW gp (+rf of wave 2)", "publish"]
     t = s[z]
     n = len(names)
     d = np.diff(t[: n + 1])
