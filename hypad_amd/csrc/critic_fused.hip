@@ -516,7 +516,9 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[t][r] = acc[r] + acc2[r];
     }
+    STAMP(20);
     epilogue(0);
+    STAMP(21);
     for (int li = 1; li < nh; ++li) {
       f32x4 N[MF];
 #pragma unroll
@@ -534,6 +536,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       for (int t = 0; t < MF; ++t) T[t] = N[t];
 #pragma unroll
       for (int x = 0; x < MAXNH; ++x) if (x == li) epilogue(x);   // (keeps DD's first index a compile-time constant)
+      STAMP(21 + li);
     }
     // critic outputs (loss terms) and the top delta: d loss / d out = -1/B (real), +1/B (fake), 1 (interpolated: the penalty's
     // gradient is taken of the plain output)
@@ -560,6 +563,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
     if (wave < 2 && lane == 0) red[32 + wave] = o;                 // sum over the real / the fake rows
+    STAMP(26);
     // first-order backward chain: delta_li^T = dm_li * (W_{li+1}^T delta_{li+1}^T), A operand from the transposed copies
     for (int li = nh - 2; li >= 0; --li) {
       f32x4 N[MF];
@@ -585,6 +589,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         DL[t] = N[t];
         if (t < NT) *reinterpret_cast<float4*>(dl + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
       }
+      STAMP(27 + li);
     }
   } else if (wave < 5) {
     const int CTg = Lp >> 4;                                       // Gram tiles per side

@@ -27,3 +27,8 @@ for z, nm in ((0, "critic_x"), (1, "critic_z")):
     d = np.diff(t[: n + 1])
     print(nm, "total cycles", t[40] - t[0], "| prologue: to adam-coef", t[50] - t[0], "barrier", t[51] - t[50], "tiles", t[1] - t[51])
     print("   " + ", ".join(f"{a} {b}" for a, b in zip(names, d)))
+
+    c = s[z]
+    marks = [2, 20, 21] + [21 + li for li in range(1, nh)] + [26] + [27 + li for li in range(nh - 2, -1, -1)]
+    lab = ["B1", "fwd0 mfma", "fwd0 epi"] + [f"fwd{li}" for li in range(1, nh)] + ["top"] + [f"bwd{li}" for li in range(nh - 2, -1, -1)]
+    print("   chain (wave 0): " + ", ".join(f"{lab[i]} {c[marks[i]] - c[marks[i-1]]}" for i in range(1, len(marks))))
