@@ -501,6 +501,23 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         *reinterpret_cast<float4*>(act + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(T[t]);
       }
     };
+    // weight operands of the layer about to run; requested one layer ahead (they do not depend on the data), before the
+    // current layer's epilogue, so that a layer starts with its A operands in registers
+    float4 Aw[MF][MF];
+    auto load_fwd = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MF; ++t)
+#pragma unroll
+        for (int gg = 0; gg < MF; ++gg)
+          if (t < NT && gg < NT) { const int m = 16 * t + j; Aw[t][gg] = *reinterpret_cast<const float4*>(wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ + 4 * q + 16 * gg); }
+    };
+    auto load_bwd = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < MF; ++t)
+#pragma unroll
+        for (int gg = 0; gg < MF; ++gg)
+          if (t < NT && gg < NT) Aw[t][gg] = *reinterpret_cast<const float4*>(whT + (li * Lp + 16 * t + j) * LQ + 4 * q + 16 * gg);
+    };
     // layer 0: the input rows come from LDS
 #pragma unroll
     for (int t = 0; t < MF; ++t) {
@@ -517,6 +534,7 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       for (int r = 0; r < 4; ++r) T[t][r] = acc[r] + acc2[r];
     }
     STAMP(20);
+    if (nh > 1) load_fwd(1);
     epilogue(0);
     STAMP(21);
     for (int li = 1; li < nh; ++li) {
@@ -524,16 +542,15 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
       for (int t = 0; t < MF; ++t) {
         if (t >= NT) continue;
-        const int m = 16 * t + j;
-        const float* ap = wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int gg = 0; gg < MF; ++gg)
-          if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), as4(T[gg]), acc);
+          if (gg < NT) acc = mfma4(Aw[t][gg], as4(T[gg]), acc);
         N[t] = acc;
       }
 #pragma unroll
       for (int t = 0; t < MF; ++t) T[t] = N[t];
+      if (li + 1 < nh) load_fwd(li + 1); else if (nh > 1) load_bwd(nh - 2);
 #pragma unroll
       for (int x = 0; x < MAXNH; ++x) if (x == li) epilogue(x);   // (keeps DD's first index a compile-time constant)
       STAMP(21 + li);
@@ -558,11 +575,6 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       }
       *reinterpret_cast<float4*>(dl + ((nh - 1) * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
     }
-    o += __shfl_xor(o, 16, 64);
-    o += __shfl_xor(o, 32, 64);                                    // row j's output, in every lane of column j
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
-    if (wave < 2 && lane == 0) red[32 + wave] = o;                 // sum over the real / the fake rows
     STAMP(26);
     // first-order backward chain: delta_li^T = dm_li * (W_{li+1}^T delta_{li+1}^T), A operand from the transposed copies
     for (int li = nh - 2; li >= 0; --li) {
@@ -571,11 +583,10 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       for (int t = 0; t < MF; ++t) {
         N[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t >= NT) continue;
-        const float* ap = whT + (li * Lp + 16 * t + j) * LQ + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int gg = 0; gg < MF; ++gg)
-          if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), as4(DL[gg]), acc);
+          if (gg < NT) acc = mfma4(Aw[t][gg], as4(DL[gg]), acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float ddl = 0.f;
@@ -589,8 +600,15 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         DL[t] = N[t];
         if (t < NT) *reinterpret_cast<float4*>(dl + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
       }
+      if (li > 0) load_bwd(li - 1);
       STAMP(27 + li);
     }
+    // (off the chain: the passes' output sums)
+    o += __shfl_xor(o, 16, 64);
+    o += __shfl_xor(o, 32, 64);                                    // row j's output, in every lane of column j
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+    if (wave < 2 && lane == 0) red[32 + wave] = o;                 // sum over the real / the fake rows
   } else if (wave < 5) {
     const int CTg = Lp >> 4;                                       // Gram tiles per side
     for (int t = wave - 3; t < CTg * CTg; t += 2) {
