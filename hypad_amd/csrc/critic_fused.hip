@@ -65,7 +65,9 @@ HD CritGeom cz_geom(int L) { return crit_geom(L, L, 2, cz_layout(L).total); }
 HD bool geom_supported(const CritGeom& g) {
   const int Q = (g.L + 3) >> 2;
   const int nitems = Q * (g.in_dim + 1) + (g.nh - 1) * Q * (g.L + 1) + g.L + 1;      // valid quads (critic_iteration_body)
-  return g.ntiles <= MAXT * NW && g.rec_rows4 <= MAX_ROW4 * FT && g.rec_mask4 <= MAX_MASK4 * FT && nitems <= NITEM * FT;
+  // (the layer-0 quads take NITEM - 1 register slots of all threads; the other layers' quads loop on waves 3-7)
+  (void)nitems;
+  return g.ntiles <= MAXT * NW && g.rec_rows4 <= MAX_ROW4 * FT && g.rec_mask4 <= MAX_MASK4 * FT && Q * (g.in_dim + 1) <= (NITEM - 1) * FT;
 }
 
 // LDS plan of the iteration kernel (floats).  Row strides are (multiple of 16) + 4: operand fetches are ds_read_b128
@@ -335,11 +337,16 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     const float* sc = prev + (int64_t)w * g.slab_floats + g.ntiles * 512;
     gsum += sc[0]; sreal += sc[1]; sfake += sc[2];
   }
-#pragma unroll
-  for (int u = 0; u < NITEM; ++u) {            // straight-line code: selects, no branches, so all loads leave together
-    if (u * FT >= nitems) continue;            // block-uniform
-    const int e0 = threadIdx.x + u * FT;
-    const bool live = e0 < nitems;
+  // Two phases.  A: the quads of layer 0 (505 of the 841), dealt to all 512 threads -- the first chain layer needs nothing
+  // else, so the chains start after ONE round.  B: the quads of the other layers, dealt to the 320 threads of waves 3-7,
+  // which have ~10 k idle cycles while waves 0-2 carry the chains; their results (hidden weights, transposed copies, output
+  // layer) are published through an LDS counter the chain waves check before the second layer.  All loads of A and of B's
+  // first round are issued up front.
+  constexpr int BW0 = 3, BT = (NW - BW0) * 64;                       // phase-B waves, threads
+  const int NA = (I0 + FT - 1) / FT;                                  // phase-A rounds (1 at S = 100)
+  const bool bthread = wave >= BW0;
+  const int btid = threadIdx.x - BW0 * 64;
+  auto issue = [&](int u, int e0, bool live) __attribute__((always_inline)) {
     const int e = live ? e0 : 0;
     const bool first = e < I0;
     const int e1 = e - I0;
@@ -372,7 +379,14 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       const int oc = ok ? o : 0;
       pv[u][r] = src_p[oc]; mv[u][r] = src_m[oc]; vv[u][r] = src_v[oc];
     }
+  };
+  // register slots 0 .. NA-1: phase A; the remaining ones: phase B's first rounds (waves 3-7 only)
+#pragma unroll
+  for (int u = 0; u < NITEM; ++u) {            // straight-line code: selects, no branches, so all loads leave together
+    if (u < NA) issue(u, threadIdx.x + u * FT, threadIdx.x + u * FT < I0);
+    else if (bthread && u < NITEM && I0 + (u - NA) * BT < nitems) issue(u, I0 + (u - NA) * BT + btid, I0 + (u - NA) * BT + btid < nitems);
   }
+  constexpr int UB = NITEM - 1;                // the slot any further phase-B rounds re-use
   float coef = 0.f;
   {
     const float nrm = sqrtf(gsum + 1e-12f);             // train.py:90, whole batch
@@ -386,45 +400,31 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   }
   STAMP(51);
   const bool upd = it > 0;
-  // chunks 0-3 came with the batch above; batches above 64 rows bring more, fetched four chunks x NITEM items at a time
-  // (one round trip per group) and added in chunk order
-  f32x4 grf_[NITEM], ggp_[NITEM];
-#pragma unroll
-  for (int u = 0; u < NITEM; ++u) {
-    grf_[u] = f32x4{0.f, 0.f, 0.f, 0.f}; ggp_[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (u * FT >= nitems) continue;
+  // a slot's quad: sum over the chunks in chunk order (chunks 0-3 came with the batch; batches above 64 rows bring more, four at
+  // a time), Adam, state and LDS weight image
+  auto finish = [&](int u) __attribute__((always_inline)) {
+    f32x4 grf = {0.f, 0.f, 0.f, 0.f}, ggp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float on = w < nchunks ? 1.f : 0.f;
-      grf_[u][0] += on * sx[u][w].x; grf_[u][1] += on * sx[u][w].y; grf_[u][2] += on * sx[u][w].z; grf_[u][3] += on * sx[u][w].w;
-      ggp_[u][0] += on * sy[u][w].x; ggp_[u][1] += on * sy[u][w].y; ggp_[u][2] += on * sy[u][w].z; ggp_[u][3] += on * sy[u][w].w;
+      grf[0] += on * sx[u][w].x; grf[1] += on * sx[u][w].y; grf[2] += on * sx[u][w].z; grf[3] += on * sx[u][w].w;
+      ggp[0] += on * sy[u][w].x; ggp[1] += on * sy[u][w].y; ggp[2] += on * sy[u][w].z; ggp[3] += on * sy[u][w].w;
     }
-  }
-  for (int w0 = 4; w0 < nchunks; w0 += 4) {
-    float4 x[NITEM][4], y[NITEM][4];
-#pragma unroll
-    for (int u = 0; u < NITEM; ++u)
+    for (int w0c = 4; w0c < nchunks; w0c += 4) {
+      float4 x[4], y[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        if (u * FT >= nitems) continue;
-        const float* sl = prev + (int64_t)(w0 + w < nchunks ? w0 + w : 0) * g.slab_floats + i_so[u];
-        x[u][w] = *reinterpret_cast<const float4*>(sl); y[u][w] = *reinterpret_cast<const float4*>(sl + 256);
+        const float* sl = prev + (int64_t)(w0c + w < nchunks ? w0c + w : 0) * g.slab_floats + i_so[u];
+        x[w] = *reinterpret_cast<const float4*>(sl); y[w] = *reinterpret_cast<const float4*>(sl + 256);
       }
-#pragma unroll
-    for (int u = 0; u < NITEM; ++u)
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        if (u * FT >= nitems) continue;
-        const float on = w0 + w < nchunks ? 1.f : 0.f;
-        grf_[u][0] += on * x[u][w].x; grf_[u][1] += on * x[u][w].y; grf_[u][2] += on * x[u][w].z; grf_[u][3] += on * x[u][w].w;
-        ggp_[u][0] += on * y[u][w].x; ggp_[u][1] += on * y[u][w].y; ggp_[u][2] += on * y[u][w].z; ggp_[u][3] += on * y[u][w].w;
+        const float on = w0c + w < nchunks ? 1.f : 0.f;
+        grf[0] += on * x[w].x; grf[1] += on * x[w].y; grf[2] += on * x[w].z; grf[3] += on * x[w].w;
+        ggp[0] += on * y[w].x; ggp[1] += on * y[w].y; ggp[2] += on * y[w].z; ggp[3] += on * y[w].w;
       }
-  }
-#pragma unroll
-  for (int u = 0; u < NITEM; ++u) {
-    if (u * FT >= nitems) continue;
+    }
     const int li = i_li[u];
-    const f32x4 grf = grf_[u], ggp = ggp_[u];
     const int N = li == nh ? 1 : L;
     const int n = i_n[u], k = i_k[u];
 #pragma unroll
@@ -442,8 +442,22 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
         if (li > 0 && li < nh && k < L) whT[((li - 1) * Lp + k) * LQ + n + r] = pw;
       }
     }
-  }
-  if (fin) return;
+  };
+#pragma unroll
+  for (int u = 0; u < NITEM; ++u)
+    if (u < NA) finish(u);
+  // phase B (waves 3-7): the slot loaded up front, then any further rounds one after the other (off the critical path)
+  int* bdone = reinterpret_cast<int*>(red + 40);
+  auto phase_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NITEM; ++u)
+      if (u >= NA && I0 + (u - NA) * BT < nitems) finish(u);
+    for (int eb = I0 + (NITEM - NA) * BT + btid; eb - btid < nitems; eb += BT) {     // (uniform trip count; none at S = 100)
+      issue(UB, eb, eb < nitems);
+      finish(UB);
+    }
+  };
+  if (fin) { if (bthread) phase_b(); return; }
   STAMP(1);
 
   // ---- record -> LDS; constant d loss / d out (column 0 of dl[nh]: the left operand of the output layer's weight gradient)
@@ -458,7 +472,10 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
   }
   if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
-  __syncthreads();
+  if (threadIdx.x == 0) *bdone = 0;
+  // LDS-only barrier: what crosses it is LDS data (record, layer-0 weights); __syncthreads() would also make waves 3-7 wait
+  // for their phase-B loads (vmcnt(0)), which are still in flight and not needed yet
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   STAMP(2);
   int sk = 3;
 
@@ -534,9 +551,12 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
       for (int r = 0; r < 4; ++r) T[t][r] = acc[r] + acc2[r];
     }
     STAMP(20);
-    if (nh > 1) load_fwd(1);
     epilogue(0);
     STAMP(21);
+    // the other layers' weights come from phase B
+    while (__hip_atomic_load(bdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW - BW0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (nh > 1) load_fwd(1);
     for (int li = 1; li < nh; ++li) {
       f32x4 N[MF];
 #pragma unroll
@@ -609,9 +629,14 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
     if (wave < 2 && lane == 0) red[32 + wave] = o;                 // sum over the real / the fake rows
-  } else if (wave < 5) {
+  } else {
+    phase_b();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(bdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (wave == 3 || wave == 7) {                                    // (SIMD 3: no chain wave there)
     const int CTg = Lp >> 4;                                       // Gram tiles per side
-    for (int t = wave - 3; t < CTg * CTg; t += 2) {
+    for (int t = wave == 3 ? 0 : 1; t < CTg * CTg; t += 2) {
       const int mt = t / CTg, nt = t - mt * CTg;
       const int m = mt * 16 + j, n = nt * 16 + j;
       const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
