@@ -503,10 +503,9 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   TSTAMP(30);
   PackedPre nxt{};
   if (next_W) nxt = gemm_nt_prefetch(next_W, next_K, next_N);
-  gemm_nt_packed<MT, PRE>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0, 0, pre2);
+  struct Tanh { __device__ __forceinline__ float operator()(float v) const { return tanhf_(v); } };
+  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0, 0, pre2);      // tanh in the epilogue
   TSTAMP(31);
-  __syncthreads();
-  tile_for(rows, S, [&](int r, int c) { bufA[r * ldS + c] = tanhf_(bufA[r * ldS + c]); });
   __syncthreads();
   return nxt;
 #undef TSTAMP

@@ -204,10 +204,13 @@ __device__ __forceinline__ PackedPre gemm_nt_prefetch(const float* __restrict__ 
   for (int u = 0; u < 8; ++u) p.w[u] = wp[(size_t)(u < kg ? u : kg - 1) * 64];
   return p;
 }
-template <int MT, bool PRE = false>
+struct ActIdentity { __device__ __forceinline__ float operator()(float v) const { return v; } };
+// Act: applied to (product + bias) in the epilogue -- an elementwise activation costs nothing there, and a pass + barrier as a
+// stage of its own.
+template <int MT, bool PRE = false, class Act = ActIdentity>
 __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
                                                const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
-                                               const PackedPre& pre = PackedPre{}) {
+                                               const PackedPre& pre = PackedPre{}, Act act = Act{}) {
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
@@ -251,7 +254,7 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = acc[m][r] + acc2[m][r] + bs;
+        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = act(acc[m][r] + acc2[m][r] + bs);
     }
   };
   if (wave < ntiles) run(wave, std::integral_constant<bool, PRE>{});
