@@ -349,7 +349,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const GenPack gp = gen_pack(S, L, HYPER ? 1 : 0);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* small = smem + lp.small;
-  float* dzs = small + 16 * LP;             // [16][LP] total gradient of the encoder output
   float* red = small + 3 * 16 * LP;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   const uint32_t tick = (uint32_t)a.counters[3];
@@ -587,12 +586,10 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
   gemm_nt_packed<1, true>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0, 0, pre_d1t);
   __syncthreads();
-  tile_for(16, L, [&](int r, int c) { dzs[r * LP + c] = dP[r * LP + c]; });        // (the critic_z part of dZ: chain Z)
-  __syncthreads();
-  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dzs, LP, 16, L, 16);
+  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dP, LP, 16, L, 16);               // (the critic_z part of dZ: chain Z)
   GEN_STAMP(10);
   // ---- encoder backward
-  gemm_nt_packed<1, true>(dzs, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
+  gemm_nt_packed<1, true>(dP, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
   __syncthreads();
   lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
   __syncthreads();
