@@ -207,6 +207,7 @@ __device__ __forceinline__ float rowdist_row_bwd(const R& u, const R& v, float g
 template <class F>
 __device__ __forceinline__ void epl16_dispatch(int dim, F f) {
   if (dim <= 64) f(std::integral_constant<int, 4>{});
+  else if (dim <= 112) f(std::integral_constant<int, 7>{});      // window 100: 7 elements per lane instead of 8 (the row chains are VALU-bound)
   else if (dim <= 128) f(std::integral_constant<int, 8>{});
   else f(std::integral_constant<int, 16>{});
 }
