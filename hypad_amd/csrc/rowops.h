@@ -109,9 +109,10 @@ __device__ __forceinline__ R mobius_add_row(const R& x, const R& y) {
   float x2 = row_dot(x, x), y2 = row_dot(y, y), xy = row_dot(x, y);
   float A = 1.f + 2.f * xy + y2, Bc = 1.f - x2;
   float D = fmaxf(1.f + 2.f * xy + x2 * y2, MIN_NORM);
+  const float rD = 1.f / D;              // one division per row; an IEEE division per element is ~12 instructions each
   R m;
 #pragma unroll
-  for (int e = 0; e < R::EPL; ++e) m.v[e] = (A * x.v[e] + Bc * y.v[e]) / D;
+  for (int e = 0; e < R::EPL; ++e) m.v[e] = (A * x.v[e] + Bc * y.v[e]) * rD;
   return m;
 }
 template <class R>
@@ -120,13 +121,14 @@ __device__ __forceinline__ void mobius_add_row_bwd(const R& x, const R& y, const
   float A = 1.f + 2.f * xy + y2, Bc = 1.f - x2;
   float Draw = 1.f + 2.f * xy + x2 * y2;
   float D = fmaxf(Draw, MIN_NORM);
+  const float rD = 1.f / D;
   R m, dN;
 #pragma unroll
   for (int e = 0; e < R::EPL; ++e) {
-    m.v[e] = (A * x.v[e] + Bc * y.v[e]) / D;
-    dN.v[e] = dm.v[e] / D;
+    m.v[e] = (A * x.v[e] + Bc * y.v[e]) * rD;
+    dN.v[e] = dm.v[e] * rD;
   }
-  float dD = Draw >= MIN_NORM ? -row_dot(dm, m) / D : 0.f;
+  float dD = Draw >= MIN_NORM ? -row_dot(dm, m) * rD : 0.f;
   float dA = row_dot(dN, x), dBc = row_dot(dN, y);
   float dxy = 2.f * dA + 2.f * dD, dx2 = -dBc + y2 * dD, dy2 = dA + x2 * dD;
 #pragma unroll
@@ -142,8 +144,9 @@ __device__ __forceinline__ R project_row(const R& x) {
   float n = fmaxf(sqrtf(row_dot(x, x)), MIN_NORM);
   R o = x;
   if (n > BALL_MAXNORM) {
+    const float sc = BALL_MAXNORM / n;
 #pragma unroll
-    for (int e = 0; e < R::EPL; ++e) o.v[e] = x.v[e] / n * BALL_MAXNORM;
+    for (int e = 0; e < R::EPL; ++e) o.v[e] = x.v[e] * sc;
   }
   return o;
 }
@@ -154,8 +157,9 @@ __device__ __forceinline__ R project_row_bwd(const R& x, const R& go) {
   if (!(n > BALL_MAXNORM)) return go;
   float s = raw >= MIN_NORM ? row_dot(x, go) / (n * n) : 0.f;
   R gx;
+  const float sc = BALL_MAXNORM / n;
 #pragma unroll
-  for (int e = 0; e < R::EPL; ++e) gx.v[e] = (BALL_MAXNORM / n) * (go.v[e] - x.v[e] * s);
+  for (int e = 0; e < R::EPL; ++e) gx.v[e] = sc * (go.v[e] - x.v[e] * s);
   return gx;
 }
 
