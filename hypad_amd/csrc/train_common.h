@@ -174,17 +174,19 @@ __device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, Ro
 #pragma unroll
   for (int e = 0; e < MAX_EPL; ++e) g.v[e] += c.wd * P.v[e];
   float lam = 2.f / fmaxf(1.f - row_dot(P, P), MIN_NORM);
+  // (per-row reciprocals and the hardware rcp / sqrt, as in adam_update: this item is the longest of the dW + Adam launch)
+  const float ilam2 = 1.f / (lam * lam), ibc1 = 1.f / c.bc1, ibc2 = 1.f / c.bc2;
   RowVec rg;
 #pragma unroll
-  for (int e = 0; e < MAX_EPL; ++e) rg.v[e] = g.v[e] / (lam * lam);
+  for (int e = 0; e < MAX_EPL; ++e) rg.v[e] = g.v[e] * ilam2;
   float inner = lam * lam * row_dot(rg, rg);
   RowVec np;
 #pragma unroll
   for (int e = 0; e < MAX_EPL; ++e) {
     Mv.v[e] = c.b1 * Mv.v[e] + (1.f - c.b1) * rg.v[e];
     V.v[e] = c.b2 * V.v[e] + (1.f - c.b2) * inner;
-    float den = sqrtf(V.v[e] / c.bc2) + c.eps;
-    np.v[e] = P.v[e] - c.lr * (Mv.v[e] / c.bc1) / den;
+    float den = __builtin_amdgcn_sqrtf(V.v[e] * ibc2) + c.eps;
+    np.v[e] = P.v[e] - c.lr * (Mv.v[e] * ibc1) * __builtin_amdgcn_rcpf(den);
   }
   np = project_row(np);
   // parallel transport of the first moment: gyr[np, -p] m * lambda_p / lambda_np (math_.py:1738-1746, 656-676)
@@ -196,8 +198,9 @@ __device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, Ro
   float cb = -vw * u2 - uw;
   float d = fmaxf(1.f + 2.f * uv + u2 * v2, MIN_NORM);
   float lam_n = 2.f / fmaxf(1.f - u2, MIN_NORM);
+  const float id2 = 2.f / d, sc = lam / lam_n;
 #pragma unroll
-  for (int e = 0; e < MAX_EPL; ++e) Mv.v[e] = (Mv.v[e] + 2.f * (ca * np.v[e] + cb * nb.v[e]) / d) * lam / lam_n;
+  for (int e = 0; e < MAX_EPL; ++e) Mv.v[e] = (Mv.v[e] + (ca * np.v[e] + cb * nb.v[e]) * id2) * sc;
   if (c.stabilize > 0 && c.step % c.stabilize == 0) np = project_row(np);
   row_store(p, np, dim, lane);
   row_store(m, Mv, dim, lane);
