@@ -303,8 +303,10 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const CriticLayout clz = cz_layout(L);
   const CriticPad cpz = critic_pad(L, L, 2);
-  const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
+  // (the gather first: loads return in order, and the weight prefetch -- cold lines, rewritten by the previous launch -- would
+  // hold its two dependent round trips back)
   tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+  const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
   stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
   __syncthreads();
   tile_store(ws + gw.xg + (int64_t)(B + g0) * S, S, xs, ldS, 16, S, 16);
@@ -396,8 +398,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // ---- encoder(x)  (critic_z(encoder(x)) and its way back through the encoder: chain Z)
     // the window gather is two dependent memory round trips (row index, then the row)
     GEN_STAMP(14);
-    const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
     tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+    const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);      // behind the gather (loads return in order)
     GEN_STAMP(15);
     GEN_STAMP(12);
     __syncthreads();
