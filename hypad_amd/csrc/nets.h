@@ -456,7 +456,8 @@ template <int MT, bool PRE = false, class RowFn>
 __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* Zs, int L, int S, const float* pk, const GenPack& gp,
                                                                    float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
                                                                    const DecSave& sv, int valid, const PackedPre& pred1 = PackedPre{},
-                                                                   const float* next_W = nullptr, int next_K = 0, int next_N = 0) {
+                                                                   const float* next_W = nullptr, int next_K = 0, int next_N = 0,
+                                                                   float* Eout = nullptr) {            // Eout: where the tanh output goes (default bufA)
   constexpr int rows = MT * 16;
   constexpr int ldA0 = 52, ldH = 2 * DEC_H + 4;
 // development aid (scripts/diag_gen.py): per-wave shader-clock marks 16-19, 27-31 of the generator kernel's timeline
@@ -504,7 +505,7 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   PackedPre nxt{};
   if (next_W) nxt = gemm_nt_prefetch(next_W, next_K, next_N);
   struct Tanh { __device__ __forceinline__ float operator()(float v) const { return tanhf_(v); } };
-  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, bufA, ldS, 0, 0, pre2);      // tanh in the epilogue
+  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, Eout ? Eout : bufA, ldS, 0, 0, pre2);      // tanh in the epilogue
   TSTAMP(31);
   __syncthreads();
   return nxt;

@@ -262,7 +262,7 @@ HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) 
 // One workgroup per (16-row tile, role): blockIdx.z = role.  Operand rows in the workspace are pass-major as before:
 // pass 0 = decoder(z), pass 1 = decoder(encoder(x)), pass 2 (hyperbolic only) = hyperbolic_linear(x).
 struct GenLds {
-  int xs, zs, bufA, bufB, small, cw, ct, total, ldS;
+  int hb, xs, zs, bufA, bufB, small, cw, ct, total, ldS;
 };
 HD GenLds gen_lds(int S, int L, int hyper, int role) {
   GenLds p;
@@ -272,7 +272,8 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
   const int a = 16 * (6 * DEC_H + 4), b = rows_head * p.ldS;
   const int bufFloats = a > b ? a : b;
   int o = 0;
-  p.xs = o; o += role >= 1 ? 16 * p.ldS : 0;     // the real windows: roles R and Z
+  p.hb = o; o += (role == 1 && hyper) ? 16 * p.ldS : 0;   // chain R, hyperbolic: the head's 32 input rows = [tanh output | real windows],
+  p.xs = o; o += role >= 1 ? 16 * p.ldS : 0;              // contiguous: the windows are gathered straight into the second half
   p.zs = o; o += 32 * LP;
   p.bufA = o; o += bufFloats;
   p.bufB = o; o += bufFloats;
@@ -353,6 +354,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* small = smem + lp.small;
   float* red = small + 3 * 16 * LP;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
+  float* Ein = (HYPER && role == 1) ? smem + lp.hb : bufA;      // the Moebius head's input rows
   const uint32_t tick = (uint32_t)a.counters[3];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     // optimizer step number and its bias corrections (double-precision powers): once, here, for the dW + Adam launch
@@ -428,19 +430,15 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
   const int growp = pass * B + g0;
   const PackedPre pre_head = decoder_trunk_fwd_tile_packed<1, true>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16,
-                                                                    pre_d1, HYPER ? pk + gp.head : nullptr, S, S);
+                                                                    pre_d1, HYPER ? pk + gp.head : nullptr, S, S, Ein);
   GEN_STAMP(3);
-  // E = tanh output in bufA[0..15]
+  // E = tanh output in Ein[0..15]
   const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
   if (HYPER) {
-    if (role == 1) {
-      tile_for(16, S, [&](int r, int c) { bufA[(16 + r) * ldS + c] = xs[r * ldS + c]; });
-      __syncthreads();
-    }
-    tile_store_p(ws + gw.ecat + prow0 * S, S, B, bufA, ldS, hrows, S, hrows);
+    tile_store_p(ws + gw.ecat + prow0 * S, S, B, Ein, ldS, hrows, S, hrows);      // (chain R: rows 16-31 are the gathered windows)
     GEN_STAMP(20);
-    if (role == 1) gemm_nt_packed<2, true>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
-    else gemm_nt_packed<1, true>(bufA, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
     __syncthreads();
     GEN_STAMP(21);
     tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
