@@ -210,7 +210,10 @@ struct ActIdentity { __device__ __forceinline__ float operator()(float v) const 
 template <int MT, bool PRE = false, class Act = ActIdentity>
 __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
                                                const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
-                                               const PackedPre& pre = PackedPre{}, Act act = Act{}) {
+                                               const PackedPre& pre = PackedPre{}, Act act = Act{},
+                                               const float* __restrict__ escale = nullptr, int es_ld = 0) {
+  // escale (may be null): global [rows][es_ld] factors multiplied into the result (a dropout mask in the backward pass);
+  // fetched before the product so that the epilogue does not wait for them
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
@@ -218,6 +221,11 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
     const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)t * kg * 64 + lane;
     const int n = t * 16 + j;
     const float bs = (bsum && n < N) ? bsum[n] : 0.f;
+    float es[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) es[m][r] = (escale && n < N) ? escale[(size_t)(m * 16 + 4 * q + r) * es_ld + n] : 1.f;
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -254,7 +262,7 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = act(acc[m][r] + acc2[m][r] + bs);
+        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = act(acc[m][r] + acc2[m][r] + bs) * es[m][r];
     }
   };
   if (wave < ntiles) run(wave, std::integral_constant<bool, PRE>{});

@@ -553,14 +553,12 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
   const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
   GEN_STAMP(34);
-  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0, 0, pre_l1t);     // both directions: one stacked reduction
+  // both directions: one stacked reduction; the inter-layer dropout's backward (x mask) rides in the epilogue
+  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0, 0, pre_l1t, ActIdentity{},
+                          a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H);
   GEN_STAMP(35);
   __syncthreads();
   GEN_STAMP(36);
-  if (a.drop_mode != 0) {
-    tile_for(16, 2 * DEC_H, [&](int r, int c) { oth[r * ldH + c] *= ws[gw.mask + (prow0 + r) * 2 * DEC_H + c]; });
-    __syncthreads();
-  }
   GEN_STAMP(8);
   // layer 0
   lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
