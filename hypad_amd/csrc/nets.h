@@ -163,6 +163,36 @@ __device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, co
         }
     }
 }
+// The same cell backward as the epilogue of the product that makes dH (tile_gemm.h gemm_nt_packed_epi, 16 rows): output column
+// n = d H + unit of dH turns into the three gate deltas of that unit, written to dGs[row][d 3H + {0, H, 2H} + unit]; the saved
+// gates (and an optional [rows][mask_ld] factor on dH: the inter-layer dropout's backward) are requested before the reduction.
+struct LstmCellBwdEpi {
+  const float* gates_saved; int H; float* dGs; int ldg; int valid; int ps; const float* mask; int mask_ld;
+  float gi[4], gg[4], go[4], tc[4], ms[4];
+  __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
+    const int nn = ok ? n : 0, d = nn >= H ? 1 : 0, jj = nn - d * H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      const float* s = gates_saved + prow(row < valid ? row : 0, ps) * 8 * H + d * 4 * H + jj;
+      gi[r] = s[0]; gg[r] = s[H]; go[r] = s[2 * H]; tc[r] = s[3 * H];
+      ms[r] = mask ? mask[(size_t)row * mask_ld + nn] : 1.f;
+    }
+  }
+  __device__ __forceinline__ void emit(int, int r, int row, int n, float v) {
+    const int d = n >= H ? 1 : 0, jj = n - d * H;
+    float di = 0.f, dg = 0.f, dov = 0.f;
+    if (row < valid) {
+      const float dh = v * ms[r];
+      dov = dh * tc[r] * go[r] * (1.f - go[r]);
+      const float dc = dh * go[r] * (1.f - tc[r] * tc[r]);
+      di = dc * gg[r] * gi[r] * (1.f - gi[r]);
+      dg = dc * gi[r] * (1.f - gg[r] * gg[r]);
+    }
+    float* o = dGs + row * ldg + d * 3 * H;
+    o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
+  }
+};
 // dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)
 template <int MT>
 __device__ __forceinline__ void lstm_bwd_data_tile(const float* dGs, int ldg, const float* P, const LstmDir& d0,

@@ -205,15 +205,15 @@ __device__ __forceinline__ PackedPre gemm_nt_prefetch(const float* __restrict__ 
   return p;
 }
 struct ActIdentity { __device__ __forceinline__ float operator()(float v) const { return v; } };
-// Act: applied to (product + bias) in the epilogue -- an elementwise activation costs nothing there, and a pass + barrier as a
-// stage of its own.
-template <int MT, bool PRE = false, class Act = ActIdentity>
-__device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
-                                               const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
-                                               const PackedPre& pre = PackedPre{}, Act act = Act{},
-                                               const float* __restrict__ escale = nullptr, int es_ld = 0) {
-  // escale (may be null): global [rows][es_ld] factors multiplied into the result (a dropout mask in the backward pass);
-  // fetched before the product so that the epilogue does not wait for them
+// The product with a caller-supplied epilogue object (MT * 16 rows):
+//   epi.prefetch(n, q, ok)          before a tile's reduction: request whatever the epilogue needs for output column n and
+//                                   rows 16 m + 4 q + r (ok: n < N) -- it arrives under the MFMAs;
+//   epi.emit(m, r, row, n, value)   for every element of the tile (value = product + summed bias), n < N.
+// An elementwise stage that follows a product costs a pass over LDS and a workgroup barrier on its own; in the epilogue it costs
+// its arithmetic.
+template <int MT, bool PRE, class Epi>
+__device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
+                                                   const float* __restrict__ bsum, int wave_rot, const PackedPre& pre, Epi& epi) {
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
@@ -221,11 +221,7 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
     const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)t * kg * 64 + lane;
     const int n = t * 16 + j;
     const float bs = (bsum && n < N) ? bsum[n] : 0.f;
-    float es[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) es[m][r] = (escale && n < N) ? escale[(size_t)(m * 16 + 4 * q + r) * es_ld + n] : 1.f;
+    epi.prefetch(n, q, n < N);
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -262,11 +258,33 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ys[(m * 16 + 4 * q + r) * ldy + ycol0 + n] = act(acc[m][r] + acc2[m][r] + bs) * es[m][r];
+        for (int r = 0; r < 4; ++r) epi.emit(m, r, m * 16 + 4 * q + r, n, acc[m][r] + acc2[m][r] + bs);
     }
   };
   if (wave < ntiles) run(wave, std::integral_constant<bool, PRE>{});
   for (int t = wave + nwaves; t < ntiles; t += nwaves) run(t, std::false_type{});
+}
+// The plain epilogue: Ys[row][ycol0 + n] = act(value) * escale[row][n].  escale (may be null): global [rows][es_ld] factors (a
+// dropout mask in the backward pass), fetched before the reduction so that the epilogue does not wait for them.
+template <int MT, class Act>
+struct PlainEpi {
+  float* Ys; int ldy, ycol0; Act act; const float* escale; int es_ld;
+  float es[MT][4];
+  __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) es[m][r] = (escale && ok) ? escale[(size_t)(m * 16 + 4 * q + r) * es_ld + n] : 1.f;
+  }
+  __device__ __forceinline__ void emit(int m, int r, int row, int n, float v) { Ys[row * ldy + ycol0 + n] = act(v) * es[m][r]; }
+};
+template <int MT, bool PRE = false, class Act = ActIdentity>
+__device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
+                                               const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
+                                               const PackedPre& pre = PackedPre{}, Act act = Act{},
+                                               const float* __restrict__ escale = nullptr, int es_ld = 0) {
+  PlainEpi<MT, Act> epi{Ys, ldy, ycol0, act, escale, es_ld, {}};
+  gemm_nt_packed_epi<MT, PRE>(Xs, ldx, K, N, Wp, bsum, wave_rot, pre, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------- gemm_nn

@@ -322,10 +322,11 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
                                              [&](int li, int r, int c) { return dz.get(li, g0 + r, c, L); }, dzc, LP);
   tile_store(ws + gw.dzenc + (int64_t)(B + g0) * L, L, dzc, LP, 16, L, 16);
   // encoder backward of that gradient
-  float* oth = bufB; float* dP = bufA;
-  gemm_nt_packed<1, true>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
-  __syncthreads();
-  lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, gates, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
+  float* dP = bufA;
+  {
+    LstmCellBwdEpi epi{gates, ENC_H, dP, 6 * ENC_H + 4, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    gemm_nt_packed_epi<1, true>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);      // dH, cell backward in the epilogue
+  }
   __syncthreads();
   tile_store(ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
   float* part_out = ws + gw.partial + tile * 4;
@@ -535,43 +536,45 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     });
     __syncthreads();
   }
-  float* dP = HYPER ? R : dR;               // d(pre-tanh) [16][ldS]
-  float* oth = HYPER ? dR : R;
+  // The backward half ping-pongs between the two big LDS tiles X (holds d(pre-tanh)) and Y; every LSTM cell backward runs in
+  // the epilogue of the product that makes its dH (LstmCellBwdEpi), so a layer is one stage: product -> gate deltas.
+  float* X = HYPER ? R : dR;                // d(pre-tanh) [16][ldS]
+  float* Y = HYPER ? dR : R;
   GEN_STAMP(6);
   const PackedPre pre_d2t = gemm_nt_prefetch(pk + gp.d2_t, S, 2 * DEC_H);
-  tile_store(ws + gw.dpre2 + prow0 * S, S, dP, ldS, 16, S, 16);
+  tile_store(ws + gw.dpre2 + prow0 * S, S, X, ldS, 16, S, 16);
   const PackedPre pre_l1t = gemm_nt_prefetch(pk + gp.l_t[1], 6 * DEC_H, 2 * DEC_H);
-  // dH1 = dpre W2
-  gemm_nt_packed<1, true>(dP, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, oth, ldH, 0, 0, pre_d2t);
-  __syncthreads();
-  GEN_STAMP(7);
-  // layer 1 cell backward -> dG1 (in dP's buffer), dH0d = dG1 W_ih(l1)
-  lstm_cell_bwd_tile(oth, ldH, ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
+  // dH1 = dpre W2, layer 1 cell backward -> dG1 in Y
+  {
+    LstmCellBwdEpi epi{ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, Y, ldG, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    gemm_nt_packed_epi<1, true>(X, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, 0, pre_d2t, epi);
+  }
   GEN_STAMP(32);
   __syncthreads();
+  GEN_STAMP(7);
   GEN_STAMP(33);
-  tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
+  tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, Y, ldG, 16, 6 * DEC_H, 16);
   const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
   GEN_STAMP(34);
-  // both directions: one stacked reduction; the inter-layer dropout's backward (x mask) rides in the epilogue
-  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, oth, ldH, 0, 0, pre_l1t, ActIdentity{},
-                          a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H);
+  // dH0d = dG1 W_ih(l1) (both directions: one stacked reduction), x the inter-layer dropout mask, layer 0 cell backward -> dG0 in X
+  {
+    LstmCellBwdEpi epi{ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, X, ldG, 16, 16,
+                       a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H, {}, {}, {}, {}, {}};
+    gemm_nt_packed_epi<1, true>(Y, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, 0, pre_l1t, epi);
+  }
   GEN_STAMP(35);
   __syncthreads();
   GEN_STAMP(36);
   GEN_STAMP(8);
-  // layer 0
-  lstm_cell_bwd_tile(oth, ldH, ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, 16, dP, ldG, 16);
   GEN_STAMP(37);
-  __syncthreads();
-  tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, dP, ldG, 16, 6 * DEC_H, 16);
+  tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, X, ldG, 16, 6 * DEC_H, 16);
   PackedPre pre_d1t{};
   if (role == 1) pre_d1t = gemm_nt_prefetch(pk + gp.d1_t, DEC_D1, L);
   GEN_STAMP(38);
-  gemm_nt_packed<1, true>(dP, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, oth, ldA0, 0, 0, pre_l0t);
+  gemm_nt_packed<1, true>(X, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, Y, ldA0, 0, 0, pre_l0t);
   GEN_STAMP(39);
   __syncthreads();
-  tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, oth, ldA0, 16, DEC_D1, 16);
+  tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, Y, ldA0, 16, DEC_D1, 16);
   GEN_STAMP(9);
   float* part_out = ws + gw.partial + tile * 4;
   if (role == 0) {
@@ -582,16 +585,17 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   }
   // dZ = dA0 W1: the gradient reaching the encoder's output
   const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
-  gemm_nt_packed<1, true>(oth, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, dP, LP, 0, 0, pre_d1t);
+  gemm_nt_packed<1, true>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t);
   __syncthreads();
-  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, dP, LP, 16, L, 16);               // (the critic_z part of dZ: chain Z)
+  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, X, LP, 16, L, 16);                // (the critic_z part of dZ: chain Z)
   GEN_STAMP(10);
-  // ---- encoder backward
-  gemm_nt_packed<1, true>(dP, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, oth, 2 * ENC_H + 4, 0, 0, pre_edt);
+  // ---- encoder backward: dH = dZ W_dense, cell backward -> dG in Y
+  {
+    LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, 6 * ENC_H + 4, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    gemm_nt_packed_epi<1, true>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
+  }
   __syncthreads();
-  lstm_cell_bwd_tile(oth, 2 * ENC_H + 4, ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, 16, dP, 6 * ENC_H + 4, 16);
-  __syncthreads();
-  tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
+  tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, Y, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
   if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
   GEN_STAMP(11);
