@@ -508,16 +508,21 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     tile_store_p(ws + gw.du + prow0 * S, S, B, dR, ldS, hrows, S, hrows);
     __syncthreads();
     GEN_STAMP(25);
-    // dE = dU W_h for the decoder pass
-    gemm_nt_packed<1, true>(dR, ldS, S, S, pk + gp.head_t, nullptr, R, ldS, 0, 0, pre_ht);
+    // dE = dU W_h for the decoder pass, and d(pre-tanh) = dE * (1 - E^2) in its epilogue (E re-read from the workspace,
+    // requested before the reduction)
+    {
+      struct TanhBwdEpi {
+        float* Ys; int ldy; const float* E; int ldE; float e[4];
+        __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = ok ? E[(size_t)(4 * q + r) * ldE + n] : 0.f;
+        }
+        __device__ __forceinline__ void emit(int, int r, int row, int n, float v) { Ys[row * ldy + n] = v * (1.f - e[r] * e[r]); }
+      } epi{R, ldS, ws + gw.ecat + prow0 * S, S, {}};
+      gemm_nt_packed_epi<1, true>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
+    }
     __syncthreads();
     GEN_STAMP(26);
-    // d(pre-tanh) = dE * (1 - E^2), E re-read from the workspace
-    tile_for(16, S, [&](int r, int c) {
-      const float e = ws[gw.ecat + (prow0 + r) * S + c];
-      R[r * ldS + c] *= 1.f - e * e;
-    });
-    __syncthreads();
   } else {
     if (role == 1) {
       // ---- 10 * MSE(x, x_rec) (train.py:241-242): E in bufA (= R), gradients into bufB (= dR)
