@@ -168,6 +168,7 @@ __device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, co
 // gates (and an optional [rows][mask_ld] factor on dH: the inter-layer dropout's backward) are requested before the reduction.
 struct LstmCellBwdEpi {
   const float* gates_saved; int H; float* dGs; int ldg; int valid; int ps; const float* mask; int mask_ld;
+  float* gout;               // global mirror [rows][6H] of the gate deltas (the weight-gradient kernel's operand rows), or null
   float gi[4], gg[4], go[4], tc[4], ms[4];
   __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
     const int nn = ok ? n : 0, d = nn >= H ? 1 : 0, jj = nn - d * H;
@@ -191,6 +192,7 @@ struct LstmCellBwdEpi {
     }
     float* o = dGs + row * ldg + d * 3 * H;
     o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
+    if (gout && row < valid) { float* w = gout + (size_t)row * 6 * H + d * 3 * H; w[jj] = di; w[H + jj] = dg; w[2 * H + jj] = dov; }
   }
 };
 // dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)

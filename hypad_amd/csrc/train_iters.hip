@@ -324,11 +324,9 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   // encoder backward of that gradient
   float* dP = bufA;
   {
-    LstmCellBwdEpi epi{gates, ENC_H, dP, 6 * ENC_H + 4, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    LstmCellBwdEpi epi{gates, ENC_H, dP, 6 * ENC_H + 4, 16, 16, nullptr, 0, ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);      // dH, cell backward in the epilogue
   }
-  __syncthreads();
-  tile_store(ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, 6 * ENC_H, dP, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
   float* part_out = ws + gw.partial + tile * 4;
   if (threadIdx.x == 0) part_out[2] = sum_crit;
 }
@@ -512,13 +510,16 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // requested before the reduction)
     {
       struct TanhBwdEpi {
-        float* Ys; int ldy; const float* E; int ldE; float e[4];
+        float* Ys; int ldy; const float* E; int ldE; float* gout; float e[4];
         __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = ok ? E[(size_t)(4 * q + r) * ldE + n] : 0.f;
         }
-        __device__ __forceinline__ void emit(int, int r, int row, int n, float v) { Ys[row * ldy + n] = v * (1.f - e[r] * e[r]); }
-      } epi{R, ldS, ws + gw.ecat + prow0 * S, S, {}};
+        __device__ __forceinline__ void emit(int, int r, int row, int n, float v) {
+          const float o = v * (1.f - e[r] * e[r]);
+          Ys[row * ldy + n] = o; gout[(size_t)row * ldE + n] = o;        // LDS tile + the dW kernel's operand rows
+        }
+      } epi{R, ldS, ws + gw.ecat + prow0 * S, S, ws + gw.dpre2 + prow0 * S, {}};
       gemm_nt_packed_epi<1, true>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
     }
     __syncthreads();
@@ -547,24 +548,23 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* Y = HYPER ? dR : R;
   GEN_STAMP(6);
   const PackedPre pre_d2t = gemm_nt_prefetch(pk + gp.d2_t, S, 2 * DEC_H);
-  tile_store(ws + gw.dpre2 + prow0 * S, S, X, ldS, 16, S, 16);
+  if (!HYPER) tile_store(ws + gw.dpre2 + prow0 * S, S, X, ldS, 16, S, 16);        // (hyperbolic: written by the epilogue above)
   const PackedPre pre_l1t = gemm_nt_prefetch(pk + gp.l_t[1], 6 * DEC_H, 2 * DEC_H);
   // dH1 = dpre W2, layer 1 cell backward -> dG1 in Y
   {
-    LstmCellBwdEpi epi{ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, Y, ldG, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    LstmCellBwdEpi epi{ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, Y, ldG, 16, 16, nullptr, 0, ws + gw.dg1 + prow0 * 6 * DEC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true>(X, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, 0, pre_d2t, epi);
   }
   GEN_STAMP(32);
   __syncthreads();
   GEN_STAMP(7);
   GEN_STAMP(33);
-  tile_store(ws + gw.dg1 + prow0 * 6 * DEC_H, 6 * DEC_H, Y, ldG, 16, 6 * DEC_H, 16);
   const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
   GEN_STAMP(34);
   // dH0d = dG1 W_ih(l1) (both directions: one stacked reduction), x the inter-layer dropout mask, layer 0 cell backward -> dG0 in X
   {
     LstmCellBwdEpi epi{ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, X, ldG, 16, 16,
-                       a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H, {}, {}, {}, {}, {}};
+                       a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H, ws + gw.dg0 + prow0 * 6 * DEC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true>(Y, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, 0, pre_l1t, epi);
   }
   GEN_STAMP(35);
@@ -572,14 +572,13 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(36);
   GEN_STAMP(8);
   GEN_STAMP(37);
-  tile_store(ws + gw.dg0 + prow0 * 6 * DEC_H, 6 * DEC_H, X, ldG, 16, 6 * DEC_H, 16);
   PackedPre pre_d1t{};
   if (role == 1) pre_d1t = gemm_nt_prefetch(pk + gp.d1_t, DEC_D1, L);
   GEN_STAMP(38);
-  gemm_nt_packed<1, true>(X, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, Y, ldA0, 0, 0, pre_l0t);
+  gemm_nt_packed<1, true>(X, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, Y, ldA0, 0, 0, pre_l0t, ActIdentity{}, nullptr, 0,
+                          ws + gw.da0 + prow0 * DEC_D1, DEC_D1);                  // (+ the dW kernel's operand rows)
   GEN_STAMP(39);
   __syncthreads();
-  tile_store(ws + gw.da0 + prow0 * DEC_D1, DEC_D1, Y, ldA0, 16, DEC_D1, 16);
   GEN_STAMP(9);
   float* part_out = ws + gw.partial + tile * 4;
   if (role == 0) {
@@ -590,17 +589,16 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   }
   // dZ = dA0 W1: the gradient reaching the encoder's output
   const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
-  gemm_nt_packed<1, true>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t);
+  gemm_nt_packed<1, true>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t, ActIdentity{}, nullptr, 0,
+                          ws + gw.dzenc + (int64_t)g0 * L, L);                     // (the critic_z part of dZ: chain Z)
   __syncthreads();
-  tile_store(ws + gw.dzenc + (int64_t)g0 * L, L, X, LP, 16, L, 16);                // (the critic_z part of dZ: chain Z)
   GEN_STAMP(10);
   // ---- encoder backward: dH = dZ W_dense, cell backward -> dG in Y
   {
-    LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, 6 * ENC_H + 4, 16, 16, nullptr, 0, {}, {}, {}, {}, {}};
+    LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, 6 * ENC_H + 4, 16, 16, nullptr, 0,
+                       ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
   }
-  __syncthreads();
-  tile_store(ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, 6 * ENC_H, Y, 6 * ENC_H + 4, 16, 6 * ENC_H, 16);
   if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
   GEN_STAMP(11);
