@@ -297,6 +297,7 @@ struct DecSave {           // global workspace rows for this tile (null = do not
   float* mask;             // [rows][2*DEC_H]   dropout keep-scale
   float* g1;               // [rows][8*DEC_H]
   float* h1;               // [rows][2*DEC_H]
+  float* e = nullptr;      // [rows][S] tanh output (latency-chain callers: written from the last product's epilogue)
   long long* stamps = nullptr;   // development aid
 };
 // Zs [rows][LP] -> tanh output E in bufA [rows][ldS].  bufA/bufB: LDS, each >= rows * max(ldS, 6*DEC_H + 4).
@@ -374,7 +375,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
                                                       const float* __restrict__ pb0, const float* __restrict__ pk1,
                                                       const float* __restrict__ pb1, int H, float* __restrict__ Hs, int ldh,
                                                       float* __restrict__ gates_save, int valid, int ps = 16,
-                                                      const LstmPre& pre = LstmPre{}) {
+                                                      const LstmPre& pre = LstmPre{}, float* __restrict__ h_out = nullptr) {      // h_out: global mirror of Hs
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
@@ -455,6 +456,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           const float gi = sigmoidf_(ai[m][r] + b_i), gg = tanhf_(ag[m][r] + b_g), go = sigmoidf_(ao[m][r] + b_o);
           const float tc = tanhf_(gi * gg);
           Hs[row * ldh + d * H + jj] = go * tc;
+          if (h_out && row < valid) h_out[prow(row, ps) * 2 * H + d * H + jj] = go * tc;
           if (gates_save && row < valid) {
             float* sv = gates_save + prow(row, ps) * 8 * H + d * 4 * H + jj;
             sv[0] = gi; sv[H] = gg; sv[2 * H] = go; sv[3 * H] = tc;
@@ -475,9 +477,8 @@ __device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx
   PackedPre pred{};
   if constexpr (PRE) pred = gemm_nt_prefetch(pk + gp.enc_d, 2 * ENC_H, L);        // the dense layer's weights, one stage ahead
   lstm_layer_fwd_packed<1, PRE>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
-                                gates_save, valid, 16, pre);
+                                gates_save, valid, 16, pre, h_save);          // (h_save written from the epilogue)
   __syncthreads();
-  if (h_save) tile_store(h_save, 2 * ENC_H, bufH, ldh, 16, 2 * ENC_H, valid);
   gemm_nt_packed<1, PRE>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
   __syncthreads();
 }
@@ -500,10 +501,10 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   LstmPre pre0{}, pre1{};
   PackedPre pre2{};
   if constexpr (PRE) pre0 = lstm_layer_prefetch(pk + gp.l_g[0][0], pk + gp.l_g[0][1], DEC_H, DEC_D1);
-  gemm_nt_packed<MT, PRE>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0, 0, pred1);
+  // (the saved activations go to the workspace from the epilogues: valid == rows for the callers that save)
+  gemm_nt_packed<MT, PRE>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0, 0, pred1, ActIdentity{}, nullptr, 0, sv.a0, DEC_D1, sv.ps);
   TSTAMP(17);
   __syncthreads();
-  if (sv.a0) tile_store_p(sv.a0, DEC_D1, sv.ps, bufB, ldA0, rows, DEC_D1, valid);
   // layer 0: input a0 in bufB [rows][ldA0] -> h0 in bufA [rows][ldH] (the cell runs in the gate product's epilogue)
   if constexpr (PRE) pre1 = lstm_layer_prefetch(pk + gp.l_g[1][0], pk + gp.l_g[1][1], DEC_H, 2 * DEC_H);
   lstm_layer_fwd_packed<MT, PRE>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA,
@@ -529,15 +530,15 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   // layer 1: h0 (dropped) in bufA -> h1 in bufB
   if constexpr (PRE) pre2 = gemm_nt_prefetch(pk + gp.d2, 2 * DEC_H, S);
   lstm_layer_fwd_packed<MT, PRE>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB,
-                                  ldH, sv.g1, valid, sv.ps, pre1);
+                                  ldH, sv.g1, valid, sv.ps, pre1, sv.h1);
   TSTAMP(29);
   __syncthreads();
-  if (sv.h1) tile_store_p(sv.h1, 2 * DEC_H, sv.ps, bufB, ldH, rows, 2 * DEC_H, valid);
   TSTAMP(30);
   PackedPre nxt{};
   if (next_W) nxt = gemm_nt_prefetch(next_W, next_K, next_N);
   struct Tanh { __device__ __forceinline__ float operator()(float v) const { return tanhf_(v); } };
-  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, Eout ? Eout : bufA, ldS, 0, 0, pre2);      // tanh in the epilogue
+  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, Eout ? Eout : bufA, ldS, 0, 0, pre2, Tanh{}, nullptr, 0,
+                                sv.e, S, sv.ps);                               // tanh in the epilogue
   TSTAMP(31);
   __syncthreads();
   return nxt;

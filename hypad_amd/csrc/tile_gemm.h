@@ -269,7 +269,7 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
 template <int MT, class Act>
 struct PlainEpi {
   float* Ys; int ldy, ycol0; Act act; const float* escale; int es_ld;
-  float* gout; int gld;      // global mirror of the result rows (row stride gld), or null
+  float* gout; int gld, gps; // global mirror of the result rows (row stride gld; gps != 0: row r lives at (r >> 4) * gps + (r & 15)), or null
   float es[MT][4];
   __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
 #pragma unroll
@@ -280,7 +280,7 @@ struct PlainEpi {
   __device__ __forceinline__ void emit(int m, int r, int row, int n, float v) {
     const float o = act(v) * es[m][r];
     Ys[row * ldy + ycol0 + n] = o;
-    if (gout) gout[(size_t)row * gld + n] = o;
+    if (gout) gout[(size_t)(gps ? (row >> 4) * gps + (row & 15) : row) * gld + n] = o;
   }
 };
 template <int MT, bool PRE = false, class Act = ActIdentity>
@@ -288,8 +288,8 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
                                                const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
                                                const PackedPre& pre = PackedPre{}, Act act = Act{},
                                                const float* __restrict__ escale = nullptr, int es_ld = 0,
-                                               float* __restrict__ gout = nullptr, int gld = 0) {
-  PlainEpi<MT, Act> epi{Ys, ldy, ycol0, act, escale, es_ld, gout, gld, {}};
+                                               float* __restrict__ gout = nullptr, int gld = 0, int gps = 0) {
+  PlainEpi<MT, Act> epi{Ys, ldy, ycol0, act, escale, es_ld, gout, gld, gps, {}};
   gemm_nt_packed_epi<MT, PRE>(Xs, ldx, K, N, Wp, bsum, wave_rot, pre, epi);
 }
 

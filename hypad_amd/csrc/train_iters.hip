@@ -406,6 +406,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     __syncthreads();
     GEN_STAMP(13);
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
+    if (HYPER) tile_store(ws + gw.ecat + (int64_t)(2 * B + g0) * S, S, xs, ldS, 16, S, 16);      // the head's second row block (pass 2)
     zin = zs + 16 * LP;
     encoder_fwd_tile_packed<true>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
                                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, pre_enc);
@@ -423,6 +424,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   sv.mask = ws + gw.mask + prow0 * 2 * DEC_H;
   sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
+  sv.e = ws + gw.ecat + prow0 * S;
   sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
@@ -434,19 +436,17 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   // E = tanh output in Ein[0..15]
   const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
   if (HYPER) {
-    tile_store_p(ws + gw.ecat + prow0 * S, S, B, Ein, ldS, hrows, S, hrows);      // (chain R: rows 16-31 are the gathered windows)
     GEN_STAMP(20);
-    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
-    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    // (u, the head's pre-activations, goes to the workspace from the epilogue: the backward re-reads it)
+    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head, ActIdentity{}, nullptr, 0,
+                                           ws + gw.u + prow0 * S, S, B);
+    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head, ActIdentity{}, nullptr, 0,
+                                 ws + gw.u + prow0 * S, S, B);
     __syncthreads();
     GEN_STAMP(21);
-    tile_store_p(ws + gw.u + prow0 * S, S, B, bufB, ldS, hrows, S, hrows);
-    __syncthreads();
     GEN_STAMP(22);
     head_rows_tile(bufB, ldS, hrows, S, PD + dl.head_b);
     __syncthreads();
-  } else {
-    tile_store(ws + gw.ecat + prow0 * S, S, bufA, ldS, 16, S, 16);
   }
   float* R = HYPER ? bufB : bufA;           // decoder outputs (rows 0-15: this pass [, rows 16-31: hyper_x])
   float* dR = HYPER ? bufA : bufB;          // their gradients
