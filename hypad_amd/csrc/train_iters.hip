@@ -493,17 +493,26 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
         R16 du, db;
         head_row_bwd(row_load<R16>(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane), hb, row_load<R16>(dR + r * ldS, S, lane), du, db);
         row_store(dR + r * ldS, du, S, lane);
-        row_store(R + r * ldS, db, S, lane);
+        row_store(ws + gw.du + (prow0 + prow(r, B)) * S, du, S, lane);       // the dW kernel's operand rows, straight from here
+        // the wave's four bias-gradient rows are summed across its four 16-lane groups before they leave the registers: the
+        // column sums below then add one row per wave instead of four
+#pragma unroll
+        for (int e = 0; e < R16::EPL; ++e) {
+          float v = db.v[e];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          db.v[e] = v;
+        }
+        if (lane < 16) row_store(R + wave * ldS, db, S, lane);                // row `wave` of R: this wave's partial
       }
     });
     __syncthreads();
     GEN_STAMP(24);
     for (int c = threadIdx.x; c < S; c += blockDim.x) {
       float s = 0.f;
-      for (int r = 0; r < hrows; ++r) s += R[r * ldS + c];
+      for (int w = 0; w < hrows / 4; ++w) s += R[w * ldS + c];
       ws[gw.ballpart + ((int64_t)role * (B / 16) + tile) * S + c] = s;
     }
-    tile_store_p(ws + gw.du + prow0 * S, S, B, dR, ldS, hrows, S, hrows);
     __syncthreads();
     GEN_STAMP(25);
     // dE = dU W_h for the decoder pass, and d(pre-tanh) = dE * (1 - E^2) in its epilogue (E re-read from the workspace,
