@@ -521,11 +521,13 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
       hv.x *= m.x; hv.y *= m.y; hv.z *= m.z; hv.w *= m.w;
       *h = hv;
       if (sv.mask && r < valid) *reinterpret_cast<float4*>(sv.mask + prow(r, sv.ps) * 2 * DEC_H + c) = m;
+      if (sv.h0d && r < valid) *reinterpret_cast<float4*>(sv.h0d + prow(r, sv.ps) * 2 * DEC_H + c) = hv;      // saved from the same pass
     }
     __syncthreads();
+  } else if (sv.h0d) {
+    tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufA, ldH, rows, 2 * DEC_H, valid);
   }
   TSTAMP(27);
-  if (sv.h0d) tile_store_p(sv.h0d, 2 * DEC_H, sv.ps, bufA, ldH, rows, 2 * DEC_H, valid);
   TSTAMP(28);
   // layer 1: h0 (dropped) in bufA -> h1 in bufB
   if constexpr (PRE) pre2 = gemm_nt_prefetch(pk + gp.d2, 2 * DEC_H, S);
