@@ -17,13 +17,17 @@ for _ in range(5):
 torch.cuda.synchronize()
 tw = st.cpu().numpy().reshape(3, 48, 8)        # [role][mark][wave]
 t = tw[:, :, 0]
-names = ["start/enc fwd", "critic_z", "(z store)", "trunk", "head fwd", "critic_x", "loss+head bwd+dE+tanh'", "dH1", "l1 bwd", "l0 bwd", "dZ", "enc bwd"]
+# interval that STARTS at mark k (marks 0-11 of gen_body, in program order)
+names = ["start -> encoder done (R) / z + critic staging (G)", "(encoder done -> trunk start)", "decoder trunk", "head forward",
+         "critic_x fwd+bwd (G)", "loss + head backward + dE (tanh' in its epilogue)", "dH1 + layer-1 cell backward",
+         "layer-1 backward product + layer-0 cell backward", "layer-0 backward product", "dZ", "encoder backward", ""]
 for role, nm in ((0, "G"), (1, "R")):
     r = t[role]
     print(f"role {nm}: total {r[11] - r[0]} cycles = {(r[11] - r[0]) / 2400.0:.1f} us")
     ks = [k for k in range(12) if r[k] > 0]
     print("   " + ", ".join(f"{names[k1]} {r[k2] - r[k1]}" for k1, k2 in zip(ks[:-1], ks[1:])))
-    sub = {"setup+warm": (0, 14), "x gather": (14, 15), "critic stage": (15, 12), "x gather wait": (12, 13), "enc layer+dense": (13, 1), "ecat store": (3, 20), "head gemm": (20, 21), "u store": (21, 22), "head rows": (22, 4), "rowdist": (5, 23), "head bwd rows": (23, 24), "ballpart+du store": (24, 25), "dE gemm": (25, 26), "tanh'": (26, 6)}
+    sub = {"setup+warm": (0, 14), "x gather": (14, 15), "x gather wait": (12, 13), "enc layer+dense": (13, 1), "head gemm": (20, 21), "head rows": (22, 4),
+           "rowdist": (5, 23), "head bwd rows": (23, 24), "bias-gradient column sums": (24, 25), "dE gemm": (25, 26)}
     print("   sub: " + ", ".join(f"{k} {r[b] - r[a]}" for k, (a, b) in sub.items() if r[a] > 0 and r[b] > 0))
 
 # per-wave arrival at every mark, relative to wave 0's start: who is late for the barrier that follows
