@@ -291,6 +291,109 @@ def gen_scoring(N=300, S=100):
     np.savez(os.path.join(HERE, "score.npz"), **out)
 
 
+
+# ------------------------------------------------------------------------------ Riemannian primitives + ball Adam (row O2)
+def gen_riemann(S=100, steps=23):
+    """The Riemannian primitives geoopt's optimizer is assembled from, evaluated by the REFERENCE's vendored copy
+    (math_.py:382-383 lambda_x, :419-430 inner, :656-676 gyration, :1738-1746 parallel_transport, :1843-1845
+    egrad2rgrad, :340-352 project), plus trajectories of the one ball-valued parameter (`hyperbolic_linear.bias`)
+    under geoopt 0.5.0's published ``RiemannianAdam.step`` ORDER, every arithmetic step of which is a call into
+    that vendored module (no oracle code).  What stays unpinned after this fixture is only that published order."""
+    rng = np.random.default_rng(23)
+    out = {}
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+    def on_ball(n, lo, hi):
+        v = rng.standard_normal((n, S))
+        return (v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(lo, hi, (n, 1))).astype(F32)
+
+    x = np.concatenate([on_ball(12, 0.0, 0.3), on_ball(12, 0.3, 0.95), on_ball(4, 0.99, 0.996),
+                        np.zeros((1, S), F32), on_ball(1, 0.9999999, 1.0), on_ball(2, 1.0, 1.2)])   # incl. lambda's 1e-15 floor side
+    y = np.concatenate([on_ball(16, 0.0, 0.5), on_ball(16, 0.5, 0.995)])
+    u = (rng.standard_normal(x.shape) * rng.uniform(1e-3, 2.0, (len(x), 1))).astype(F32)
+    v = (rng.standard_normal(x.shape) * 0.3).astype(F32)
+    out.update(prim_x=x, prim_y=y, prim_u=u, prim_v=v)
+    out["lambda_x"] = gmath.lambda_x(T(x), k=K, keepdim=True).numpy()
+    out["inner"] = gmath.inner(T(x), T(u), T(v), k=K, keepdim=True).numpy()
+    out["inner_uu"] = gmath.inner(T(x), T(u), T(u), k=K, keepdim=True).numpy()
+    out["egrad2rgrad"] = gmath.egrad2rgrad(T(x), T(u), k=K).numpy()
+    out["gyration"] = gmath.gyration(T(x), T(y), T(u), k=K).numpy()
+    out["parallel_transport"] = gmath.parallel_transport(T(x), T(y), T(u), k=K).numpy()
+    out["project_x"] = gmath.project(T(x), k=K).numpy()
+
+    def trajectory(tag, p0, grads, lr, wd=1e-5, b1=0.9, b2=0.999, eps=1e-8, stabilize=10):
+        p = T(p0).clone()
+        m, vv = torch.zeros_like(p), torch.zeros_like(p)
+        P, M, V = [], [], []
+        for t in range(1, len(grads) + 1):
+            g = T(grads[t - 1]).clone()
+            g.add_(p, alpha=wd)                                              # weight decay into the gradient
+            g = gmath.egrad2rgrad(p, g, k=K)                                 # math_.py:1843
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            vv.mul_(b2).add_(gmath.inner(p, g, g, k=K, keepdim=True), alpha=1 - b2)   # component_inner: math_.py:419 broadcast
+            denom = vv.div(1 - b2 ** t).sqrt_()
+            direction = m.div(1 - b1 ** t) / denom.add_(eps)
+            new_p = gmath.project(p + (-lr * direction), k=K)                # Stereographic.retr: math_.py:340
+            new_m = gmath.parallel_transport(p, new_p, m, k=K)               # Stereographic.transp: math_.py:1738
+            p.copy_(new_p); m.copy_(new_m)
+            if stabilize is not None and t % stabilize == 0:
+                p.copy_(gmath.project(p, k=K))                               # stabilize_group: projx (proju = identity)
+            P.append(p.numpy().copy()); M.append(m.numpy().copy()); V.append(vv.numpy().copy())
+        out.update({f"traj_{tag}_p0": p0, f"traj_{tag}_grads": np.asarray(grads), f"traj_{tag}_lr": np.float64(lr),
+                    f"traj_{tag}_p": np.asarray(P), f"traj_{tag}_m": np.asarray(M), f"traj_{tag}_v": np.asarray(V)})
+
+    # (a) the reference's own initialisation (hyperspace/hyrnn_nets.py:176-179) and learning rate (configs/univariate.yaml)
+    p0 = gmath.expmap0(T(rng.standard_normal(S).astype(F32)) / 400, k=K).numpy()
+    trajectory("init", p0, [(rng.standard_normal(S) * 0.1).astype(F32) for _ in range(steps)], 5e-4)
+    # (b) mid-ball, larger steps: the gyration / conformal-factor ratio of the transport is far from the identity
+    p0 = on_ball(1, 0.7, 0.7)[0]
+    trajectory("mid", p0, [(rng.standard_normal(S) * 2.0).astype(F32) for _ in range(steps)], 2e-2)
+    # (c) against the boundary: gradients push outwards, so the retraction's projection (norm > 1 - 4e-3) fires
+    #     (the Riemannian step has length ~ lr / lambda_p, lambda_p ~ 230 here, hence the start at 0.9955 and lr = 0.05)
+    p0 = on_ball(1, 0.9955, 0.9955)[0]
+    trajectory("edge", p0, [(-(3.0 + rng.uniform()) * p0 + 0.05 * rng.standard_normal(S)).astype(F32) for _ in range(steps)], 5e-2)
+    np.savez(os.path.join(HERE, "riemann.npz"), **out)
+
+
+# ------------------------------------------------------------------------------ area / DTW errors by the reference's own functions
+def gen_area_dtw(N=300, S=100):
+    """`_area_error` (:780-812) and `_dtw_error` (:815-863) of the reference run as they stand, with
+    `scipy.integrate.trapz` aliased to its current name and `pyts.metrics.dtw` served by refharness's independent DTW;
+    then `reconstruction_errors` / `score_anomalies` (:407-576, :866-962) for both error types."""
+    sc = load_npz("score.npz")
+    y, y_hat, critic = sc["y"], sc["y_hat"], sc["critic"]
+    out = {}
+    rng = np.random.default_rng(77)
+    # the two error functions on their own: a general series, one shorter than the DTW length, one of exactly 11/12 samples
+    for tag, n in (("a", 257), ("b", 7), ("c", 11), ("d", 12), ("e", 30)):
+        t = np.sin(np.arange(n) / 9.0) + 0.1 * rng.standard_normal(n)
+        p = t + 0.2 * rng.standard_normal(n)
+        out[f"ser_{tag}_true"], out[f"ser_{tag}_pred"] = t, p
+        out[f"area_{tag}"] = np.asarray(ref_adu._area_error(t, p, 10), dtype=np.float64)
+        out[f"dtw_{tag}"] = np.asarray(ref_adu._dtw_error(t, p, 10), dtype=np.float64)
+    out["area_sw6"] = np.asarray(ref_adu._area_error(out["ser_a_true"], out["ser_a_pred"], 6), dtype=np.float64)
+    out["dtw_sw6"] = np.asarray(ref_adu._dtw_error(out["ser_a_true"], out["ser_a_pred"], 6), dtype=np.float64)
+    out["dtw_sw7"] = np.asarray(ref_adu._dtw_error(out["ser_a_true"], out["ser_a_pred"], 7), dtype=np.float64)
+    w = int(N * 0.01)
+    for kind in ("area", "dtw"):
+        raw, _ = ref_adu.reconstruction_errors(y, y_hat, 1, 10, w, False, kind)
+        sm, _ = ref_adu.reconstruction_errors(y, y_hat, 1, 10, w, True, kind)
+        out[f"rec_{kind}_raw"] = np.asarray(raw, dtype=np.float64)
+        out[f"rec_{kind}_smooth"] = np.asarray(sm, dtype=np.float64)
+        for comb in ("mult", "sum", "rec"):
+            fs, _, _, _ = ref_adu.score_anomalies(y, y_hat, critic, None, rec_error_type=kind, comb=comb)
+            out[f"eucl_{kind}_{comb}"] = np.asarray(fs, dtype=np.float64)
+    # the DTW stand-in itself on a few pairs, so that tests can hold the oracle's recurrence against it
+    xs = rng.standard_normal((6, 11)); ys = rng.standard_normal((6, 11))
+    from pyts.metrics import dtw as stub_dtw
+    out.update(dtw_pairs_x=xs, dtw_pairs_y=ys, dtw_pairs_out=np.array([stub_dtw(a, b) for a, b in zip(xs, ys)]))
+    np.savez(os.path.join(HERE, "score_area_dtw.npz"), **out)
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(HERE, name), allow_pickle=False))
+
+
 # ------------------------------------------------------------------------------ interval extraction + metrics (SURVEY §8f-3)
 def gen_intervals():
     """find_anomalies (:1363-1472) and its helpers, contextual_confusion_matrix (:606-655, weighted=False)."""
@@ -523,6 +626,14 @@ def gen_multivariate():
 if __name__ == "__main__":
     import pandas
     import scipy
+    if len(sys.argv) > 1 and sys.argv[1] == "riemann":
+        gen_riemann()
+        print("riemann.npz written")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "area_dtw":
+        gen_area_dtw()
+        print("score_area_dtw.npz written")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "multivariate":
         gen_multivariate()
         print("multivariate.npz written")
@@ -541,6 +652,8 @@ if __name__ == "__main__":
     gen_iters(100, 64, True, "hyper_S100")
     gen_iters(100, 64, False, "eucl_S100")
     gen_scoring()
+    gen_riemann()
+    gen_area_dtw()
     gen_intervals()
     gen_dataloader()
     with open(os.path.join(HERE, "versions.json"), "w") as f:

@@ -14,7 +14,9 @@ The reference needs three things this image lacks:
   published geoopt definitions.  ``geoopt.optim.RiemannianAdam`` is not
   vendored at all: the stand-in registered here is ``oracle.radam`` (parity
   UNPINNED for that one class; see oracle/radam.py).
-* ``torchvision.transforms`` and ``pyts.metrics`` -- import-time only stubs.
+* ``torchvision.transforms`` -- import-time only stub.  ``pyts.metrics.dtw`` -- an independently written
+  classic DTW (memoised path search; NOT oracle/scoring.py) so that the reference's own ``_dtw_error``
+  framing can run; ``scipy.integrate.trapz`` (removed in SciPy 1.14) is aliased to ``numpy.trapezoid``.
 * a GPU -- ``.cuda()`` is patched to the identity.
 
 ``PYTORCH_JIT=0`` must be set before torch is imported (torch 2.10 cannot
@@ -137,13 +139,45 @@ def install(repo_root=None):
     pyts.__path__ = []
     pm = types.ModuleType("pyts.metrics")
 
-    def _dtw_unavailable(*a, **k):
-        raise RuntimeError("pyts is not installed; DTW parity is pinned by oracle/scoring.py only")
+    def _dtw_independent(x, y, **kwargs):
+        """Stand-in for ``pyts.metrics.dtw(x, y)`` with its defaults (pyts==0.12.0 is not installed):
+        classic DTW, squared point cost, square root of the cheapest warping path's cost.  Written as a
+        memoised search over warping paths from the END cell backwards -- deliberately NOT the forward
+        table fill of ``oracle/scoring.py:dtw_classic`` -- so that the fixtures it produces pin the
+        reference's own padding / loop bound / framing (``utils/anomaly_detection_utils.py:834-861``)
+        and cross-check the oracle's recurrence with independently written code."""
+        import functools
+        import math
+        if kwargs:
+            raise RuntimeError("the reference calls dtw(x, y) with defaults only")
+        xs, ys = [float(v) for v in x], [float(v) for v in y]
 
-    pm.dtw = _dtw_unavailable
+        @functools.lru_cache(maxsize=None)
+        def cheapest(i, j):          # cheapest path from (0, 0) to (i, j), both inclusive
+            here = (xs[i] - ys[j]) * (xs[i] - ys[j])
+            if i == 0 and j == 0:
+                return here
+            prev = []
+            if i > 0:
+                prev.append(cheapest(i - 1, j))
+            if j > 0:
+                prev.append(cheapest(i, j - 1))
+            if i > 0 and j > 0:
+                prev.append(cheapest(i - 1, j - 1))
+            return here + min(prev)
+
+        return math.sqrt(cheapest(len(xs) - 1, len(ys) - 1))
+
+    pm.dtw = _dtw_independent
     pyts.metrics = pm
     sys.modules.setdefault("pyts", pyts)
     sys.modules.setdefault("pyts.metrics", pm)
+
+    # ---- SciPy >= 1.14 dropped integrate.trapz (utils/anomaly_detection_utils.py:802,807 call it) ----------
+    import numpy as _np
+    import scipy.integrate as _integrate
+    if not hasattr(_integrate, "trapz"):
+        _integrate.trapz = _np.trapezoid     # the same function under its current name (SciPy's trapz WAS numpy's)
 
     # ---- no GPU here ----------------------------------------------------------------
     torch.Tensor.cuda = lambda self, *a, **k: self

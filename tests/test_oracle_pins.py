@@ -232,3 +232,70 @@ def test_dtw_and_area_known_answers():
     i = 20
     manual = abs(np.trapezoid(t[i - 5:i + 5]) - np.trapezoid(p[i - 5:i + 5]))
     assert abs(a[i] - manual) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------- round 2 pins
+def test_riemannian_primitives_match_the_reference_module():
+    """oracle/gmath.py:69-99 against the reference's vendored math_.py (riemann.npz, gen_fixtures.gen_riemann)."""
+    fx = load("riemann.npz")
+    x, y, u, v = (torch.from_numpy(fx[k]) for k in ("prim_x", "prim_y", "prim_u", "prim_v"))
+
+    def close(got, ref):
+        ref = torch.from_numpy(ref)
+        return bool(torch.all((got - ref).abs() <= 2e-6 * ref.abs().clamp_min(1.0)))
+
+    assert close(gmath.lambda_x(x, keepdim=True), fx["lambda_x"])
+    assert close(gmath.inner(x, u, v, keepdim=True), fx["inner"])
+    assert close(gmath.inner(x, u, u, keepdim=True), fx["inner_uu"])
+    assert close(gmath.egrad2rgrad(x, u), fx["egrad2rgrad"])
+    assert close(gmath.gyration(x, y, u), fx["gyration"])
+    assert close(gmath.parallel_transport(x, y, u), fx["parallel_transport"])
+    assert close(gmath.project(x), fx["project_x"])
+
+
+@pytest.mark.parametrize("tag", ["init", "mid", "edge"])
+def test_riemannian_adam_ball_trajectory(tag):
+    """oracle/radam.py's ball branch vs a 23-step trajectory whose every arithmetic step was a call into the
+    reference's math_.py, in geoopt 0.5.0's published order (stabilize at steps 10 and 20 included)."""
+    from oracle.tadgan import BallParameter
+    fx = load("riemann.npz")
+    p = BallParameter(torch.from_numpy(fx[f"traj_{tag}_p0"].copy()))
+    opt = RiemannianAdam([p], lr=float(fx[f"traj_{tag}_lr"]), weight_decay=1e-5, stabilize=10)
+    for t, g in enumerate(fx[f"traj_{tag}_grads"]):
+        p.grad = torch.from_numpy(g.copy())
+        opt.step()
+        st = opt.state[p]
+        assert maxdiff(p.detach(), fx[f"traj_{tag}_p"][t]) < 1e-6, (tag, t)
+        assert maxdiff(st["exp_avg"], fx[f"traj_{tag}_m"][t]) < 1e-6 * max(1.0, np.abs(fx[f"traj_{tag}_m"][t]).max()), (tag, t)
+        ref_v = fx[f"traj_{tag}_v"][t]
+        assert maxdiff(st["exp_avg_sq"], ref_v) < 1e-6 * max(1.0, np.abs(ref_v).max()), (tag, t)
+    if tag == "edge":     # the retraction's projection did fire in this trajectory
+        assert abs(float(np.linalg.norm(fx["traj_edge_p"][-1])) - (1 - 4e-3)) < 1e-5
+
+
+def test_area_and_dtw_errors_match_the_reference_functions():
+    """oracle/scoring.py area_error / dtw_error / reconstruction_errors / score_anomalies vs the reference's own
+    `_area_error` (:780-812), `_dtw_error` (:815-863), `score_anomalies` (:407-576) run by gen_fixtures.gen_area_dtw."""
+    fx = load("score_area_dtw.npz")
+    for tag in "abcde":
+        t, p = fx[f"ser_{tag}_true"], fx[f"ser_{tag}_pred"]
+        assert np.allclose(scoring.area_error(t, p, 10), fx[f"area_{tag}"], rtol=0, atol=1e-12, equal_nan=True), tag
+        got = scoring.dtw_error(t, p, 10)
+        assert got.shape == fx[f"dtw_{tag}"].shape and maxdiff(got, fx[f"dtw_{tag}"]) < 1e-12, tag
+    t, p = fx["ser_a_true"], fx["ser_a_pred"]
+    assert np.allclose(scoring.area_error(t, p, 6), fx["area_sw6"], rtol=0, atol=1e-12, equal_nan=True)
+    assert maxdiff(scoring.dtw_error(t, p, 6), fx["dtw_sw6"]) < 1e-12
+    assert maxdiff(scoring.dtw_error(t, p, 7), fx["dtw_sw7"]) < 1e-12
+    for a, b, ref in zip(fx["dtw_pairs_x"], fx["dtw_pairs_y"], fx["dtw_pairs_out"]):
+        assert abs(scoring.dtw_classic(a, b) - ref) < 1e-12
+    sc = load("score.npz")
+    y, y_hat, critic = sc["y"], sc["y_hat"], sc["critic"]
+    w = int(len(y) * 0.01)
+    for kind in ("area", "dtw"):
+        raw, _ = scoring.reconstruction_errors(y, y_hat, 10, w, False, kind, with_summary=False)
+        sm, _ = scoring.reconstruction_errors(y, y_hat, 10, w, True, kind, with_summary=False)
+        assert np.allclose(raw, fx[f"rec_{kind}_raw"], rtol=0, atol=1e-12, equal_nan=True), kind
+        assert np.allclose(sm, fx[f"rec_{kind}_smooth"], rtol=0, atol=1e-12, equal_nan=True), kind
+        for comb in ("mult", "sum", "rec"):
+            got, _, _ = scoring.score_anomalies(y, y_hat, critic, kind, comb)
+            assert np.allclose(got, fx[f"eucl_{kind}_{comb}"], rtol=0, atol=1e-9, equal_nan=True), (kind, comb)
