@@ -5,7 +5,7 @@ library raises, and every call checks its status code.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 import torch
 
@@ -56,10 +56,20 @@ class IterIO(Structure):
                 ("drop", Dropout), ("losses", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
+class EpochNoise(Structure):
+    _fields_ = [("z_cx", c_void_p), ("alpha_cx", c_void_p), ("z_cz", c_void_p), ("alpha_cz", c_void_p), ("z_gen", c_void_p),
+                ("masks_cx", c_void_p), ("masks_cz", c_void_p), ("masks_gen", c_void_p)]
+
+
 class EpochIO(Structure):
     _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise))]
+
+
+class RecordInfo(Structure):
+    _fields_ = [("offset_floats", c_int64), ("record_floats", c_int), ("row_stride", c_int), ("mask_offset_floats", c_int),
+                ("mask_row_stride", c_int), ("n_layers", c_int), ("in_dim", c_int)]
 
 
 P = c_void_p
@@ -109,6 +119,9 @@ _SIGS = {
     "hypad_critic_z_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
+    "hypad_epoch_record_info": (c_int, [POINTER(Dims), c_int, c_int, c_int, POINTER(RecordInfo)]),
+    "hypad_rng_fill": (c_int, [c_int, c_uint64, c_uint32, c_uint32, c_uint32, c_float, P, c_int64, P]),
+    "hypad_critic_z_seed": (c_uint64, [c_uint64]),
     "hypad_profile_iteration": (c_int, [c_int, POINTER(Dims), POINTER(TrainState), POINTER(IterIO), POINTER(c_float), c_int, P]),
     "hypad_adam_step": (c_int, [P, P, P, P, c_int64, c_int, c_float, c_float, c_float, c_float, c_float, P]),
     "hypad_radam_step": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P]),

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/hypad.h"
+#include "device_utils.h"
 #include "layout.h"
 
 using namespace hypad;
@@ -75,9 +76,31 @@ bool catalogue(int net, int S, int L, int hyperbolic, std::vector<TensorInfo>& v
   return false;
 }
 
+// hypad_rng_fill: the training kernels' own draw functions (device_utils.h), one element per thread
+__global__ void rng_fill_kernel(int kind, uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, float p, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t idx = (uint32_t)i;
+    out[i] = kind == HYPAD_RNG_NORMAL    ? rng_normal(seed, tick, stream, sig, idx)
+             : kind == HYPAD_RNG_UNIFORM ? rng_uniform(seed, tick, stream, sig, idx)
+                                         : rng_dropout(seed, tick, stream, sig, idx, p);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hypad_rng_fill(int kind, uint64_t seed, uint32_t tick, uint32_t rng_stream, uint32_t signal, float p_drop, float* out, int64_t n,
+                   hypad_stream_t stream) {
+  if (kind < 0 || kind > 2 || !out || n < 0 || n > 0xffffffffLL || (kind == 2 && !(p_drop >= 0.f && p_drop < 1.f))) return HYPAD_EINVAL;
+  if (n == 0) return HYPAD_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, kind, seed, tick, rng_stream, signal, p_drop, out, n);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+uint64_t hypad_critic_z_seed(uint64_t seed) { return seed ^ CRITIC_Z_SEED_XOR; }
 
 int hypad_abi_version(void) { return HYPAD_ABI_VERSION; }
 

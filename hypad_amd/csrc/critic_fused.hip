@@ -115,6 +115,10 @@ struct PhaseArgs {
   int n_iters;
   int it;                   // iteration index of an iteration launch; == n_iters: finalise only
   long long* stamps;        // development aid: shader-clock stamps of workgroup (0, 0, z) (64 per critic), or null
+  // injected randomness (hypad_epoch_noise; null = device Philox), already advanced to this phase chunk's first iteration:
+  // (iteration, signal, per-iteration layout of hypad_iter_io)
+  const float* inj_z_x; const float* inj_al_x; const float* inj_mk_x;
+  const float* inj_z_z; const float* inj_al_z; const float* inj_mk_z;
 };
 long long* g_stamps = nullptr;
 #define STAMP(k) do { if (ph.stamps && ph.it == 1 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ph.stamps[blockIdx.z * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -146,7 +150,9 @@ HD PreLds pre_lds(int S) {
 // scales [nh][48][L4] (pass order real, fake, interpolated).  real / fake: LDS tiles of 16 rows.
 template <bool IS_X>
 __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g, float* rec, const float* real, int ldr, const float* fake,
-                                            int ldf, int sig, int g0, uint32_t tick, float p_drop) {
+                                            int ldf, int sig, int g0, uint32_t tick, float p_drop, const float* inj_alpha, const float* inj_masks) {
+  // inj_alpha: this (iteration, signal)'s (B, in_dim) interpolation weights or null; inj_masks: its keep-scales, pass blocks of
+  // [nh][B][L] in the order hypad_iter_io.drop states (critic_x: valid, fake, interpolated; critic_z: fake, valid, interpolated)
   const int in_dim = g.in_dim, Kin = g.Kin, L = g.L, nh = g.nh;
   tile_for(16, Kin, [&](int r, int c) {
     const float pad = c == in_dim ? 1.f : 0.f;
@@ -155,13 +161,15 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
     if (c >= in_dim) rec[(32 + r) * Kin + c] = pad;
   });
   for (int gi = threadIdx.x; gi < 4 * in_dim; gi += blockDim.x) {      // interpolation (train.py:64-69 / 149-154)
-    const float4 al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)(g0 * in_dim) / 4 + gi);
+    float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!inj_alpha) al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)(g0 * in_dim) / 4 + gi);
     const float alv[4] = {al.x, al.y, al.z, al.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int f = 4 * gi + e;
       const int r = f / in_dim, c = f - r * in_dim;
-      rec[(32 + r) * Kin + c] = alv[e] * real[r * ldr + c] + (1.f - alv[e]) * fake[r * ldf + c];
+      const float w = inj_alpha ? inj_alpha[(int64_t)(g0 + r) * in_dim + c] : alv[e];
+      rec[(32 + r) * Kin + c] = w * real[r * ldr + c] + (1.f - w) * fake[r * ldf + c];
     }
   }
   float* rm = rec + 48 * Kin;
@@ -171,8 +179,12 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
     const int pl = w / per, gi = w - pl * per;
     const int p = pl / nh, li = pl - p * nh;
     float v[4] = {1.f, 1.f, 1.f, 1.f};
-    if (a.drop_mode == 2) {
-      const int pass = p == 2 ? 2 : (IS_X ? p : 1 - p);                // stream numbering of the per-iteration entry points
+    const int pass = p == 2 ? 2 : (IS_X ? p : 1 - p);                  // stream / mask-block numbering of the per-iteration entry points
+    if (a.drop_mode == 1) {
+      const float* mb = inj_masks + ((int64_t)(pass * nh + li) * a.B + g0) * L;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mb[4 * gi + e];               // (row r, column c) of the tile = flat element r * L + c
+    } else if (a.drop_mode == 2) {
       const float4 uu = rng_uniform4(a.seed, tick, RS_DROP_CRITIC + 8 * pass + li, (uint32_t)sig, (uint32_t)(g0 * L) / 4 + gi);
       v[0] = uu.x >= p_drop ? keep : 0.f; v[1] = uu.y >= p_drop ? keep : 0.f;
       v[2] = uu.z >= p_drop ? keep : 0.f; v[3] = uu.w >= p_drop ? keep : 0.f;
@@ -204,9 +216,12 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
     const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
     const float* PD = ax.P.dec + (int64_t)sig * ax.pd;
-    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(ax.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
+    const int64_t isl = (int64_t)it * gridDim.y + sig;                 // (iteration, signal) slice of an injected plane
+    const float* zin = ph.inj_z_x ? ph.inj_z_x + (isl * B + g0) * L : nullptr;
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(ax.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
-    DropSrc ddrop = drop_src(ax, sig, nullptr, RS_DROP_DEC0, tick, 0.2f);
+    const float* mk = ph.inj_mk_x ? ph.inj_mk_x + isl * ax.mask_sig_stride : nullptr;
+    DropSrc ddrop = drop_src(ax, sig, mk ? mk + (int64_t)12 * B * L : nullptr, RS_DROP_DEC0, tick, 0.2f);
     DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const float* pk = ax.ws + sig * ax.ws_sig_stride + ax.pk_off;       // packed generator weights (hypad_train_epoch builds them first)
     const GenPack gp = gen_pack(S, L, ax.hyperbolic);
@@ -221,11 +236,13 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     const CritGeom g = cx_geom(S, L);
     emit_record<true>(ax, g, ph.rec_x + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, xs, lp.ldS, gen, lp.ldS, sig, g0,
-                      tick, 0.25f);
+                      tick, 0.25f, ph.inj_al_x ? ph.inj_al_x + isl * B * S : nullptr, mk);
   } else {                  // critic_z side: z_ = encoder(x), z ~ N(0, 1)  (train.py:111-116)
     const EncLayout el = enc_layout(S, L);
     const float* PE = az.P.enc + (int64_t)sig * az.pe;
-    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
+    const int64_t isl = (int64_t)it * gridDim.y + sig;
+    const float* zin = ph.inj_z_z ? ph.inj_z_z + (isl * B + g0) * L : nullptr;
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
     float* zenc = zs + 16 * LP;
     const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __syncthreads();
     const CritGeom g = cz_geom(L);
     emit_record<false>(az, g, ph.rec_z + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, zs, LP, zenc, LP, sig, g0, tick,
-                       0.2f);
+                       0.2f, ph.inj_al_z ? ph.inj_al_z + isl * B * L : nullptr, ph.inj_mk_z ? ph.inj_mk_z + isl * az.mask_sig_stride : nullptr);
   }
 }
 
@@ -827,7 +844,7 @@ size_t critic_phase_floats_per_iter(const hypad_dims& d) {
 // 4 events, profiling): recorded before the precompute, after it, after the first iteration launch (no Adam prologue)
 // and after the last one (n_iters - 1 steady-state launches back to back: event overhead amortised).
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
-                     int n_signals, hipStream_t s, hipEvent_t* ev) {
+                     int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
   const size_t fixed = critic_phase_fixed_floats(d), per_iter = critic_phase_floats_per_iter(d);
@@ -837,7 +854,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   const CritGeom gx = cx_geom(ax.S, ax.L), gz = cz_geom(ax.L);
   const int nchunks = ax.B / 16;
   // the generator-side randomness (z, decoder dropout) keeps the critic_x seed; critic_z draws from its own
-  az.seed = ax.seed ^ 0x5851F42D4C957F2DULL;
+  az.seed = ax.seed ^ CRITIC_Z_SEED_XOR;
   const size_t lds_pre = (size_t)pre_lds(ax.S).total * sizeof(float);
   if (lds_pre > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)critic_phase_precompute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
@@ -873,6 +890,17 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     ph.rec_z = recs + (size_t)n_signals * n * nchunks * gx.rec_floats;
     ph.bias_corr = bcorr;
     ph.it = 0;
+    {
+      const int64_t per = (int64_t)it0 * n_signals;                  // (iteration, signal) slices ahead of this chunk
+      auto adv = [&](const float* p, int64_t slice) { return p ? p + per * slice : nullptr; };
+      const int64_t B = ax.B;
+      ph.inj_z_x = adv(noise ? noise->z_cx : nullptr, B * ax.L);
+      ph.inj_al_x = adv(noise ? noise->alpha_cx : nullptr, B * ax.S);
+      ph.inj_z_z = adv(noise ? noise->z_cz : nullptr, B * ax.L);
+      ph.inj_al_z = adv(noise ? noise->alpha_cz : nullptr, B * ax.L);
+      ph.inj_mk_x = adv(noise && ax.drop_mode == 1 ? noise->masks_cx : nullptr, ax.mask_sig_stride);
+      ph.inj_mk_z = adv(noise && az.drop_mode == 1 ? noise->masks_cz : nullptr, az.mask_sig_stride);
+    }
     if (ev) (void)hipEventRecord(ev[0], s);
     hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
     HYPAD_CHECK_LAUNCH();
@@ -887,6 +915,21 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
     HYPAD_CHECK_LAUNCH();
   }
+  return HYPAD_OK;
+}
+
+// hypad_epoch_record_info: where the records of the last phase chunk sit inside `extra` and how one is laid out
+int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad_record_info* out) {
+  if (!critic_phase_supported(d) || n_iters <= 0 || n_iters > 512 || critic < 0 || critic > 1 || !out) return HYPAD_EINVAL;
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  const size_t nchunks = d.batch / 16;
+  size_t o = (size_t)d.n_signals * (6 * (size_t)(gx.params + gz.params) + 2 * nchunks * (size_t)(gx.slab_floats + gz.slab_floats));
+  o += pad4(4 * (n_iters + 1));
+  if (critic == 1) o += (size_t)d.n_signals * n_iters * nchunks * gx.rec_floats;
+  const CritGeom& g = critic == 0 ? gx : gz;
+  out->offset_floats = (int64_t)o;
+  out->record_floats = g.rec_floats; out->row_stride = g.Kin; out->mask_offset_floats = 48 * g.Kin; out->mask_row_stride = g.L4;
+  out->n_layers = g.nh; out->in_dim = g.in_dim;
   return HYPAD_OK;
 }
 

@@ -94,6 +94,8 @@ __device__ __forceinline__ float u32_to_unit(uint32_t x) {        // [0, 1)
 __device__ __forceinline__ uint32_t pick(const uint4& r, int i) {
   return i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w;
 }
+// critic_z draws from its own key when it runs beside critic_x in one launch group (hypad_critic_z_seed)
+constexpr uint64_t CRITIC_Z_SEED_XOR = 0x5851F42D4C957F2DULL;
 // Streams (c1): which random tensor of an iteration
 enum RngStream : uint32_t {
   RS_Z = 1, RS_ALPHA = 2, RS_DROP_DEC0 = 3, RS_DROP_DEC1 = 4, RS_DROP_CRITIC = 16 /* + pass*8 + layer */

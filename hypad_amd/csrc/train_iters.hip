@@ -1302,17 +1302,18 @@ int run_cz(const hypad_dims* d, const hypad_train_state* st, const IterCall& io,
 
 // critic_x_iteration and critic_z_iteration of one minibatch side by side (train.py:320-327: disjoint weights, frozen
 // generator): three launches with blockIdx.z selecting the critic.  losses_x / losses_z: where each writes its 4 floats.
+// io_z: critic_z's own call description when the two iterations take different injected planes (null: io for both).
 int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, float* losses_x, float* losses_z,
-                    hipStream_t s, hipEvent_t* ev = nullptr) {
+                    hipStream_t s, hipEvent_t* ev = nullptr, const IterCall* io_z = nullptr) {
   IterArgs ax, az;
-  IterCall cx = io, cz = io;
+  IterCall cx = io, cz = io_z ? *io_z : io;
   cx.losses = losses_x; cz.losses = losses_z;
   int rc = fill_args(ax, d, st, cx, 0);
   if (rc) return rc;
   rc = fill_args(az, d, st, cz, 1);
   if (rc) return rc;
   az.tick_owner = 0;                       // one rng tick per launch group; the two critics use distinct Philox streams
-  az.seed = ax.seed ^ 0x5851F42D4C957F2DULL;
+  az.seed = ax.seed ^ CRITIC_Z_SEED_XOR;
   size_t lds = cx_pass_lds(ax), l2 = cz_pass_lds(az);
   if (l2 > lds) lds = l2;
   size_t ldsg = gp_x_lds(ax), g2 = gp_z_lds(az);
@@ -1548,6 +1549,9 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   if (!io || !io->row_index || io->n_batches <= 0 || io->n_critics < 0) return HYPAD_EINVAL;
   int rc = check_dims(d);
   if (rc) return rc;
+  const hypad_epoch_noise* nz = io->noise;
+  const bool inj_masks = io->train_mode && nz && (nz->masks_cx || nz->masks_cz || nz->masks_gen);
+  if (inj_masks && !(nz->masks_cx && nz->masks_cz && nz->masks_gen)) return HYPAD_EINVAL;      // all three planes or none
   IterCall c;
   c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.x_row_stride = io->x_row_stride; c.z = nullptr; c.alpha = nullptr;
   c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
@@ -1558,6 +1562,8 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   const int64_t pass_rows = (int64_t)io->n_batches * d->batch;
   const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
   const size_t have = io->workspace_bytes / sizeof(float);
+  const int64_t B = d->batch, L = d->latent_dim, S = d->signal_shape, ns = d->n_signals;
+  const int64_t mk_cx = 12 * B * L + B * 2 * DEC_H, mk_cz = 6 * B * L, mk_gen = 6 * B * L + 2 * B * 2 * DEC_H;   // hypad_iter_io.drop layouts
   {                                                    // packed generator weights: built once, then kept current by the dW kernel
     IterArgs ag;
     c.row_index = io->row_index; c.losses = io->losses;
@@ -1571,31 +1577,56 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   if (hoisted) {                                       // train.py:315-328, generator forwards hoisted (critic_fused.hip)
     IterArgs ax, az;
     c.row_index = io->row_index; c.losses = io->losses;
+    c.masks = inj_masks ? nz->masks_cx : nullptr;      // (non-null selects the injected-mask mode; the planes travel in `nz`)
     rc = fill_args(ax, d, st, c, 0);
+    c.masks = inj_masks ? nz->masks_cz : nullptr;
     if (!rc) rc = fill_args(az, d, st, c, 1);
+    c.masks = nullptr;
     if (rc) return rc;
     const int n = io->n_critics * io->n_batches;
     rc = run_critic_phase(ax, az, io->row_index, n, io->losses, (float*)io->workspace + base, have - base, d->n_signals,
-                          (hipStream_t)s, nullptr);
+                          (hipStream_t)s, nullptr, nz);
     if (rc) return rc;
     it = 2 * n;
   } else {
     for (int k = 0; k < io->n_critics; ++k) {          // train.py:315-328, one launch group per minibatch
       for (int b = 0; b < io->n_batches; ++b) {
+        const int64_t ci = (int64_t)k * io->n_batches + b;          // critic iteration index of the injected planes
         c.row_index = io->row_index + k * pass_rows + (int64_t)b * d->batch;
         c.losses = io->losses;             // (validated by fill_args; the pair writes to the two pointers below)
-        rc = run_critic_pair(d, st, c, io->losses + (int64_t)it * 4, io->losses + (int64_t)(it + 1) * 4, (hipStream_t)s);
+        IterCall cz = c;
+        if (nz) {
+          c.z = nz->z_cx ? nz->z_cx + ci * ns * B * L : nullptr; c.alpha = nz->alpha_cx ? nz->alpha_cx + ci * ns * B * S : nullptr;
+          cz.z = nz->z_cz ? nz->z_cz + ci * ns * B * L : nullptr; cz.alpha = nz->alpha_cz ? nz->alpha_cz + ci * ns * B * L : nullptr;
+          if (inj_masks) { c.masks = nz->masks_cx + ci * ns * mk_cx; cz.masks = nz->masks_cz + ci * ns * mk_cz; }
+        }
+        rc = run_critic_pair(d, st, c, io->losses + (int64_t)it * 4, io->losses + (int64_t)(it + 1) * 4, (hipStream_t)s, nullptr, &cz);
         it += 2;
         if (rc) return rc;
       }
     }
+    c.z = nullptr; c.alpha = nullptr; c.masks = nullptr;
   }
   for (int b = 0; b < io->n_batches; ++b) {            // train.py:347-352
     c.row_index = io->row_index + io->n_critics * pass_rows + (int64_t)b * d->batch;
     c.losses = io->losses + (int64_t)(it++) * 4;
+    if (nz) {
+      c.z = nz->z_gen ? nz->z_gen + (int64_t)b * ns * B * L : nullptr;
+      c.masks = inj_masks ? nz->masks_gen + (int64_t)b * ns * mk_gen : nullptr;
+    }
     rc = run_gen(d, st, c, (hipStream_t)s, nullptr, false);
     if (rc) return rc;
   }
+  return HYPAD_OK;
+}
+
+int hypad_epoch_record_info(const hypad_dims* d, int n_batches, int n_critics, int critic, hypad_record_info* out) {
+  if (check_dims(d) || n_batches <= 0 || n_critics <= 0 || !out) return HYPAD_EINVAL;
+  const int64_t n = (int64_t)n_batches * n_critics;
+  if (n > 512) return HYPAD_EUNSUPPORTED;
+  int rc = critic_phase_record_info(*d, (int)n, critic, out);
+  if (rc) return rc;
+  out->offset_floats += (int64_t)ws_floats_per_signal(*d) * d->n_signals;
   return HYPAD_OK;
 }
 

@@ -115,6 +115,22 @@ class Engine:
     def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None, x_row_stride=0):
         return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks, x_row_stride)
 
+    def rng_fill(self, kind, n, tick, stream, signal=0, p_drop=0.0, seed=None):
+        """n draws of one device random stream (hypad_rng_fill): kind 0 N(0,1), 1 U[0,1), 2 dropout keep-scale."""
+        out = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        _C.check(_C.lib.hypad_rng_fill(int(kind), self.seed if seed is None else int(seed), int(tick), int(stream), int(signal),
+                                       float(p_drop), out.data_ptr(), int(n), _C.stream()), "rng_fill")
+        return out
+
+    def epoch_records(self, n_batches, n_critics, critic):
+        """The records the last hoisted train_epoch left in the workspace for critic 0 (x) / 1 (z), as a
+        (n_signals, n_iters, batch/16, record_floats) view, plus their geometry (hypad_epoch_record_info)."""
+        info = _C.RecordInfo()
+        _C.check(_C.lib.hypad_epoch_record_info(ctypes.byref(self.dims), n_batches, n_critics, critic, ctypes.byref(info)), "record_info")
+        n = self.n * n_batches * n_critics * (self.B // 16) * info.record_floats
+        view = self.workspace[info.offset_floats: info.offset_floats + n].view(self.n, n_batches * n_critics, self.B // 16, info.record_floats)
+        return view, info
+
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
         4 nine iterations of train_epoch's hoisted critic phase: precompute, first launch, mean steady-state launch), HIP events on the current stream."""
@@ -131,19 +147,30 @@ class Engine:
                                                 _C.stream()), "profile_iteration")
         return list(out)[: 2 if kind == 2 else 3]
 
-    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0):
+    NOISE_PLANES = ("z_cx", "alpha_cx", "z_cz", "alpha_cz", "z_gen", "masks_cx", "masks_cz", "masks_gen")
+
+    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
         hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks).
-        x_row_stride=1: x is the scaled series (SignalDataset.window_view), not a window matrix."""
+        x_row_stride=1: x is the scaled series (SignalDataset.window_view), not a window matrix.
+        noise: optional dict of injected planes (hypad_epoch_noise: z_cx, alpha_cx, z_cz, alpha_cz, z_gen, masks_*; float32
+        device tensors, iteration-major) replacing the device Philox draws -- parity runs."""
         x, stride = self._check_x(x, x_row_stride)
         if hoist:
             self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
         iters = (2 * n_critics + 1) * n_batches
         if losses is None:
             losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
+        nz = None
+        if noise:
+            unknown = set(noise) - set(self.NOISE_PLANES)
+            if unknown:
+                raise _C.HypadError(f"unknown noise planes {sorted(unknown)}")
+            nz = _C.EpochNoise(*(None if noise.get(k) is None else _C.require_cuda(noise[k], k).data_ptr() for k in self.NOISE_PLANES))
         io = _C.EpochIO(x.data_ptr(), stride, int(x_row_stride), row_index.data_ptr(), n_batches, n_critics, int(train_mode), self.seed,
                         losses.data_ptr(), self.workspace.data_ptr(),
-                        self._ws_bytes if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)))
+                        self._ws_bytes if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
+                        ctypes.pointer(nz) if nz is not None else None)
         st = self._state()
         _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")
         return losses

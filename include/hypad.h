@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HYPAD_ABI_VERSION 1
+#define HYPAD_ABI_VERSION 2
 
 enum {
   HYPAD_OK = 0,
@@ -221,6 +221,22 @@ int hypad_decoder_iteration(const hypad_dims* dims, const hypad_train_state* st,
  * minibatch, then one generator pass.  row_index: ((n_critics + 1), n_batches * batch) int32 window rows (the
  * DataLoader's shuffles); noise and dropout come from device Philox (seed).  losses: (n_signals,
  * (2 * n_critics + 1) * n_batches, 4) in launch order. */
+/* Optional injected randomness of a whole epoch (parity runs; a NULL plane = device Philox keyed by `seed`).  Planes are
+ * iteration-major, so one iteration's slice has exactly the layout hypad_iter_io states for that iteration:
+ * critic iteration it = pass * n_batches + batch (launch order), generator iteration b = batch. */
+typedef struct hypad_epoch_noise {
+  const float* z_cx;      /* (n_critics * n_batches, n_signals, batch, L)  N(0,1), decoder input of critic_x_iteration  train.py:24 */
+  const float* alpha_cx;  /* (n_critics * n_batches, n_signals, batch, S)  U[0,1)                                        train.py:64 */
+  const float* z_cz;      /* (n_critics * n_batches, n_signals, batch, L)  N(0,1), `valid` latent of critic_z_iteration   train.py:118 */
+  const float* alpha_cz;  /* (n_critics * n_batches, n_signals, batch, L)                                                train.py:149 */
+  const float* z_gen;     /* (n_batches, n_signals, batch, L)              decoder_iteration                              train.py:205 */
+  /* dropout keep-scales (0 or 1/(1-p)), read when train_mode != 0: all three planes or none.  Per (iteration, signal)
+   * the layouts of hypad_iter_io.drop for critic_x_iteration / critic_z_iteration / decoder_iteration. */
+  const float* masks_cx;
+  const float* masks_cz;
+  const float* masks_gen;
+} hypad_epoch_noise;
+
 typedef struct hypad_epoch_io {
   const float* x; int64_t x_signal_stride;
   int64_t x_row_stride;      /* as in hypad_iter_io */
@@ -230,6 +246,7 @@ typedef struct hypad_epoch_io {
   float* losses;
   void* workspace; size_t workspace_bytes;   /* >= hypad_train_workspace_bytes(dims); with >= hypad_epoch_workspace_bytes(...)
                                                 the critic phase runs in its hoisted form (see below) */
+  const hypad_epoch_noise* noise;            /* NULL: all randomness from device Philox(seed) */
 } hypad_epoch_io;
 /* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
  * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up
@@ -237,6 +254,29 @@ typedef struct hypad_epoch_io {
  * arithmetic per row as the per-iteration entry points; only floating-point summation order differs. */
 size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_critics);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
+
+/* Where hypad_train_epoch's hoisted critic phase left its precomputed records (tests and tools; valid after a call with
+ * n_critics * n_batches <= 512 iterations): records of critic `critic` (0 = critic_x, 1 = critic_z) start `offset_floats` floats
+ * into the workspace and are indexed (signal, iteration, batch / 16 chunks); one record is `record_floats` floats:
+ * [48][row_stride] input rows (16 real | 16 fake | 16 interpolated; the input, a constant-one column, zero padding) followed,
+ * at `mask_offset_floats`, by the dropout keep-scales [n_layers][48][mask_row_stride] (pass order real, fake, interpolated). */
+typedef struct hypad_record_info {
+  int64_t offset_floats;
+  int record_floats, row_stride, mask_offset_floats, mask_row_stride, n_layers, in_dim;
+} hypad_record_info;
+int hypad_epoch_record_info(const hypad_dims* dims, int n_batches, int n_critics, int critic, hypad_record_info* out);
+
+/* The device random streams the training kernels draw from when no plane is injected -- Philox4x32-10 keyed by (seed, tick,
+ * stream, signal), element index = position in the (batch, width) matrix -- exported for distribution tests.
+ * kind: 0 = N(0,1) (z), 1 = U[0,1) (alpha), 2 = dropout keep-scale 0 | 1/(1-p_drop).  tick = counters[3] at the iteration.
+ * streams: HYPAD_STREAM_*; a critic's dropout stream is HYPAD_STREAM_DROP_CRITIC + 8 * pass + layer (pass: critic_x 0 valid,
+ * 1 fake, 2 interpolated; critic_z 0 fake, 1 valid, 2 interpolated).  Inside hypad_train_epoch the critic_z side draws with
+ * hypad_critic_z_seed(seed). */
+enum { HYPAD_RNG_NORMAL = 0, HYPAD_RNG_UNIFORM = 1, HYPAD_RNG_DROPOUT = 2 };
+enum { HYPAD_STREAM_Z = 1, HYPAD_STREAM_ALPHA = 2, HYPAD_STREAM_DROP_DEC0 = 3, HYPAD_STREAM_DROP_DEC1 = 4, HYPAD_STREAM_DROP_CRITIC = 16 };
+int hypad_rng_fill(int kind, uint64_t seed, uint32_t tick, uint32_t rng_stream, uint32_t signal, float p_drop, float* out,
+                   int64_t n, hypad_stream_t stream);
+uint64_t hypad_critic_z_seed(uint64_t seed);
 
 /* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder, 3 = the critic_x ||
  * critic_z pair of the per-iteration path) or, kind 4, NINE iterations of the hoisted critic phase of hypad_train_epoch

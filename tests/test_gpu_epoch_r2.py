@@ -1,0 +1,285 @@
+"""The TIMED kernels against the oracle directly: hypad_train_epoch's hoisted critic phase (critic_phase_precompute_kernel +
+critic_iteration_kernel, critic_fused.hip) and its generator launches, fed known noise through hypad_epoch_noise and compared
+with oracle.train_iters (train.py:299-356) iteration by iteration; the device random streams themselves (distribution tests);
+eight signals per GPU (BASELINE configs[2])."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, maxdiff, params_ns, sub_state
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda")
+
+
+def cu(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype).contiguous()
+
+
+def _oracle_modules(S, hyper, seed):
+    from oracle import tadgan as ot
+    torch.manual_seed(seed)
+    mods = dict(enc=ot.Encoder(S, 20).eval(), dec=ot.Decoder(S, 20, hyper).eval(), cx=ot.CriticX(S, 20).eval(), cz=ot.CriticZ(20).eval())
+    if hyper:   # move the head off its tiny initialisation so that the ball arithmetic matters
+        with torch.no_grad():
+            mods["dec"].hyperbolic_linear.weight.mul_(50)
+    return mods
+
+
+def _engine(mods, S, B, hyper, n=1):
+    from hypad_amd.engine import Engine
+    eng = Engine(S, 20, B, hyper, n_signals=n, lr=5e-4)
+    for k, m in mods.items():
+        for s in range(n):
+            eng.load_state_dict(k, m.state_dict(), s)
+    return eng
+
+
+def _planes(rng, n_it, nb, ns, B, S, L=20):
+    return dict(z_cx=rng.standard_normal((n_it, ns, B, L)).astype(np.float32), alpha_cx=rng.uniform(size=(n_it, ns, B, S)).astype(np.float32),
+                z_cz=rng.standard_normal((n_it, ns, B, L)).astype(np.float32), alpha_cz=rng.uniform(size=(n_it, ns, B, L)).astype(np.float32),
+                z_gen=rng.standard_normal((nb, ns, B, L)).astype(np.float32))
+
+
+@pytest.mark.parametrize("S,B,hyper,nb,nc", [(100, 64, True, 2, 5), (100, 64, False, 3, 2), (150, 256, True, 2, 5)])
+def test_hoisted_epoch_matches_oracle_iteration_by_iteration(dev, S, B, hyper, nb, nc):
+    """Teacher-forced at EVERY iteration of the hoisted phase.  The phase is one fixed launch sequence, so its intermediate
+    weights are read out of a *prefix* run: an epoch of the first m critic iterations (deterministic kernels: the weights
+    after m iterations of the long run are bit-identical to those of the m-iteration run -- asserted below through the
+    losses).  The oracle (oracle.train_iters: train.py:18-186 on CPU autograd) is loaded with those weights and steps
+    iteration m with the same injected z / alpha; losses must agree to 1e-4.  Then the generator launches the same way."""
+    from oracle import train_iters as oi
+    mods = _oracle_modules(S, hyper, seed=S + B)
+    P = params_ns(B, S, hyper)
+    rng = np.random.default_rng(S)
+    n_it = nb * nc
+    N = nb * B + 37
+    x = np.clip(np.sin(np.arange(N)[:, None] / 17.0 + np.arange(S)[None, :] / 9.0) + 0.1 * rng.standard_normal((N, S)), -1, 1)
+    xs = cu(x).reshape(1, N, S)
+    perm = np.stack([rng.permutation(N)[: nb * B] for _ in range(nc + 1)]).astype(np.int32)
+    planes = _planes(rng, n_it, nb, 1, B, S)
+    dplanes = {k: cu(v) for k, v in planes.items()}
+    w0 = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in mods.items()}
+
+    def run_prefix(m):
+        """epoch made of the first m critic iterations (as one pass of m batches) + m generator batches"""
+        eng = _engine(mods_init, S, B, hyper)
+        rows = np.concatenate([perm[k].reshape(nb, B)[b] for k in range(nc) for b in range(nb)][:m])
+        ri = np.stack([rows, np.concatenate([perm[nc].reshape(nb, B)[b % nb] for b in range(m)])]).astype(np.int32)
+        nz = {k: (v[:m].contiguous() if k != "z_gen" else v[[b % nb for b in range(m)]].contiguous()) for k, v in dplanes.items()}
+        losses = eng.train_epoch(xs, cu(ri, torch.int32), m, 1, train_mode=False, noise=nz)
+        torch.cuda.synchronize()
+        return eng, losses[0].cpu().numpy()
+
+    mods_init = _oracle_modules(S, hyper, seed=S + B)
+    # the full epoch, as the product runs it
+    eng_full = _engine(mods_init, S, B, hyper)
+    full = eng_full.train_epoch(xs, cu(perm, torch.int32), nb, nc, train_mode=False, noise=dplanes)[0].cpu().numpy()
+    assert np.isfinite(full).all()
+    prev = None
+    for m in range(1, n_it + 1):
+        eng, losses = run_prefix(m)
+        # determinism of the prefix construction: iteration m-1 of the prefix run == iteration m-1 of the full epoch, bit for bit
+        assert np.array_equal(losses[2 * (m - 1): 2 * m], full[2 * (m - 1): 2 * m]), m
+        # oracle at the weights BEFORE iteration m-1 (critics from the previous prefix, generator untouched during the phase)
+        for k in ("enc", "dec"):
+            mods[k].load_state_dict(w0[k])
+        for k in ("cx", "cz"):
+            mods[k].load_state_dict(w0[k] if prev is None else {n: v.cpu() for n, v in prev.state_dict(k).items()})
+        o = oi.make_optimizers(mods["enc"], mods["dec"], mods["cx"], mods["cz"], P)
+        k_, b_ = divmod(m - 1, nb)
+        sample = torch.from_numpy(x[perm[k_].reshape(nb, B)[b_]][:, :, None])
+        ref_x = float(oi.critic_x_iteration(sample, mods["dec"], mods["cx"], o[0], P, z=planes["z_cx"][m - 1, 0], alpha=planes["alpha_cx"][m - 1, 0]))
+        ref_z = float(oi.critic_z_iteration(sample, mods["enc"], mods["cz"], o[1], P, z=planes["z_cz"][m - 1, 0], alpha=planes["alpha_cz"][m - 1, 0]))
+        got_x, got_z = float(losses[2 * (m - 1), 0]), float(losses[2 * (m - 1) + 1, 0])
+        assert abs(got_x - ref_x) < TOL * max(1, abs(ref_x)), ("critic_x", m, got_x, ref_x)
+        assert abs(got_z - ref_z) < TOL * max(1, abs(ref_z)), ("critic_z", m, got_z, ref_z)
+        if m == 1:        # first step: every gradient, read back from Adam's first moment (exp_avg = 0.1 g after one step)
+            for net in ("cx", "cz"):
+                for nm, p in mods[net].named_parameters():
+                    g = p.grad.numpy()
+                    off, shape = next((o_, s_) for n_, o_, s_ in eng.catalogue(net) if n_ == nm)
+                    got = (eng.exp_avg[net][0, off: off + g.size] / 0.1).view(shape).cpu().numpy()
+                    assert maxdiff(got, g) < 2e-5 * max(1.0, float(np.abs(g).max())), (net, nm)
+        prev = eng
+    # first generator launch of the full epoch, teacher-forced the same way: critics as the phase left them (the generator
+    # launches do not touch them), encoder / decoder still at their initial weights
+    for k in ("cx", "cz"):
+        mods[k].load_state_dict({n: v.cpu() for n, v in eng_full.state_dict(k).items()})
+    for k in ("enc", "dec"):
+        mods[k].load_state_dict(w0[k])
+    o = oi.make_optimizers(mods["enc"], mods["dec"], mods["cx"], mods["cz"], P)
+    sample = torch.from_numpy(x[perm[nc].reshape(nb, B)[0]][:, :, None])
+    r = oi.decoder_iteration(sample, mods["enc"], mods["dec"], mods["cx"], mods["cz"], o[2], P, z=planes["z_gen"][0, 0])
+    g = full[2 * n_it]
+    assert abs(float(g[0]) - float(r[0])) < 2 * TOL * max(1, abs(float(r[0]))), ("dec", g[0], float(r[0]))
+    assert abs(float(g[1]) - float(r[1] if hyper else r[2])) < TOL, "aux"
+
+
+@pytest.mark.parametrize("hyper", [True, False])
+def test_hoisted_epoch_with_injected_dropout_matches_manual_oracle(dev, hyper):
+    """Train mode: the same dropout masks on both sides (masks_cx / masks_cz / masks_gen planes), iteration 0 and the
+    steady-state iteration 1 of the hoisted phase, against oracle/manual.py (the derivation sheet, itself checked against
+    autograd in tests/test_manual_derivations.py)."""
+    from oracle import manual
+    fx = load("iters_hyper_S100.npz")
+    B, S, L, nb, nc = 64, 100, 20, 2, 1
+    sd = {k[3:]: torch.from_numpy(np.array(v)) for k, v in fx.items() if k.startswith("w0.")}
+    if hyper:
+        sd["dec.hyperbolic_linear.weight"] = sd["dec.hyperbolic_linear.weight"] * 100
+        sd["dec.hyperbolic_linear.bias"] = sd["dec.hyperbolic_linear.bias"] * 10
+    else:
+        sd = {k: v for k, v in sd.items() if not k.startswith("dec.hyperbolic_linear")}
+    from hypad_amd.engine import Engine
+
+    def fresh():
+        eng = Engine(S, L, B, hyper, lr=5e-4)
+        for net in ("enc", "dec", "cx", "cz"):
+            eng.load_state_dict(net, {k[len(net) + 1:]: v for k, v in sd.items() if k.startswith(net + ".")})
+        return eng
+
+    gen = torch.Generator().manual_seed(11)
+    x = torch.from_numpy(fx["samples"][:2, :, :, 0]).float().reshape(2 * B, S)
+    xs = x.cuda().view(1, 2 * B, S)
+    ri = torch.arange(2 * B, dtype=torch.int32).repeat(2, 1).cuda()
+    rm = lambda p, n, w=L: [(torch.rand(B, w, generator=gen) >= p).float() / (1 - p) for _ in range(n)]
+    its = []
+    for it in range(nb * nc):
+        its.append(dict(z_cx=torch.randn(B, L, generator=gen), a_cx=torch.rand(B, S, generator=gen), z_cz=torch.randn(B, L, generator=gen),
+                        a_cz=torch.rand(B, L, generator=gen),
+                        mx=dict(valid=rm(.25, 4), fake=rm(.25, 4), inter=rm(.25, 4), dec=rm(.2, 1, 128)[0]),
+                        mz=dict(fake=rm(.2, 2), valid=rm(.2, 2), inter=rm(.2, 2))))
+    gens = [dict(z=torch.randn(B, L, generator=gen), m=dict(cz=rm(.2, 2), cx=rm(.25, 4), dec_gen=rm(.2, 1, 128)[0], dec_rec=rm(.2, 1, 128)[0]))
+            for _ in range(nb)]
+    flat_x = lambda m: torch.cat([torch.stack(m["valid"]).reshape(-1), torch.stack(m["fake"]).reshape(-1), torch.stack(m["inter"]).reshape(-1), m["dec"].reshape(-1)])
+    flat_z = lambda m: torch.cat([torch.stack(m["fake"]).reshape(-1), torch.stack(m["valid"]).reshape(-1), torch.stack(m["inter"]).reshape(-1)])
+    flat_g = lambda m: torch.cat([torch.stack(m["cz"]).reshape(-1), torch.stack(m["cx"]).reshape(-1), m["dec_gen"].reshape(-1), m["dec_rec"].reshape(-1)])
+    noise = dict(z_cx=torch.stack([i["z_cx"] for i in its]).unsqueeze(1), alpha_cx=torch.stack([i["a_cx"] for i in its]).unsqueeze(1),
+                 z_cz=torch.stack([i["z_cz"] for i in its]).unsqueeze(1), alpha_cz=torch.stack([i["a_cz"] for i in its]).unsqueeze(1),
+                 z_gen=torch.stack([g["z"] for g in gens]).unsqueeze(1),
+                 masks_cx=torch.stack([flat_x(i["mx"]) for i in its]).unsqueeze(1), masks_cz=torch.stack([flat_z(i["mz"]) for i in its]).unsqueeze(1),
+                 masks_gen=torch.stack([flat_g(g["m"]) for g in gens]).unsqueeze(1))
+    noise = {k: v.contiguous().cuda() for k, v in noise.items()}
+    # one-iteration prefix: weights the steady-state launch (iteration 1) starts from
+    e1 = fresh()
+    l1 = e1.train_epoch(xs, ri[:, :B].contiguous(), 1, 1, True, noise={k: v[:1].contiguous() for k, v in noise.items()})[0].cpu().numpy()
+    e2 = fresh()
+    l2 = e2.train_epoch(xs, ri, nb, nc, True, noise=noise)[0].cpu().numpy()
+    assert np.array_equal(l1[:2], l2[:2])
+    sd_it = dict(sd)
+    for it in range(2):
+        xb = x[it * B:(it + 1) * B]
+        with torch.no_grad():
+            lx, gx = manual.cx_iteration(sd_it, xb, its[it]["z_cx"], its[it]["a_cx"], hyper, its[it]["mx"])
+            lz, gz = manual.cz_iteration(sd_it, xb, its[it]["z_cz"], its[it]["a_cz"], its[it]["mz"])
+        assert abs(float(l2[2 * it, 0]) - float(lx)) < TOL, ("cx", it, l2[2 * it, 0], float(lx))
+        assert abs(float(l2[2 * it + 1, 0]) - float(lz)) < TOL, ("cz", it, l2[2 * it + 1, 0], float(lz))
+        if it == 0:
+            for k, g in {**gx, **gz}.items():
+                net, nm = k.split(".", 1)
+                off, shape = next((o_, s_) for n_, o_, s_ in e1.catalogue(net) if n_ == nm)
+                got = (e1.exp_avg[net][0, off: off + g.numel()] / 0.1).view(shape).cpu().numpy()
+                assert maxdiff(got, g.numpy()) < 2e-5 * max(1.0, float(g.abs().max())), k
+            for net in ("cx", "cz"):      # iteration 1 of the oracle starts from the engine's weights after iteration 0
+                for k, v in e1.state_dict(net).items():
+                    sd_it[f"{net}.{k}"] = v.cpu()
+    # first generator launch at the critics the phase left
+    for net in ("cx", "cz"):
+        for k, v in e2.state_dict(net).items():
+            sd_it[f"{net}.{k}"] = v.cpu()
+    with torch.no_grad():
+        lg, aux, _ = manual.dec_iteration(sd_it, x[:B], gens[0]["z"], hyper, gens[0]["m"])
+    assert abs(float(l2[2 * nb * nc, 0]) - float(lg)) < 2 * TOL and abs(float(l2[2 * nb * nc, 1]) - float(aux)) < TOL
+
+
+def test_device_random_streams(dev):
+    """The draws the timed kernels consume when nothing is injected.  (1) the records the precompute kernel wrote hold exactly
+    the numbers hypad_rng_fill exports (z of critic_z, every dropout keep-scale), so the export IS the kernels' stream;
+    (2) distribution tests on the export: N(0,1) and U[0,1) moments + Kolmogorov-Smirnov, keep rates 0.75 / 0.8, no
+    correlation between streams, ticks, signals, or the critic_x / critic_z keys."""
+    from scipy import stats
+    from hypad_amd import _C
+    from hypad_amd.engine import Engine
+    S, B, L, nb, nc, ns = 100, 64, 20, 3, 2, 2
+    eng = Engine(S, L, B, True, n_signals=ns, lr=5e-4)
+    torch.manual_seed(0)
+    for net in ("enc", "dec", "cx", "cz"):
+        eng.params[net].normal_(0, 0.05)
+    eng.seed = 0xC0FFEE1234
+    eng.counters[3] = 7                                  # rng tick the epoch starts from
+    x = torch.rand(ns, nb * B, S, device="cuda") * 2 - 1
+    ri = torch.stack([torch.randperm(nb * B)[: nb * B] for _ in range(nc + 1)]).to(torch.int32).cuda()
+    eng.train_epoch(x, ri, nb, nc, True)
+    torch.cuda.synchronize()
+    zseed = int(_C.lib.hypad_critic_z_seed(eng.seed))
+    rec_z, iz = eng.epoch_records(nb, nc, 1)
+    rec_x, ix = eng.epoch_records(nb, nc, 0)
+    for sig in range(ns):
+        for it in (0, nb * nc - 1):
+            tick = 7 + it
+            # critic_z's real rows are its latent draw
+            want = eng.rng_fill(0, B * L, tick, 1, sig, seed=zseed).view(B, L)
+            rows = rec_z[sig, it, :, : 48 * iz.row_stride].reshape(B // 16, 48, iz.row_stride)[:, :16, :L].reshape(B, L)
+            assert torch.equal(rows, want), (sig, it)
+            for rec, info, p, seed in ((rec_x, ix, 0.25, eng.seed), (rec_z, iz, 0.2, zseed)):
+                m = rec[sig, it, :, info.mask_offset_floats:].reshape(B // 16, info.n_layers, 3, 16, info.mask_row_stride)[..., :L]
+                for layer in range(info.n_layers):
+                    for p_rec in range(3):                 # record pass order: real, fake, interpolated
+                        pass_id = p_rec if (rec is rec_x or p_rec == 2) else 1 - p_rec
+                        want = eng.rng_fill(2, B * L, tick, 16 + 8 * pass_id + layer, sig, p_drop=p, seed=seed).view(B // 16, 16, L)
+                        assert torch.equal(m[:, layer, p_rec], want), (sig, it, layer, p_rec)
+    n = 1 << 20
+    z = eng.rng_fill(0, n, 3, 1).cpu().numpy().astype(np.float64)
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 4 * np.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 0.02 and abs(stats.kurtosis(z)) < 0.04
+    assert stats.kstest(z[: 200000], "norm").pvalue > 1e-3
+    assert np.abs(z).max() > 4.0                           # tails exist (Box-Muller with a 24-bit uniform reaches 5.7)
+    u = eng.rng_fill(1, n, 3, 2).cpu().numpy().astype(np.float64)
+    assert u.min() >= 0 and u.max() < 1
+    assert abs(u.mean() - 0.5) < 4 / np.sqrt(12 * n) and abs(u.var() - 1 / 12) < 4 * np.sqrt(1 / 180 / n)
+    assert stats.kstest(u[: 200000], "uniform").pvalue > 1e-3
+    for p in (0.25, 0.2):
+        d = eng.rng_fill(2, n, 3, 16, p_drop=p).cpu().numpy()
+        assert set(np.unique(d)) == {0.0, np.float32(1 / (1 - p))}
+        assert abs((d > 0).mean() - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n)
+    # independence: adjacent elements, other stream / tick / signal / key
+    base = eng.rng_fill(0, n, 3, 1).cpu().numpy().astype(np.float64)
+    others = dict(lag1=np.roll(base, 1), stream=eng.rng_fill(0, n, 3, 2).cpu().numpy(), tick=eng.rng_fill(0, n, 4, 1).cpu().numpy(),
+                  signal=eng.rng_fill(0, n, 3, 1, signal=1).cpu().numpy(), key=eng.rng_fill(0, n, 3, 1, seed=zseed).cpu().numpy())
+    for k, o in others.items():
+        assert abs(np.corrcoef(base, o.astype(np.float64))[0, 1]) < 5 / np.sqrt(n), k
+        assert not np.array_equal(base, o)
+
+
+def test_eight_signals_per_gpu_match_single_models(dev):
+    """BASELINE configs[2]: 8 independent models advanced by the same launches of hypad_train_epoch == each model trained
+    alone with the same noise (device Philox is keyed by the signal index, so the planes are injected to make them equal)."""
+    S, B, nb, nc, ns = 100, 64, 2, 2, 8
+    rng = np.random.default_rng(8)
+    mods = [_oracle_modules(S, True, seed=100 + s) for s in range(ns)]
+    from hypad_amd.engine import Engine
+    N = nb * B
+    x = np.clip(np.sin(np.arange(N)[None, :, None] / (11.0 + np.arange(ns)[:, None, None]) + np.arange(S)[None, None, :] / 9.0)
+                + 0.05 * rng.standard_normal((ns, N, S)), -1, 1)
+    perm = np.stack([rng.permutation(N) for _ in range(nc + 1)]).astype(np.int32)
+    planes = _planes(rng, nb * nc, nb, ns, B, S)
+    eng8 = Engine(S, 20, B, True, n_signals=ns, lr=5e-4)
+    for s in range(ns):
+        for k, m in mods[s].items():
+            eng8.load_state_dict(k, m.state_dict(), s)
+    l8 = eng8.train_epoch(cu(x), cu(perm, torch.int32), nb, nc, False, noise={k: cu(v) for k, v in planes.items()})
+    torch.cuda.synchronize()
+    assert eng8.counters.cpu().tolist() == [nb * nc, nb * nc, nb, nb * nc + nb]
+    for s in (0, 3, 7):
+        e1 = _engine(mods[s], S, B, True)
+        l1 = e1.train_epoch(cu(x[s:s + 1]), cu(perm, torch.int32), nb, nc, False, noise={k: cu(v[:, s:s + 1]) for k, v in planes.items()})
+        assert torch.equal(l1[0], l8[s]), s
+        for net in ("enc", "dec", "cx", "cz"):
+            assert torch.equal(e1.params[net][0], eng8.params[net][s]), (s, net)
+    assert not torch.equal(l8[0], l8[1])
