@@ -53,6 +53,25 @@ def global_zscore_stats(local_sum, local_sumsq, local_count, group=None):
     return mean, var ** 0.5
 
 
+def broadcast_weights(modules, src=0, group=None):
+    """One-time broadcast of the shared generator / critic weights for sharded scoring (~1 MB, RCCL
+    broadcast over xGMI): every module's flat parameter arena is overwritten with rank ``src``'s.  A no-op without a
+    process group.  Returns the number of bytes broadcast."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    nbytes = 0
+    for m in modules:
+        arena = m.arena()
+        if dist.get_backend(group) == "nccl":
+            dist.broadcast(arena, src, group=group)
+        else:
+            host = arena.cpu()
+            dist.broadcast(host, src, group=group)
+            arena.copy_(host)
+        nbytes += arena.numel() * arena.element_size()
+    return nbytes
+
+
 def gather_signal_metrics(local, group=None):
     """{signal_id: metrics} from every rank -> merged dict on every rank (end-of-run only; KB-sized)."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -75,13 +94,14 @@ def _all_gather_ranges(local, total, ranges, group=None):
     width = max(e - b for b, e in ranges)
     piece = torch.zeros(width, dtype=local.dtype, device=local.device)
     piece[: local.numel()] = local
-    out = torch.empty(world * width, dtype=local.dtype, device=local.device)
-    if local.is_cuda:
+    if dist.get_backend(group) == "nccl":                                   # RCCL: device buffers, one collective
+        out = torch.empty(world * width, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, piece, group=group)
-    else:                                                                   # gloo (the CPU tests)
-        parts = [torch.empty_like(piece) for _ in range(world)]
-        dist.all_gather(parts, piece, group=group)
-        out = torch.cat(parts)
+    else:                                                                   # gloo (CPU tests; device tensors staged through the host)
+        host = piece.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        out = torch.cat(parts).to(local.device)
     full = torch.cat([out[r * width: r * width + (e - b)] for r, (b, e) in enumerate(ranges)])
     assert full.numel() == total
     return full
@@ -134,7 +154,7 @@ def score_windows_sharded(x, encoder, decoder, critic_x, signal_shape, combinati
     from .hyperspace import gmath
     from .utils import anomaly_detection_utils as adu
     if not decoder.hyperbolic:
-        raise ValueError("score_windows_sharded: the Euclidean branch un-rolls reconstructions; shard it with timestep_range()")
+        raise ValueError("score_windows_sharded is the hyperbolic branch; use score_anomalies_sharded for Euclidean models")
     S, L = signal_shape, encoder.latent_space_dim
     N = n_windows if n_windows is not None else (x.shape[0] if x_row_stride == 0 else x.numel() - S + 1)
     need_norms = "uncertainty" in combination
@@ -162,3 +182,125 @@ def score_windows_sharded(x, encoder, decoder, critic_x, signal_shape, combinati
         return adu.combine_scores(combination, critic_scores, rowdist, norms=norms)
 
     return sharded_hyperbolic_scores(N, S, evaluate, adu.kde_modes, finish, need_norms, group)
+
+
+# ---------------------------------------------------------------------------------------------- sharded Euclidean scoring
+def error_halo(score_window=10):
+    """Timesteps an error value reaches on either side.  `_area_error`'s centred window of `score_window` covers [t-5, t+4].
+    `_dtw_error` (:834-861) pads by 5, compares y_pad[i : i+11] and files the result at position i + 5 -- so the value at t
+    looks at true[t-10 .. t] (not a centred window), positions t < 5 and t >= T - 6 are framed with zeros, and t < 10 sees
+    pad zeros.  length + 1 = 12 covers all of it."""
+    return 2 * (score_window // 2) + 2
+
+
+
+def extended_timestep_range(n_windows, world, rank, window, smooth_window, score_window=10):
+    """Timesteps a rank must *compute* so that the smoothed error of every timestep it owns is exact: its own range widened
+    by the reach of the error function and of the centred rolling mean (:953-961), clipped to the series."""
+    tb, te = timestep_range(n_windows, world, rank, window)
+    h = error_halo(score_window) + smooth_window // 2 + 1
+    return max(0, tb - h), min(n_windows + window - 1, te + h)
+
+
+def sharded_euclidean_scores(n_windows, window, smooth_window, evaluate, unroll_median, error_fn, rolling_mean, kde_modes, finish,
+                             score_window=10, group=None, zscore="gather"):
+    """Timestep scores of the Euclidean branch -- ``score_anomalies`` (utils/anomaly_detection_utils.py:407-576) -- with the
+    windows split over the ranks (the DTW leg of BASELINE.json configs[4]).  Every rank gets the full result.
+
+    rank r owns the un-rolled timesteps ``timestep_range`` gives it and computes, locally and without any exchange:
+      * ``evaluate(lo, hi)`` on the windows that reach its *extended* timestep range (own range + error halo + rolling-mean
+        halo, then the S-1 windows before it) -> dict(recon (n, S), critic (n,), true (n + S - 1,) = the un-rolled true
+        series of those windows, :908-910);
+      * ``unroll_median(recon)`` (:918-923), ``error_fn(true, pred)`` (point / area / DTW, :761-863) over the extended range
+        as a series of its own -- only values whose whole footprint lies inside the range (or at a true end of the series,
+        where the reference's own edge handling applies) are kept;
+      * ``rolling_mean(err, smooth_window)`` (:953-961) the same way;  ``kde_modes(critic, window)`` for its timesteps.
+    Exchanged: one all-gather each of the (T,) smoothed errors and (T,) critic modes -- 16 MB at 10^6 windows -- then
+    ``finish(err, modes)`` runs the global steps (z-score / clip, quantile-trimmed critic z-score, combination) on the full
+    vectors on every rank: the scores do not depend on the world size.  ``zscore="allreduce"`` instead normalises each
+    rank's errors with the global (sum, sum of squares, count) of ONE 24-byte all-reduce before the gather (``finish`` then
+    receives z-scores; the summation order, hence the last bits, depend on the world size)."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    T = n_windows + window - 1
+    tb, te = timestep_range(n_windows, world, rank, window)
+    a, b = extended_timestep_range(n_windows, world, rank, window, smooth_window, score_window)
+    if te > tb:
+        wlo, whi = max(0, a - (window - 1)), min(n_windows, b)
+        got = evaluate(wlo, whi)
+        pred = unroll_median(got["recon"])[a - wlo: b - wlo]            # local timestep k == global wlo + k
+        true = got["true"][a - wlo: b - wlo]
+        err = error_fn(true, pred)
+        # keep what does not feel the artificial ends of the extended range
+        h_err = error_halo(score_window)
+        va, vb = (a + h_err if a > 0 else 0), (b - h_err if b < T else T)
+        sm = rolling_mean(err[va - a: vb - a].contiguous(), smooth_window)
+        mine = sm[tb - va: te - va]
+        # critic modes of the owned timesteps (they see windows [tb - S + 1, te), a subset of the evaluated ones)
+        modes = kde_modes(got["critic"], window)[tb - wlo: te - wlo]
+    else:
+        ref = evaluate(0, min(1, n_windows))
+        mine = ref["true"][:0].to(torch.float64)
+        modes = ref["true"][:0].to(torch.float64)
+    tr = [timestep_range(n_windows, world, r, window) for r in range(world)]
+    if zscore == "allreduce":
+        m64 = mine.to(torch.float64)
+        mean, std = global_zscore_stats(float(m64.sum()), float((m64 * m64).sum()), int(m64.numel()), group)
+        mine = (m64 - mean) / std
+    elif zscore != "gather":
+        raise ValueError(zscore)
+    err_full = _all_gather_ranges(mine.contiguous(), T, tr, group)
+    modes_full = _all_gather_ranges(modes.contiguous(), T, tr, group)
+    return finish(err_full, modes_full)
+
+
+def score_anomalies_sharded(y, encoder, decoder, critic_x, signal_shape, rec_error_type="point", comb="mult", score_window=10,
+                            group=None, zscore="gather"):
+    """``sharded_euclidean_scores`` on the device kernels: the Euclidean branch of the reference's scoring
+    (``test_tadgan`` batch body anomaly_detection.py:67-113 -> ``score_anomalies`` utils/anomaly_detection_utils.py:407-576)
+    for a window matrix ``y`` (N, S) -- float32 or float64, resident on every rank like the weights.  Returns the final
+    scores, (N + S - 1,) float64 NumPy, on every rank; equal bit for bit to ``utils.anomaly_detection_utils.score_anomalies``
+    on the un-sharded reconstructions (``zscore="gather"``)."""
+    import math
+    from . import _C
+    from .utils import anomaly_detection_utils as adu
+    if decoder.hyperbolic:
+        raise ValueError("score_anomalies_sharded is the Euclidean branch; use score_windows_sharded for hyperbolic models")
+    S, L = signal_shape, encoder.latent_space_dim
+    N = y.shape[0]
+    y = y.reshape(N, S)
+    w = math.trunc(N * 0.01)
+    kind = rec_error_type.lower()
+    if kind not in ("point", "area", "dtw"):
+        raise ValueError(rec_error_type)
+    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 0)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=y.device)
+    encoder.eval(); decoder.eval(); critic_x.eval()
+
+    def evaluate(lo, hi):
+        n = hi - lo
+        xs = y[lo:hi].to(torch.float32).contiguous()
+        recon = torch.empty(n, S, device=y.device, dtype=torch.float32)
+        critic = torch.empty(n, device=y.device, dtype=torch.float32)
+        _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(encoder.arena()), _C.ptr(decoder.arena()), _C.ptr(critic_x.arena()), _C.ptr(xs), 0,
+                                                   None, _C.ptr(recon), None, _C.ptr(critic), None, n, S, L, 0, ws.data_ptr(), ws_bytes,
+                                                   _C.stream()), "score_forward_packed")
+        return {"recon": recon, "critic": critic, "true": adu.unroll_true(y[lo:hi])}
+
+    def error_fn(true, pred):
+        true, pred = true.contiguous(), pred.contiguous()
+        if kind == "point":
+            return adu._point_wise_error(true, pred)
+        return (adu._area_error if kind == "area" else adu._dtw_error)(true, pred, score_window)
+
+    def finish(err, modes):
+        rec_scores = err if zscore == "allreduce" else None
+        if rec_scores is None:
+            rec_scores = adu.zscore_clip(err)
+        else:
+            rec_scores = torch.clamp(rec_scores, min=0) + 1
+        critic_scores = adu._compute_critic_score(modes, w)
+        return adu.combine_euclidean(comb, critic_scores, rec_scores)
+
+    return sharded_euclidean_scores(N, S, w, evaluate, lambda r: adu.unroll_predictions(r, False)[0], error_fn, adu.rolling_mean,
+                                    adu.kde_modes, finish, score_window, group, zscore)

@@ -74,7 +74,11 @@ def _dtw_error(y, y_hat, score_window=10):
 
 
 def rolling_mean(x, window):
+    """pandas ``rolling(window, center=True, min_periods=window // 2).mean()`` (:953-961, :325-330).  ``window == 0`` -- the
+    reference's ``math.trunc(n * 0.01)`` for fewer than 100 windows -- gives all-NaN, as pandas does."""
     x = _f64(x)
+    if int(window) == 0:
+        return torch.full_like(x, float("nan"))
     out = torch.empty_like(x)
     _C.check(_C.lib.hypad_rolling_mean(_C.ptr(x), _C.ptr(out), x.numel(), int(window), _C.stream()), "rolling_mean")
     return out

@@ -106,3 +106,97 @@ def test_two_rank_sharded_hyperbolic_scores_equal_unsharded():
         ret = mp.Manager().dict()
         mp.spawn(_score_worker, args=(2, port, 157, 20, combination, ret), nprocs=2, join=True)
         assert ret[0] == ret[1]
+
+
+# ---------------------------------------------------------------------------------------------- sharded Euclidean scoring
+def _direct_rolling_mean(x, w):
+    """Centred rolling mean with each window summed on its own (position-deterministic, like hypad_rolling_mean; pandas'
+    online add/remove update makes the last bits depend on where the series starts)."""
+    x = np.asarray(x, dtype=np.float64)
+    if w == 0:
+        return np.full_like(x, np.nan)
+    out = np.full_like(x, np.nan)
+    for i in range(len(x)):
+        lo, hi = max(0, i - w // 2), min(len(x), i + (w - 1) // 2 + 1)
+        v = x[lo:hi]
+        v = v[~np.isnan(v)]
+        if len(v) >= max(w // 2, 1):
+            out[i] = v.sum() / len(v)
+    return out
+
+
+def _eucl_ops(kind, y, y_hat, critic, n_windows, window, calls=None):
+    import math
+    from oracle import scoring
+    w = math.trunc(n_windows * 0.01)
+
+    def evaluate(lo, hi):
+        if calls is not None:
+            calls.append((lo, hi))
+        return {"recon": torch.from_numpy(y_hat[lo:hi]), "critic": torch.from_numpy(critic[lo:hi]),
+                "true": torch.from_numpy(scoring.unroll_true(y[lo:hi]))}
+
+    unroll = lambda r: torch.from_numpy(scoring.unroll_predictions(r.numpy(), False)[0])
+    err = {"point": scoring.point_error, "area": scoring.area_error, "dtw": scoring.dtw_error}[kind]
+    error_fn = lambda t, p: torch.from_numpy(np.asarray(err(t.numpy(), p.numpy().astype(np.float64)), dtype=np.float64))
+    rolling = lambda e, ww: torch.from_numpy(_direct_rolling_mean(e.numpy(), ww))
+
+    def kde_modes(c, ww):
+        ext = np.repeat(c.numpy().astype(np.float64).reshape(-1, 1), ww, axis=1)
+        return torch.tensor([scoring.kde_mode(scoring.antidiagonal(ext, i)) for i in range(len(ext) + ww - 1)], dtype=torch.float64)
+
+    def finish(e, modes):
+        rec = scoring.zscore_clip(e.numpy())
+        crit = scoring.compute_critic_score(modes.numpy(), w)
+        return scoring.combine_euclidean("mult", crit, rec)
+
+    return w, evaluate, unroll, error_fn, rolling, kde_modes, finish
+
+
+def _eucl_inputs(n_windows, window):
+    rng = np.random.default_rng(3)
+    series = np.sin(np.arange(n_windows + window - 1) / 13.0) + 0.1 * rng.standard_normal(n_windows + window - 1)
+    idx = np.arange(n_windows)[:, None] + np.arange(window)[None, :]
+    y = series[idx]
+    y_hat = (y + 0.1 * rng.standard_normal(y.shape)).astype(np.float32)
+    critic = rng.standard_normal(n_windows).astype(np.float32)
+    return y, y_hat, critic
+
+
+def _eucl_worker(rank, world, port, n_windows, window, kind, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        y, y_hat, critic = _eucl_inputs(n_windows, window)
+        calls = []
+        w, *ops = _eucl_ops(kind, y, y_hat, critic, n_windows, window, calls)
+        got = par.sharded_euclidean_scores(n_windows, window, w, *ops)
+        a, b = par.extended_timestep_range(n_windows, world, rank, window, w)
+        assert calls == [(max(0, a - window + 1), min(n_windows, b))]        # own range + halos, evaluated once
+        if w > 0 and not np.isnan(got).any():                                 # one-all-reduce variant: same scores to rounding
+            alt = par.sharded_euclidean_scores(n_windows, window, w, *ops[:-1],
+                                               lambda e, m: ops[-1].__globals__["np"].clip(e.numpy(), 0, None) + 1, zscore="allreduce")
+            from oracle import scoring
+            want_rec = scoring.zscore_clip(scoring.reconstruction_errors(y, y_hat, 10, w, True, kind, with_summary=False)[0])
+            assert np.allclose(alt, want_rec, rtol=0, atol=1e-9)
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_euclidean_scores_equal_unsharded():
+    """The DTW leg of BASELINE.json configs[4]: timestep ranges + error / rolling-mean halos + the S-1 window halo, two
+    all-gathers.  Two ranks == one rank bit for bit (position-deterministic ops), and == oracle.scoring.score_anomalies
+    (pandas' rolling mean differs from a direct mean in the last bits: 1e-12)."""
+    from oracle import scoring
+    for kind, n_windows, window in (("point", 257, 40), ("dtw", 331, 25), ("area", 212, 30), ("dtw", 57, 20)):
+        port = _free_port()
+        ret = mp.Manager().dict()
+        mp.spawn(_eucl_worker, args=(2, port, n_windows, window, kind, ret), nprocs=2, join=True)
+        y, y_hat, critic = _eucl_inputs(n_windows, window)
+        w, *ops = _eucl_ops(kind, y, y_hat, critic, n_windows, window)
+        one = par.sharded_euclidean_scores(n_windows, window, w, *ops)       # no process group: world 1
+        assert np.array_equal(ret[0], ret[1], equal_nan=True) and np.array_equal(ret[0], one, equal_nan=True), kind
+        want, _, _ = scoring.score_anomalies(y, y_hat, critic, kind, "mult")
+        assert np.allclose(one, want, rtol=0, atol=1e-10, equal_nan=True), kind
+        assert np.isnan(one).all() == (w == 0)                                # fewer than 100 windows: pandas' window-0 NaNs
