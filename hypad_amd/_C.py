@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhypad_hip.so")
+# HYPAD_DEV_LIB=1 (scripts/diag_*.py only): the development build with in-kernel stamps and the hypad_diag_* entry points
+LIB_PATH = os.path.join(_HERE, "lib", "libhypad_hip_dev.so" if os.environ.get("HYPAD_DEV_LIB") == "1" else "libhypad_hip.so")
 
 
 class HypadError(RuntimeError):

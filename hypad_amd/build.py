@@ -1,4 +1,11 @@
-"""Build libhypad_hip.so (gfx950) in-tree with hipcc.  `python -m hypad_amd.build [--force]`."""
+"""Build libhypad_hip.so (gfx950) in-tree with hipcc.  `python -m hypad_amd.build [--force] [--dev]`.
+
+Two libraries:
+* ``lib/libhypad_hip.so`` -- the product: exactly the entry points include/hypad.h declares.
+* ``lib/libhypad_hip_dev.so`` (``--dev``; loaded when ``HYPAD_DEV_LIB=1``) -- the same sources compiled with
+  ``-DHYPAD_DIAG=1`` plus ``csrc/diag.hip``: shader-clock stamps inside the training kernels and the ``hypad_diag_*``
+  micro-benchmarks the scripts under ``scripts/diag_*.py`` drive.  Never loaded by the product path, tests or bench.py.
+"""
 import os
 import subprocess
 import sys
@@ -7,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libhypad_hip.so")
-SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip", "diag.hip"]
+DEV_LIB = os.path.join(LIB_DIR, "libhypad_hip_dev.so")
+SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip"]
+DEV_SOURCES = SOURCES + ["diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 
 
@@ -16,13 +25,14 @@ def _newest_source():
     return max(os.path.getmtime(f) for f in files)
 
 
-def _fresh():
-    return os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source()
+def _fresh(lib):
+    return os.path.exists(lib) and os.path.getmtime(lib) >= _newest_source()
 
 
-def build(force=False, verbose=False):
-    if not force and _fresh():
-        return LIB
+def build(force=False, verbose=False, dev=False):
+    lib = DEV_LIB if dev else LIB
+    if not force and _fresh(lib):
+        return lib
     os.makedirs(LIB_DIR, exist_ok=True)
     # one builder at a time (bench.py runs one process per GPU and every rank calls build()): the others wait on the lock
     # and then find the library fresh
@@ -30,21 +40,25 @@ def build(force=False, verbose=False):
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and _fresh():
-                return LIB
-            return _build_locked(verbose)
+            if not force and _fresh(lib):
+                return lib
+            return _build_locked(verbose, dev)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
+def _build_locked(verbose, dev):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = DEV_LIB if dev else LIB
+    objdir = os.path.join(LIB_DIR, "dev") if dev else LIB_DIR
+    os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + (["-DHYPAD_DIAG=1"] if dev else ["-DHYPAD_DIAG=0"])
     objs = []
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+    for src in (DEV_SOURCES if dev else SOURCES):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -54,11 +68,11 @@ def _build_locked(verbose):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    tmp = LIB + ".tmp.%d" % os.getpid()
+    tmp = lib + ".tmp.%d" % os.getpid()
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
-    os.replace(tmp, LIB)                       # atomic: a concurrent importer never maps a half-written library
-    return LIB
+    os.replace(tmp, lib)                       # atomic: a concurrent importer never maps a half-written library
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -120,8 +120,14 @@ struct PhaseArgs {
   const float* inj_z_x; const float* inj_al_x; const float* inj_mk_x;
   const float* inj_z_z; const float* inj_al_z; const float* inj_mk_z;
 };
+// (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
+// neither the stamps nor their setter)
+#if HYPAD_DIAG
 long long* g_stamps = nullptr;
 #define STAMP(k) do { if (ph.stamps && ph.it == 1 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) ph.stamps[blockIdx.z * 64 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 // four consecutive uniforms of a stream: the numbers rng_uniform gives for idx = 4 group + e, from one Philox evaluation
 __device__ __forceinline__ float4 rng_uniform4(uint64_t seed, uint32_t tick, uint32_t stream, uint32_t sig, uint32_t group) {
@@ -880,7 +886,11 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   ph.slab_z = p; p += (size_t)n_signals * 2 * nchunks * gz.slab_floats;
   float* bcorr = p; p += pad4(4 * (cap + 1));
   float* recs = p;
+#if HYPAD_DIAG
   ph.stamps = g_stamps;
+#else
+  ph.stamps = nullptr;
+#endif
   for (int it0 = 0; it0 < n_iters; it0 += cap) {
     const int n = n_iters - it0 < cap ? n_iters - it0 : cap;
     ph.n_iters = n;
@@ -936,5 +946,7 @@ int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad
 }  // namespace train
 }  // namespace hypad
 
-// development aid (not declared in hypad.h): device buffer of 128 int64 that the next critic launches stamp, or null
+#if HYPAD_DIAG
+// development aid (dev library only): device buffer of 128 int64 that the next critic launches stamp, or null
 extern "C" void hypad_diag_set_fused_stamps(long long* p) { g_stamps = p; }
+#endif

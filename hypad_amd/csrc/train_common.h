@@ -93,7 +93,11 @@ struct IterArgs {
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
   long long* stamps;               // development aid: shader-clock stamps [role][48 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null
 };
+#if HYPAD_DIAG
 #define GEN_STAMP(k) do { if (a.stamps && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) a.stamps[(blockIdx.z * 48 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEN_STAMP(k) do { } while (0)
+#endif
 
 struct LdsPlan {
   int xs, zs, bufA, bufB, crit, small, wst, cparams, total, ldS, bufFloats;

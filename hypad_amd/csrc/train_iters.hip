@@ -1194,7 +1194,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
-long long* g_gen_stamps = nullptr;
+#if HYPAD_DIAG
+long long* g_gen_stamps = nullptr;     // development builds only (libhypad_hip_dev.so)
+#endif
 
 struct IterCall {
   const float* x; int64_t x_sig_stride; int64_t x_row_stride; const int32_t* row_index;
@@ -1226,7 +1228,10 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.ws_sig_stride = per;
   a.pk_off = ws_pack_offset(*d) - (opt == 1 ? ws_cz_offset(*d) : 0);       // a.ws is shifted for critic_z
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
-  a.opt = opt; a.tick_owner = 1; a.stamps = g_gen_stamps;
+  a.opt = opt; a.tick_owner = 1; a.stamps = nullptr;
+#if HYPAD_DIAG
+  a.stamps = g_gen_stamps;
+#endif
   if (opt == 0) {
     if (!st->exp_avg.cx || !st->exp_avg_sq.cx) return HYPAD_EINVAL;
     a.mask_sig_stride = (int64_t)12 * a.B * a.L + (int64_t)a.B * 2 * DEC_H;
@@ -1405,7 +1410,9 @@ __global__ __launch_bounds__(64) void radam_ball_kernel(float* p, const float* g
 }  // namespace
 
 // development aid (not declared in hypad.h): device buffer of 64 int64 stamped by the generator kernel, or null
+#if HYPAD_DIAG
 extern "C" void hypad_diag_set_gen_stamps(long long* p) { g_gen_stamps = p; }
+#endif
 
 extern "C" {
 

@@ -30,14 +30,17 @@ _NET_OF = {tadgan.Encoder: "enc", tadgan.Decoder: "dec", tadgan.CriticX: "cx", t
 class _Fused:
     """Flat Adam moments + device counters attached to one optimizer."""
 
-    def __init__(self, optim, modules, dims):
+    def __init__(self, optim, modules, dims, resume_epoch=None):
+        _check_optimizer(optim, modules)
         g = optim.param_groups[0]
         self.modules = modules
+        self.key = _fused_key(modules, dims)
         self.exp_avg = {k: torch.zeros_like(m.arena()) for k, m in modules.items()}
         self.exp_avg_sq = {k: torch.zeros_like(m.arena()) for k, m in modules.items()}
         dev = next(iter(modules.values())).arena().device
         S, L, B, hyp = dims
         salt = sum(ord(c) for k in modules for c in k) * 0x9E3779B97F4A7C15        # decorrelate the three optimizers' streams
+        salt += _resume_salt(resume_epoch)
         self.engine = Engine(S, L, B, hyp, 1, dev, lr=g["lr"], betas=g.get("betas", (0.9, 0.999)), eps=g.get("eps", 1e-8),
                              gen_weight_decay=g.get("weight_decay", 0.0), gen_stabilize=g.get("stabilize") or 0,
                              seed=torch.initial_seed() + salt)
@@ -64,12 +67,46 @@ class _Fused:
                 st["step"].fill_(self.steps)
 
 
+def _resume_salt(resume_epoch):
+    """A resumed run (params.resume) builds fresh engines whose device counters -- the Philox tick among them -- start at
+    zero: without this the resumed epochs would replay the latent draws, interpolation weights, dropout masks and shuffles
+    of the original run's first epochs.  The resume epoch is folded into the seed instead."""
+    return 0 if resume_epoch is None else (int(resume_epoch) + 1) * 0xD1B54A32D192ED03
+
+
+def _check_optimizer(optim, modules):
+    """Only lr, betas, eps (and, for the generator's RiemannianAdam, weight_decay / stabilize) are honoured by the fused step:
+    refuse anything else loudly instead of ignoring it."""
+    if len(optim.param_groups) != 1:
+        raise _C.HypadError("the fused iterations support exactly one param group per optimizer (train.py:274-288 builds one)")
+    g = optim.param_groups[0]
+    for flag in ("amsgrad", "maximize", "capturable", "differentiable", "fused"):
+        if g.get(flag):
+            raise _C.HypadError(f"optimizer option {flag}=True is not supported by the fused iterations")
+    if g.get("weight_decay", 0.0) and not ("dec" in modules and (getattr(optim, "riemannian", False) or "stabilize" in g)):
+        raise _C.HypadError("weight_decay is only supported on the hyperbolic generator's RiemannianAdam (train.py:282-288); "
+                            "the critics' torch.optim.Adam steps have none (train.py:274-281)")
+    owned = {id(p) for m in modules.values() for p in m.parameters()}
+    if {id(p) for p in g["params"]} != owned:
+        raise _C.HypadError("the optimizer must hold exactly the parameters of the module(s) this iteration updates")
+
+
+def _fused_key(modules, dims):
+    return (tuple(sorted((k, id(m)) for k, m in modules.items())), tuple(dims))
+
+
 def _fused(optim, modules, params, hyperbolic):
+    """The flat moments + engine attached to `optim`.  Bound to the modules and dimensions of its first use: a later call with
+    other modules, window length, latent width, batch size or geometry would silently restart Adam from zero moments, so it
+    raises instead (build a new optimizer, as the reference would)."""
     f = getattr(optim, "_hypad", None)
     dims = (params.signal_shape, params.latent_space_dim, params.batch_size, bool(hyperbolic))
-    if f is None or f.engine.B != params.batch_size or f.engine.hyperbolic != bool(hyperbolic):
-        f = _Fused(optim, modules, dims)
+    if f is None:
+        f = _Fused(optim, modules, dims, params.resume_epoch if getattr(params, "resume", False) else None)
         optim._hypad = f
+    elif f.key != _fused_key(modules, dims):
+        raise _C.HypadError("this optimizer is already bound to other modules / dimensions (signal_shape, latent_space_dim, "
+                            "batch_size, hyperbolic): its Adam moments cannot be carried over -- create a new optimizer")
     return f
 
 
@@ -273,7 +310,8 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     dev = encoder.arena().device
     eng = Engine(S, params.latent_space_dim, B, bool(params.hyperbolic), 1, dev, lr=params.lr,
                  gen_weight_decay=1e-5 if params.hyperbolic else 0.0, gen_stabilize=10 if params.hyperbolic else 0,
-                 seed=torch.initial_seed() if seed is None else seed)
+                 seed=(torch.initial_seed() if seed is None else seed)
+                 + _resume_salt(params.resume_epoch if getattr(params, "resume", False) else None))
     mods = {"enc": encoder, "dec": decoder, "cx": critic_x, "cz": critic_z}
     eng.adopt({k: m.arena() for k, m in mods.items()})
     if hasattr(dataset, "window_view"):

@@ -1,4 +1,5 @@
 """Per-stage shader-clock timeline of critic_iteration_kernel (workgroup 0 of each critic), configs[1] shape."""
+import os, sys; sys.path.insert(0, "."); os.environ["HYPAD_DEV_LIB"] = "1"   # development library: python -m hypad_amd.build --dev
 import sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, ".")

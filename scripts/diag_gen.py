@@ -1,4 +1,5 @@
 """Per-section shader-clock timeline of gen_kernel (workgroup 0), configs[1] shape."""
+import os, sys; sys.path.insert(0, "."); os.environ["HYPAD_DEV_LIB"] = "1"   # development library: python -m hypad_amd.build --dev
 import sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, ".")

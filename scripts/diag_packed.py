@@ -1,4 +1,5 @@
 """Decoder forward (16 rows / workgroup) with MFMA-native packed weights vs the streamed + LDS re-shaped gemm_nt."""
+import os, sys; sys.path.insert(0, "."); os.environ["HYPAD_DEV_LIB"] = "1"   # development library: python -m hypad_amd.build --dev
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 """Per-stage latency of the row-tile kernels (development aid): mean kernel time over back-to-back launches."""
+import os, sys; sys.path.insert(0, "."); os.environ["HYPAD_DEV_LIB"] = "1"   # development library: python -m hypad_amd.build --dev
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in include/hypad.h but not exported"
     from hypad_amd import _C
     assert set(_C.EXPORTS) == declared
+    # ... and nothing else: the product library's dynamic symbol table holds exactly the declared entry points
+    # (development aids live in libhypad_hip_dev.so, hypad_amd/build.py)
+    import subprocess
+    from hypad_amd import build
+    nm = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if len(l.split()) == 3 and l.split()[1] in "TW" and l.split()[-1].startswith("hypad_")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
 
 
 def test_abi_version_limits_and_errors(lib):
