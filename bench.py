@@ -11,11 +11,16 @@ pass of decoder_iteration over the 29 minibatches = 319 optimizer steps, train-m
 the device.  Metric: epoch-windows/s = n_gpus * signals_per_gpu * 29 * 64 * steps / wall time.
 With N GPUs every rank trains its own signal(s) (one model per signal, no collective on the data path): weak scaling.
 
+`python bench.py --gpus N` starts its own one-process-per-GPU launcher when none is present.
+
 The JSON line also carries
-  roofline     -- the kernel holding the largest share of the epoch, its algorithmic FLOPs per launch over its mean
-                  duration measured with HIP events on the launch stream (hypad_profile_iteration);
-  cpu_baseline -- the CPU oracle (oracle/train_iters.py: the reference's nn.LSTM / autograd / Adam structure)
-                  timed on this node's host cores over a bounded sample of the same workload.
+  roofline         -- the kernel holding the largest share of the epoch, its algorithmic FLOPs per launch over its mean
+                      duration measured with HIP events on the launch stream (hypad_profile_iteration);
+  roofline_hbm     -- kernel-only GB/s of the row-wise Poincare-ball kernels (pre-allocated outputs, HIP events);
+  roofline_scoring -- the same for every scoring kernel (fused test-loop forward, un-roll median, DTW, ...);
+  secondary        -- BASELINE.json configs[2]'s per-GPU share: 8 signals per GPU;
+  cpu_baseline     -- the CPU oracle (oracle/train_iters.py: the reference's nn.LSTM / autograd / Adam structure)
+                      timed on this node's host cores over a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -77,43 +82,70 @@ def build_engine(spg, rank, hyperbolic, device):
 
 
 def cpu_baseline(hyperbolic, budget_s=24.0):
-    """The oracle's epoch (same iteration mix) on a bounded number of minibatches, at 1 thread and at all cores."""
+    """The oracle's epoch (same iteration mix) on a bounded number of minibatches: at 1 thread and at a modest intra-op pool
+    (the baseline is the better of the two), and ONCE at every core of the host (SURVEY.md §8d asks for it; recorded even when
+    slower -- these layer sizes, <= 256 x 128, do not scale past a few cores and a 256-thread pool mostly waits on itself)."""
     from types import SimpleNamespace
     from oracle import tadgan as ot
     from oracle import train_iters as oi
     P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=hyperbolic)
     data = torch.from_numpy(synth_windows(4 * B, S, 0)[:, :, None])
     ncores = os.cpu_count() or 1
-    best = None
-    # 1 thread and a modest intra-op pool: these layer sizes (<= 256 x 128) do not scale past a few cores, and a pool of
-    # every core of a 256-core host spends minutes in thread hand-offs alone
-    for threads in sorted({1, min(ncores, 8)}):
+    batches = [data[i * B:(i + 1) * B] for i in range(4)]
+
+    def run(threads, budget, max_batches):
         torch.set_num_threads(threads)
         enc, dec, cx, cz = ot.build_models(S, L, hyperbolic, seed=0)
         opt = oi.make_optimizers(enc, dec, cx, cz, P)
         np.random.seed(0)
-        batches = [data[i * B:(i + 1) * B] for i in range(4)]
         oi.train_epoch(batches[:1], enc, dec, cx, cz, opt, P)                  # warm-up: one minibatch's 11 iterations
         t0 = time.perf_counter()
         nb = 0
-        while nb < 1 or (time.perf_counter() - t0 < budget_s / 2 and nb < 4096):
+        while nb < 1 or (time.perf_counter() - t0 < budget and nb < max_batches):
             oi.train_epoch(batches[nb % 4: nb % 4 + 1], enc, dec, cx, cz, opt, P)
             nb += 1
         dt = time.perf_counter() - t0
-        rate = nb * B / dt
+        return nb * B / dt, nb, dt
+
+    best = None
+    for threads in sorted({1, min(ncores, 8)}):
+        rate, nb, dt = run(threads, budget_s / 2, 4096)
         if best is None or rate > best["value"]:
             best = dict(value=rate, cores=threads, sample=f"{nb} minibatches x (5 critic_x + 5 critic_z + 1 decoder) iterations, "
                                                                f"B={B}, window={S}, train-mode dropout, {dt:.1f} s")
+    all_cores = None
+    if ncores > 8:
+        rate, nb, dt = run(ncores, 4.0, 64)
+        all_cores = dict(value=rate, cores=ncores, sample=f"{nb} minibatch(es), {dt:.1f} s")
+        if rate > best["value"]:
+            best = dict(value=rate, cores=ncores, sample=all_cores["sample"])
     torch.set_num_threads(ncores)
-    best.update(unit="windows/s", kind="port", host_cores=ncores)
+    best.update(unit="windows/s", kind="port", host_cores=ncores, all_cores=all_cores)
     return best
 
 
+def _event_ms(fn, reps):
+    """Mean duration of fn's kernels, HIP events on the stream they are launched on (torch's current stream = _C.stream())."""
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec; 6 290 measured for a float4 copy
+
+
 def bench_scoring(device, n=125_000, reps=5):
-    """BASELINE.json's second metric, anomaly-score windows/s, on this GPU's share of configs[4] (10^6 windows over 8
-    GPUs): the test-loop forward with the hyperbolic row distance (anomaly_detection.py:67-113), then un-roll median +
-    point and DTW errors + rolling mean + z-score (utils/anomaly_detection_utils.py:866-962, 516-524); and the HBM
-    rate of the row-wise Poincare-ball kernels (algorithmic bytes per row)."""
+    """BASELINE.json's second metric, anomaly-score windows/s, on this GPU's share of configs[4] (10^6 windows over 8 GPUs): the
+    test-loop forward with the hyperbolic row distance (anomaly_detection.py:67-113), then un-roll median + point and DTW errors +
+    rolling mean + z-score (utils/anomaly_detection_utils.py:866-962, 516-524).  Returns (scoring, roofline_hbm, roofline_scoring):
+    kernel-only rates -- every output pre-allocated, HIP events around back-to-back launches through the C ABI -- of the row-wise
+    Poincare-ball kernels (algorithmic bytes per row) and of each scoring kernel."""
     from hypad_amd import _C
     from hypad_amd.hyperspace import gmath
     from hypad_amd.models import tadgan
@@ -122,8 +154,9 @@ def bench_scoring(device, n=125_000, reps=5):
     enc, dec, cx = tadgan.Encoder(S, L).to(device).eval(), tadgan.Decoder(S, L, True).to(device).eval(), tadgan.CriticX(S, L).to(device).eval()
     g = torch.Generator(device=device).manual_seed(3)
     x = (torch.rand(n, S, device=device, generator=g) * 2 - 1).contiguous()
-    new = lambda *shape: torch.empty(*shape, device=device, dtype=torch.float32)
+    new = lambda *shape, dtype=torch.float32: torch.empty(*shape, device=device, dtype=dtype)
     hyper, eucl, hreal, critic, dist = new(n, S), new(n, S), new(n, S), new(n), new(n)
+    st = _C.stream
 
     def timed(fn):
         fn()
@@ -140,7 +173,7 @@ def bench_scoring(device, n=125_000, reps=5):
     def forward():
         _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(x), 0, _C.ptr(hyper),
                                                    _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist), n, S, L, 1, ws.data_ptr(),
-                                                   ws_bytes, _C.stream()), "score_forward_packed")
+                                                   ws_bytes, st()), "score_forward_packed")
 
     def numerics():
         true = adu.unroll_true(x)
@@ -150,43 +183,102 @@ def bench_scoring(device, n=125_000, reps=5):
         return adu.zscore_clip(e1), adu.zscore_clip(e2)
 
     t_fwd, t_num = timed(forward), timed(numerics)
-    # row-wise ball kernels on 2 * 10^6 rows (0.8 GB per operand: well past the 256 MB Infinity Cache, so the rate is HBM's)
+    scoring = {"windows": n, "value": n / (t_fwd + t_num), "unit": "windows/s", "forward_windows_per_s": n / t_fwd,
+               "numerics_windows_per_s": n / t_num,
+               "numerics": "un-roll median, point + DTW(11) errors, rolling mean(200), z-score (host wall clock around the wrappers)"}
+
+    # ---- each scoring kernel on its own: pre-allocated outputs, HIP events
+    T = n + S - 1
+    true64, pred32 = adu.unroll_true(x), new(T)
+    err64, sm64, z64, modes64, stats = new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(4, dtype=torch.float64)
+    x64 = x.to(torch.float64)
+    C = _C.lib
+    kern = {
+        "score_forward_packed_kernel": (forward, "mfma", 340312.0 * n, None),
+        "unroll_median_kernel": (lambda: C.hypad_unroll_median(_C.ptr(eucl), _C.ptr(pred32), None, n, S, st()), "hbm", None, (4 * S + 4) * n),
+        "unroll_true": (lambda: C.hypad_unroll_true(_C.ptr(x64), _C.ptr(true64), n, S, st()), "hbm", None, 16 * T),
+        "point_error": (lambda: C.hypad_point_error(_C.ptr(true64), _C.ptr(pred32), _C.ptr(err64), T, st()), "hbm", None, 20 * T),
+        "dtw_error_kernel<11>": (lambda: C.hypad_dtw_error(_C.ptr(true64), _C.ptr(pred32), _C.ptr(err64), T, 10, st()), "valu", 121.0 * T, 20 * T),
+        "rolling_mean_kernel(200)": (lambda: C.hypad_rolling_mean(_C.ptr(err64), _C.ptr(sm64), T, 200, st()), "hbm", None, 16 * T),
+        "zscore_clip": (lambda: C.hypad_zscore_clip(_C.ptr(sm64), _C.ptr(z64), T, _C.ptr(stats), 32, st()), "hbm", None, 24 * T),
+        "kde_mode_kernel": (lambda: C.hypad_kde_mode(_C.ptr(critic), _C.ptr(modes64), n, S, st()), "valu", float(S) * S * T, 4 * n + 8 * T),
+    }
+    roofline_scoring = {}
+    for name, (fn, bound, work, nbytes) in kern.items():
+        ms = _event_ms(fn, reps)
+        ent = {"bound": bound, "ms": ms, "windows_per_s": n / (ms * 1e-3)}
+        if bound == "mfma":
+            ent.update(achieved=work / (ms * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")
+            ent["frac"] = ent["achieved"] / ent["peak"]
+        else:
+            ent.update(achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s", algorithmic_bytes=nbytes)
+            ent["frac"] = ent["achieved"] / ent["peak"]
+            if work:
+                ent["work_per_s"] = work / (ms * 1e-3)          # DTW cell updates/s; KDE kernel evaluations/s
+        roofline_scoring[name] = ent
+
+    # ---- row-wise ball kernels on 2 * 10^6 rows (0.8 GB per operand: well past the 256 MB Infinity Cache, so the rate is HBM's)
     m = 2_000_000
     xb = (torch.rand(m, S, device=device, generator=g) * 2 - 1).contiguous()
     ball = gmath.expmap0(0.03 * torch.randn(m, S, device=device, generator=g))
     other = gmath.expmap0(0.03 * torch.randn(m, S, device=device, generator=g))
-    ops = {"expmap0": (lambda: gmath.expmap0(xb), 8 * S), "logmap0": (lambda: gmath.logmap0(ball), 8 * S),
-           "project": (lambda: gmath.project(xb), 8 * S), "mobius_add": (lambda: gmath.mobius_add(ball, other), 12 * S),
-           "poincare_rowdist": (lambda: gmath.poincare_rowdist(ball, other), 8 * S + 4)}
-    gbps = {k: m * b / timed(f) / 1e9 for k, (f, b) in ops.items()}
-    return {"windows": n, "value": n / (t_fwd + t_num), "unit": "windows/s",
-            "forward_windows_per_s": n / t_fwd, "forward_tflops": n * 340312 / t_fwd / 1e12,
-            "numerics_windows_per_s": n / t_num,
-            "numerics": "un-roll median, point + DTW(11) errors, rolling mean(200), z-score",
-            "hyperbolic_ops_GBps": gbps, "hyperbolic_ops_rows": m, "hbm_peak_GBps": 8000.0,
-            "note": "row-wise ball ops: algorithmic bytes (800-1204 B/row at S=100) / time; includes the output allocation of the torch-facing wrappers"}
+    out, dv = new(m, S), new(m)
+    ops = {"expmap0 (unary_rows)": (lambda: C.hypad_expmap0_fwd(_C.ptr(xb), _C.ptr(out), m, S, st()), 8 * S),
+           "logmap0 (unary_rows)": (lambda: C.hypad_logmap0_fwd(_C.ptr(ball), _C.ptr(out), m, S, st()), 8 * S),
+           "project (unary_rows)": (lambda: C.hypad_project_fwd(_C.ptr(xb), _C.ptr(out), m, S, st()), 8 * S),
+           "mobius_add (mobius_add_rows)": (lambda: C.hypad_mobius_add_fwd(_C.ptr(ball), _C.ptr(other), _C.ptr(out), m, S, m, st()), 12 * S),
+           "poincare_rowdist (rowdist_rows)": (lambda: C.hypad_poincare_rowdist_fwd(_C.ptr(ball), _C.ptr(other), _C.ptr(dv), m, S, st()), 8 * S + 4)}
+    roofline_hbm = {"rows": m, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
+    for name, (fn, bpr) in ops.items():
+        ms = _event_ms(fn, reps)
+        gb = m * bpr / (ms * 1e-3) / 1e9
+        roofline_hbm["kernels"][name] = {"bytes_per_row": bpr, "ms": ms, "achieved": gb, "frac": gb / HBM_PEAK_GBPS}
+    return scoring, roofline_hbm, roofline_scoring
 
 
-def bench_scoring_sharded(device, world, per_gpu=125_000, reps=3):
-    """configs[4] across the ranks (opt-in: --sharded-scoring): 125 000 windows per GPU of one long series, every rank scoring
-    its window range (+ halo) and all-gathering the per-window / per-timestep vectors (hypad_amd/parallel.py).  All ranks call this."""
+def bench_scoring_sharded(device, world, rank, per_gpu=125_000, reps=3):
+    """configs[4] across the ranks (opt-in: --sharded-scoring): 125 000 windows per GPU of one long series.  Rank 0 holds the
+    trained weights; ONE RCCL broadcast of the parameter arenas (~1 MB) gives them to every rank (parallel.broadcast_weights);
+    every rank then scores its window range (+ halos) and all-gathers the per-window / per-timestep vectors.  Hyperbolic branch
+    (row-wise Poincare distance) and Euclidean branch (un-roll median + DTW): hypad_amd/parallel.py.  All ranks call this."""
+    import torch.distributed as dist
     from hypad_amd import parallel as par
     from hypad_amd.models import tadgan
-    torch.manual_seed(0)                                                  # the same weights on every rank
-    enc, dec, cx = tadgan.Encoder(S, L).to(device).eval(), tadgan.Decoder(S, L, True).to(device).eval(), tadgan.CriticX(S, L).to(device).eval()
+    out = {"rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+           "backend": dist.get_backend() if dist.is_initialized() else None}
     n = per_gpu * world
     g = torch.Generator(device=device).manual_seed(3)
     series = (torch.rand(n + S - 1, device=device, generator=g) * 2 - 1).contiguous()
-    par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        scores = par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    assert scores.shape == (n,) and np.isfinite(scores).all()
-    return {"windows": n, "value": n / dt, "unit": "windows/s", "what": "forward + row-wise Poincare distance + KDE critic modes sharded by window "
-            "range; all-gather; quantile z-score, rolling mean, combination 'mult' on the full vectors (every rank)"}
+    for hyperbolic in (True, False):
+        torch.manual_seed(1000 * rank + 7)                               # every rank starts from DIFFERENT weights ...
+        mods = [tadgan.Encoder(S, L).to(device).eval(), tadgan.Decoder(S, L, hyperbolic).to(device).eval(), tadgan.CriticX(S, L).to(device).eval()]
+        out["broadcast_bytes"] = par.broadcast_weights(mods, src=0)       # ... and takes rank 0's
+        enc, dec, cx = mods
+        if hyperbolic:
+            fn = lambda: par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
+            want = n
+        else:
+            y = series.unfold(0, S, 1)[:n].contiguous()                   # (N, S) window matrix for the un-roll
+            fn = lambda: par.score_anomalies_sharded(y, enc, dec, cx, S, rec_error_type="dtw", comb="mult")
+            want = n + S - 1
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            scores = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert scores.shape == (want,) and np.isfinite(scores).all()
+        if dist.is_initialized():                                         # every rank must hold the same scores
+            chk = torch.tensor([float(np.sum(scores))], device=device, dtype=torch.float64)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert float(lo) == float(hi), "ranks disagree on the gathered scores"
+        out["hyperbolic" if hyperbolic else "euclidean_dtw"] = {"windows": n, "value": n / dt, "unit": "windows/s"}
+    out["what"] = ("hyperbolic: forward + row-wise Poincare distance + KDE critic modes by window range, all-gather, global steps on every "
+                   "rank; euclidean_dtw: forward + un-roll median + DTW(11) + rolling mean by timestep range, all-gather, z-score + KDE critic "
+                   "scores + 'mult' on every rank")
+    return out
 
 
 def self_launch(n):
@@ -218,6 +310,7 @@ def main():
     ap.add_argument("--euclidean", action="store_true", help="configs[0]-style hyperbolic=False instead of configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
     ap.add_argument("--sharded-scoring", action="store_true", help="also time configs[4]-style scoring sharded over all ranks")
     args = ap.parse_args()
 
@@ -270,40 +363,75 @@ def main():
     assert all(np.isfinite(last)), "training diverged"
 
     # ---- per-kernel durations, HIP events on the launch stream (same workload, after the timed region)
-    # kind 4 = nine iterations of the critic phase exactly as train_epoch launches them (precompute of their records, the
-    # first critic_x || critic_z iteration launch, the mean of eight steady-state launches back to back -- event overhead
-    # amortised); kind 2 = decoder_iteration
-    names = {4: ["critic_precompute", "critic_iteration_first", "critic_iteration"], 2: ["gen", "dw_gen"]}
+    # kind 4 = the critic phase of one epoch (145 iterations) exactly as train_epoch launches it: the precompute of the records,
+    # then ONE resident launch (critic_persistent_kernel; reported per iteration and per launch) or, where that form cannot run,
+    # 145 per-iteration launches (the mean of the steady-state ones); kind 2 = decoder_iteration (generator kernel, dW + Adam)
+    persistent = eng.critic_phase_persistent()
+    names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 2: ["gen", "dw_gen"]}
     acc = {n: [] for v in names.values() for n in v}
     idx = torch.arange(B, device=device, dtype=torch.int32)
-    for rep in range(60):
+    for rep in range(24):
         for kind in (4, 2):
             ms = eng.profile_iteration(kind, x, idx, train_mode=True)
-            if rep >= 10:
+            if rep >= 4:
                 for n, v in zip(names[kind], ms):
                     acc[n].append(v)
-    kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_iteration_first"}
-    # the precompute runs ONCE per epoch for all 145 iterations; profiled here for nine iterations' rows (a lower bound
-    # on its efficiency), so its epoch share is not extrapolated from this number
-    launches = {"gen": N_BATCHES, "dw_gen": N_BATCHES, "critic_iteration": N_CRITICS * N_BATCHES + 1, "critic_precompute": 1}
-    share = {n: kern_ms[n] * launches[n] for n in kern_ms}
+    kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_first_or_reinit"}
+    n_it = N_CRITICS * N_BATCHES
+    # launches per epoch and milliseconds per launch of each kernel
+    if persistent:
+        per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
+                      "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
+        launches = {"critic_persistent_kernel": 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+    else:
+        per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
+                      "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
+        launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+    share = {k: per_launch[k] * launches[k] for k in per_launch}
     dom = max(share, key=share.get)
-    flop = 2.0 * MAC_PER_WINDOW[dom] * B * spg
-    achieved = flop / (kern_ms[dom] * 1e-3) / 1e12
+    mac = {"critic_persistent_kernel": MAC_PER_WINDOW["critic_iteration"] * n_it, "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
+           "critic_phase_precompute_kernel": MAC_PER_WINDOW["critic_precompute"] * n_it, "gen_kernel": MAC_PER_WINDOW["gen"],
+           "dw_adam_kernel": MAC_PER_WINDOW["dw_gen"]}
+    flop = 2.0 * mac[dom] * B * spg                      # algorithmic FLOPs of ONE launch of the dominant kernel
+    achieved = flop / (per_launch[dom] * 1e-3) / 1e12
 
-    # memory-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run, so this is the
-    # figure of the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_traffic.json, with the
-    # gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); null when the profile does not cover the kernel / config
-    traffic = None
+    # memory-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run, so this is the figure
+    # of the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_traffic.json, gfx950 FETCH_SIZE correction
+    # of MI355X_MICROARCH.md) -- but only while the kernel sources are the ones that profile was taken on (sha256 recorded in the
+    # profile); null otherwise
+    traffic, traffic_note = None, "no committed PMC profile matches these kernel sources"
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        key = {"gen": "gen_kernel", "dw_gen": "dw_adam_kernel", "critic_iteration": "critic_iteration_kernel"}.get(dom)
-        if key in pm and hyperbolic and spg == 1:
-            traffic = pm[key]["hbm_bytes_per_launch"]
+        from hypad_amd.build import source_digest
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        if prof.get("source_sha256") == source_digest() and dom in prof["kernels"] and hyperbolic and spg == 1:
+            traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_note = "profiles/r02_pmc_traffic.json (same kernel sources: sha256 matches)"
     except (OSError, KeyError, ValueError):
         pass
 
-    sharded = bench_scoring_sharded(device, world) if args.sharded_scoring else None
+    # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU
+    secondary = None
+    if spg == 1 and hyperbolic and not args.no_secondary:
+        eng8, x8 = build_engine(8, 8 * rank, True, device)
+        l8 = torch.empty(8, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
+        def step8():
+            perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
+            eng8.train_epoch(x8, perm.to(torch.int32).contiguous(), N_BATCHES, N_CRITICS, train_mode=True, losses=l8)
+        for _ in range(2):
+            step8()
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        for _ in range(8):
+            step8()
+        torch.cuda.synchronize()
+        t8 = (time.perf_counter() - t8) / 8
+        assert bool(torch.isfinite(l8).all())
+        secondary = {"workload": "configs[2] per-GPU share: 8 signals (8 models) per GPU, otherwise as configs[1]", "signals_per_gpu": 8,
+                     "ms_per_step": 1e3 * t8, "value": 8 * N_BATCHES * B / t8, "unit": "windows/s (this GPU)",
+                     "critic_phase_persistent": eng8.critic_phase_persistent()}
+        del eng8, x8
+
+    sharded = bench_scoring_sharded(device, world, rank) if args.sharded_scoring else None
     if rank == 0:
         windows = world * spg * N_BATCHES * B * args.steps
         out = {
@@ -323,14 +451,21 @@ def main():
                                     "latent=20, 1916 windows/signal, %d signal(s) per GPU; step = 1 epoch = 29 x "
                                     "(5 critic_x + 5 critic_z + 1 decoder) iterations") % (hyperbolic, spg),
                        "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,
-                       "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed},
+                       "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed,
+                       "critic_phase": "one resident launch per epoch (critic_persistent_kernel)" if persistent else "one launch per iteration",
+                       "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "epoch_share_ms": share, "flop_per_launch": flop},
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                         "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
+                         "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
+                         "us_per_critic_iteration": 1e3 * kern_ms["critic_iteration"],
+                         "kernel_ms": per_launch, "epoch_share_ms": share, "flop_per_launch": flop},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_scoring:
-            out["scoring"] = bench_scoring(device)
+            out["scoring"], out["roofline_hbm"], out["roofline_scoring"] = bench_scoring(device)
         if sharded is not None:
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:

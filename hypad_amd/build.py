@@ -20,6 +20,17 @@ DEV_SOURCES = SOURCES + ["diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 
 
+def source_digest():
+    """sha256 over the kernel sources and the ABI header: what a committed profile (profiles/*.json) was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "hypad.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _newest_source():
     files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hypad.h")]
     return max(os.path.getmtime(f) for f in files)

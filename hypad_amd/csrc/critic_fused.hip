@@ -22,6 +22,10 @@
 // the bias there, and the bias gradient is column K of the weight-gradient tile.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
 #include "../../include/hypad.h"
 #include "critic_mfma.h"
 #include "train_common.h"
@@ -119,6 +123,12 @@ struct PhaseArgs {
   // (iteration, signal, per-iteration layout of hypad_iter_io)
   const float* inj_z_x; const float* inj_al_x; const float* inj_mk_x;
   const float* inj_z_z; const float* inj_al_z; const float* inj_mk_z;
+  // exchange buffers of the persistent form (critic_persistent_kernel): see PersistPlan
+  float* xslab_x; float* xslab_z;              // (n_signals, 2 parities, B/16, nitems x 4) merged gradient shares, compact valid quads
+  unsigned long long* gran_x;                  // (n_signals, 2 parities, B/16, 4) granules {epoch << 32 | float bits}: sum g^2, sum real out, sum fake out
+  unsigned long long* gran_z;
+  unsigned* flags;                             // (2 critics, n_signals, B/16) epoch counters: value k = "slab of iteration k - 1 is published"
+  unsigned* err;                               // first word: set when a bounded wait gave up
 };
 // (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
 // neither the stamps nor their setter)
@@ -816,6 +826,661 @@ __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterA
   if (blockIdx.z == 0) critic_iteration_body<true, SC, LC, BC>(ax, ph, smem); else critic_iteration_body<false, SC, LC, BC>(az, ph, smem);
 }
 
+
+// ---------------------------------------------------------------------------------------------- persistent form
+// The whole critic phase as ONE launch: every (signal, critic, 16-row chunk) workgroup stays resident for all iterations and
+// keeps, across iterations, what the per-iteration launches reload each time:
+//   * the critic's weights in LDS and its Adam state (p, exp_avg, exp_avg_sq) in registers -- each thread owns the same
+//     accumulator quads every iteration (layer 0: one quad per thread; the other layers: waves 3-7, as in the prologue of
+//     critic_iteration_body), so the optimiser state never travels (40 KB read + 40 KB written per launch before);
+//   * the chunk's own share of nothing else: what crosses between the B / 16 workgroups of a critic per iteration is
+//       - three 8-byte granules {epoch, value} per chunk (sum g^2, the two output sums), published as soon as g exists, so that
+//         every chunk knows the whole-batch norm, hence the penalty's coefficient, BEFORE it publishes, and
+//       - ONE merged gradient share per chunk, dW(real, fake) + coef * dW(penalty rows), as compact valid quads (13.5 KB for
+//         critic_x; the launches exchanged 57 KB of padded tile images per chunk, two parts).
+// Hand-off (cdna_hip_programming.md Guideline 16, R1 with sc1 loads; MI355X_MICROARCH.md, valid forms, first table row): the
+// share is stored write-through (buffer_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at
+// a barrier, ONE lane stores the chunk's epoch word (sc1); a consumer polls the B / 16 epoch words with relaxed agent-scope
+// loads from one wave, meets its workgroup at a barrier and reads the shares with buffer_load ... sc1 (every load of
+// handed-off bytes is such a load).  Granules are R2: the data is the flag.  Shares and granules are double-buffered by
+// iteration parity: a chunk can run at most one iteration ahead of its slowest sibling (it needs the sibling's share of
+// iteration k to start k + 1), so parity k + 1's buffers are never rewritten while a sibling still reads parity k + 1 ... k.
+// Every wait is bounded: on a timeout the workgroup sets ph.err, poisons its loss row with NaN and leaves; siblings follow.
+// Residency: one workgroup per CU (the launcher asks for the full LDS plan for both critics and checks
+// workgroups <= CUs before choosing this form; otherwise the per-iteration launches run).
+#if HYPAD_DIAG
+#define PSTAMP(k) do { if (ph.stamps && it == 5 && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) ph.stamps[(blockIdx.z * 32 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+constexpr int PSLOT = 4;                     // Adam-state quads per thread
+constexpr int MAXCH = 21;                    // chunks whose granules one wave sweeps in one pass (3 x 21 <= 64 lanes)
+constexpr unsigned SPIN_LIMIT = 1u << 21;    // bounded waits: ~1 s of polling
+// the 16-byte payload type of the raw-buffer builtins.  hipcc (ROCm 7.2) pitfall: indexing a result of
+// __builtin_amdgcn_raw_buffer_load_b128 element by element (v[1], v[2] ...) is narrowed to ONE buffer_load_dword whose value
+// stands for all four elements; bit-cast the whole vector to f32x4 first (and build stores the same way round).
+typedef unsigned int u32x4_t __attribute__((vector_size(16)));
+
+HD bool persist_geom_supported(const CritGeom& g, int nchunks) {
+  const int Q = (g.L + 3) >> 2;
+  const int I0 = Q * (g.in_dim + 1), nitems = I0 + (g.nh - 1) * Q * (g.L + 1) + g.L + 1;
+  const int NA = (I0 + FT - 1) / FT, BT = (NW - 3) * 64;
+  return geom_supported(g) && g.ntiles <= MAXT * (NW - 1) && nchunks <= MAXCH && NA + (nitems - I0 + BT - 1) / BT <= PSLOT;
+}
+constexpr int persist_tiles(int in_dim, int L, int nh) {       // == crit_geom(...).ntiles
+  return ((L + 15) / 16) * (((in_dim + 1 + 15) & ~15) / 16) + (nh - 1) * ((L + 15) / 16) * (((L + 1 + 15) & ~15) / 16) + ((L + 1 + 15) & ~15) / 16;
+}
+HD int persist_items(const CritGeom& g) {
+  const int Q = (g.L + 3) >> 2;
+  return Q * (g.in_dim + 1) + (g.nh - 1) * Q * (g.L + 1) + g.L + 1;
+}
+
+template <bool IS_X, int SC, int LC, int BC>
+__device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
+  const int L = LC ? LC : a.L, B = BC ? BC : a.B, S = SC ? SC : a.S;
+  const int sig = blockIdx.y, chunk = blockIdx.x, nchunks = B / 16;
+  constexpr int nh = IS_X ? 4 : 2;
+  // weight-gradient tiles per wave (seven waves share them): exact at the compile-time shapes, MAXT otherwise
+  constexpr int TPW = (SC && LC) ? (persist_tiles(IS_X ? SC : LC, LC, nh) + NW - 2) / (NW - 1) : MAXT;
+  // state quads per thread: window 100 needs 1 (layer 0) + 2 (the other layers over waves 3-7); critic_z fewer still
+  constexpr int PS = !IS_X ? 2 : (SC == 100 && LC == 20 ? 3 : PSLOT);
+  const CriticLayout cl = IS_X ? cx_layout(S, L) : cz_layout(L);
+  const CritGeom g = IS_X ? cx_geom(S, L) : cz_geom(L);
+  const IterLds fl = iter_lds(g);
+  const int in_dim = g.in_dim, ldin = g.ldin, LQ = g.LQ, Kin = g.Kin, Lp = g.Lp;
+  float* in0 = smem + fl.in0; float* act = smem + fl.act; float* dm = smem + fl.dm; float* dl = smem + fl.dl;
+  float* w0 = smem + fl.w0; float* wh = smem + fl.wh; float* wl = smem + fl.wl; float* red = smem + fl.red;
+  float* gram = smem + fl.gram; float* whT = smem + fl.whT;
+  float* xsc = smem + fl.total;                            // [3][MAXCH] the chunks' scalars of this iteration (+ 4 control words)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int n_iters = ph.n_iters;
+  const float invB = 1.f / B;
+
+  float* arena_p = (IS_X ? a.P.cx + (int64_t)sig * a.pcx : a.P.cz + (int64_t)sig * a.pcz);
+  float* arena_m = (IS_X ? a.M.cx + (int64_t)sig * a.pcx : a.M.cz + (int64_t)sig * a.pcz);
+  float* arena_v = (IS_X ? a.V.cx + (int64_t)sig * a.pcx : a.V.cz + (int64_t)sig * a.pcz);
+  const bool writer = chunk == 0;
+  AdamCoef co;
+  co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = 0.f; co.riemannian = 0; co.stabilize = 0; co.step = 0;
+  co.bc1 = 1.f; co.sqrt_bc2 = 1.f; co.bc2 = 1.f;
+
+  const int Q = (L + 3) >> 2;
+  const int C0 = in_dim + 1, Ch = L + 1;
+  const int I0 = Q * C0, Ih = Q * Ch, nitems = I0 + (nh - 1) * Ih + Ch;
+  constexpr int BW0 = 3, BT = (NW - BW0) * 64;
+  const int NA = (I0 + FT - 1) / FT;
+  const bool bthread = wave >= BW0;
+  const int btid = threadIdx.x - BW0 * 64;
+  const int slabf = nitems * 4;
+  float* xslab = (IS_X ? ph.xslab_x : ph.xslab_z) + (int64_t)sig * 2 * nchunks * slabf;
+  unsigned long long* gran = (IS_X ? ph.gran_x : ph.gran_z) + (int64_t)sig * 2 * nchunks * 4;
+  unsigned* flags = ph.flags + ((int64_t)(IS_X ? 0 : 1) * gridDim.y + sig) * nchunks;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xslab, 0, 0x7fffffff, 0x00020000);
+  float* lo_base = ph.losses + sig * a.loss_sig_stride + (IS_X ? 0 : 4);
+
+  auto tile_desc = [&](int t, int& li, int& n0, int& k0) __attribute__((always_inline)) {
+    if (t < g.tiles0) { li = 0; n0 = (t / g.tk0) * 16; k0 = (t % g.tk0) * 16; return; }
+    t -= g.tiles0;
+    li = 1 + t / g.tilesh;
+    t -= (li - 1) * g.tilesh;
+    n0 = (t / g.tkh) * 16; k0 = (t % g.tkh) * 16;
+  };
+
+  // ---- once: zero the weight images' padding, take this thread's quads of the optimiser state into registers
+  for (int i = threadIdx.x; i < L * (ldin - C0); i += FT) { const int n = i / (ldin - C0), c = i - n * (ldin - C0); w0[n * ldin + C0 + c] = 0.f; }
+  for (int i = threadIdx.x; i < (nh - 1) * Lp * LQ; i += FT) {
+    const int rr = i / LQ, k = i - rr * LQ, m = rr % Lp;
+    if (m >= L || k >= L) whT[i] = 0.f;
+  }
+  for (int i = threadIdx.x; i < ((nh - 1) * L + 1) * (LQ - Ch); i += FT) {
+    const int n = i / (LQ - Ch), c = i - n * (LQ - Ch);
+    wh[n * LQ + Ch + c] = 0.f;
+  }
+  const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
+  int i_li[PS], i_n[PS], i_k[PS], i_e[PS];
+  float pv[PS][4], mv[PS][4], vv[PS][4];
+  // arena offset of row r of slot u (or -1); recomputed where needed (setup, final write) instead of held in registers
+  auto arena_off = [&](int u, int r) __attribute__((always_inline)) {
+    const int li = i_li[u];
+    if (li < 0) return -1;
+    const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
+    if (i_n[u] + r >= N) return -1;
+    int wof = cw_[0], bof = cb_[0];
+#pragma unroll
+    for (int x = 1; x <= nh; ++x) { wof = li == x ? cw_[x] : wof; bof = li == x ? cb_[x] : bof; }
+    return i_k[u] < K ? wof + (i_n[u] + r) * K + i_k[u] : bof + i_n[u] + r;
+  };
+#pragma unroll
+  for (int u = 0; u < PS; ++u) {
+    int e = -1;
+    if (u < NA) { const int e0 = threadIdx.x + u * FT; e = e0 < I0 ? e0 : -1; }
+    else if (bthread) { const int e0 = I0 + (u - NA) * BT + btid; e = e0 < nitems ? e0 : -1; }
+    i_e[u] = e;
+    const int ee = e < 0 ? 0 : e;
+    const bool first = ee < I0;
+    const int e1 = ee - I0;
+    const int lh = first ? 0 : e1 / Ih;
+    const bool last = !first && lh >= nh - 1;
+    const int li = first ? 0 : (last ? nh : 1 + lh);
+    const int er = first ? ee : (last ? e1 - (nh - 1) * Ih : e1 - lh * Ih);
+    const int cols = first ? C0 : Ch;
+    const int qq = last ? 0 : er / cols, k = er - qq * cols;
+    i_li[u] = e < 0 ? -1 : li; i_n[u] = 4 * qq; i_k[u] = k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = arena_off(u, r);
+      pv[u][r] = o >= 0 ? arena_p[o] : 0.f; mv[u][r] = o >= 0 ? arena_m[o] : 0.f; vv[u][r] = o >= 0 ? arena_v[o] : 0.f;
+    }
+  }
+  if (threadIdx.x < 4) reinterpret_cast<int*>(xsc)[3 * MAXCH + threadIdx.x] = 0;      // control words: [0] "give up"
+  auto clear_tiles = [&]() __attribute__((always_inline)) {         // act | dl: zero padding columns, fresh accumulation targets
+    for (int i = threadIdx.x * 4; i < (2 * nh + 1) * 48 * LQ; i += FT * 4)
+      *reinterpret_cast<float4*>(act + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  clear_tiles();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (the first iteration writes d loss / d out into the cleared tiles)
+
+  // record of iteration `it` in registers (requested one hand-off ahead)
+  float4 rrow[MAX_ROW4], rmask[MAX_MASK4];
+  auto request_record = [&](int it) __attribute__((always_inline)) {
+    const float* rec = (IS_X ? ph.rec_x : ph.rec_z) + (((int64_t)sig * n_iters + it) * nchunks + chunk) * g.rec_floats;
+#pragma unroll
+    for (int u = 0; u < MAX_ROW4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rrow[u] = i < g.rec_rows4 ? reinterpret_cast<const float4*>(rec)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < MAX_MASK4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rmask[u] = i < g.rec_mask4 ? reinterpret_cast<const float4*>(rec + 4 * g.rec_rows4)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (n_iters > 0) request_record(0);
+  int* ctl = reinterpret_cast<int*>(xsc) + 3 * MAXCH;
+  auto give_up = [&](unsigned code) __attribute__((always_inline)) {   // called by one lane: tell the workgroup and the siblings
+    __hip_atomic_store(ph.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl[0] = 1;
+  };
+
+  const int j_ = j, q_ = q, lane_ = lane;
+  // Wave specialisation: the loop is instantiated twice -- for the three chain waves (which carry the register-resident
+  // forward / backward chains and, of the optimiser state, only their layer-0 quads) and for the five helper waves (which carry
+  // the other layers' state, the Gram matrix and no chain registers).  Both instantiations meet at the same barriers; the
+  // register allocation is the larger of the two, not their sum (it spilled 110 registers as one body).
+  auto run = [&](auto chain_tag) __attribute__((always_inline)) {
+  constexpr bool CHAIN = decltype(chain_tag)::value;
+  for (int it = 0;; ++it) {
+    // (the loop body runs ~30 k cycles: nothing is gained by hoisting its address arithmetic out of the loop, and the hoisted
+    // values would occupy registers across it -- 260 spilled registers before this; re-derive the lane indices per iteration)
+    int j = j_, q = q_, lane = lane_;
+    asm volatile("" : "+v"(j), "+v"(q), "+v"(lane));
+    PSTAMP(0);
+    const bool fin = it == n_iters;
+    const int ppar = (it - 1) & 1;
+    u32x4_t x0[PS][4];
+    int obase = 0;
+    if (it > 0) {
+      // ---- every chunk's share of iteration it - 1
+      if (CHAIN && wave == 0) {
+        bool ok = false;
+        for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+          const unsigned f = lane < nchunks ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)it;
+          ok = __all((int)(f >= (unsigned)it));
+          if (ok) break;
+          if ((spins & 1023) == 1023 && __hip_atomic_load(ph.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok && lane == 0) give_up(0x100u + (unsigned)it);
+      }
+      __syncthreads();
+      if (ctl[0]) { if (writer && threadIdx.x == 0 && it <= n_iters) lo_base[(int64_t)(2 * (it - 1)) * 4] = __builtin_nanf(""); return; }
+      PSTAMP(1);                                                         // siblings' shares are there
+      obase = ppar * nchunks * slabf;
+      // the first four chunks' shares of this thread's layer-0 quads: requested together, before anything is waited for (clamped
+      // addresses, no branches).  The other layers' quads (helper waves) are requested inside phase B, which has the chains'
+      // whole first layer to hide them: a helper wave's phase A does not wait for them, and they occupy no registers until
+      // then.  Fixed chunk order: every sibling sums the same bits.
+#pragma unroll
+      for (int u = 0; u < PS; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (u >= NA) continue;                                         // (compile-time for the reference shapes: NA is)
+          x0[u][w] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (obase + (w < nchunks ? w : 0) * slabf + (i_e[u] < 0 ? 0 : i_e[u]) * 4) * 4, 0, 16);
+        }
+      // Adam's bias corrections of this step (written by the precompute launch)
+      const float* bc = ph.bias_corr + ((int64_t)(IS_X ? 0 : 1) * (n_iters + 1) + it) * 2;
+      co.bc1 = bc[0]; co.sqrt_bc2 = bc[1];
+    }
+    // ---- Adam on this thread's quads, weight images in LDS.  Phase A (layer 0, every thread) first: the chains need nothing else
+    // to start; phase B (the other layers, waves 3-7) runs beside the chains' first layer.
+    auto finish = [&](int u) __attribute__((always_inline)) {
+      const int li = i_li[u];
+      f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+      if (it > 0) {
+        if (u < NA) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float on = w < nchunks ? 1.f : 0.f;
+            const f32x4 xf = __builtin_bit_cast(f32x4, x0[u < NA ? u : 0][w]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gsum[r] += on * xf[r];
+          }
+        }
+        for (int w0c = u < NA ? 4 : 0; w0c < nchunks; w0c += 4) {                     // batches above 64 rows: four more chunks at a time
+          u32x4_t x[4];
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            x[w] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (obase + (w0c + w < nchunks ? w0c + w : 0) * slabf + (i_e[u] < 0 ? 0 : i_e[u]) * 4) * 4, 0, 16);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float on = w0c + w < nchunks ? 1.f : 0.f;
+            const f32x4 xf = __builtin_bit_cast(f32x4, x[w]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gsum[r] += on * xf[r];
+          }
+        }
+      }
+      if (li < 0) return;
+      const int N = li == nh ? 1 : L;
+      const int n = i_n[u], k = i_k[u];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (n + r >= N) continue;
+        if (it > 0) adam_update(pv[u][r], mv[u][r], vv[u][r], gsum[r], co);
+        const float pw = pv[u][r];
+        float* wdst = li == 0 ? w0 + (n + r) * ldin + k : (li < nh ? wh + ((li - 1) * L + n + r) * LQ + k : wl + k);
+        *wdst = pw;
+        if (li > 0 && li < nh && k < L) whT[((li - 1) * Lp + k) * LQ + n + r] = pw;
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PS; ++u)
+      if (u < NA) finish(u);
+    PSTAMP(2);                                                           // phase A: shares loaded, Adam, layer-0 image
+    auto phase_b = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < PS; ++u)
+        if (u >= NA) finish(u);
+    };
+    if (fin) {
+      if (!CHAIN) phase_b();
+      if (writer) {                                                   // the phase's last state -> arenas
+#pragma unroll
+        for (int u = 0; u < PS; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int o = arena_off(u, r);
+            if (o >= 0) { arena_p[o] = pv[u][r]; arena_m[o] = mv[u][r]; arena_v[o] = vv[u][r]; }
+          }
+      }
+      return;
+    }
+
+    // ---- record -> LDS; constant d loss / d out  (act | dl were cleared at the end of the previous iteration)
+#pragma unroll
+    for (int u = 0; u < MAX_ROW4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<float4*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < MAX_MASK4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
+    }
+    if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
+    int* bdone = reinterpret_cast<int*>(red + 40);
+    if (threadIdx.x == 0) *bdone = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PSTAMP(3);                                                           // record staged
+
+    // ---- forward and first backward: three register-resident chains (critic_iteration_body has the commentary)
+    constexpr int MF = 3, MAXNH = 4;
+    const int NT = Lp >> 4;
+    f32x4 DD[MAXNH][MF], DL[MF];
+    const int myrow = 16 * wave + j;
+    auto as4 = [](const f32x4& v) __attribute__((always_inline)) { return make_float4(v[0], v[1], v[2], v[3]); };
+    if constexpr (CHAIN) {
+      f32x4 T[MF];
+#pragma unroll
+      for (int li = 0; li < MAXNH; ++li)
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          DD[li][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (li < nh && t < NT) { const float4 v = *reinterpret_cast<const float4*>(dm + (li * 48 + myrow) * LQ + 16 * t + 4 * q); DD[li][t] = f32x4{v.x, v.y, v.z, v.w}; }
+        }
+      auto epilogue = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          if (t >= NT) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = 16 * t + 4 * q + r;
+            const float pre = T[t][r];
+            const float dd = f < L ? leaky_slope(pre) * DD[li][t][r] : 0.f;
+            DD[li][t][r] = dd;
+            T[t][r] = f < L ? pre * dd : (f == L ? 1.f : 0.f);
+          }
+          *reinterpret_cast<float4*>(act + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(T[t]);
+        }
+      };
+      float4 Aw[MF][MF];
+      auto load_fwd = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MF; ++t)
+#pragma unroll
+          for (int gg = 0; gg < MF; ++gg)
+            if (t < NT && gg < NT) { const int m = 16 * t + j; Aw[t][gg] = *reinterpret_cast<const float4*>(wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ + 4 * q + 16 * gg); }
+      };
+      auto load_bwd = [&](int li) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MF; ++t)
+#pragma unroll
+          for (int gg = 0; gg < MF; ++gg)
+            if (t < NT && gg < NT) Aw[t][gg] = *reinterpret_cast<const float4*>(whT + (li * Lp + 16 * t + j) * LQ + 4 * q + 16 * gg);
+      };
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        if (t >= NT) continue;
+        const int m = 16 * t + j;
+        const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
+        const float* bp = in0 + myrow * ldin + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        for (int g16 = 0; g16 < Kin; g16 += 32) {
+          acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
+          if (g16 + 16 < Kin) acc2 = mfma4(*reinterpret_cast<const float4*>(ap + g16 + 16), *reinterpret_cast<const float4*>(bp + g16 + 16), acc2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[t][r] = acc[r] + acc2[r];
+      }
+      epilogue(0);
+      PSTAMP(4);                                                         // layer 0 forward
+      while (__hip_atomic_load(bdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW - BW0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      PSTAMP(5);                                                         // phase B's weights seen
+      if (nh > 1) load_fwd(1);
+      for (int li = 1; li < nh; ++li) {
+        f32x4 N[MF];
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          if (t >= NT) continue;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int gg = 0; gg < MF; ++gg)
+            if (gg < NT) acc = mfma4(Aw[t][gg], as4(T[gg]), acc);
+          N[t] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < MF; ++t) T[t] = N[t];
+        if (li + 1 < nh) load_fwd(li + 1); else if (nh > 1) load_bwd(nh - 2);
+#pragma unroll
+        for (int x = 0; x < MAXNH; ++x) if (x == li) epilogue(x);
+      }
+      PSTAMP(6);                                                         // forward done
+      const float doutp = wave == 0 ? -invB : (wave == 1 ? invB : 1.f);
+      float o = 0.f;
+#pragma unroll
+      for (int t = 0; t < MF; ++t) {
+        DL[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t >= NT) continue;
+        const float4 wv = *reinterpret_cast<const float4*>(wl + 16 * t + 4 * q);
+        const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o += T[t][r] * wq[r];
+          float ddtop = 0.f;
+#pragma unroll
+          for (int x = 0; x < MAXNH; ++x) ddtop = x == nh - 1 ? DD[x][t][r] : ddtop;
+          DL[t][r] = doutp * wq[r] * ddtop;
+        }
+        *reinterpret_cast<float4*>(dl + ((nh - 1) * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
+      }
+      for (int li = nh - 2; li >= 0; --li) {
+        f32x4 N[MF];
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          N[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (t >= NT) continue;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int gg = 0; gg < MF; ++gg)
+            if (gg < NT) acc = mfma4(Aw[t][gg], as4(DL[gg]), acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float ddl = 0.f;
+#pragma unroll
+            for (int x = 0; x < MAXNH; ++x) ddl = x == li ? DD[x][t][r] : ddl;
+            N[t][r] = acc[r] * ddl;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          DL[t] = N[t];
+          if (t < NT) *reinterpret_cast<float4*>(dl + (li * 48 + myrow) * LQ + 16 * t + 4 * q) = as4(DL[t]);
+        }
+        if (li > 0) load_bwd(li - 1);
+      }
+      o += __shfl_xor(o, 16, 64);
+      o += __shfl_xor(o, 32, 64);
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+      if (wave < 2 && lane == 0) red[32 + wave] = o;
+      PSTAMP(7);                                                         // backward done
+    } else {
+      // (waves 4-6 share their SIMDs with the chain waves' back-to-back MFMAs and run this at half the speed of waves 3 and 7;
+      // the chains wait ~1 k cycles for it before their second layer.  Raising these waves' priority for it did not help.)
+      phase_b();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(bdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      PSTAMP(4);                                                         // phase B done (helper waves)
+    }
+    if (!CHAIN && (wave == 3 || wave == 7)) {
+      const int CTg = Lp >> 4;
+      for (int t = wave == 3 ? 0 : 1; t < CTg * CTg; t += 2) {
+        const int mt = t / CTg, nt = t - mt * CTg;
+        const int m = mt * 16 + j, n = nt * 16 + j;
+        const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
+        const float* bp = w0 + (n < L ? n : L - 1) * ldin + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int g16 = 0; g16 < Kin; g16 += 16) {
+          float4 av = *reinterpret_cast<const float4*>(ap + g16);
+          const float4 bv = *reinterpret_cast<const float4*>(bp + g16);
+          const int k = g16 + 4 * q;
+          av.x = k == in_dim ? 0.f : av.x; av.y = k + 1 == in_dim ? 0.f : av.y; av.z = k + 2 == in_dim ? 0.f : av.z; av.w = k + 3 == in_dim ? 0.f : av.w;
+          acc = mfma4(av, bv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mm = mt * 16 + 4 * q + r;
+          gram[mm * LQ + n] = (mm < L && n < L) ? acc[r] : 0.f;
+        }
+      }
+    }
+    PSTAMP(8);                                                           // (helpers: Gram done)
+    __syncthreads();
+    PSTAMP(9);
+    float gsq = 0.f;
+    f32x4 acc_rf[TPW], acc_gp[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) { acc_rf[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_gp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    // tiles are dealt over the seven waves that do NOT carry the second-order chain (wave 2, the interpolated rows' chain wave):
+    // 28 tiles = 7 x 4 at window 100.  Wave 2 did both parts of its tiles after its chain and finished 2.4 k cycles behind.
+    const int tslot = wave < 2 ? wave : wave - 1;
+    auto dw_tile = [&](int i, bool rf, bool gpp) __attribute__((always_inline)) {
+      const int t = tslot + (NW - 1) * i;
+      if (t < g.ntiles) {
+        int li, n0, k0;
+        tile_desc(t, li, n0, k0);
+        const int N = li == nh ? 1 : L;
+        const int nj = n0 + j < N ? n0 + j : N - 1;
+        const float* left = dl + li * 48 * LQ + nj;
+        const float* right = li == 0 ? in0 + k0 + j : act + (li - 1) * 48 * LQ + k0 + j;
+        const int ldr = li == 0 ? ldin : LQ;
+        if (rf) {
+          float la[8], rb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { la[u] = left[(4 * u + q) * LQ]; rb[u] = right[(4 * u + q) * ldr]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc_rf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_rf[i], 0, 0, 0);
+        }
+        if (gpp) {
+          float la[4], rb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { la[u] = left[(32 + 4 * u + q) * LQ]; rb[u] = right[(32 + 4 * u + q) * ldr]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc_gp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_gp[i], 0, 0, 0);
+        }
+      }
+    };
+    // (measured and dropped: requesting the operands of all of a wave's tiles first and running the k-steps tile-interleaved --
+    // independent accumulators, no dependent-latency stalls -- left this stage at the same 6 k cycles and cost 54 spilled
+    // registers: the stage is not bound by the MFMAs' dependent latency)
+    if (CHAIN && wave == 2) {
+      f32x4 E[MF];
+      for (int li = 0; li < nh; ++li) {
+        f32x4 N[MF];
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          N[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (t >= NT) continue;
+          const int m = 16 * t + j;
+          const float* ap = (li == 0 ? gram + m * LQ : wh + ((li - 1) * L + (m < L ? m : L - 1)) * LQ) + 4 * q;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int gg = 0; gg < MF; ++gg)
+            if (gg < NT) acc = mfma4(*reinterpret_cast<const float4*>(ap + 16 * gg), li == 0 ? as4(DL[gg]) : as4(E[gg]), acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float ddl = 0.f;
+#pragma unroll
+            for (int x = 0; x < MAXNH; ++x) ddl = x == li ? DD[x][t][r] : ddl;
+            N[t][r] = acc[r] * ddl;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < MF; ++t) {
+          E[t] = N[t];
+          if (t < NT) *reinterpret_cast<float4*>(act + (li * 48 + 32 + j) * LQ + 16 * t + 4 * q) = as4(E[t]);
+        }
+      }
+    } else {
+      const int CT = (in_dim + 1 + 15) >> 4, slot = wave < 2 ? wave : wave - 1;
+      const float* av = dl + (32 + j) * LQ + 4 * q;
+      for (int ct = slot; ct < CT; ct += NW - 1) {
+        int c = ct * 16 + j; c = c < in_dim ? c : in_dim - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int g16 = 0; g16 < Lp; g16 += 16) {
+          const int o = g16 + 4 * q;
+          float4 bv;
+          bv.x = w0[(o < L ? o : L - 1) * ldin + c];
+          bv.y = w0[(o + 1 < L ? o + 1 : L - 1) * ldin + c];
+          bv.z = w0[(o + 2 < L ? o + 2 : L - 1) * ldin + c];
+          bv.w = w0[(o + 3 < L ? o + 3 : L - 1) * ldin + c];
+          acc = mfma4(*reinterpret_cast<const float4*>(av + g16), bv, acc);
+        }
+        const int cc = ct * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * q + r;
+          if (cc < in_dim) { in0[(32 + row) * ldin + cc] = acc[r]; gsq += acc[r] * acc[r]; }
+          else if (cc == in_dim) in0[(32 + row) * ldin + cc] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) dw_tile(i, true, false);
+    }
+    {
+      const float tot = wave_sum(gsq);
+      if (lane == 0) red[wave] = tot;
+    }
+    PSTAMP(10);                                                          // second-order chain (wave 2) | g + dW(real, fake)
+    __syncthreads();
+    PSTAMP(11);
+    // ---- this chunk's scalars -> its siblings (granules: the data is the flag), as early as they exist
+    const unsigned epoch = (unsigned)it + 1u;
+    unsigned long long* gr = gran + (int64_t)(it & 1) * nchunks * 4;
+    if (threadIdx.x < 3) {
+      float v;
+      if (threadIdx.x == 0) { v = 0.f; for (int w = 0; w < NW; ++w) v += red[w]; }
+      else v = red[31 + threadIdx.x];
+      __hip_atomic_store(gr + chunk * 4 + threadIdx.x, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (it + 1 < n_iters) request_record(it + 1);         // lands during the tiles below and the waits that follow
+    if (!(CHAIN && wave == 2)) {
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) dw_tile(i, false, true);
+    }
+    PSTAMP(12);                                                          // dW(penalty rows)
+    // ---- the siblings' scalars: whole-batch norm, penalty coefficient, this iteration's loss
+    if (CHAIN && wave == 2) {                               // (wave 2 has no tiles: it waits for the scalars meanwhile)
+      bool ok = false;
+      const int c = lane / 3, f = lane - 3 * c;
+      for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        unsigned long long x = (unsigned long long)epoch << 32;
+        if (c < nchunks) x = __hip_atomic_load(gr + c * 4 + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = __all((int)((unsigned)(x >> 32) == epoch));
+        if (ok) { if (c < nchunks) xsc[f * MAXCH + c] = __uint_as_float((unsigned)x); break; }
+        if ((spins & 1023) == 1023 && __hip_atomic_load(ph.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok && lane == 0) give_up(0x200u + (unsigned)it);
+    }
+    __syncthreads();
+    if (ctl[0]) { if (writer && threadIdx.x == 0) lo_base[(int64_t)(2 * it) * 4] = __builtin_nanf(""); return; }
+    PSTAMP(13);                                                          // siblings' scalars are there
+    clear_tiles();                                        // (every read of this iteration's tiles is behind the barrier above; one
+                                                          // wave -- wave 2 has no share to store -- clearing alone took 5 k cycles)
+    float gs = 0.f, sreal = 0.f, sfake = 0.f;
+    for (int w = 0; w < nchunks; ++w) { gs += xsc[w]; sreal += xsc[MAXCH + w]; sfake += xsc[2 * MAXCH + w]; }   // fixed order
+    const float nrm = sqrtf(gs + 1e-12f);                 // train.py:90, whole batch
+    const float coef = 20.f * (nrm - 1.f) / nrm;          // d(10 gp) / d g = coef * g
+    if (writer && threadIdx.x == 0) {
+      const float gp = (nrm - 1.f) * (nrm - 1.f);
+      float* lo = lo_base + (int64_t)(2 * it) * 4;
+      lo[0] = sfake * invB - sreal * invB + 10.f * gp;    // train.py:98-99
+      lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
+    }
+    // ---- merged share -> compact valid quads, write-through; then the epoch word
+    {
+      const int obase = ((it & 1) * nchunks + chunk) * slabf;
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = tslot + (NW - 1) * i;
+        if (t < g.ntiles && !(CHAIN && wave == 2)) {
+          int li, n0, k0;
+          tile_desc(t, li, n0, k0);
+          const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
+          const int n = n0 + 4 * q, k = k0 + j;
+          if (n < N && k <= K) {
+            const int qq = n >> 2;
+            const int e = li == 0 ? qq * C0 + k : (li < nh ? I0 + (li - 1) * Ih + qq * Ch + k : I0 + (nh - 1) * Ih + k);
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc_rf[i][r] + coef * acc_gp[i][r];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, (obase + e * 4) * 4, 0, 16);
+          }
+        }
+      }
+    }
+    PSTAMP(14);                                                          // share stored
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+    __syncthreads();                                      // ... before ONE lane signals for all of them
+    if (threadIdx.x == 0) __hip_atomic_store(flags + chunk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PSTAMP(15);                                                          // drained, epoch word out
+    PSTAMP(16);
+  }
+  };
+  if (wave < BW0) run(std::true_type{}); else run(std::false_type{});
+}
+
+template <int SC, int LC, int BC>
+__global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.z == 0) critic_persistent_body<true, SC, LC, BC>(ax, ph, smem); else critic_persistent_body<false, SC, LC, BC>(az, ph, smem);
+}
+
 __global__ void advance_counters_kernel(int32_t* counters, int n) {
   if (threadIdx.x == 0) { counters[0] += n; counters[1] += n; counters[3] += n; }
 }
@@ -849,8 +1514,31 @@ size_t critic_phase_floats_per_iter(const hypad_dims& d) {
 // losses: iteration `it` writes rows 2*it (critic_x) and 2*it+1 (critic_z) of each signal's loss table.  ev (optional,
 // 4 events, profiling): recorded before the precompute, after it, after the first iteration launch (no Adam prologue)
 // and after the last one (n_iters - 1 steady-state launches back to back: event overhead amortised).
+// CUs of the current device (cached): the persistent form needs every workgroup resident, one per CU
+static int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] > 0 ? cus[dev] : 0;
+}
+bool critic_phase_persistent(const hypad_dims& d) {
+  const char* env = getenv("HYPAD_CRITIC_PERSISTENT");
+  if (env && env[0] == '0') return false;
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  const int nchunks = d.batch / 16;
+  if (!persist_geom_supported(gx, nchunks) || !persist_geom_supported(gz, nchunks)) return false;
+  const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
+  if ((size_t)((lx > lz ? lx : lz) + 3 * MAXCH + 4) * sizeof(float) > 160 * 1024) return false;
+  return (long long)nchunks * d.n_signals * 2 <= device_cus();       // all resident, one workgroup per CU
+}
+
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
-                     int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise) {
+                     int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
   const size_t fixed = critic_phase_fixed_floats(d), per_iter = critic_phase_floats_per_iter(d);
@@ -859,6 +1547,8 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   if (cap > n_iters) cap = n_iters;
   const CritGeom gx = cx_geom(ax.S, ax.L), gz = cz_geom(ax.L);
   const int nchunks = ax.B / 16;
+  const bool persistent = critic_phase_persistent(d);
+  if (persistent_used) *persistent_used = persistent ? 1 : 0;
   // the generator-side randomness (z, decoder dropout) keeps the critic_x seed; critic_z draws from its own
   az.seed = ax.seed ^ CRITIC_Z_SEED_XOR;
   const size_t lds_pre = (size_t)pre_lds(ax.S).total * sizeof(float);
@@ -867,23 +1557,44 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     if (e != hipSuccess) return (int)e;
   }
   const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
-  const size_t lds = (size_t)(lx > lz ? lx : lz) * sizeof(float);
+  // (persistent form: the same -- full -- LDS request for both critics keeps it at one workgroup per CU)
+  const size_t lds = (size_t)((lx > lz ? lx : lz) + (persistent ? 3 * MAXCH + 4 : 0)) * sizeof(float);
   // compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
   using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
-  const IterKernel kern = (ax.S == 100 && ax.L == 20 && ax.B == 64)    ? critic_iteration_kernel<100, 20, 64>
-                          : (ax.S == 150 && ax.L == 20 && ax.B == 256) ? critic_iteration_kernel<150, 20, 0>
-                                                                       : critic_iteration_kernel<0, 0, 0>;
+  const bool s100 = ax.S == 100 && ax.L == 20 && ax.B == 64, s150 = ax.S == 150 && ax.L == 20 && ax.B == 256;
+  const IterKernel kern = persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 0> : critic_persistent_kernel<0, 0, 0>)
+                                     : (s100 ? critic_iteration_kernel<100, 20, 64> : s150 ? critic_iteration_kernel<150, 20, 0> : critic_iteration_kernel<0, 0, 0>);
   const void* kfn = (const void*)kern;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  PhaseArgs ph;
+  PhaseArgs ph{};
+  // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
+  // persistent form's exchange buffers: [epoch words | error word] (zeroed before every launch), granules, merged shares
   float* p = extra;
-  ph.state_x = p; p += (size_t)n_signals * 6 * gx.params;
-  ph.state_z = p; p += (size_t)n_signals * 6 * gz.params;
-  ph.slab_x = p; p += (size_t)n_signals * 2 * nchunks * gx.slab_floats;
-  ph.slab_z = p; p += (size_t)n_signals * 2 * nchunks * gz.slab_floats;
+  size_t sync_bytes = 0;
+  if (persistent) {
+    // [epoch words | error word | granules]: ONE block, zeroed before every launch (a granule left by an earlier launch
+    // carries a valid-looking epoch tag: Guideline 16, "re-initialise every call")
+    uintptr_t up = ((uintptr_t)p + 15) & ~(uintptr_t)15;
+    ph.flags = (unsigned*)up;
+    const size_t nflags = (size_t)2 * n_signals * nchunks;
+    const size_t flag_bytes = ((nflags + 4) * sizeof(unsigned) + 15) & ~(size_t)15;
+    ph.err = ph.flags + nflags;
+    ph.gran_x = (unsigned long long*)(up + flag_bytes);
+    ph.gran_z = ph.gran_x + (size_t)n_signals * 2 * nchunks * 4;
+    sync_bytes = flag_bytes + (size_t)2 * n_signals * 2 * nchunks * 4 * sizeof(unsigned long long);
+    ph.xslab_x = (float*)(ph.gran_z + (size_t)n_signals * 2 * nchunks * 4);
+    ph.xslab_z = ph.xslab_x + (size_t)n_signals * 2 * nchunks * persist_items(gx) * 4;
+    if ((size_t)((ph.xslab_z + (size_t)n_signals * 2 * nchunks * persist_items(gz) * 4) - extra) > fixed) return HYPAD_EWORKSPACE;
+    p = extra + fixed - 8;
+  } else {
+    ph.state_x = p; p += (size_t)n_signals * 6 * gx.params;
+    ph.state_z = p; p += (size_t)n_signals * 6 * gz.params;
+    ph.slab_x = p; p += (size_t)n_signals * 2 * nchunks * gx.slab_floats;
+    ph.slab_z = p; p += (size_t)n_signals * 2 * nchunks * gz.slab_floats;
+  }
   float* bcorr = p; p += pad4(4 * (cap + 1));
   float* recs = p;
 #if HYPAD_DIAG
@@ -915,12 +1626,21 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
     HYPAD_CHECK_LAUNCH();
     if (ev) (void)hipEventRecord(ev[1], s);
-    for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
-      ph.it = it;
-      const dim3 grid((1 << XS) * (it == n ? 1 : nchunks), n_signals, 2);
-      hipLaunchKernelGGL(kern, grid, dim3(FT), lds, s, ax, az, ph);
+    if (persistent) {
+      hipError_t e = hipMemsetAsync(ph.flags, 0, sync_bytes, s);     // epoch words and the error word: zero before EVERY launch
+      if (e != hipSuccess) return (int)e;
+      if (ev) (void)hipEventRecord(ev[2], s);
+      hipLaunchKernelGGL(kern, dim3(nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
-      if (ev && (it == 0 || it == n - 1)) (void)hipEventRecord(ev[it == 0 ? 2 : 3], s);
+      if (ev) (void)hipEventRecord(ev[3], s);
+    } else {
+      for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
+        ph.it = it;
+        const dim3 grid((1 << XS) * (it == n ? 1 : nchunks), n_signals, 2);
+        hipLaunchKernelGGL(kern, grid, dim3(FT), lds, s, ax, az, ph);
+        HYPAD_CHECK_LAUNCH();
+        if (ev && (it == 0 || it == n - 1)) (void)hipEventRecord(ev[it == 0 ? 2 : 3], s);
+      }
     }
     hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
     HYPAD_CHECK_LAUNCH();
@@ -933,7 +1653,7 @@ int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad
   if (!critic_phase_supported(d) || n_iters <= 0 || n_iters > 512 || critic < 0 || critic > 1 || !out) return HYPAD_EINVAL;
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
   const size_t nchunks = d.batch / 16;
-  size_t o = (size_t)d.n_signals * (6 * (size_t)(gx.params + gz.params) + 2 * nchunks * (size_t)(gx.slab_floats + gz.slab_floats));
+  size_t o = critic_phase_fixed_floats(d) - 8;            // the fixed area (either form of the phase)
   o += pad4(4 * (n_iters + 1));
   if (critic == 1) o += (size_t)d.n_signals * n_iters * nchunks * gx.rec_floats;
   const CritGeom& g = critic == 0 ? gx : gz;

@@ -115,6 +115,10 @@ class Engine:
     def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None, x_row_stride=0):
         return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks, x_row_stride)
 
+    def critic_phase_persistent(self):
+        """True when train_epoch runs the critic phase as one resident launch (hypad_critic_phase_persistent)."""
+        return bool(_C.lib.hypad_critic_phase_persistent(ctypes.byref(self.dims)))
+
     def rng_fill(self, kind, n, tick, stream, signal=0, p_drop=0.0, seed=None):
         """n draws of one device random stream (hypad_rng_fill): kind 0 N(0,1), 1 U[0,1), 2 dropout keep-scale."""
         out = torch.empty(int(n), dtype=torch.float32, device=self.device)
@@ -133,11 +137,12 @@ class Engine:
 
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
-        4 nine iterations of train_epoch's hoisted critic phase: precompute, first launch, mean steady-state launch), HIP events on the current stream."""
+        4 = 145 iterations of train_epoch's hoisted critic phase: precompute, first launch / re-initialisation, mean time per
+        iteration), HIP events on the current stream."""
         x, stride = self._check_x(x)
         if kind == 4:
-            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 9, 1))
-        losses = torch.empty(18 * self.n, 4, dtype=torch.float32, device=self.device)
+            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 145, 1))
+        losses = torch.empty(290 * self.n, 4, dtype=torch.float32, device=self.device)
         drop = _C.Dropout(int(train_mode), None, self.seed, 0)
         io = _C.IterIO(x.data_ptr(), stride, 0, None if row_index is None else row_index.data_ptr(), None, None, drop,
                        losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)

@@ -253,6 +253,11 @@ typedef struct hypad_epoch_io {
  * to 512 iterations of precomputed rows (longer phases are processed in chunks).  Same random streams and the same
  * arithmetic per row as the per-iteration entry points; only floating-point summation order differs. */
 size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_critics);
+/* 1 when hypad_train_epoch (given that workspace) runs the critic phase of these dimensions as ONE resident launch -- every
+ * (signal, critic, 16-row chunk) workgroup stays on its CU for all iterations, weights in LDS, Adam state in registers, gradient
+ * shares exchanged through write-through stores and epoch words -- instead of one launch per iteration.  Needs
+ * 2 * n_signals * batch / 16 <= CUs of the device; HYPAD_CRITIC_PERSISTENT=0 in the environment selects the launches. */
+int hypad_critic_phase_persistent(const hypad_dims* dims);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
 /* Where hypad_train_epoch's hoisted critic phase left its precomputed records (tests and tools; valid after a call with
@@ -279,13 +284,15 @@ int hypad_rng_fill(int kind, uint64_t seed, uint32_t tick, uint32_t rng_stream, 
 uint64_t hypad_critic_z_seed(uint64_t seed);
 
 /* Measurement aid (bench.py): run ONE iteration (kind 0 = critic_x, 1 = critic_z, 2 = decoder, 3 = the critic_x ||
- * critic_z pair of the per-iteration path) or, kind 4, NINE iterations of the hoisted critic phase of hypad_train_epoch
+ * critic_z pair of the per-iteration path) or, kind 4, 145 iterations of the hoisted critic phase of hypad_train_epoch
  * over rows 0 .. batch-1 (row_index is ignored), with HIP events recorded on `stream` between the kernels; synchronise;
  * return the per-kernel durations in ms: critic iterations -> {pass kernel, gradient-penalty kernel, dW+Adam};
- * decoder -> {generator kernel, dW+Adam}; kind 4 -> {precompute kernel (nine iterations' records), first iteration
- * launch (no Adam in its prologue), mean of the eight steady-state launches that follow back to back}.  losses: room for
- * 2 * n_signals * 4 floats (kind 3) / 18 * n_signals * 4 floats (kind 4); workspace for kind 4:
- * hypad_epoch_workspace_bytes(dims, 9, 1).
+ * decoder -> {generator kernel, dW+Adam}; kind 4 -> {precompute kernel (the 145 iterations' records), X, mean time of one
+ * critic_x || critic_z iteration}: when the phase runs as one resident launch (hypad_critic_phase_persistent) X is the
+ * re-initialisation of its epoch words and the mean is that launch's duration / 145; otherwise X is the first iteration launch
+ * (no Adam in its prologue) and the mean is over the 144 steady-state launches that follow back to back.  losses: room for
+ * 2 * n_signals * 4 floats (kind 3) / 290 * n_signals * 4 floats (kind 4); workspace for kind 4:
+ * hypad_epoch_workspace_bytes(dims, 145, 1).
  * Not capturable into a graph. */
 int hypad_profile_iteration(int kind, const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io,
                             float* ms_out, int n_out, hypad_stream_t stream);

@@ -9,7 +9,9 @@ correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced re
 import csv, glob, json, re, sys
 import numpy as np
 
-KERNELS = ["critic_iteration_kernel", "critic_phase_precompute_kernel", "dw_adam_kernel", "gen_kernel", "pack_generator_kernel"]
+sys.path.insert(0, ".")
+KERNELS = ["critic_persistent_kernel", "critic_iteration_kernel", "critic_phase_precompute_kernel", "dw_adam_kernel", "gen_kernel", "pack_generator_kernel",
+           "score_forward_packed_kernel", "unroll_median_kernel", "dtw_error_kernel", "unary_rows", "mobius_add_rows", "rowdist_rows"]
 
 
 def medians(d, counter):
@@ -25,8 +27,10 @@ def medians(d, counter):
 
 
 fetch, write = medians(sys.argv[1], "FETCH_SIZE"), medians(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-                  "--no-cpu-baseline --no-scoring (two separate passes; scripts/pmc_traffic.py)",
+from hypad_amd.build import source_digest
+out = {"source_sha256": source_digest(),
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+                  "--no-cpu-baseline (two separate passes; scripts/pmc_traffic.py)",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE reads half of a wide coalesced read stream on gfx950 "
                      "(MI355X_MICROARCH.md, HBM)",
        "kernels": {k: {"launches_sampled": fetch[k][1], "FETCH_SIZE_KB_median": fetch[k][0], "WRITE_SIZE_KB_median": write[k][0],
