@@ -945,7 +945,9 @@ struct TableBuilder {
     d.left_off = left_off; d.left_ld = left_ld; d.red_rows = red;
     push(d, (n + 15) / 16);
   }
+  bool skip_decay = false;                     // decay-only ranges are left to decay_steps_kernel (hypad_train_epoch)
   void decay(int net, int p_off, int n) {
+    if (skip_decay) return;
     DwDesc d{};
     d.kind = DW_DECAY; d.net = (int16_t)net; d.p_off = p_off; d.nrows = n; d.p_off2 = -1;
     push(d, (n + 255) / 256);
@@ -983,7 +985,59 @@ DwTableS critic_table(int net, const CriticLayout& cl, const CritWs& cw, int B, 
   return tb.done();
 }
 
-DwTable gen_table(const hypad_dims& dm) {
+// Parameters that never receive a data gradient -- W_hh and the f-gate rows of W_ih / b_ih / b_hh of every LSTM direction (h0 =
+// c0 = 0 at T = 1: SURVEY.md A.2) -- but still move under RiemannianAdam's weight decay (train.py:286): 119 k of the generator's
+// 245 k floats at window 100, 45 % of the dW + Adam launch's optimiser traffic.  No kernel ever reads them, so inside an epoch
+// they are advanced ONCE, after the last generator step, by all the epoch's steps at a time (decay_steps_kernel): the same
+// arithmetic in the same order, element by element -- bit-identical -- with 1 / n_batches of the traffic.
+struct DecayTable { int n, total; int net[24], off[24], len[24], begin[24]; };
+DecayTable decay_table(const hypad_dims& dm) {
+  DecayTable t{};
+  const int S = dm.signal_shape, L = dm.latent_dim;
+  const EncLayout el = enc_layout(S, L);
+  const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
+  auto add = [&](int net, int off, int len) { t.net[t.n] = net; t.off[t.n] = off; t.len[t.n] = len; t.begin[t.n] = t.total; t.total += (len + 255) & ~255; ++t.n; };
+  auto dir = [&](int net, const LstmDir& ld, int H, int K) { add(net, ld.w_ih + H * K, H * K); add(net, ld.w_hh, 4 * H * H); add(net, ld.b_ih + H, H); add(net, ld.b_hh + H, H); };
+  for (int d = 0; d < 2; ++d) dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S);
+  for (int d = 0; d < 2; ++d) { dir(HYPAD_NET_DECODER, dl.l[0][d], DEC_H, DEC_D1); dir(HYPAD_NET_DECODER, dl.l[1][d], DEC_H, 2 * DEC_H); }
+  return t;
+}
+// the last `nsteps` generator steps of the decay-only parameters; counters[opt] already holds the last step's number
+__global__ __launch_bounds__(256) void decay_steps_kernel(IterArgs a, DecayTable tab, int nsteps) {
+  __shared__ float bc[2 * 64];
+  const int sig = blockIdx.y;
+  const int last = a.counters[a.opt];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  int r = 0;
+  for (int i = 1; i < tab.n; ++i) r = e >= tab.begin[i] ? i : r;          // (ranges start on 256-element boundaries: block-uniform)
+  const int idx = e - tab.begin[r];
+  const bool live = idx < tab.len[r];
+  const int net = tab.net[r];
+  const int64_t o = (int64_t)sig * (net == HYPAD_NET_ENCODER ? a.pe : a.pd) + tab.off[r] + (live ? idx : 0);
+  float* P = (net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + o;
+  float* M = (net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + o;
+  float* V = (net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + o;
+  float p = *P, m = *M, v = *V;
+  AdamCoef co;
+  co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize; co.step = 0;
+  co.bc1 = 1.f; co.bc2 = 1.f; co.sqrt_bc2 = 1.f;
+  for (int s0 = 0; s0 < nsteps; s0 += 64) {                               // bias corrections of 64 steps at a time (double-precision powers)
+    __syncthreads();
+    if (threadIdx.x < 64 && s0 + threadIdx.x < nsteps) {
+      const AdamCoef c = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, last - nsteps + 1 + s0 + threadIdx.x);
+      bc[2 * threadIdx.x] = c.bc1; bc[2 * threadIdx.x + 1] = c.bc2;
+    }
+    __syncthreads();
+    const int n = nsteps - s0 < 64 ? nsteps - s0 : 64;
+    for (int k = 0; k < n; ++k) {
+      co.bc1 = bc[2 * k]; co.bc2 = bc[2 * k + 1];
+      adam_update(p, m, v, 0.f, co);
+    }
+  }
+  if (live) { *P = p; *M = m; *V = v; }
+}
+
+DwTable gen_table(const hypad_dims& dm, bool with_decay = true) {
   const int B = dm.batch, S = dm.signal_shape, L = dm.latent_dim;
   const bool hyp = dm.hyperbolic != 0;
   const EncLayout el = enc_layout(S, L);
@@ -991,6 +1045,7 @@ DwTable gen_table(const hypad_dims& dm) {
   const GenWs gw = gen_ws(B, S, L);
   TableBuilder<DwTable> tb;
   tb.t.finalize = 1;
+  tb.skip_decay = !with_decay;
   for (int d = 0; d < 2; ++d)
     tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, 2 * B, hyp);     // chains R and Z
   tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, 2 * B);
@@ -1343,7 +1398,9 @@ int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const Iter
   return HYPAD_OK;
 }
 
-int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr, bool pack = true) {
+// with_decay = false: the decay-only parameters are left alone (the caller advances them with run_decay_steps)
+int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr, bool pack = true,
+            bool with_decay = true) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
@@ -1369,13 +1426,24 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
 #undef HYPAD_LAUNCH_GEN
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
-  const DwTable tab = gen_table(*d);
+  const DwTable tab = gen_table(*d, with_decay);
   const dim3 dgrid(dw_blocks(tab.total_items), d->n_signals);
   if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
+  return HYPAD_OK;
+}
+
+int run_decay_steps(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, int nsteps, hipStream_t s) {
+  if (!d->hyperbolic || nsteps <= 0) return HYPAD_OK;          // torch.optim.Adam (Euclidean generator) has no weight decay: nothing moves
+  IterArgs a;
+  int rc = fill_args(a, d, st, io, 2);
+  if (rc) return rc;
+  const DecayTable tab = decay_table(*d);
+  hipLaunchKernelGGL(decay_steps_kernel, dim3(tab.total / 256, d->n_signals), dim3(256), 0, s, a, tab, nsteps);
+  HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
 
@@ -1625,10 +1693,12 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
       c.z = nz->z_gen ? nz->z_gen + (int64_t)b * ns * B * L : nullptr;
       c.masks = inj_masks ? nz->masks_gen + (int64_t)b * ns * mk_gen : nullptr;
     }
-    rc = run_gen(d, st, c, (hipStream_t)s, nullptr, false);
+    rc = run_gen(d, st, c, (hipStream_t)s, nullptr, false, false);
     if (rc) return rc;
   }
-  return HYPAD_OK;
+  // W_hh and the f-gate rows: all of the epoch's weight-decay steps at once (see decay_table)
+  c.losses = io->losses;
+  return run_decay_steps(d, st, c, io->n_batches, (hipStream_t)s);
 }
 
 int hypad_critic_phase_persistent(const hypad_dims* d) {

@@ -283,3 +283,32 @@ def test_eight_signals_per_gpu_match_single_models(dev):
         for net in ("enc", "dec", "cx", "cz"):
             assert torch.equal(e1.params[net][0], eng8.params[net][s]), (s, net)
     assert not torch.equal(l8[0], l8[1])
+
+
+@pytest.mark.parametrize("hyper", [True, False])
+def test_epoch_generator_pass_equals_per_iteration_steps(dev, hyper):
+    """Inside an epoch the parameters that never see a data gradient (W_hh, f-gate rows: weight decay only) are advanced once, by
+    all the epoch's steps at a time (decay_steps_kernel).  Same arithmetic, same order: every generator tensor after a
+    generator pass of hypad_train_epoch is BIT-equal to the same minibatches stepped one hypad_decoder_iteration at a time
+    (which decays them every step), and the decay-only tensors did move."""
+    S, B, nb = 100, 64, 5
+    mods = _oracle_modules(S, hyper, seed=77)
+    rng = np.random.default_rng(3)
+    N = nb * B
+    x = cu(np.clip(np.sin(np.arange(N)[:, None] / 13.0 + np.arange(S)[None, :] / 7.0) + 0.1 * rng.standard_normal((N, S)), -1, 1)).reshape(1, N, S)
+    perm = rng.permutation(N).astype(np.int32).reshape(1, N)
+    z = rng.standard_normal((nb, 1, B, 20)).astype(np.float32)
+    e_epoch, e_iter = _engine(mods, S, B, hyper), _engine(mods, S, B, hyper)
+    w_before = e_epoch.state_dict("enc")["lstm.weight_hh_l0"].clone()
+    l_epoch = e_epoch.train_epoch(x, cu(perm, torch.int32), nb, 0, train_mode=False, noise={"z_gen": cu(z)})[0]
+    l_iter = []
+    for b in range(nb):
+        idx = cu(perm[0, b * B:(b + 1) * B], torch.int32)
+        l_iter.append(e_iter.decoder_iteration(x, idx, cu(z[b]), train_mode=False)[0].clone())
+    torch.cuda.synchronize()
+    assert torch.equal(l_epoch, torch.stack(l_iter))
+    for net in ("enc", "dec"):
+        for k in ("params", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(e_epoch, k)[net], getattr(e_iter, k)[net]), (net, k)
+    moved = not torch.equal(e_epoch.state_dict("enc")["lstm.weight_hh_l0"], w_before)
+    assert moved == hyper          # RiemannianAdam's weight decay moves W_hh; torch Adam (Euclidean) leaves it alone
