@@ -154,6 +154,29 @@ class Engine:
 
     NOISE_PLANES = ("z_cx", "alpha_cx", "z_cz", "alpha_cz", "z_gen", "masks_cx", "masks_cz", "masks_gen")
 
+    def train_epoch_graph(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, x_row_stride=0):
+        """train_epoch captured once into a hipGraph and replayed: the epoch is a fixed launch sequence (device counters, device
+        Philox, no host round trip; include/hypad.h: "every call may be captured"), ~62 launches at the reference
+        configuration.  `x`, `row_index` and `losses` must be the SAME buffers on every call (their addresses are frozen
+        in the graph; refill `row_index` in place with the epoch's shuffles).  Returns `losses`."""
+        x, _ = self._check_x(x, x_row_stride)
+        iters = (2 * n_critics + 1) * n_batches
+        if losses is None:
+            losses = getattr(self, "_graph_losses", None)
+            if losses is None or losses.shape != (self.n, iters, 4):
+                losses = self._graph_losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
+        key = (x.data_ptr(), row_index.data_ptr(), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride), self.seed)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        if key not in graphs:
+            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):                    # (side stream: _C.stream() is torch's current stream inside the block)
+                self.train_epoch(x, row_index, n_batches, n_critics, train_mode, losses=losses, x_row_stride=x_row_stride)
+            graphs[key] = g
+            # the capture itself did not execute anything
+        graphs[key].replay()
+        return losses
+
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
         hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks).

@@ -312,3 +312,32 @@ def test_epoch_generator_pass_equals_per_iteration_steps(dev, hyper):
             assert torch.equal(getattr(e_epoch, k)[net], getattr(e_iter, k)[net]), (net, k)
     moved = not torch.equal(e_epoch.state_dict("enc")["lstm.weight_hh_l0"], w_before)
     assert moved == hyper          # RiemannianAdam's weight decay moves W_hh; torch Adam (Euclidean) leaves it alone
+
+
+def test_epoch_as_hip_graph_equals_eager(dev):
+    """hypad_train_epoch is capturable: the epoch replayed from a hipGraph (Engine.train_epoch_graph) gives the same bits as the
+    eager launch sequence -- device counters and device Philox advance inside the graph, epoch after epoch."""
+    fx = load("iters_hyper_S100.npz")
+    from hypad_amd.engine import Engine
+    xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100)
+    nb, nc = 4, 2
+    perms = [torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(10 * e + i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+             for e in range(3)]
+
+    def engine():
+        e = Engine(100, 20, 64, True, lr=5e-4, seed=99)
+        for net in ("enc", "dec", "cx", "cz"):
+            e.load_state_dict(net, sub_state(fx, net, "w0"))
+        return e
+
+    ea, eb = engine(), engine()
+    buf = perms[0].clone()
+    for e in range(3):
+        la = ea.train_epoch(xs, perms[e], nb, nc, True).clone()
+        buf.copy_(perms[e])
+        lb = eb.train_epoch_graph(xs, buf, nb, nc, True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb), e
+    for net in ("enc", "dec", "cx", "cz"):
+        assert torch.equal(ea.params[net], eb.params[net]), net
+    assert ea.counters.cpu().tolist() == eb.counters.cpu().tolist() == [3 * nb * nc, 3 * nb * nc, 3 * nb, 3 * (nb * nc + nb)]
