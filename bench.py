@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--euclidean", action="store_true", help="configs[0]-style hyperbolic=False instead of configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
+    ap.add_argument("--no-graph", action="store_true", help="launch every epoch eagerly instead of replaying its captured hipGraph")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
     ap.add_argument("--sharded-scoring", action="store_true", help="also time configs[4]-style scoring sharded over all ranks")
     args = ap.parse_args()
@@ -350,11 +351,18 @@ def main():
     gen = torch.Generator(device=device).manual_seed(100 + rank)
     losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
 
+    perm_buf = torch.empty(N_CRITICS + 1, N_BATCHES * B, dtype=torch.int32, device=device)
+
     def step():
         # the DataLoader's shuffles: a fresh permutation for each of the 5 critic passes and the generator pass
-        # (argsort of uniform keys: six independent uniform permutations from one batched sort instead of six randperm calls)
+        # (argsort of uniform keys: six independent uniform permutations from one batched sort instead of six randperm calls),
+        # written into the buffer whose address the captured epoch reads
         perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
-        eng.train_epoch(x, perm.to(torch.int32).contiguous(), N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+        perm_buf.copy_(perm)
+        if args.no_graph:
+            eng.train_epoch(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+        else:       # the epoch's fixed launch sequence, captured once as a hipGraph and replayed (same bits as eager)
+            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
 
     def barrier():
         if dist is not None:
@@ -467,7 +475,7 @@ def main():
                        "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,
                        "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed,
                        "critic_phase": "one resident launch per epoch (critic_persistent_kernel)" if persistent else "one launch per iteration",
-                       "rccl_world_size": world},
+                       "launch": "eager" if args.no_graph else "hipGraph replay of the captured epoch", "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],

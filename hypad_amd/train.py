@@ -324,6 +324,7 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
         raise _C.HypadError(f"{n_windows} windows do not fill one batch of {B}")
     n_critics = 5
     gen = torch.Generator(device=dev).manual_seed(int(eng.seed) & 0x7FFFFFFF)
+    perm_buf = torch.empty(n_critics + 1, n_batches * B, dtype=torch.int32, device=dev)
     history = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[])
     actual_epoch = 0
     if getattr(params, "resume", False):
@@ -332,7 +333,9 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     for epoch in range(n_epochs):
         # one uniform permutation per pass (argsort of uniform keys: one batched sort instead of six randperm calls)
         perm = torch.rand(n_critics + 1, n_windows, device=dev, generator=gen).argsort(dim=1)[:, : n_batches * B]
-        losses = eng.train_epoch(x, perm.to(torch.int32).contiguous(), n_batches, n_critics, True, x_row_stride=stride)[0]
+        perm_buf.copy_(perm)
+        # the epoch is a fixed launch sequence: captured once as a hipGraph, replayed every epoch (Engine.train_epoch_graph)
+        losses = eng.train_epoch_graph(x, perm_buf, n_batches, n_critics, True, x_row_stride=stride)[0]
         crit = losses[: 2 * n_critics * n_batches, 0].reshape(n_critics * n_batches, 2).mean(0)
         gl = losses[2 * n_critics * n_batches:].mean(0)
         history.cx.append(float(crit[0])); history.cz.append(float(crit[1])); history.dec.append(float(gl[0]))
