@@ -2,8 +2,11 @@
 
 Same class names, constructor signatures, ``state_dict`` keys and output shapes as the reference; each
 network's weights live in one flat device arena (hypad_amd/arena.py) consumed by the HIP kernels.
-``forward`` is inference-grade (no autograd graph): training goes through the fused iteration functions
-of ``hypad_amd.train`` exactly where the reference calls ``loss.backward(); optim.step()``.
+Training goes through the fused iteration functions of ``hypad_amd.train`` exactly where the reference calls
+``loss.backward(); optim.step()``.  ``forward`` itself has two forms: one fused inference kernel when nothing can be
+differentiated (``torch.no_grad()``, ``requires_grad_(False)``: the test loop, scoring), and -- when autograd is recording and a
+parameter or the input requires a gradient, as in the reference's default state -- a chain of differentiable layer kernels
+(``hypad_amd/autograd.py``), so that a caller's own ``loss.backward(); optimizer.step()`` works as with the reference.
 
 The LSTMs run the reference's effective configuration: the window is the feature axis, sequence length is 1
 and h0 = c0 = 0 (models/tadgan.py:24-25,59-60), so ``weight_hh`` is carried (and decayed by
@@ -15,6 +18,7 @@ import torch
 from torch import nn
 
 from .. import _C
+from .. import autograd as hag
 from ..arena import ArenaModule
 from ..hyperspace.hyrnn_nets import MobiusLinear
 
@@ -53,6 +57,8 @@ class Encoder(ArenaModule):
         self._init_arena(_C.NET_ENCODER, signal_shape, latent_space_dim, False, init)
 
     def forward(self, x):
+        if hag.wants_graph(self, x):
+            return hag.encoder_forward(self, _rows(x, self.signal_shape)).view(1, -1, self.latent_space_dim)
         x = _rows(x, self.signal_shape)
         out = torch.empty(x.shape[0], self.latent_space_dim, device=x.device, dtype=torch.float32)
         _C.check(_C.lib.hypad_encoder_fwd(_C.ptr(self.arena()), _C.ptr(x), _C.ptr(out), x.shape[0], self.signal_shape,
@@ -80,6 +86,10 @@ class Decoder(ArenaModule):
         self._init_arena(_C.NET_DECODER, signal_shape, latent_space_dim, hyperbolic, init)
 
     def forward(self, x, dropout_mask=None):
+        if dropout_mask is None and hag.wants_graph(self, x):
+            S = self.signal_shape
+            out = hag.decoder_forward(self, _rows(x, self.latent_space_dim))
+            return (out[0].view(1, -1, S), out[1].view(1, -1, S)) if self.hyperbolic else out.view(1, -1, S)
         z = _rows(x, self.latent_space_dim)
         rows, S = z.shape[0], self.signal_shape
         eucl = torch.empty(rows, S, device=z.device, dtype=torch.float32)
@@ -105,6 +115,8 @@ class CriticX(ArenaModule):
         self._init_arena(_C.NET_CRITIC_X, signal_shape, latent_space_dim, False, init)
 
     def forward(self, x, dropout_masks=None):
+        if dropout_masks is None and hag.wants_graph(self, x):
+            return hag.critic_forward(self, _rows(x, self.signal_shape), 4, 0.25).view(1, -1, 1)
         x = _rows(x, self.signal_shape)
         out = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
         _C.check(_C.lib.hypad_critic_x_fwd(_C.ptr(self.arena()), _C.ptr(x), _C.ptr(out), x.shape[0], self.signal_shape,
@@ -124,6 +136,8 @@ class CriticZ(ArenaModule):
         self._init_arena(_C.NET_CRITIC_Z, latent_space_dim, latent_space_dim, False, init)
 
     def forward(self, x, dropout_masks=None):
+        if dropout_masks is None and hag.wants_graph(self, x):
+            return hag.critic_forward(self, _rows(x, self.latent_space_dim), 2, 0.2).view(*x.shape[:-1], 1)
         lead = x.shape[:-1]
         z = _rows(x, self.latent_space_dim)
         out = torch.empty(z.shape[0], device=z.device, dtype=torch.float32)

@@ -38,6 +38,10 @@ def params_ns(B=64, S=100, hyperbolic=True, lr=5e-4):
     return SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=20, lr=lr, hyperbolic=hyperbolic)
 
 
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+
+
 def maxdiff(a, b):
-    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    a, b = np.asarray(_np(a), dtype=np.float64), np.asarray(_np(b), dtype=np.float64)
     return float(np.max(np.abs(a - b))) if a.size else 0.0

@@ -124,13 +124,18 @@ def test_network_forwards_match_reference_fixtures(dev, tag, S, B):
     fx = load(f"fwd_{tag}.npz")
     enc, dec, cx, cz = _hip_models(fx, S, True)
     x, z = cu(fx["x"], torch.float64), cu(fx["z"]).view(1, B, 20)
-    hyper, eucl = dec(z)
-    assert maxdiff(enc(x).cpu(), fx["enc_x"]) < TOL
-    assert maxdiff(hyper.cpu(), fx["dec_hyper"]) < TOL and maxdiff(eucl.cpu(), fx["dec_eucl"]) < TOL
-    assert maxdiff(dec.hyperbolic_linear(x.view(-1, S).float()).detach().cpu(), fx["head_x"]) < TOL
-    assert maxdiff(cx(x).cpu(), fx["cx_x"]) < TOL and maxdiff(cz(z).cpu(), fx["cz_z"]) < TOL
     _, dec_e, _, _ = _hip_models(fx, S, False)
-    assert maxdiff(dec_e(z).cpu(), fx["dec_e_out"]) < TOL
+    # both forms of forward(): the differentiable chain of layer kernels (autograd recording, the reference's default state)
+    # and the fused inference kernel (no_grad)
+    for grad in (True, False):
+        with torch.set_grad_enabled(grad):
+            hyper, eucl = dec(z)
+            assert hyper.requires_grad == grad
+            assert maxdiff(enc(x), fx["enc_x"]) < TOL
+            assert maxdiff(hyper, fx["dec_hyper"]) < TOL and maxdiff(eucl, fx["dec_eucl"]) < TOL
+            assert maxdiff(dec.hyperbolic_linear(x.view(-1, S).float()), fx["head_x"]) < TOL
+            assert maxdiff(cx(x), fx["cx_x"]) < TOL and maxdiff(cz(z), fx["cz_z"]) < TOL
+            assert maxdiff(dec_e(z), fx["dec_e_out"]) < TOL
     # fused scoring forward == reference test loop body (anomaly_detection.py:67-95)
     from hypad_amd.anomaly_detection import score_batches
     res = score_batches([torch.from_numpy(fx["x"])], enc, dec, cx, S)
@@ -142,9 +147,10 @@ def test_network_forwards_match_reference_fixtures(dev, tag, S, B):
     ref = og.rowwise_poincare_distance(torch.from_numpy(fx["head_x"]), torch.from_numpy(fx["s0_hyper"].reshape(-1, S)))
     assert maxdiff(res["rowdist"].cpu(), ref) < TOL
     # ragged tail: 37 rows (not a multiple of the 16-row tile)
-    assert maxdiff(enc(x[:37]).cpu(), fx["enc_x"][:, :37]) < TOL
-    h37, _ = dec(z[:, :37])
-    assert maxdiff(h37.cpu(), fx["dec_hyper"][:, :37]) < TOL
+    with torch.no_grad():
+        assert maxdiff(enc(x[:37]), fx["enc_x"][:, :37]) < TOL
+        h37, _ = dec(z[:, :37])
+        assert maxdiff(h37, fx["dec_hyper"][:, :37]) < TOL
 
 
 def test_dense_building_blocks(dev):
