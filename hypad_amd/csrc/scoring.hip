@@ -246,21 +246,34 @@ __global__ __launch_bounds__(THREADS) void zscore_apply_kernel(const double* __r
 // windows covering it, critic[t - j] for the valid j (each window's score repeated along the window, un-rolled along
 // anti-diagonals).  Its score is the sample at which a Scott-bandwidth Gaussian KDE of those values is largest
 // (scipy.stats.gaussian_kde(v)(v), first arg-max), the median when fewer than two values or a singular covariance.
+constexpr int KDE_CB = 4;                    // candidates per pass-2 batch
+//
+// Selection in two passes.  The result is a SAMPLE (the arg-max's value), so only the arg-max must be exact, not the densities:
+// pass 1 evaluates every density in fp32 (v_exp_f32: cnt^2 = 10^4 exponentials per timestep at window 100 -- in fp64 this pass
+// was 97 % of the kernel, 1.7 ms for 125 000 windows); pass 2 re-evaluates in fp64, exactly as before, only the samples whose
+// fp32 density lies within 1e-3 of the fp32 maximum -- a superset of the true arg-max set (the fp32 density's relative error is
+// below 3e-5: arguments carry <= 4 ulp, |argument| < 88 wherever the term is not 0, v_exp_f32 adds 2 ulp) -- with the same
+// first-maximum tie rule.  Clustered samples (many near-equal densities) simply put more candidates into pass 2.
 __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
                                                             int64_t n, int W) {
   __shared__ double vals[THREADS / 64][MAX_WINDOW];
+  __shared__ float vals32[THREADS / 64][MAX_WINDOW];
+  __shared__ double terms[THREADS / 64][KDE_CB * MAX_WINDOW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t T = n + W - 1;
   double* v = vals[wave];
+  float* vf = vals32[wave];
+  constexpr int KPL = MAX_WINDOW / 64;                     // samples per lane
   for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
     const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
     const int j1 = (int)(t + 1 < W ? t + 1 : W);
     const int cnt = j1 - j0;
     double s = 0.0;
     for (int k = lane; k < cnt; k += 64) {
-      const double x = (double)critic[t - (j0 + k)];
-      v[k] = x;
-      s += x;
+      const float xf = critic[t - (j0 + k)];
+      v[k] = (double)xf;
+      vf[k] = xf;
+      s += (double)xf;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -272,19 +285,68 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
     double out;
     if (cnt > 1 && cov > 0.0 && cov == cov) {
       const double inv = 0.5 / cov;
-      double best = -1.0;
-      int besti = 0x7fffffff;
-      for (int k = lane; k < cnt; k += 64) {
-        const double xk = v[k];
-        double dens = 0.0;
-        for (int m = 0; m < cnt; ++m) { const double d = xk - v[m]; dens += exp(-d * d * inv); }
-        if (dens > best) { best = dens; besti = k; }                               // k ascending per lane: first max kept
+      // pass 1: fp32 densities of this lane's samples
+      const float invf = (float)inv * 1.44269504088896341f;                       // exp(-d^2 inv) = exp2(-d^2 inv log2 e)
+      float d32[KPL];
+      float mx = -1.f;
+#pragma unroll
+      for (int u = 0; u < KPL; ++u) {
+        const int k = lane + 64 * u;
+        d32[u] = -1.f;
+        if (k < cnt) {
+          const float xk = vf[k];
+          float dens = 0.f;
+          for (int m = 0; m < cnt; ++m) { const float d = xk - vf[m]; dens += __builtin_amdgcn_exp2f(-d * d * invf); }
+          d32[u] = dens;
+          mx = fmaxf(mx, dens);
+        }
       }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ob = __shfl_xor(best, off, WAVE);
-        const int oi = __shfl_xor(besti, off, WAVE);
-        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+      const float thr = mx * (1.f - 1e-3f);
+      // pass 2: fp64 densities of the candidates, in ascending sample order (the first maximum is kept); of every sample if
+      // pass 1 produced no candidate (a bandwidth so small that its reciprocal leaves the fp32 range makes the screen NaN).
+      // A wave pays for a sequential sum as if all 64 lanes ran it, so a candidate's sum is NOT given to one lane with its
+      // exponentials: the lanes compute a candidate's cnt exponentials side by side into LDS (two per lane at window 100), four
+      // candidates per batch, then lane c adds candidate c's terms in index order -- the same additions in the same order as
+      // the one-lane loop, hence the same bits, at 1/20 of its cycles.
+      double best = -1.0;
+      int besti = 0x7fffffff;
+      double* tm = terms[wave];
+      for (int round = 0; round < 2 && besti == 0x7fffffff; ++round) {
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) {
+          const int ku = lane + 64 * u;
+          unsigned long long mask = __ballot(ku < cnt && (round == 1 || d32[u] >= thr));
+          while (mask) {                                                          // wave-uniform
+            int kc[KDE_CB];
+            int nb = 0;
+#pragma unroll
+            for (int c = 0; c < KDE_CB; ++c) {
+              kc[c] = -1;
+              if (mask) { kc[c] = __builtin_ctzll(mask) + 64 * u; mask &= mask - 1; nb = c + 1; }
+            }
+#pragma unroll
+            for (int c = 0; c < KDE_CB; ++c) {
+              if (kc[c] < 0) continue;
+              const double xk = v[kc[c]];
+              for (int m = lane; m < cnt; m += 64) { const double d = xk - v[m]; tm[c * MAX_WINDOW + m] = exp(-d * d * inv); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            double dens = -1.0;
+            if (lane < nb) {
+              dens = 0.0;
+              for (int m = 0; m < cnt; ++m) dens += tm[lane * MAX_WINDOW + m];
+            }
+#pragma unroll
+            for (int c = 0; c < KDE_CB; ++c) {
+              const double dc = __shfl(dens, c, WAVE);
+              if (c < nb && dc > best) { best = dc; besti = kc[c]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       }
       out = v[besti];
     } else {
