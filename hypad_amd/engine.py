@@ -177,10 +177,13 @@ class Engine:
         graphs[key].replay()
         return losses
 
-    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None):
+    def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None,
+                    workspace_iters=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
         hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks).
         x_row_stride=1: x is the scaled series (SignalDataset.window_view), not a window matrix.
+        workspace_iters: hand the library only the workspace of that many critic iterations (it then processes the phase in
+        slices of that length: what it does on its own for phases longer than 512 iterations) -- tests.
         noise: optional dict of injected planes (hypad_epoch_noise: z_cx, alpha_cx, z_cz, alpha_cz, z_gen, masks_*; float32
         device tensors, iteration-major) replacing the device Philox draws -- parity runs."""
         x, stride = self._check_x(x, x_row_stride)
@@ -197,7 +200,8 @@ class Engine:
             nz = _C.EpochNoise(*(None if noise.get(k) is None else _C.require_cuda(noise[k], k).data_ptr() for k in self.NOISE_PLANES))
         io = _C.EpochIO(x.data_ptr(), stride, int(x_row_stride), row_index.data_ptr(), n_batches, n_critics, int(train_mode), self.seed,
                         losses.data_ptr(), self.workspace.data_ptr(),
-                        self._ws_bytes if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
+                        (self._ws_bytes if workspace_iters is None else _C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), int(workspace_iters), 1))
+                        if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
                         ctypes.pointer(nz) if nz is not None else None)
         st = self._state()
         _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")

@@ -341,3 +341,31 @@ def test_epoch_as_hip_graph_equals_eager(dev):
     for net in ("enc", "dec", "cx", "cz"):
         assert torch.equal(ea.params[net], eb.params[net]), net
     assert ea.counters.cpu().tolist() == eb.counters.cpu().tolist() == [3 * nb * nc, 3 * nb * nc, 3 * nb, 3 * (nb * nc + nb)]
+
+
+@pytest.mark.parametrize("persistent", ["1", "0"])
+def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
+    """Phases longer than the workspace's record capacity (512 iterations by default) are processed in slices, the critics'
+    state passing through the arenas in between.  Forced here with a workspace of 4 iterations for a phase of 10: same bits
+    as the phase in one piece -- for the resident-launch form and for the per-iteration launches."""
+    monkeypatch.setenv("HYPAD_CRITIC_PERSISTENT", persistent)
+    fx = load("iters_hyper_S100.npz")
+    from hypad_amd.engine import Engine
+    xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100)
+    nb, nc = 5, 2
+    perm = torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+    outs = []
+    for wi in (None, 4, 3):
+        e = Engine(100, 20, 64, True, n_signals=2, lr=5e-4, seed=5)
+        for net in ("enc", "dec", "cx", "cz"):
+            for sgn in range(2):
+                e.load_state_dict(net, sub_state(fx, net, "w0"), sgn)
+            e.params[net][1].mul_(1.02)
+        assert e.critic_phase_persistent() == (persistent == "1")
+        l = e.train_epoch(xs, perm, nb, nc, True, workspace_iters=wi)
+        torch.cuda.synchronize()
+        outs.append((l.clone(), {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}, e.counters.cpu().tolist()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and o[2] == outs[0][2]
+        for k in ("cx", "cz", "enc", "dec"):
+            assert torch.equal(o[1][k], outs[0][1][k]), k
