@@ -12,6 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # HYPAD_DEV_LIB=1 (scripts/diag_*.py only): the development build with in-kernel stamps and the hypad_diag_* entry points
 LIB_PATH = os.path.join(_HERE, "lib", "libhypad_hip_dev.so" if os.environ.get("HYPAD_DEV_LIB") == "1" else "libhypad_hip.so")
+if os.environ.get("HYPAD_LIB_PATH"):        # A/B timing of two builds of the same library (scripts/ab_libs.sh)
+    LIB_PATH = os.environ["HYPAD_LIB_PATH"]
 
 
 class HypadError(RuntimeError):

@@ -175,7 +175,75 @@ __global__ void diag_mfma32_kernel(long long* out, float seed) {
   long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = t1 - t0; out[1] = (long long)(acc[0][0] + acc[1][0]); }
 }
+// co-issue: wave 0 runs fp32 MFMAs, wave 4 (same SIMD of a 512-thread workgroup) runs VALU work; each reports its own time.
+// mode bit 0: wave 0 active (MFMA); bit 1: wave 4 active; bits 2-3: what wave 4 runs (0 v_fma_f32, 1 v_exp_f32, 2 MFMA, 3 ds_read)
+template <int kind, int NV = 0>
+__global__ void diag_coissue_kernel(long long* out, float seed, int mode, int w2) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  __shared__ float lds[4096];
+  const int wave = threadIdx.x >> 6;
+  lds[threadIdx.x] = seed; lds[threadIdx.x + 512] = seed;
+  __syncthreads();
+  if ((wave == 0 && (mode & 1)) || (wave == w2 && (mode & 2) && kind == 2)) {
+    f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{seed, 0.f, 0.f, 0.f};
+    float a = seed + threadIdx.x, b = seed * 0.5f;
+    long long t0 = __builtin_amdgcn_s_memtime();
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed + i;
+    for (int it = 0; it < 64; ++it) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {      // the same wave interleaves NV VALU instructions behind every MFMA
+            if (kind == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x[v & 7]));
+            else asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(x[v & 7]) : "v"(a), "v"(b));
+          }
+        }
+    }
+    acc[0][1] += x[0] + x[1] + x[2] + x[3] + x[4] + x[5] + x[6] + x[7];
+    long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) { out[wave == 0 ? 0 : 1] = t1 - t0; out[2 + wave] = (long long)(acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] + acc[0][1]); }
+  } else if (wave == w2 && (mode & 2)) {
+    float x[8];
+    for (int i = 0; i < 8; ++i) x[i] = seed + i;
+    float a = 1.0001f, b = 0.5f;
+    if (mode & 16) __builtin_amdgcn_s_setprio(3);
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < 128; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (kind == 0) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+        else if (kind == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+        else { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((int)((threadIdx.x & 63) * 4 + i * 256))); x[i] = v; }
+      }
+      if (kind == 3) asm volatile("s_waitcnt lgkmcnt(0)");
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) sum += x[i];
+    if ((threadIdx.x & 63) == 0) { out[1] = t1 - t0; out[2 + wave] = (long long)sum; }
+  }
+}
 }  // namespace
+extern "C" int hypad_diag_coissue(int mode, int w2, long long* out, hypad_stream_t s) {
+  const int kind = (mode >> 2) & 3;
+  if (mode & 32) {
+#define CO(K, N) hipLaunchKernelGGL((diag_coissue_kernel<K, N>), dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, 4)
+    if (kind == 0) { if (w2 == 0) CO(0, 0); else if (w2 == 1) CO(0, 1); else if (w2 == 2) CO(0, 2); else if (w2 == 4) CO(0, 4); else if (w2 == 6) CO(0, 6); else CO(0, 8); }
+    else { if (w2 == 0) CO(1, 0); else if (w2 == 1) CO(1, 1); else if (w2 == 2) CO(1, 2); else if (w2 == 4) CO(1, 4); else if (w2 == 6) CO(1, 6); else CO(1, 8); }
+#undef CO
+    return (int)hipGetLastError();
+  }
+  if (kind == 0) hipLaunchKernelGGL(diag_coissue_kernel<0>, dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, w2);
+  else if (kind == 1) hipLaunchKernelGGL(diag_coissue_kernel<1>, dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, w2);
+  else if (kind == 2) hipLaunchKernelGGL(diag_coissue_kernel<2>, dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, w2);
+  else hipLaunchKernelGGL(diag_coissue_kernel<3>, dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, w2);
+  return (int)hipGetLastError();
+}
 extern "C" int hypad_diag_mfma(int variant, int threads, long long* out, hypad_stream_t s) {
   if (variant == 1) hipLaunchKernelGGL(diag_mfma_kernel<1>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
   else if (variant == 2) hipLaunchKernelGGL(diag_mfma_kernel<2>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);

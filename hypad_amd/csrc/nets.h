@@ -375,7 +375,8 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
                                                       const float* __restrict__ pb0, const float* __restrict__ pk1,
                                                       const float* __restrict__ pb1, int H, float* __restrict__ Hs, int ldh,
                                                       float* __restrict__ gates_save, int valid, int ps = 16,
-                                                      const LstmPre& pre = LstmPre{}, float* __restrict__ h_out = nullptr) {      // h_out: global mirror of Hs
+                                                      const LstmPre& pre = LstmPre{}, float* __restrict__ h_out = nullptr,
+                                                      long long* xst = nullptr) {      // h_out: global mirror of Hs
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
@@ -386,6 +387,10 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     const float4* wg = wi + (size_t)nb * kg * 64;
     const float4* wo = wg + (size_t)nb * kg * 64;
     const float* pb = d ? pb1 : pb0;
+    // (the biases are requested here, ahead of the products: behind them they are an exposed memory round trip per task)
+    const int jj = 16 * ub + j;
+    float b_i = 0.f, b_g = 0.f, b_o = 0.f;
+    if constexpr (PRE) { b_i = pb[jj < H ? jj : 0]; b_g = pb[Hp + (jj < H ? jj : 0)]; b_o = pb[2 * Hp + (jj < H ? jj : 0)]; }
     f32x4 ai[MT], ag[MT], ao[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { ai[m] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[m] = ai[m]; ao[m] = ai[m]; }
@@ -422,6 +427,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
         bi[u] = wi[o]; bg[u] = wg[o]; bo[u] = wo[o];
       }
     };
+    mfma_prio_begin<PRE>();
     if constexpr (decltype(first_from_pre)::value) {
       // latency-chain callers: the first batch is already in registers (lstm_layer_prefetch), and two batches of four
       // k-groups stay in flight -- the next one is requested before the current one is consumed
@@ -445,9 +451,10 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
         consume(bi, bg, bo, g0);
       }
     }
-    const int jj = 16 * ub + j;
+    mfma_prio_end<PRE>();
+    if (xst && (threadIdx.x & 63) == 0) xst[41 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
     if (jj < H) {
-      const float b_i = pb[jj], b_g = pb[Hp + jj], b_o = pb[2 * Hp + jj];
+      if constexpr (!PRE) { b_i = pb[jj]; b_g = pb[Hp + jj]; b_o = pb[2 * Hp + jj]; }      // (throughput callers: fewer live registers)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -464,7 +471,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
         }
     }
   };
+  if (xst && (threadIdx.x & 63) == 0) xst[40 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
   if (wave < 2 * nb) run(wave, std::integral_constant<bool, PRE>{});
+  if (xst && (threadIdx.x & 63) == 0) xst[42 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
   for (int task = wave + nwaves; task < 2 * nb; task += nwaves) run(task, std::false_type{});
 }
 
@@ -532,7 +541,7 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   // layer 1: h0 (dropped) in bufA -> h1 in bufB
   if constexpr (PRE) pre2 = gemm_nt_prefetch(pk + gp.d2, 2 * DEC_H, S);
   lstm_layer_fwd_packed<MT, PRE>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB,
-                                  ldH, sv.g1, valid, sv.ps, pre1, sv.h1);
+                                  ldH, sv.g1, valid, sv.ps, pre1, sv.h1, sv.stamps);
   TSTAMP(29);
   __syncthreads();
   TSTAMP(30);

@@ -28,7 +28,15 @@
 #include <type_traits>
 #include "device_utils.h"
 
+// Wave priority around the fp32 MFMA streams of the latency-chain kernels.  Measured (scripts/diag_coissue.py): while one wave of a
+// SIMD streams v_mfma_f32_16x16x4_f32 back to back, the other wave of that SIMD issues ONE VALU / LDS instruction per MFMA
+// (38 cycles instead of 6): the fp32 MFMA occupies the SIMD's FMA lanes, so MFMA time and VALU time of a SIMD add up, and an
+// epilogue or an address prologue next to a streaming wave is starved.  The latency-chain callers (PRE) run at priority 2 and
+// drop to 0 inside the MFMA loops: the wave with scalar / VALU work gets its issue slots first.
 namespace hypad {
+template <bool ON> __device__ __forceinline__ void mfma_prio_begin() { if constexpr (ON) __builtin_amdgcn_s_setprio(0); }
+template <bool ON> __device__ __forceinline__ void mfma_prio_end() { if constexpr (ON) __builtin_amdgcn_s_setprio(2); }
+
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
@@ -243,6 +251,7 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
       }
     };
     int gbeg = 0;
+    mfma_prio_begin<PRE>();
     if constexpr (decltype(first_from_pre)::value) {
       consume(pre.w, 0);
       gbeg = 8;
@@ -254,6 +263,7 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
       __builtin_amdgcn_sched_barrier(0);
       consume(w, g0);
     }
+    mfma_prio_end<PRE>();
     if (n < N) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)

@@ -338,6 +338,7 @@ template <bool HYPER, int SC, int LC, int BC>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
   const int sig = blockIdx.y, tile = blockIdx.x >> 3, role = blockIdx.z;
+  __builtin_amdgcn_s_setprio(2);            // (tile_gemm.h mfma_prio_*: the MFMA loops run below everything else)
   if (role == 2) { gen_role_z<SC, LC, BC>(a, smem); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
@@ -435,17 +436,29 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(3);
   // E = tanh output in Ein[0..15]
   const int hrows = (HYPER && role == 1) ? 32 : 16;       // rows through the Moebius head: role R adds pass 2 = the real window
+  float u_keep[16], hb_keep[16];            // this wave's head rows: pre-activations and bias (lane's elements), forward -> backward
   if (HYPER) {
     GEN_STAMP(20);
-    // (u, the head's pre-activations, goes to the workspace from the epilogue: the backward re-reads it)
-    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head, ActIdentity{}, nullptr, 0,
-                                           ws + gw.u + prow0 * S, S, B);
-    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head, ActIdentity{}, nullptr, 0,
-                                 ws + gw.u + prow0 * S, S, B);
+    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
     __syncthreads();
     GEN_STAMP(21);
     GEN_STAMP(22);
-    head_rows_tile(bufB, ldS, hrows, S, PD + dl.head_b);
+    // the Moebius head, row-wise in place (head_rows_tile's row dealing: four rows per wave, one per 16-lane DPP row).  The wave
+    // that carries a row forward carries it backward as well: u (the head's pre-activations) and the bias stay in its registers
+    // until then -- the backward used to re-read u from the workspace, a memory round trip in the middle of the chain.
+    epl16_dispatch(S, [&](auto tag) {
+      constexpr int EPL = decltype(tag)::value;
+      using R16 = RowT<16, EPL>;
+      const R16 hb = row_load<R16>(PD + dl.head_b, S, lane);
+      const int r = wave * 4 + (lane >> 4);
+      if (wave * 4 < hrows) {
+        const R16 u = row_load<R16>(bufB + r * ldS, S, lane);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { u_keep[e] = u.v[e]; hb_keep[e] = hb.v[e]; }
+        row_store(bufB + r * ldS, head_row(u, hb), S, lane);
+      }
+    });
     __syncthreads();
   }
   float* R = HYPER ? bufB : bufA;           // decoder outputs (rows 0-15: this pass [, rows 16-31: hyper_x])
@@ -486,12 +499,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     // (four rows per wave, one per 16-lane DPP row; the row's bias gradient goes to its own row of R: the head outputs are dead)
     epl16_dispatch(S, [&](auto tag) {
-      using R16 = RowT<16, decltype(tag)::value>;
-      const R16 hb = row_load<R16>(PD + dl.head_b, S, lane);
+      constexpr int EPL = decltype(tag)::value;
+      using R16 = RowT<16, EPL>;
       const int r = wave * 4 + (lane >> 4);
       if (wave * 4 < hrows) {
-        R16 du, db;
-        head_row_bwd(row_load<R16>(ws + gw.u + (prow0 + prow(r, B)) * S, S, lane), hb, row_load<R16>(dR + r * ldS, S, lane), du, db);
+        R16 du, db, u, hb;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { u.v[e] = u_keep[e]; hb.v[e] = hb_keep[e]; }
+        head_row_bwd(u, hb, row_load<R16>(dR + r * ldS, S, lane), du, db);
         row_store(dR + r * ldS, du, S, lane);
         row_store(ws + gw.du + (prow0 + prow(r, B)) * S, du, S, lane);       // the dW kernel's operand rows, straight from here
         // the wave's four bias-gradient rows are summed across its four 16-lane groups before they leave the registers: the

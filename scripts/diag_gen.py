@@ -32,7 +32,7 @@ for role, nm in ((0, "G"), (1, "R")):
     print("   sub: " + ", ".join(f"{k} {r[b] - r[a]}" for k, (a, b) in sub.items() if r[a] > 0 and r[b] > 0))
 
 # per-wave arrival at every mark, relative to wave 0's start: who is late for the barrier that follows
-order = [0, 14, 15, 12, 13, 1, 2, 16, 17, 18, 19, 27, 28, 29, 30, 31, 3, 20, 21, 22, 4, 5, 23, 24, 25, 26, 6, 7, 32, 33, 34, 35, 36, 8, 37, 38, 39, 9, 10, 11]
+order = [0, 14, 15, 12, 13, 1, 2, 16, 17, 18, 19, 27, 28, 40, 41, 42, 29, 30, 31, 3, 20, 21, 22, 4, 5, 23, 24, 25, 26, 6, 7, 32, 33, 34, 35, 36, 8, 37, 38, 39, 9, 10, 11]
 for role, nm in ((0, "G"), (1, "R")):
     print(f"role {nm}: mark: arrival of waves 0..7 (cycles since start), spread")
     base = tw[role, 0, 0]
