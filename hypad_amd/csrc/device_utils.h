@@ -6,6 +6,10 @@
 namespace hypad {
 
 constexpr int WAVE = 64;
+// The wave's index in its workgroup as a SCALAR: task / tile selection and weight base addresses derived from it stay on the
+// scalar unit (free next to the vector stream: every VALU instruction of the latency-chain kernels costs SIMD time the fp32
+// MFMAs cannot overlap, scripts/diag_coissue.py).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 constexpr float MIN_NORM = 1e-15f;          // math_.py:1134,1269,349
 constexpr float TANH_CLAMP = 15.0f;         // math_.py:53
 constexpr float ARTANH_EPS = 1e-7f;         // math_.py:58

@@ -50,7 +50,7 @@ __device__ __forceinline__ void tile_load(float* __restrict__ dst, int ld, const
 }
 __device__ __forceinline__ void tile_load_rows(float* __restrict__ dst, int ld, const float* __restrict__ base, int64_t gld,
                                                const int32_t* __restrict__ row_index, int row0, int rows, int cols, int valid) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nw = blockDim.x >> 6;
   // a gathered row is two dependent memory round trips (index, then row): a wave takes its rows two at a time so that
   // the round trips of the pair overlap
   for (int r = wave; r < rows; r += 2 * nw) {
@@ -126,7 +126,7 @@ __device__ __forceinline__ void lstm_cell_tile(const float* Gs, int ldg, int H, 
 // element-at-a-time loop paid one per element on a chain that runs this once per layer).
 __device__ __forceinline__ void lstm_cell_bwd_tile(const float* dHs, int ldh, const float* gates_saved, int H, int rows,
                                                    float* dGs, int ldg, int valid, int ps = 16) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nw = blockDim.x >> 6;
   constexpr int RB = 2, CB = 2;                         // rows x column steps per batch (16 rows on 8 waves, 2H <= 128: one batch)
   for (int r0 = wave; r0 < rows; r0 += RB * nw)
     for (int c0 = lane; c0 < 2 * H; c0 += CB * 64) {
@@ -355,7 +355,7 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
 // operands already in registers instead of an L2 round trip.
 struct LstmPre { float4 bi[4], bg[4], bo[4]; };
 __device__ __forceinline__ LstmPre lstm_layer_prefetch(const float* __restrict__ pk0, const float* __restrict__ pk1, int H, int K) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
   const int task = wave < 2 * nb ? wave : 0;
   const int d = task / nb, ub = task - d * nb;
@@ -370,6 +370,12 @@ __device__ __forceinline__ LstmPre lstm_layer_prefetch(const float* __restrict__
   }
   return p;
 }
+// development aid (scripts/diag_gen.py): per-wave marks 40-42 inside one layer (entry, products done, first task done)
+#if HYPAD_DIAG
+#define LSTAMP(k) do { if (xst && (threadIdx.x & 63) == 0) xst[(k) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSTAMP(k) do { (void)xst; } while (0)
+#endif
 template <int MT, bool PRE = false>
 __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ As, int lda, int K, const float* __restrict__ pk0,
                                                       const float* __restrict__ pb0, const float* __restrict__ pk1,
@@ -377,7 +383,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
                                                       float* __restrict__ gates_save, int valid, int ps = 16,
                                                       const LstmPre& pre = LstmPre{}, float* __restrict__ h_out = nullptr,
                                                       long long* xst = nullptr) {      // h_out: global mirror of Hs
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
   // one task = 16 units of one direction: the i, g, o gate tiles side by side, the cell in the epilogue
@@ -452,7 +458,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
       }
     }
     mfma_prio_end<PRE>();
-    if (xst && (threadIdx.x & 63) == 0) xst[41 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
+    LSTAMP(41);
     if (jj < H) {
       if constexpr (!PRE) { b_i = pb[jj]; b_g = pb[Hp + jj]; b_o = pb[2 * Hp + jj]; }      // (throughput callers: fewer live registers)
 #pragma unroll
@@ -471,9 +477,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
         }
     }
   };
-  if (xst && (threadIdx.x & 63) == 0) xst[40 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
+  LSTAMP(40);
   if (wave < 2 * nb) run(wave, std::integral_constant<bool, PRE>{});
-  if (xst && (threadIdx.x & 63) == 0) xst[42 * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime();
+  LSTAMP(42);
   for (int task = wave + nwaves; task < 2 * nb; task += nwaves) run(task, std::false_type{});
 }
 
@@ -560,7 +566,7 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
 // Four rows per wave, one per 16-lane DPP row (RowT<16, EPL>): the chain's per-row scalars cost one instruction for four
 // rows and its ~5 reductions are 4 DPP steps each.
 __device__ __forceinline__ void head_rows_tile(float* Us, int ld, int rows, int S, const float* bias_g) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6, sub = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nw = blockDim.x >> 6, sub = lane >> 4;
   epl16_dispatch(S, [&](auto tag) {
     using R = RowT<16, decltype(tag)::value>;
     const R b = row_load<R>(bias_g, S, lane);

@@ -166,7 +166,7 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
                         float* __restrict__ Ys, int ldy, int ycol0, float* __restrict__ wstage, int wave_rot = 0) {
   // wave_rot: tile t goes to wave (t + wave_rot) mod nwaves -- back-to-back calls without a barrier between them (the two
   // directions of an LSTM layer) rotate the deal so the same waves do not get the odd tile every time
-  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4;
   const uintptr_t wa = reinterpret_cast<uintptr_t>(W);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
 // B operands in registers instead of an L2 round trip (~2 k cycles on a chain that runs every product once).
 struct PackedPre { float4 w[8]; };
 __device__ __forceinline__ PackedPre gemm_nt_prefetch(const float* __restrict__ Wp, int K, int N, int wave_rot = 0) {
-  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
   const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)(wave < ntiles ? wave : 0) * kg * 64 + lane;
   PackedPre p;
@@ -222,7 +222,7 @@ struct ActIdentity { __device__ __forceinline__ float operator()(float v) const 
 template <int MT, bool PRE, class Epi>
 __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
                                                    const float* __restrict__ bsum, int wave_rot, const PackedPre& pre, Epi& epi) {
-  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = ((threadIdx.x >> 6) + nwaves - wave_rot % nwaves) % nwaves;
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
   auto run = [&](int t, auto first_from_pre) __attribute__((always_inline)) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int
 template <int MT>
 __device__ __forceinline__ void gemm_nn(const float* __restrict__ Ds, int ldd, int dcol0, const float* __restrict__ W, int ldw,
                         int Nred, RowMap map, int C, float* __restrict__ Ys, int ldy, bool accumulate) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nwaves = blockDim.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const bool vec = ((C | ldw) & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && Nred >= 64;
   if (vec) {

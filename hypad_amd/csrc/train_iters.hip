@@ -369,7 +369,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int64_t prow0 = (int64_t)pass * B + g0;          // its first operand row in the pass-major workspace arrays
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const int64_t BL = (int64_t)B * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id(), nw = blockDim.x >> 6;
   float sum_crit = 0.f, sum_aux = 0.f;
   constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
   GEN_STAMP(0);
@@ -741,7 +741,7 @@ template <class Table, int SC = 0, int LC = 0, int BC = 0, int KS = 48>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
   const int item = blockIdx.x * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   float* cw = smem + lp.cw; float* outv = smem + lp.small;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)(a.rows - r0 < 16 ? a.rows - r0 : 16);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   tile_load(xs, ldS, a.x + r0 * a.x_ld, a.x_ld, 16, S, valid);
   if (a.critic) {
     const CriticLayout clx = cx_layout(S, L);

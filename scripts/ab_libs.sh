@@ -11,7 +11,7 @@ if [ "$1" = "prepare" ]; then
 else
   for rep in 1 2 3; do
     for v in base new; do
-      echo -n "$v: "; HYPAD_LIB_PATH=$(pwd)/ab_libs/$v.so timeout 300 python scripts/time_graph.py 2>&1 | tail -1
+      echo -n "$v: "; HYPAD_LIB_PATH=$(pwd)/ab_libs/$v.so timeout 300 python scripts/${2:-time_graph.py} 2>&1 | tail -1
     done
   done
 fi
