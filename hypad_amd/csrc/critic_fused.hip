@@ -129,6 +129,10 @@ struct PhaseArgs {
   unsigned long long* gran_z;
   unsigned* flags;                             // (2 critics, n_signals, B/16) epoch counters: value k = "slab of iteration k - 1 is published"
   unsigned* err;                               // first word: set when a bounded wait gave up
+  // launch folding (persistent form): the precompute launch zeroes the [epoch words | error word | granules] block for the launch
+  // that follows it (it was a memset node + its dependency gaps: ~8 us per epoch), and that launch advances the step counters and
+  // the rng tick itself when it ends (it was a one-thread kernel: another ~8 us)
+  unsigned* zero_ptr; int zero_words; int advance;
 };
 // (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
 // neither the stamps nor their setter)
@@ -222,6 +226,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   const uint32_t tick = (uint32_t)ax.counters[3] + (uint32_t)it;
   const int g0 = tile * 16, nchunks = B / 16;
+  if (ph.zero_words) {                                // (see PhaseArgs: one word per thread, the first workgroups of the grid)
+    const int64_t flat = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * TB + threadIdx.x;
+    if (flat < ph.zero_words) ph.zero_ptr[flat] = 0u;
+  }
   if (tile == 0 && sig == 0 && threadIdx.x == 0) {   // Adam bias corrections of the step that launch it + 1 applies (train.py:274-281)
     const IterArgs& c = role == 0 ? ax : az;
     const AdamCoef co = adam_coef(c.lr, c.b1, c.b2, c.eps, 0.f, 0, 0, c.counters[c.opt] + it + 1);
@@ -1105,6 +1113,9 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     };
     if (fin) {
       if (!CHAIN) phase_b();
+      if (IS_X && ph.advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {      // step counters and rng tick: nobody reads
+        a.counters[0] += n_iters; a.counters[1] += n_iters; a.counters[3] += n_iters;           // them inside this launch
+      }
       if (writer) {                                                   // the phase's last state -> arenas
 #pragma unroll
         for (int u = 0; u < PS; ++u)
@@ -1623,12 +1634,18 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
       ph.inj_mk_z = adv(noise && az.drop_mode == 1 ? noise->masks_cz : nullptr, az.mask_sig_stride);
     }
     if (ev) (void)hipEventRecord(ev[0], s);
+    // epoch words, error word and granules: zero before EVERY resident launch -- by the precompute launch when its grid has a
+    // thread per word (always, at the shapes the resident form takes), by a memset node otherwise
+    const bool fold = persistent && sync_bytes / 4 <= (size_t)nchunks * n_signals * 2 * n * TB;
+    ph.zero_ptr = fold ? ph.flags : nullptr; ph.zero_words = fold ? (int)(sync_bytes / 4) : 0; ph.advance = persistent ? 1 : 0;
     hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
     HYPAD_CHECK_LAUNCH();
     if (ev) (void)hipEventRecord(ev[1], s);
     if (persistent) {
-      hipError_t e = hipMemsetAsync(ph.flags, 0, sync_bytes, s);     // epoch words and the error word: zero before EVERY launch
-      if (e != hipSuccess) return (int)e;
+      if (!fold) {
+        hipError_t e = hipMemsetAsync(ph.flags, 0, sync_bytes, s);
+        if (e != hipSuccess) return (int)e;
+      }
       if (ev) (void)hipEventRecord(ev[2], s);
       hipLaunchKernelGGL(kern, dim3(nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
@@ -1642,8 +1659,10 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
         if (ev && (it == 0 || it == n - 1)) (void)hipEventRecord(ev[it == 0 ? 2 : 3], s);
       }
     }
-    hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
-    HYPAD_CHECK_LAUNCH();
+    if (!persistent) {
+      hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
+      HYPAD_CHECK_LAUNCH();
+    }
   }
   return HYPAD_OK;
 }

@@ -9,9 +9,9 @@ if [ "$1" = "prepare" ]; then
   python -m hypad_amd.build > /dev/null && cp hypad_amd/lib/libhypad_hip.so ab_libs/new.so
   ls -la ab_libs
 else
-  for rep in 1 2 3; do
+  for rep in 1 2 3 4; do
     for v in base new; do
-      echo -n "$v: "; HYPAD_LIB_PATH=$(pwd)/ab_libs/$v.so timeout 300 python scripts/${2:-time_graph.py} 2>&1 | tail -1
+      echo -n "$v: "; HYPAD_LIB_PATH=$(pwd)/ab_libs/$v.so timeout 300 python scripts/${2:-time_graph.py} ${3:-} ${4:-} ${5:-} 2>&1 | tail -1
     done
   done
 fi
