@@ -64,6 +64,7 @@ def _build_locked(verbose, dev):
     objdir = os.path.join(LIB_DIR, "dev") if dev else LIB_DIR
     os.makedirs(objdir, exist_ok=True)
     flags = FLAGS + (["-DHYPAD_DIAG=1"] if dev else ["-DHYPAD_DIAG=0"])
+    flags += os.environ.get("HYPAD_FLAGS", "").split()      # (A/B experiments: scripts/ab_libs.sh)
     if dev:                                    # kernel experiments: extra -D switches for the development library only
         flags += os.environ.get("HYPAD_DEV_FLAGS", "").split()
     objs = []

@@ -37,6 +37,7 @@ namespace {
 
 constexpr int FT = 512;                      // threads of the critic iteration kernel (8 waves)
 constexpr int NW = FT / 64;
+typedef unsigned int u32x4_t __attribute__((vector_size(16)));
 static_assert(NW == CM_NW, "critic_mfma.h deals tiles over 8 waves");
 constexpr int MAXT = 5;                      // weight tiles per wave
 constexpr int MAX_ROW4 = 4, MAX_MASK4 = 3;   // float4 record loads per thread (rows / masks)
@@ -47,7 +48,8 @@ constexpr int XS = 3;                        // log2 of the blockIdx.x stretch t
 struct CritGeom {
   int in_dim, L, nh, params;
   int Kin, Lp, ldin, LQ, L4;
-  int rec_rows4, rec_mask4, rec_floats;      // record = [48][Kin] rows then [nh][48][L4] dropout scales
+  int rec_rows4, rec_mask4, rec_floats;      // record = [48][Kin] rows, [nh][48][L4] dropout scales, then a tail of 32 floats:
+                                             // Adam's {1 - beta1^t, sqrt(1 - beta2^t)} of the step the NEXT iteration's prologue applies, then zeros
   int tk0, tn, tkh, tiles0, tilesh, ntiles;
   int slab_floats;                           // [ntiles][2][256] accumulator images + 4 scalars
 };
@@ -57,7 +59,7 @@ HD CritGeom crit_geom(int in_dim, int L, int nh, int params) {
   g.Kin = up16(in_dim + 1); g.Lp = up16(L + 1);
   g.ldin = g.Kin + 4; g.LQ = g.Lp + 4; g.L4 = pad4(L);
   g.rec_rows4 = 12 * g.Kin; g.rec_mask4 = 12 * nh * g.L4;
-  g.rec_floats = 4 * (g.rec_rows4 + g.rec_mask4);
+  g.rec_floats = 4 * (g.rec_rows4 + g.rec_mask4) + 32;          // (a 128-byte tail: records stay cache-line aligned)
   g.tk0 = g.Kin >> 4; g.tn = (L + 15) >> 4; g.tkh = g.Lp >> 4;
   g.tiles0 = g.tn * g.tk0; g.tilesh = g.tn * g.tkh;
   g.ntiles = g.tiles0 + (nh - 1) * g.tilesh + g.tkh;
@@ -133,6 +135,10 @@ struct PhaseArgs {
   // that follows it (it was a memset node + its dependency gaps: ~8 us per epoch), and that launch advances the step counters and
   // the rng tick itself when it ends (it was a one-thread kernel: another ~8 us)
   unsigned* zero_ptr; int zero_words; int advance;
+  // records produced INSIDE the resident launch (blockIdx.z >= 2 of critic_persistent_kernel): one word per record, set (write-
+  // through, after the record's write-through stores have drained) by the workgroup that wrote it; null = the records come from
+  // the precompute launch in front
+  unsigned* rec_flags;                         // (2 critics, n_signals, n_iters, B/16)
 };
 // (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
 // neither the stamps nor their setter)
@@ -218,29 +224,48 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
   }
 }
 
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int sig = blockIdx.y, tile = blockIdx.x, S = ax.S, L = ax.L, B = ax.B;
-  const int it = blockIdx.z >> 1, role = blockIdx.z & 1;
+// One (iteration, critic, signal, 16-row tile) of the critic phase's critic-independent work -> its record.  FUSED: the workgroup
+// is a producer inside the resident launch -- the record is assembled in LDS, leaves as 16-byte write-through stores, and its
+// flag word follows once every storing wave has drained (cdna_hip_programming.md Guideline 16 R1: the consumer loads it sc1).
+template <bool FUSED>
+__device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterArgs& az, const PhaseArgs& ph, float* smem, int tile, int sig, int it,
+                                                int role, int n_signals) {
+  const int S = ax.S, L = ax.L, B = ax.B;
   const PreLds lp = pre_lds(S);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   const uint32_t tick = (uint32_t)ax.counters[3] + (uint32_t)it;
   const int g0 = tile * 16, nchunks = B / 16;
-  if (ph.zero_words) {                                // (see PhaseArgs: one word per thread, the first workgroups of the grid)
+  if (!FUSED && ph.zero_words) {                      // (see PhaseArgs: one word per thread, the first workgroups of the grid)
     const int64_t flat = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * TB + threadIdx.x;
     if (flat < ph.zero_words) ph.zero_ptr[flat] = 0u;
   }
-  if (tile == 0 && sig == 0 && threadIdx.x == 0) {   // Adam bias corrections of the step that launch it + 1 applies (train.py:274-281)
+  // Adam bias corrections of the step that iteration it + 1's prologue applies (train.py:274-281): into the record's tail (the
+  // resident launch reads them there) and, from one workgroup, into the table the per-iteration launches read
+  float bc1 = 0.f, bc2s = 0.f;
+  if (threadIdx.x == 0) {
     const IterArgs& c = role == 0 ? ax : az;
     const AdamCoef co = adam_coef(c.lr, c.b1, c.b2, c.eps, 0.f, 0, 0, c.counters[c.opt] + it + 1);
-    float* bc = ph.bias_corr + ((int64_t)role * (ph.n_iters + 1) + it + 1) * 2;
-    bc[0] = co.bc1; bc[1] = co.sqrt_bc2;
+    bc1 = co.bc1; bc2s = co.sqrt_bc2;
+    if (!FUSED && tile == 0 && sig == 0) {
+      float* bc = ph.bias_corr + ((int64_t)role * (ph.n_iters + 1) + it + 1) * 2;
+      bc[0] = co.bc1; bc[1] = co.sqrt_bc2;
+    }
   }
+  // where the record goes: straight to its place, or (FUSED) to an LDS image behind the layer buffers first
+  float* stage = smem + ((lp.total + 3) & ~3);
+  const CritGeom grec = role == 0 ? cx_geom(S, L) : cz_geom(L);
+  float* rec_g = (role == 0 ? ph.rec_x : ph.rec_z) + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * grec.rec_floats;
+  float* rec_w = FUSED ? stage : rec_g;
+  if (threadIdx.x == 0) {
+    float* tail = rec_w + 4 * (grec.rec_rows4 + grec.rec_mask4);
+    tail[0] = bc1; tail[1] = bc2s;
+  }
+  if (threadIdx.x >= 2 && threadIdx.x < 32) rec_w[4 * (grec.rec_rows4 + grec.rec_mask4) + threadIdx.x] = 0.f;
   tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ph.row_index ? ph.row_index + (int64_t)it * B : nullptr, g0, 16, S, 16);
   if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
     const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
     const float* PD = ax.P.dec + (int64_t)sig * ax.pd;
-    const int64_t isl = (int64_t)it * gridDim.y + sig;                 // (iteration, signal) slice of an injected plane
+    const int64_t isl = (int64_t)it * n_signals + sig;                 // (iteration, signal) slice of an injected plane
     const float* zin = ph.inj_z_x ? ph.inj_z_x + (isl * B + g0) * L : nullptr;
     tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(ax.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
@@ -259,12 +284,11 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       gen = bufB;
     }
     const CritGeom g = cx_geom(S, L);
-    emit_record<true>(ax, g, ph.rec_x + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, xs, lp.ldS, gen, lp.ldS, sig, g0,
-                      tick, 0.25f, ph.inj_al_x ? ph.inj_al_x + isl * B * S : nullptr, mk);
+    emit_record<true>(ax, g, rec_w, xs, lp.ldS, gen, lp.ldS, sig, g0, tick, 0.25f, ph.inj_al_x ? ph.inj_al_x + isl * B * S : nullptr, mk);
   } else {                  // critic_z side: z_ = encoder(x), z ~ N(0, 1)  (train.py:111-116)
     const EncLayout el = enc_layout(S, L);
     const float* PE = az.P.enc + (int64_t)sig * az.pe;
-    const int64_t isl = (int64_t)it * gridDim.y + sig;
+    const int64_t isl = (int64_t)it * n_signals + sig;
     const float* zin = ph.inj_z_z ? ph.inj_z_z + (isl * B + g0) * L : nullptr;
     tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
@@ -273,9 +297,26 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
     __syncthreads();
     const CritGeom g = cz_geom(L);
-    emit_record<false>(az, g, ph.rec_z + (((int64_t)sig * ph.n_iters + it) * nchunks + tile) * g.rec_floats, zs, LP, zenc, LP, sig, g0, tick,
-                       0.2f, ph.inj_al_z ? ph.inj_al_z + isl * B * L : nullptr, ph.inj_mk_z ? ph.inj_mk_z + isl * az.mask_sig_stride : nullptr);
+    emit_record<false>(az, g, rec_w, zs, LP, zenc, LP, sig, g0, tick, 0.2f, ph.inj_al_z ? ph.inj_al_z + isl * B * L : nullptr,
+                       ph.inj_mk_z ? ph.inj_mk_z + isl * az.mask_sig_stride : nullptr);
   }
+  if constexpr (FUSED) {
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rec_g, 0, 0x7fffffff, 0x00020000);
+    for (int i = threadIdx.x; i < grec.rec_floats / 4; i += TB) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + 4 * i);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, i * 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
+    __syncthreads();                                      // ... before ONE lane signals for all of them
+    if (threadIdx.x == 0)
+      __hip_atomic_store(ph.rec_flags + ((((int64_t)role * n_signals + sig) * ph.n_iters + it) * nchunks + tile), 1u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  precompute_body<false>(ax, az, ph, smem, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, gridDim.y);
 }
 
 // ---------------------------------------------------------------------------------------------- iteration kernel
@@ -867,7 +908,6 @@ constexpr unsigned SPIN_LIMIT = 1u << 21;    // bounded waits: ~1 s of polling
 // the 16-byte payload type of the raw-buffer builtins.  hipcc (ROCm 7.2) pitfall: indexing a result of
 // __builtin_amdgcn_raw_buffer_load_b128 element by element (v[1], v[2] ...) is narrowed to ONE buffer_load_dword whose value
 // stands for all four elements; bit-cast the whole vector to f32x4 first (and build stores the same way round).
-typedef unsigned int u32x4_t __attribute__((vector_size(16)));
 
 HD bool persist_geom_supported(const CritGeom& g, int nchunks) {
   const int Q = (g.L + 3) >> 2;
@@ -990,26 +1030,51 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (the first iteration writes d loss / d out into the cleared tiles)
 
   // record of iteration `it` in registers (requested one hand-off ahead)
-  float4 rrow[MAX_ROW4], rmask[MAX_MASK4];
-  auto request_record = [&](int it) __attribute__((always_inline)) {
-    const float* rec = (IS_X ? ph.rec_x : ph.rec_z) + (((int64_t)sig * n_iters + it) * nchunks + chunk) * g.rec_floats;
-#pragma unroll
-    for (int u = 0; u < MAX_ROW4; ++u) {
-      const int i = threadIdx.x + u * FT;
-      rrow[u] = i < g.rec_rows4 ? reinterpret_cast<const float4*>(rec)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < MAX_MASK4; ++u) {
-      const int i = threadIdx.x + u * FT;
-      rmask[u] = i < g.rec_mask4 ? reinterpret_cast<const float4*>(rec + 4 * g.rec_rows4)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  if (n_iters > 0) request_record(0);
   int* ctl = reinterpret_cast<int*>(xsc) + 3 * MAXCH;
   auto give_up = [&](unsigned code) __attribute__((always_inline)) {   // called by one lane: tell the workgroup and the siblings
     __hip_atomic_store(ph.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ctl[0] = 1;
   };
+  // Records come from the precompute launch in front of this one, or (ph.rec_flags) from producer workgroups of THIS launch
+  // (blockIdx.z >= 2): then one wave waits for the record's flag word -- the producers run far ahead of the critics: a poll
+  // that finds it set costs one memory round trip on a wave with slack -- and the workgroup loads behind a barrier that wave
+  // joins.  Every record load is a 16-byte sc1 buffer load either way (Guideline 16 R1).
+  auto await_record = [&](int it) __attribute__((always_inline)) {     // one wave calls it; a workgroup barrier follows
+    if (!ph.rec_flags) return;
+    const unsigned* f = ph.rec_flags + ((((int64_t)(IS_X ? 0 : 1) * gridDim.y + sig) * n_iters + it) * nchunks + chunk);
+    bool ok = false;
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+      ok = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      if (ok) break;
+      if ((spins & 1023) == 1023 && __hip_atomic_load(ph.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok && lane == 0) give_up(0x300u + (unsigned)it);
+  };
+  // (record registers stay in the load's own type: the LDS image is written from them as they are.  Lanes past the record's
+  // rows / scales point outside the descriptor's range -- 1 GB: run_critic_phase keeps the records below it -- and get zeros
+  // without a memory access.)
+  u32x4_t rrow[MAX_ROW4], rmask[MAX_MASK4];
+  const __amdgpu_buffer_rsrc_t rrs1 = __builtin_amdgcn_make_buffer_rsrc(IS_X ? ph.rec_x : ph.rec_z, 0, 0x40000000, 0x00020000);
+  auto request_record = [&](int it) __attribute__((always_inline)) {
+    const int rec_off = (int)(((((int64_t)sig * n_iters + it) * nchunks + chunk) * g.rec_floats) * 4);       // bytes (< 2^31: run_critic_phase)
+#pragma unroll
+    for (int u = 0; u < MAX_ROW4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rrow[u] = __builtin_amdgcn_raw_buffer_load_b128(rrs1, i < g.rec_rows4 ? i * 16 : 0x7ffffff0, rec_off, 16);
+    }
+#pragma unroll
+    for (int u = 0; u < MAX_MASK4; ++u) {
+      const int i = threadIdx.x + u * FT;
+      rmask[u] = __builtin_amdgcn_raw_buffer_load_b128(rrs1, i < g.rec_mask4 ? (g.rec_rows4 + i) * 16 : 0x7ffffff0, rec_off, 16);
+    }
+  };
+  if (n_iters > 0) {
+    if (wave == 0) await_record(0);
+    __syncthreads();
+    if (ctl[0]) { if (writer && threadIdx.x == 0) lo_base[0] = __builtin_nanf(""); return; }
+    request_record(0);
+  }
 
   const int j_ = j, q_ = q, lane_ = lane;
   // Wave specialisation: the loop is instantiated twice -- for the three chain waves (which carry the register-resident
@@ -1056,9 +1121,12 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
           if (u >= NA) continue;                                         // (compile-time for the reference shapes: NA is)
           x0[u][w] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (obase + (w < nchunks ? w : 0) * slabf + (i_e[u] < 0 ? 0 : i_e[u]) * 4) * 4, 0, 16);
         }
-      // Adam's bias corrections of this step (written by the precompute launch)
-      const float* bc = ph.bias_corr + ((int64_t)(IS_X ? 0 : 1) * (n_iters + 1) + it) * 2;
-      co.bc1 = bc[0]; co.sqrt_bc2 = bc[1];
+      // Adam's bias corrections of this step: the tail of the previous iteration's record (whose flag this workgroup has seen:
+      // sc1 loads, requested with the shares above)
+      const int prev_off = (int)(((((int64_t)sig * n_iters + (it - 1)) * nchunks + chunk) * g.rec_floats) * 4);
+      const int tv = 16 * (g.rec_rows4 + g.rec_mask4);
+      co.bc1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs1, tv, prev_off, 16));
+      co.sqrt_bc2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs1, tv + 4, prev_off, 16));
     }
     // ---- Adam on this thread's quads, weight images in LDS.  Phase A (layer 0, every thread) first: the chains need nothing else
     // to start; phase B (the other layers, waves 3-7) runs beside the chains' first layer.
@@ -1132,12 +1200,12 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
 #pragma unroll
     for (int u = 0; u < MAX_ROW4; ++u) {
       const int i = threadIdx.x + u * FT;
-      if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<float4*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
+      if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<u32x4_t*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
     }
 #pragma unroll
     for (int u = 0; u < MAX_MASK4; ++u) {
       const int i = threadIdx.x + u * FT;
-      if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<float4*>(dm + r * LQ + 4 * c4) = rmask[u]; }
+      if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<u32x4_t*>(dm + r * LQ + 4 * c4) = rmask[u]; }
     }
     if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
     int* bdone = reinterpret_cast<int*>(red + 40);
@@ -1307,6 +1375,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         }
       }
     }
+    if (!CHAIN && wave == BW0 + 1 && it + 1 < n_iters) await_record(it + 1);     // (a helper wave with ~6 k idle cycles here: the chains run)
     PSTAMP(8);                                                           // (helpers: Gram done)
     __syncthreads();
     PSTAMP(9);
@@ -1489,6 +1558,10 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
 template <int SC, int LC, int BC>
 __global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (blockIdx.z >= 2) {            // producer workgroups (ph.rec_flags): the records, in iteration order behind the resident critics
+    precompute_body<true>(ax, az, ph, smem, blockIdx.x, blockIdx.y, (blockIdx.z - 2) >> 1, (blockIdx.z - 2) & 1, gridDim.y);
+    return;
+  }
   if (blockIdx.z == 0) critic_persistent_body<true, SC, LC, BC>(ax, ph, smem); else critic_persistent_body<false, SC, LC, BC>(az, ph, smem);
 }
 
@@ -1548,17 +1621,53 @@ bool critic_phase_persistent(const hypad_dims& d) {
   return (long long)nchunks * d.n_signals * 2 <= device_cus();       // all resident, one workgroup per CU
 }
 
+// How a phase of n_iters iterations runs in `extra`: iterations per slice, and whether the resident launch carries its own record
+// producers (no precompute launch in front; HYPAD_CRITIC_PRODUCERS=0 turns it off: A/B timing and the equality test)
+struct PhasePlan { bool ok, persistent, fused; int cap; size_t fixed, per_iter; };
+static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iters) {
+  PhasePlan p{};
+  p.fixed = critic_phase_fixed_floats(d); p.per_iter = critic_phase_floats_per_iter(d);
+  if (!critic_phase_supported(d) || extra_floats < p.fixed + p.per_iter) return p;
+  p.ok = true;
+  p.cap = (int)((extra_floats - p.fixed) / p.per_iter);
+  if (p.cap > n_iters) p.cap = n_iters;
+  const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
+  p.persistent = critic_phase_persistent(d);
+  const char* prod = getenv("HYPAD_CRITIC_PRODUCERS");
+  p.fused = p.persistent && !(prod && prod[0] == '0') &&
+            (size_t)d.n_signals * n_iters * (d.batch / 16) * (size_t)(gx.rec_floats > gz.rec_floats ? gx.rec_floats : gz.rec_floats) * 4 < ((size_t)1 << 30);
+  return p;
+}
+// [epoch words | error word | granules | record flags]: ONE block at the (16-byte aligned) start of `extra`, zero before every
+// resident launch (a word left by an earlier launch looks valid: Guideline 16, "re-initialise every call")
+static size_t sync_block_bytes(const hypad_dims& d, const PhasePlan& p) {
+  const size_t nchunks = d.batch / 16, ns = d.n_signals;
+  const size_t flag_bytes = ((2 * ns * nchunks + 4) * sizeof(unsigned) + 15) & ~(size_t)15;
+  size_t b = flag_bytes + 2 * ns * 2 * nchunks * 4 * sizeof(unsigned long long);
+  if (p.fused) b += ((2 * ns * p.cap * nchunks) * sizeof(unsigned) + 15) & ~(size_t)15;
+  return b;
+}
+// What hypad_train_epoch's first launch (the weight pack) can zero for the phase: the first slice's block, or nothing
+void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words) {
+  *ptr = nullptr; *words = 0;
+  const PhasePlan p = plan_phase(d, extra_floats, n_iters);
+  if (!p.ok || !p.persistent) return;
+  *ptr = (unsigned*)(((uintptr_t)extra + 15) & ~(uintptr_t)15);
+  *words = (int)(sync_block_bytes(d, p) / 4);
+}
+
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
-                     int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used) {
+                     int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
+                     const unsigned* zeroed) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
-  const size_t fixed = critic_phase_fixed_floats(d), per_iter = critic_phase_floats_per_iter(d);
-  if (extra_floats < fixed + per_iter) return HYPAD_EWORKSPACE;
-  int cap = (int)((extra_floats - fixed) / per_iter);
-  if (cap > n_iters) cap = n_iters;
+  const PhasePlan plan = plan_phase(d, extra_floats, n_iters);
+  if (!plan.ok) return HYPAD_EWORKSPACE;
+  const size_t fixed = plan.fixed;
+  const int cap = plan.cap;
   const CritGeom gx = cx_geom(ax.S, ax.L), gz = cz_geom(ax.L);
   const int nchunks = ax.B / 16;
-  const bool persistent = critic_phase_persistent(d);
+  const bool persistent = plan.persistent, fused = plan.fused;
   if (persistent_used) *persistent_used = persistent ? 1 : 0;
   // the generator-side randomness (z, decoder dropout) keeps the critic_x seed; critic_z draws from its own
   az.seed = ax.seed ^ CRITIC_Z_SEED_XOR;
@@ -1569,7 +1678,11 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   }
   const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
   // (persistent form: the same -- full -- LDS request for both critics keeps it at one workgroup per CU)
-  const size_t lds = (size_t)((lx > lz ? lx : lz) + (persistent ? 3 * MAXCH + 4 : 0)) * sizeof(float);
+  size_t lds = (size_t)((lx > lz ? lx : lz) + (persistent ? 3 * MAXCH + 4 : 0)) * sizeof(float);
+  if (fused) {                                            // producer workgroups: layer buffers + the record's LDS image
+    const size_t need = (size_t)(pre_lds(ax.S).total + 4 + (gx.rec_floats > gz.rec_floats ? gx.rec_floats : gz.rec_floats)) * sizeof(float);
+    if (need > lds) lds = need;
+  }
   // compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
   using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
   const bool s100 = ax.S == 100 && ax.L == 20 && ax.B == 64, s150 = ax.S == 150 && ax.L == 20 && ax.B == 256;
@@ -1595,8 +1708,10 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     ph.err = ph.flags + nflags;
     ph.gran_x = (unsigned long long*)(up + flag_bytes);
     ph.gran_z = ph.gran_x + (size_t)n_signals * 2 * nchunks * 4;
-    sync_bytes = flag_bytes + (size_t)2 * n_signals * 2 * nchunks * 4 * sizeof(unsigned long long);
-    ph.xslab_x = (float*)(ph.gran_z + (size_t)n_signals * 2 * nchunks * 4);
+    sync_bytes = sync_block_bytes(d, plan);
+    unsigned* after_gran = (unsigned*)(ph.gran_z + (size_t)n_signals * 2 * nchunks * 4);
+    if (fused) { ph.rec_flags = after_gran; after_gran = (unsigned*)((char*)up + sync_bytes); }
+    ph.xslab_x = (float*)after_gran;
     ph.xslab_z = ph.xslab_x + (size_t)n_signals * 2 * nchunks * persist_items(gx) * 4;
     if ((size_t)((ph.xslab_z + (size_t)n_signals * 2 * nchunks * persist_items(gz) * 4) - extra) > fixed) return HYPAD_EWORKSPACE;
     p = extra + fixed - 8;
@@ -1634,20 +1749,22 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
       ph.inj_mk_z = adv(noise && az.drop_mode == 1 ? noise->masks_cz : nullptr, az.mask_sig_stride);
     }
     if (ev) (void)hipEventRecord(ev[0], s);
-    // epoch words, error word and granules: zero before EVERY resident launch -- by the precompute launch when its grid has a
-    // thread per word (always, at the shapes the resident form takes), by a memset node otherwise
-    const bool fold = persistent && sync_bytes / 4 <= (size_t)nchunks * n_signals * 2 * n * TB;
+    // epoch words, error word, granules (and record flags): zero before EVERY resident launch -- by the precompute launch when
+    // there is one and its grid has a thread per word, by a memset node otherwise
+    const bool fold = persistent && !fused && sync_bytes / 4 <= (size_t)nchunks * n_signals * 2 * n * TB;
     ph.zero_ptr = fold ? ph.flags : nullptr; ph.zero_words = fold ? (int)(sync_bytes / 4) : 0; ph.advance = persistent ? 1 : 0;
-    hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
-    HYPAD_CHECK_LAUNCH();
+    if (!fused) {
+      hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
+      HYPAD_CHECK_LAUNCH();
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (persistent) {
-      if (!fold) {
+      if (!fold && !(it0 == 0 && zeroed == ph.flags)) {   // (the first slice's block may come zeroed from the caller's previous launch)
         hipError_t e = hipMemsetAsync(ph.flags, 0, sync_bytes, s);
         if (e != hipSuccess) return (int)e;
       }
       if (ev) (void)hipEventRecord(ev[2], s);
-      hipLaunchKernelGGL(kern, dim3(nchunks, n_signals, 2), dim3(FT), lds, s, ax, az, ph);
+      hipLaunchKernelGGL(kern, dim3(nchunks, n_signals, fused ? 2 + 2 * n : 2), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
       if (ev) (void)hipEventRecord(ev[3], s);
     } else {

@@ -1103,7 +1103,11 @@ struct PackDesc {
   int src0, src1, ld, H;
 };
 struct PackTable { int n; int max_units; PackDesc d[32]; };
-__global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab) {
+__global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab, unsigned* zero_ptr, int zero_words) {
+  if (zero_words) {                            // (launch_pack: one word per thread of the grid)
+    const int64_t flat = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (flat < zero_words) zero_ptr[flat] = 0u;
+  }
   const PackDesc d = tab.d[blockIdx.y];
   const int sig = blockIdx.z;
   const float* P = d.net == HYPAD_NET_ENCODER ? a.P.enc + (int64_t)sig * a.pe : a.P.dec + (int64_t)sig * a.pd;
@@ -1183,9 +1187,13 @@ PackTable pack_table(const hypad_dims& dm) {
   push(2, D, gp.d1_t, L, DEC_D1, dl.d1_w, -1, L, 0);
   return t;
 }
-int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s) {
+// zero_ptr / zero_words: a block the next launches need zeroed (the critic phase's epoch words and flags), one word per thread
+int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned* zero_ptr = nullptr, int zero_words = 0, bool* zeroed = nullptr) {
   const PackTable t = pack_table(dm);
-  hipLaunchKernelGGL(pack_generator_kernel, dim3((t.max_units + 255) / 256, t.n, dm.n_signals), dim3(256), 0, s, a, t);
+  const dim3 grid((t.max_units + 255) / 256, t.n, dm.n_signals);
+  const bool z = zero_ptr && zero_words > 0 && (int64_t)zero_words <= (int64_t)grid.x * grid.y * grid.z * 256;
+  if (zeroed) *zeroed = z;
+  hipLaunchKernelGGL(pack_generator_kernel, grid, dim3(256), 0, s, a, t, z ? zero_ptr : nullptr, z ? zero_words : 0);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -1658,16 +1666,20 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   const size_t have = io->workspace_bytes / sizeof(float);
   const int64_t B = d->batch, L = d->latent_dim, S = d->signal_shape, ns = d->n_signals;
   const int64_t mk_cx = 12 * B * L + B * 2 * DEC_H, mk_cz = 6 * B * L, mk_gen = 6 * B * L + 2 * B * 2 * DEC_H;   // hypad_iter_io.drop layouts
+  const char* legacy = getenv("HYPAD_EPOCH_LEGACY");
+  const bool hoisted = io->n_critics > 0 && critic_phase_supported(*d) &&
+                       have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
+  unsigned* zero_ptr = nullptr;                        // the resident critic launch's epoch words / flags: zeroed by the pack launch
+  int zero_words = 0;
+  bool zeroed = false;
+  if (hoisted) critic_phase_zero_block(*d, (float*)io->workspace + base, have - base, io->n_critics * io->n_batches, &zero_ptr, &zero_words);
   {                                                    // packed generator weights: built once, then kept current by the dW kernel
     IterArgs ag;
     c.row_index = io->row_index; c.losses = io->losses;
     rc = fill_args(ag, d, st, c, 2);
-    if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s);
+    if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s, zero_ptr, zero_words, &zeroed);
     if (rc) return rc;
   }
-  const char* legacy = getenv("HYPAD_EPOCH_LEGACY");
-  const bool hoisted = io->n_critics > 0 && critic_phase_supported(*d) &&
-                       have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
   if (hoisted) {                                       // train.py:315-328, generator forwards hoisted (critic_fused.hip)
     IterArgs ax, az;
     c.row_index = io->row_index; c.losses = io->losses;
@@ -1679,7 +1691,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
     if (rc) return rc;
     const int n = io->n_critics * io->n_batches;
     rc = run_critic_phase(ax, az, io->row_index, n, io->losses, (float*)io->workspace + base, have - base, d->n_signals,
-                          (hipStream_t)s, nullptr, nz);
+                          (hipStream_t)s, nullptr, nz, nullptr, zeroed ? zero_ptr : nullptr);
     if (rc) return rc;
     it = 2 * n;
   } else {

@@ -264,7 +264,10 @@ int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const
  * n_critics * n_batches <= 512 iterations): records of critic `critic` (0 = critic_x, 1 = critic_z) start `offset_floats` floats
  * into the workspace and are indexed (signal, iteration, batch / 16 chunks); one record is `record_floats` floats:
  * [48][row_stride] input rows (16 real | 16 fake | 16 interpolated; the input, a constant-one column, zero padding) followed,
- * at `mask_offset_floats`, by the dropout keep-scales [n_layers][48][mask_row_stride] (pass order real, fake, interpolated). */
+ * at `mask_offset_floats`, by the dropout keep-scales [n_layers][48][mask_row_stride] (pass order real, fake, interpolated) and
+ * a tail of 32 floats (Adam's bias corrections of the step the next iteration applies, then zeros: records stay 128-byte
+ * aligned).  With the resident form of the phase the records are written by producer workgroups of that launch itself
+ * (HYPAD_CRITIC_PRODUCERS=0 in the environment: by a launch in front of it) -- same layout, same bits. */
 typedef struct hypad_record_info {
   int64_t offset_floats;
   int record_floats, row_stride, mask_offset_floats, mask_row_stride, n_layers, in_dim;

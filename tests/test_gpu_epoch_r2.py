@@ -228,7 +228,8 @@ def test_device_random_streams(dev):
             rows = rec_z[sig, it, :, : 48 * iz.row_stride].reshape(B // 16, 48, iz.row_stride)[:, :16, :L].reshape(B, L)
             assert torch.equal(rows, want), (sig, it)
             for rec, info, p, seed in ((rec_x, ix, 0.25, eng.seed), (rec_z, iz, 0.2, zseed)):
-                m = rec[sig, it, :, info.mask_offset_floats:].reshape(B // 16, info.n_layers, 3, 16, info.mask_row_stride)[..., :L]
+                mend = info.mask_offset_floats + info.n_layers * 48 * info.mask_row_stride          # (a 32-float tail follows the scales)
+                m = rec[sig, it, :, info.mask_offset_floats: mend].reshape(B // 16, info.n_layers, 3, 16, info.mask_row_stride)[..., :L]
                 for layer in range(info.n_layers):
                     for p_rec in range(3):                 # record pass order: real, fake, interpolated
                         pass_id = p_rec if (rec is rec_x or p_rec == 2) else 1 - p_rec
@@ -369,3 +370,34 @@ def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
         assert torch.equal(o[0], outs[0][0]) and o[2] == outs[0][2]
         for k in ("cx", "cz", "enc", "dec"):
             assert torch.equal(o[1][k], outs[0][1][k]), k
+
+
+def test_records_from_producer_workgroups_equal_the_precompute_launch(dev, monkeypatch):
+    """The resident critic launch carries its own record producers (blockIdx.z >= 2: no precompute launch in front, records handed
+    over through write-through stores and a flag word each).  Same records, same epoch: every loss, every weight and the record
+    area itself are bit-identical to the form with the precompute launch (HYPAD_CRITIC_PRODUCERS=0) -- one and eight signals."""
+    fx = load("iters_hyper_S100.npz")
+    from hypad_amd.engine import Engine
+    for ns in (1, 8):
+        xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100).repeat(ns, 1, 1).contiguous()
+        nb, nc = 4, 3
+        perm = torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+        outs = []
+        for producers in ("1", "0"):
+            monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", producers)
+            e = Engine(100, 20, 64, True, n_signals=ns, lr=5e-4, seed=11)
+            for net in ("enc", "dec", "cx", "cz"):
+                for sgn in range(ns):
+                    e.load_state_dict(net, sub_state(fx, net, "w0"), sgn)
+                e.params[net][ns - 1].mul_(1.01)
+            assert e.critic_phase_persistent()
+            l = e.train_epoch(xs, perm, nb, nc, True)
+            torch.cuda.synchronize()
+            recs = [e.epoch_records(nb, nc, c)[0].clone() for c in (0, 1)]
+            outs.append((l.clone(), {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}, recs))
+        assert torch.isfinite(outs[0][0]).all()
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k in ("cx", "cz", "enc", "dec"):
+            assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+        for c in (0, 1):
+            assert torch.equal(outs[0][2][c], outs[1][2][c]), c
