@@ -401,17 +401,22 @@ def main():
     kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_first_or_reinit"}
     n_it = N_CRITICS * N_BATCHES
     # launches per epoch and milliseconds per launch of each kernel
+    producers = persistent and eng.critic_phase_producers(n_it)      # the resident launch writes its own records: no precompute launch
     if persistent:
-        per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
-                      "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
-        launches = {"critic_persistent_kernel": 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+        per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
+        launches = {"critic_persistent_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+        if not producers:
+            per_launch["critic_phase_precompute_kernel"] = kern_ms["critic_precompute"]
+            launches["critic_phase_precompute_kernel"] = 1
     else:
         per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
                       "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
         launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
     share = {k: per_launch[k] * launches[k] for k in per_launch}
     dom = max(share, key=share.get)
-    mac = {"critic_persistent_kernel": MAC_PER_WINDOW["critic_iteration"] * n_it, "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
+    # (with producers the resident launch also does the precompute's work: both parts are its algorithmic FLOPs)
+    mac = {"critic_persistent_kernel": (MAC_PER_WINDOW["critic_iteration"] + (MAC_PER_WINDOW["critic_precompute"] if producers else 0)) * n_it,
+           "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
            "critic_phase_precompute_kernel": MAC_PER_WINDOW["critic_precompute"] * n_it, "gen_kernel": MAC_PER_WINDOW["gen"],
            "dw_adam_kernel": MAC_PER_WINDOW["dw_gen"]}
     flop = 2.0 * mac[dom] * B * spg                      # algorithmic FLOPs of ONE launch of the dominant kernel
@@ -474,14 +479,18 @@ def main():
                                     "(5 critic_x + 5 critic_z + 1 decoder) iterations") % (hyperbolic, spg),
                        "signals_per_gpu": spg, "iterations_per_step": (2 * N_CRITICS + 1) * N_BATCHES,
                        "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed,
-                       "critic_phase": "one resident launch per epoch (critic_persistent_kernel)" if persistent else "one launch per iteration",
+                       "critic_phase": ("one resident launch per epoch (critic_persistent_kernel)" + (", records produced by that launch's own "
+                                        "producer workgroups" if producers else " behind a precompute launch")) if persistent else "one launch per iteration",
                        "launch": "eager" if args.no_graph else "hipGraph replay of the captured epoch", "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
                          "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
                          "us_per_critic_iteration": 1e3 * kern_ms["critic_iteration"],
-                         "kernel_ms": per_launch, "epoch_share_ms": share, "flop_per_launch": flop},
+                         "kernel_ms": per_launch, "epoch_share_ms": share, "flop_per_launch": flop,
+                         "flop_per_launch_parts": ({"critic_iterations": 2.0 * MAC_PER_WINDOW["critic_iteration"] * n_it * B * spg,
+                                                    "record_producers": 2.0 * (MAC_PER_WINDOW["critic_precompute"] if producers else 0) * n_it * B * spg}
+                                                   if dom == "critic_persistent_kernel" else None)},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
         if secondary is not None:

@@ -123,6 +123,7 @@ _SIGS = {
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
     "hypad_critic_phase_persistent": (c_int, [POINTER(Dims)]),
+    "hypad_critic_phase_producers": (c_int, [POINTER(Dims), c_int]),
     "hypad_epoch_record_info": (c_int, [POINTER(Dims), c_int, c_int, c_int, POINTER(RecordInfo)]),
     "hypad_rng_fill": (c_int, [c_int, c_uint64, c_uint32, c_uint32, c_uint32, c_float, P, c_int64, P]),
     "hypad_critic_z_seed": (c_uint64, [c_uint64]),

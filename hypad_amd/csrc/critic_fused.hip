@@ -1634,9 +1634,18 @@ static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iter
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
   p.persistent = critic_phase_persistent(d);
   const char* prod = getenv("HYPAD_CRITIC_PRODUCERS");
-  p.fused = p.persistent && !(prod && prod[0] == '0') &&
+  // Producers share the chip with the resident critics, one workgroup per CU either way: they must find free CUs (every CU taken
+  // by a critic that waits for its record would be a deadlock -- the bounded polls would end it with an error) and enough of
+  // them to keep up: the critics may hold half of the CUs at most (measured: 12 signals 4.67 -> 3.94 ms per epoch, 16 signals --
+  // half the chip -- 5.02 -> 4.95; beyond that the precompute launch in front is the better form).
+  const long long critics = (long long)(d.batch / 16) * d.n_signals * 2;
+  p.fused = p.persistent && !(prod && prod[0] == '0') && 2 * critics <= device_cus() &&
             (size_t)d.n_signals * n_iters * (d.batch / 16) * (size_t)(gx.rec_floats > gz.rec_floats ? gx.rec_floats : gz.rec_floats) * 4 < ((size_t)1 << 30);
   return p;
+}
+bool critic_phase_producers(const hypad_dims& d, int n_iters) {
+  if (!critic_phase_supported(d) || n_iters <= 0) return false;
+  return plan_phase(d, critic_phase_fixed_floats(d) + (size_t)n_iters * critic_phase_floats_per_iter(d), n_iters).fused;
 }
 // [epoch words | error word | granules | record flags]: ONE block at the (16-byte aligned) start of `extra`, zero before every
 // resident launch (a word left by an earlier launch looks valid: Guideline 16, "re-initialise every call")

@@ -220,6 +220,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
                      const unsigned* zeroed = nullptr);
 // the block the resident form needs zero in front of its first launch (null: none) -- the caller's previous launch may zero it
 void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words);
+bool critic_phase_producers(const hypad_dims& d, int n_iters);      // ... and that launch produces the records itself
 bool critic_phase_persistent(const hypad_dims& d);         // the phase runs as ONE resident launch (critic_persistent_kernel)
 int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad_record_info* out);
 

@@ -1733,6 +1733,11 @@ int hypad_critic_phase_persistent(const hypad_dims* d) {
   return critic_phase_persistent(*d) ? 1 : 0;
 }
 
+int hypad_critic_phase_producers(const hypad_dims* d, int n_iters) {
+  if (check_dims(d)) return 0;
+  return critic_phase_producers(*d, n_iters) ? 1 : 0;
+}
+
 int hypad_epoch_record_info(const hypad_dims* d, int n_batches, int n_critics, int critic, hypad_record_info* out) {
   if (check_dims(d) || n_batches <= 0 || n_critics <= 0 || !out) return HYPAD_EINVAL;
   const int64_t n = (int64_t)n_batches * n_critics;

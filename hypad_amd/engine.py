@@ -119,6 +119,10 @@ class Engine:
         """True when train_epoch runs the critic phase as one resident launch (hypad_critic_phase_persistent)."""
         return bool(_C.lib.hypad_critic_phase_persistent(ctypes.byref(self.dims)))
 
+    def critic_phase_producers(self, n_iters):
+        """True when that resident launch also produces the phase's records itself (hypad_critic_phase_producers)."""
+        return bool(_C.lib.hypad_critic_phase_producers(ctypes.byref(self.dims), int(n_iters)))
+
     def rng_fill(self, kind, n, tick, stream, signal=0, p_drop=0.0, seed=None):
         """n draws of one device random stream (hypad_rng_fill): kind 0 N(0,1), 1 U[0,1), 2 dropout keep-scale."""
         out = torch.empty(int(n), dtype=torch.float32, device=self.device)
