@@ -9,7 +9,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary"   # (one signal per GPU only: every launch of a kernel is a like launch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/bench_write.json 2> $OUT/bench_write.err
