@@ -401,3 +401,48 @@ def test_records_from_producer_workgroups_equal_the_precompute_launch(dev, monke
             assert torch.equal(outs[0][1][k], outs[1][1][k]), k
         for c in (0, 1):
             assert torch.equal(outs[0][2][c], outs[1][2][c]), c
+
+
+def test_hand_offs_hold_under_uneven_load(dev, monkeypatch):
+    """The resident critic launch's hand-offs (gradient shares, scalar granules, records from its producer workgroups) with the
+    rest of the chip busy and uneven: a side stream streams 256 MB copies and runs matrix products while the epoch runs.  Every
+    repetition must reproduce, bit for bit, what the form without in-kernel hand-offs of records (precompute launch in front)
+    computed on a quiet chip -- a stale or torn read anywhere would show in the losses and the weights."""
+    fx = load("iters_hyper_S100.npz")
+    from hypad_amd.engine import Engine
+    ns, nb, nc = 2, 6, 3
+    xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100).repeat(ns, 1, 1).contiguous()
+    perm = torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
+
+    def fresh():
+        e = Engine(100, 20, 64, True, n_signals=ns, lr=5e-4, seed=23)
+        for net in ("enc", "dec", "cx", "cz"):
+            for sgn in range(ns):
+                e.load_state_dict(net, sub_state(fx, net, "w0"), sgn)
+            e.params[net][1].mul_(0.99)
+        return e
+
+    monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", "0")
+    e = fresh()
+    want_l = e.train_epoch(xs, perm, nb, nc, True).clone()
+    want_p = {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}
+    torch.cuda.synchronize()
+    monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", "1")
+    side = torch.cuda.Stream()
+    a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    m = torch.randn(2048, 2048, device="cuda")
+    for rep in range(12):
+        e = fresh()
+        assert e.critic_phase_producers(nb * nc)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):                       # uneven background load, different every repetition
+            for k in range(1 + rep % 4):
+                b.copy_(a)
+                if rep % 3:
+                    m = (m @ m) * 1e-3
+        l = e.train_epoch(xs, perm, nb, nc, True)
+        torch.cuda.synchronize()
+        assert torch.equal(l, want_l), rep
+        for k in ("cx", "cz", "enc", "dec"):
+            assert torch.equal(e.params[k], want_p[k]), (rep, k)
