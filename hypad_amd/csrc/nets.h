@@ -354,19 +354,19 @@ __device__ __forceinline__ void decoder_trunk_fwd_tile(const float* Zs, int L, i
 // caller issues lstm_layer_prefetch() before the previous stage's epilogue / barrier and the layer starts with its
 // operands already in registers instead of an L2 round trip.
 struct LstmPre { float4 bi[4], bg[4], bo[4]; };
+template <bool SC1 = false>
 __device__ __forceinline__ LstmPre lstm_layer_prefetch(const float* __restrict__ pk0, const float* __restrict__ pk1, int H, int K) {
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int Hp = (H + 15) & ~15, nb = Hp >> 4, kg = (K + 15) >> 4;
   const int task = wave < 2 * nb ? wave : 0;
   const int d = task / nb, ub = task - d * nb;
-  const float4* wi = reinterpret_cast<const float4*>(d ? pk1 : pk0) + (size_t)ub * kg * 64 + lane;
-  const float4* wg = wi + (size_t)nb * kg * 64;
-  const float4* wo = wg + (size_t)nb * kg * 64;
+  const WeightBlocks<SC1> wb(d ? pk1 : pk0, lane);
+  const int bi0 = ub * kg, bg0 = bi0 + nb * kg, bo0 = bg0 + nb * kg;
   LstmPre p;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const size_t o = (size_t)(u < kg ? u : kg - 1) * 64;
-    p.bi[u] = wi[o]; p.bg[u] = wg[o]; p.bo[u] = wo[o];
+    const int o = u < kg ? u : kg - 1;
+    p.bi[u] = wb(bi0 + o); p.bg[u] = wb(bg0 + o); p.bo[u] = wb(bo0 + o);
   }
   return p;
 }
@@ -376,7 +376,7 @@ __device__ __forceinline__ LstmPre lstm_layer_prefetch(const float* __restrict__
 #else
 #define LSTAMP(k) do { (void)xst; } while (0)
 #endif
-template <int MT, bool PRE = false>
+template <int MT, bool PRE = false, bool SC1 = false>
 __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ As, int lda, int K, const float* __restrict__ pk0,
                                                       const float* __restrict__ pb0, const float* __restrict__ pk1,
                                                       const float* __restrict__ pb1, int H, float* __restrict__ Hs, int ldh,
@@ -389,14 +389,16 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
   // one task = 16 units of one direction: the i, g, o gate tiles side by side, the cell in the epilogue
   auto run = [&](int task, auto first_from_pre) __attribute__((always_inline)) {
     const int d = task / nb, ub = task - d * nb;
-    const float4* wi = reinterpret_cast<const float4*>(d ? pk1 : pk0) + (size_t)ub * kg * 64 + lane;
-    const float4* wg = wi + (size_t)nb * kg * 64;
-    const float4* wo = wg + (size_t)nb * kg * 64;
+    const WeightBlocks<SC1> wb(d ? pk1 : pk0, lane);
+    const int bi0 = ub * kg, bg0 = bi0 + nb * kg, bo0 = bg0 + nb * kg;
     const float* pb = d ? pb1 : pb0;
     // (the biases are requested here, ahead of the products: behind them they are an exposed memory round trip per task)
     const int jj = 16 * ub + j;
     float b_i = 0.f, b_g = 0.f, b_o = 0.f;
-    if constexpr (PRE) { b_i = pb[jj < H ? jj : 0]; b_g = pb[Hp + (jj < H ? jj : 0)]; b_o = pb[2 * Hp + (jj < H ? jj : 0)]; }
+    if constexpr (PRE) {
+      b_i = weight_scalar<SC1>(pb + (jj < H ? jj : 0)); b_g = weight_scalar<SC1>(pb + Hp + (jj < H ? jj : 0));
+      b_o = weight_scalar<SC1>(pb + 2 * Hp + (jj < H ? jj : 0));
+    }
     f32x4 ai[MT], ag[MT], ao[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { ai[m] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[m] = ai[m]; ao[m] = ai[m]; }
@@ -429,8 +431,8 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     auto fetch = [&](float4 (&bi)[4], float4 (&bg)[4], float4 (&bo)[4], int g0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const size_t o = (size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64;
-        bi[u] = wi[o]; bg[u] = wg[o]; bo[u] = wo[o];
+        const int o = g0 + u < kg ? g0 + u : kg - 1;
+        bi[u] = wb(bi0 + o); bg[u] = wb(bg0 + o); bo[u] = wb(bo0 + o);
       }
     };
     mfma_prio_begin<PRE>();
@@ -460,7 +462,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     mfma_prio_end<PRE>();
     LSTAMP(41);
     if (jj < H) {
-      if constexpr (!PRE) { b_i = pb[jj]; b_g = pb[Hp + jj]; b_o = pb[2 * Hp + jj]; }      // (throughput callers: fewer live registers)
+      if constexpr (!PRE) { b_i = weight_scalar<SC1>(pb + jj); b_g = weight_scalar<SC1>(pb + Hp + jj); b_o = weight_scalar<SC1>(pb + 2 * Hp + jj); }      // (throughput callers: fewer live registers)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -484,23 +486,23 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
 }
 
 // PRE: the caller requested the layer's first weights earlier (lstm_layer_prefetch on gp.enc_g) and passes them in.
-template <bool PRE = false>
+template <bool PRE = false, bool SC1 = false>
 __device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx, int S, int L, const float* pk, const GenPack& gp,
                                                         float* bufG, int ldg, float* bufH, int ldh, float* Zs,
                                                         float* gates_save, float* h_save, int valid, const LstmPre& pre = LstmPre{}) {
   (void)bufG; (void)ldg;
   PackedPre pred{};
-  if constexpr (PRE) pred = gemm_nt_prefetch(pk + gp.enc_d, 2 * ENC_H, L);        // the dense layer's weights, one stage ahead
-  lstm_layer_fwd_packed<1, PRE>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
+  if constexpr (PRE) pred = gemm_nt_prefetch<SC1>(pk + gp.enc_d, 2 * ENC_H, L);   // the dense layer's weights, one stage ahead
+  lstm_layer_fwd_packed<1, PRE, SC1>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
                                 gates_save, valid, 16, pre, h_save);          // (h_save written from the epilogue)
   __syncthreads();
-  gemm_nt_packed<1, PRE>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
+  gemm_nt_packed<1, PRE, ActIdentity, SC1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
   __syncthreads();
 }
 // PRE: the caller requested d1's first weights earlier (gemm_nt_prefetch on gp.d1) and passes them in.  next_W (may be
 // null): packed weights of the product that follows the trunk; their first batch is requested before the last product
 // here and returned.
-template <int MT, bool PRE = false, class RowFn>
+template <int MT, bool PRE = false, bool SC1 = false, class RowFn>
 __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* Zs, int L, int S, const float* pk, const GenPack& gp,
                                                                    float* bufA, float* bufB, int ldS, const DropSrc& drop, RowFn grow,
                                                                    const DecSave& sv, int valid, const PackedPre& pred1 = PackedPre{},
@@ -515,14 +517,14 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   // activations.  Throughput callers (scoring, the critic phase's precompute) keep the registers for occupancy instead.
   LstmPre pre0{}, pre1{};
   PackedPre pre2{};
-  if constexpr (PRE) pre0 = lstm_layer_prefetch(pk + gp.l_g[0][0], pk + gp.l_g[0][1], DEC_H, DEC_D1);
+  if constexpr (PRE) pre0 = lstm_layer_prefetch<SC1>(pk + gp.l_g[0][0], pk + gp.l_g[0][1], DEC_H, DEC_D1);
   // (the saved activations go to the workspace from the epilogues: valid == rows for the callers that save)
-  gemm_nt_packed<MT, PRE>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0, 0, pred1, ActIdentity{}, nullptr, 0, sv.a0, DEC_D1, sv.ps);
+  gemm_nt_packed<MT, PRE, ActIdentity, SC1>(Zs, LP, L, DEC_D1, pk + gp.d1, pk + gp.d1b, bufB, ldA0, 0, 0, pred1, ActIdentity{}, nullptr, 0, sv.a0, DEC_D1, sv.ps);
   TSTAMP(17);
   __syncthreads();
   // layer 0: input a0 in bufB [rows][ldA0] -> h0 in bufA [rows][ldH] (the cell runs in the gate product's epilogue)
-  if constexpr (PRE) pre1 = lstm_layer_prefetch(pk + gp.l_g[1][0], pk + gp.l_g[1][1], DEC_H, 2 * DEC_H);
-  lstm_layer_fwd_packed<MT, PRE>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA,
+  if constexpr (PRE) pre1 = lstm_layer_prefetch<SC1>(pk + gp.l_g[1][0], pk + gp.l_g[1][1], DEC_H, 2 * DEC_H);
+  lstm_layer_fwd_packed<MT, PRE, SC1>(bufB, ldA0, DEC_D1, pk + gp.l_g[0][0], pk + gp.l_gb[0][0], pk + gp.l_g[0][1], pk + gp.l_gb[0][1], DEC_H, bufA,
                                   ldH, sv.g0, valid, sv.ps, pre0);
   TSTAMP(18);
   __syncthreads();
@@ -545,16 +547,16 @@ __device__ __forceinline__ PackedPre decoder_trunk_fwd_tile_packed(const float* 
   TSTAMP(27);
   TSTAMP(28);
   // layer 1: h0 (dropped) in bufA -> h1 in bufB
-  if constexpr (PRE) pre2 = gemm_nt_prefetch(pk + gp.d2, 2 * DEC_H, S);
-  lstm_layer_fwd_packed<MT, PRE>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB,
+  if constexpr (PRE) pre2 = gemm_nt_prefetch<SC1>(pk + gp.d2, 2 * DEC_H, S);
+  lstm_layer_fwd_packed<MT, PRE, SC1>(bufA, ldH, 2 * DEC_H, pk + gp.l_g[1][0], pk + gp.l_gb[1][0], pk + gp.l_g[1][1], pk + gp.l_gb[1][1], DEC_H, bufB,
                                   ldH, sv.g1, valid, sv.ps, pre1, sv.h1, sv.stamps);
   TSTAMP(29);
   __syncthreads();
   TSTAMP(30);
   PackedPre nxt{};
-  if (next_W) nxt = gemm_nt_prefetch(next_W, next_K, next_N);
+  if (next_W) nxt = gemm_nt_prefetch<SC1>(next_W, next_K, next_N);
   struct Tanh { __device__ __forceinline__ float operator()(float v) const { return tanhf_(v); } };
-  gemm_nt_packed<MT, PRE, Tanh>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, Eout ? Eout : bufA, ldS, 0, 0, pre2, Tanh{}, nullptr, 0,
+  gemm_nt_packed<MT, PRE, Tanh, SC1>(bufB, ldH, 2 * DEC_H, S, pk + gp.d2, pk + gp.d2b, Eout ? Eout : bufA, ldS, 0, 0, pre2, Tanh{}, nullptr, 0,
                                 sv.e, S, sv.ps);                               // tanh in the epilogue
   TSTAMP(31);
   __syncthreads();

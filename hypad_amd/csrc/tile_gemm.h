@@ -203,13 +203,39 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
 // gemm_nt_prefetch() before the previous stage's work and pass the result with PRE = true; the product then starts with its
 // B operands in registers instead of an L2 round trip (~2 k cycles on a chain that runs every product once).
 struct PackedPre { float4 w[8]; };
+// Packed weights through one of two doors.  SC1 = false: plain global loads (throughput callers).  SC1 = true: `sc1` buffer loads
+// on a descriptor built from the (wave-uniform) matrix pointer -- 1 KB blocks at scalar offsets, the lane's 16 bytes at a
+// constant vector offset: no vector address arithmetic at all, which is what the latency-chain kernels pay for (measured on the
+// generator step: -1.7 us of 40.6; the sc1 bit itself costs nothing there -- every weight line is read once per workgroup).
+// It is also the form a consumer must use for EVERY byte another workgroup of the same launch has just written with `sc1`
+// stores (cdna_hip_programming.md Guideline 16 R1).
+typedef unsigned int wl_u32x4 __attribute__((vector_size(16)));
+template <bool SC1>
+struct WeightBlocks {
+  const float4* wp; __amdgpu_buffer_rsrc_t rs; int voff;
+  __device__ __forceinline__ WeightBlocks(const float* W, int lane) {
+    if constexpr (SC1) { rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7fffffff, 0x00020000); voff = lane * 16; wp = nullptr; }
+    else { wp = reinterpret_cast<const float4*>(W) + lane; voff = 0; }
+  }
+  __device__ __forceinline__ float4 operator()(int blk) const {             // block index: wave-uniform
+    if constexpr (SC1) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 16));
+    else return wp[(size_t)blk * 64];
+  }
+};
+template <bool SC1>
+__device__ __forceinline__ float weight_scalar(const float* p) {            // one float of handed-off data (bias sums, ...)
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1 = false>
 __device__ __forceinline__ PackedPre gemm_nt_prefetch(const float* __restrict__ Wp, int K, int N, int wave_rot = 0) {
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
-  const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)(wave < ntiles ? wave : 0) * kg * 64 + lane;
+  const WeightBlocks<SC1> wb(Wp, lane);
+  const int b0 = (wave < ntiles ? wave : 0) * kg;
   PackedPre p;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) p.w[u] = wp[(size_t)(u < kg ? u : kg - 1) * 64];
+  for (int u = 0; u < 8; ++u) p.w[u] = wb(b0 + (u < kg ? u : kg - 1));
   return p;
 }
 struct ActIdentity { __device__ __forceinline__ float operator()(float v) const { return v; } };
@@ -219,16 +245,17 @@ struct ActIdentity { __device__ __forceinline__ float operator()(float v) const 
 //   epi.emit(m, r, row, n, value)   for every element of the tile (value = product + summed bias), n < N.
 // An elementwise stage that follows a product costs a pass over LDS and a workgroup barrier on its own; in the epilogue it costs
 // its arithmetic.
-template <int MT, bool PRE, class Epi>
+template <int MT, bool PRE, class Epi, bool SC1 = false>
 __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
                                                    const float* __restrict__ bsum, int wave_rot, const PackedPre& pre, Epi& epi) {
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
   const int j = lane & 15, q = lane >> 4;
   const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
   auto run = [&](int t, auto first_from_pre) __attribute__((always_inline)) {
-    const float4* wp = reinterpret_cast<const float4*>(Wp) + (size_t)t * kg * 64 + lane;
+    const WeightBlocks<SC1> wb(Wp, lane);
+    const int b0 = t * kg;
     const int n = t * 16 + j;
-    const float bs = (bsum && n < N) ? bsum[n] : 0.f;
+    const float bs = (bsum && n < N) ? weight_scalar<SC1>(bsum + n) : 0.f;
     epi.prefetch(n, q, n < N);
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
@@ -259,7 +286,7 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
     for (int g0 = gbeg; g0 < kg; g0 += 8) {            // 8 k-groups (128 k) of weights in flight per lane
       float4 w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = wp[(size_t)(g0 + u < kg ? g0 + u : kg - 1) * 64];
+      for (int u = 0; u < 8; ++u) w[u] = wb(b0 + (g0 + u < kg ? g0 + u : kg - 1));
       __builtin_amdgcn_sched_barrier(0);
       consume(w, g0);
     }
@@ -293,14 +320,14 @@ struct PlainEpi {
     if (gout) gout[(size_t)(gps ? (row >> 4) * gps + (row & 15) : row) * gld + n] = o;
   }
 };
-template <int MT, bool PRE = false, class Act = ActIdentity>
+template <int MT, bool PRE = false, class Act = ActIdentity, bool SC1 = false>
 __device__ __forceinline__ void gemm_nt_packed(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
                                                const float* __restrict__ bsum, float* __restrict__ Ys, int ldy, int ycol0, int wave_rot = 0,
                                                const PackedPre& pre = PackedPre{}, Act act = Act{},
                                                const float* __restrict__ escale = nullptr, int es_ld = 0,
                                                float* __restrict__ gout = nullptr, int gld = 0, int gps = 0) {
   PlainEpi<MT, Act> epi{Ys, ldy, ycol0, act, escale, es_ld, gout, gld, gps, {}};
-  gemm_nt_packed_epi<MT, PRE>(Xs, ldx, K, N, Wp, bsum, wave_rot, pre, epi);
+  gemm_nt_packed_epi<MT, PRE, PlainEpi<MT, Act>, SC1>(Xs, ldx, K, N, Wp, bsum, wave_rot, pre, epi);
 }
 
 // ---------------------------------------------------------------------------------------------------- gemm_nn

@@ -286,7 +286,7 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 
 // Chain Z of the generator step (see above): encoder forward of the tile's windows, critic_z forward / backward, encoder
 // backward of that gradient; operand rows into the second halves of xg / enc_h / dzenc / dgenc.
-template <int SC, int LC, int BC>
+template <int SC, int LC, int BC, bool WSC1 = false>
 __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
   const int sig = blockIdx.y, tile = blockIdx.x >> 3;
@@ -307,15 +307,15 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   // (the gather first: loads return in order, and the weight prefetch -- cold lines, rewritten by the previous launch -- would
   // hold its two dependent round trips back)
   tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
-  const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
+  const LstmPre pre_enc = lstm_layer_prefetch<WSC1>(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
   stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
   __syncthreads();
   tile_store(ws + gw.xg + (int64_t)(B + g0) * S, S, xs, ldS, 16, S, 16);
   float* zin = zs + 16 * LP;
   float* gates = ws + gw.enc_g2 + (int64_t)g0 * 8 * ENC_H;
-  encoder_fwd_tile_packed<true>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin, gates,
+  encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin, gates,
                                 ws + gw.enc_h + (int64_t)(B + g0) * 2 * ENC_H, 16, pre_enc);
-  const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
+  const PackedPre pre_edt = gemm_nt_prefetch<WSC1>(pk + gp.enc_d_t, L, 2 * ENC_H);
   // critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
   const DropSrc dz = drop_src(a, sig, mbase, RS_DROP_CRITIC + 8 * 0, tick, clz.p_drop);
   const float sum_crit = critic_tile_fwd_bwd(zin, LP, cw, clz, L, cpz, ct, -1.f / B, [&](int li, int r, int c) { return dz.get4(li, g0 + r, c, L); },
@@ -325,7 +325,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   float* dP = bufA;
   {
     LstmCellBwdEpi epi{gates, ENC_H, dP, 6 * ENC_H + 4, 16, 16, nullptr, 0, ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, {}, {}, {}, {}, {}};
-    gemm_nt_packed_epi<1, true>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);      // dH, cell backward in the epilogue
+    gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);      // dH, cell backward in the epilogue
   }
   float* part_out = ws + gw.partial + tile * 4;
   if (threadIdx.x == 0) part_out[2] = sum_crit;
@@ -334,12 +334,12 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
 // SC / LC / BC: window length, latent width, batch as compile-time constants (0 = from the arguments); see
 // critic_fused.hip: every layer of the chain runs once per launch, so index arithmetic is never amortised.
 static_assert(TB == 512, "gen_body deals rows over 8 waves");
-template <bool HYPER, int SC, int LC, int BC>
+template <bool HYPER, int SC, int LC, int BC, bool WSC1 = false>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
   const int sig = blockIdx.y, tile = blockIdx.x >> 3, role = blockIdx.z;
   __builtin_amdgcn_s_setprio(2);            // (tile_gemm.h mfma_prio_*: the MFMA loops run below everything else)
-  if (role == 2) { gen_role_z<SC, LC, BC>(a, smem); return; }
+  if (role == 2) { gen_role_z<SC, LC, BC, WSC1>(a, smem); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
@@ -390,7 +390,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* zin;                               // decoder input rows [16][LP]
   PackedPre pre_d1;                         // first weights of the decoder's first layer, requested a stage ahead
   if (role == 0) {
-    pre_d1 = gemm_nt_prefetch(pk + gp.d1, L, DEC_D1);
+    pre_d1 = gemm_nt_prefetch<WSC1>(pk + gp.d1, L, DEC_D1);
     const CriticLayout clx = cx_layout(S, L);
     stage_critic_padded(cw, a.P.cx + (int64_t)sig * a.pcx, clx, L, critic_pad(S, L, 4));
     load_z(a, sig, tile, tick, zs);
@@ -401,7 +401,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // the window gather is two dependent memory round trips (row index, then the row)
     GEN_STAMP(14);
     tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
-    const LstmPre pre_enc = lstm_layer_prefetch(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);      // behind the gather (loads return in order)
+    const LstmPre pre_enc = lstm_layer_prefetch<WSC1>(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);      // behind the gather (loads return in order)
     GEN_STAMP(15);
     GEN_STAMP(12);
     __syncthreads();
@@ -409,10 +409,10 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
     if (HYPER) tile_store(ws + gw.ecat + (int64_t)(2 * B + g0) * S, S, xs, ldS, 16, S, 16);      // the head's second row block (pass 2)
     zin = zs + 16 * LP;
-    encoder_fwd_tile_packed<true>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
+    encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
                                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, pre_enc);
     GEN_STAMP(1);
-    pre_d1 = gemm_nt_prefetch(pk + gp.d1, L, DEC_D1);
+    pre_d1 = gemm_nt_prefetch<WSC1>(pk + gp.d1, L, DEC_D1);
   }
   GEN_STAMP(2);
   // ---- decoder trunk on this role's pass
@@ -431,7 +431,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
   const int growp = pass * B + g0;
-  const PackedPre pre_head = decoder_trunk_fwd_tile_packed<1, true>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16,
+  const PackedPre pre_head = decoder_trunk_fwd_tile_packed<1, true, WSC1>(zin, L, S, pk, gp, bufA, bufB, ldS, dd, [growp](int r) { return growp + r; }, sv, 16,
                                                                     pre_d1, HYPER ? pk + gp.head : nullptr, S, S, Ein);
   GEN_STAMP(3);
   // E = tanh output in Ein[0..15]
@@ -439,8 +439,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float u_keep[16], hb_keep[16];            // this wave's head rows: pre-activations and bias (lane's elements), forward -> backward
   if (HYPER) {
     GEN_STAMP(20);
-    if (role == 1) gemm_nt_packed<2, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
-    else gemm_nt_packed<1, true>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    if (role == 1) gemm_nt_packed<2, true, ActIdentity, WSC1>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
+    else gemm_nt_packed<1, true, ActIdentity, WSC1>(Ein, ldS, S, S, pk + gp.head, nullptr, bufB, ldS, 0, 0, pre_head);
     __syncthreads();
     GEN_STAMP(21);
     GEN_STAMP(22);
@@ -495,7 +495,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
       for (int w = 0; w < nw; ++w) sum_aux += red[16 + w];
     }
     GEN_STAMP(23);
-    const PackedPre pre_ht = gemm_nt_prefetch(pk + gp.head_t, S, S);        // the backward products' weights, each a stage ahead
+    const PackedPre pre_ht = gemm_nt_prefetch<WSC1>(pk + gp.head_t, S, S);        // the backward products' weights, each a stage ahead
     // ---- Moebius head backward, row-wise: dR -> dU (in place); this wave's share of the bias gradient in registers
     // (four rows per wave, one per 16-lane DPP row; the row's bias gradient goes to its own row of R: the head outputs are dead)
     epl16_dispatch(S, [&](auto tag) {
@@ -544,7 +544,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
           Ys[row * ldy + n] = o; gout[(size_t)row * ldE + n] = o;        // LDS tile + the dW kernel's operand rows
         }
       } epi{R, ldS, ws + gw.ecat + prow0 * S, S, ws + gw.dpre2 + prow0 * S, {}};
-      gemm_nt_packed_epi<1, true>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
+      gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
     }
     __syncthreads();
     GEN_STAMP(26);
@@ -571,25 +571,25 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* X = HYPER ? R : dR;                // d(pre-tanh) [16][ldS]
   float* Y = HYPER ? dR : R;
   GEN_STAMP(6);
-  const PackedPre pre_d2t = gemm_nt_prefetch(pk + gp.d2_t, S, 2 * DEC_H);
+  const PackedPre pre_d2t = gemm_nt_prefetch<WSC1>(pk + gp.d2_t, S, 2 * DEC_H);
   if (!HYPER) tile_store(ws + gw.dpre2 + prow0 * S, S, X, ldS, 16, S, 16);        // (hyperbolic: written by the epilogue above)
-  const PackedPre pre_l1t = gemm_nt_prefetch(pk + gp.l_t[1], 6 * DEC_H, 2 * DEC_H);
+  const PackedPre pre_l1t = gemm_nt_prefetch<WSC1>(pk + gp.l_t[1], 6 * DEC_H, 2 * DEC_H);
   // dH1 = dpre W2, layer 1 cell backward -> dG1 in Y
   {
     LstmCellBwdEpi epi{ws + gw.g1 + prow0 * 8 * DEC_H, DEC_H, Y, ldG, 16, 16, nullptr, 0, ws + gw.dg1 + prow0 * 6 * DEC_H, {}, {}, {}, {}, {}};
-    gemm_nt_packed_epi<1, true>(X, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, 0, pre_d2t, epi);
+    gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(X, ldS, S, 2 * DEC_H, pk + gp.d2_t, nullptr, 0, pre_d2t, epi);
   }
   GEN_STAMP(32);
   __syncthreads();
   GEN_STAMP(7);
   GEN_STAMP(33);
-  const PackedPre pre_l0t = gemm_nt_prefetch(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
+  const PackedPre pre_l0t = gemm_nt_prefetch<WSC1>(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
   GEN_STAMP(34);
   // dH0d = dG1 W_ih(l1) (both directions: one stacked reduction), x the inter-layer dropout mask, layer 0 cell backward -> dG0 in X
   {
     LstmCellBwdEpi epi{ws + gw.g0 + prow0 * 8 * DEC_H, DEC_H, X, ldG, 16, 16,
                        a.drop_mode != 0 ? ws + gw.mask + prow0 * 2 * DEC_H : nullptr, 2 * DEC_H, ws + gw.dg0 + prow0 * 6 * DEC_H, {}, {}, {}, {}, {}};
-    gemm_nt_packed_epi<1, true>(Y, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, 0, pre_l1t, epi);
+    gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(Y, ldG, 6 * DEC_H, 2 * DEC_H, pk + gp.l_t[1], nullptr, 0, pre_l1t, epi);
   }
   GEN_STAMP(35);
   __syncthreads();
@@ -597,9 +597,9 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(8);
   GEN_STAMP(37);
   PackedPre pre_d1t{};
-  if (role == 1) pre_d1t = gemm_nt_prefetch(pk + gp.d1_t, DEC_D1, L);
+  if (role == 1) pre_d1t = gemm_nt_prefetch<WSC1>(pk + gp.d1_t, DEC_D1, L);
   GEN_STAMP(38);
-  gemm_nt_packed<1, true>(X, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, Y, ldA0, 0, 0, pre_l0t, ActIdentity{}, nullptr, 0,
+  gemm_nt_packed<1, true, ActIdentity, WSC1>(X, ldG, 6 * DEC_H, DEC_D1, pk + gp.l_t[0], nullptr, Y, ldA0, 0, 0, pre_l0t, ActIdentity{}, nullptr, 0,
                           ws + gw.da0 + prow0 * DEC_D1, DEC_D1);                  // (+ the dW kernel's operand rows)
   GEN_STAMP(39);
   __syncthreads();
@@ -612,8 +612,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     return;
   }
   // dZ = dA0 W1: the gradient reaching the encoder's output
-  const PackedPre pre_edt = gemm_nt_prefetch(pk + gp.enc_d_t, L, 2 * ENC_H);
-  gemm_nt_packed<1, true>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t, ActIdentity{}, nullptr, 0,
+  const PackedPre pre_edt = gemm_nt_prefetch<WSC1>(pk + gp.enc_d_t, L, 2 * ENC_H);
+  gemm_nt_packed<1, true, ActIdentity, WSC1>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t, ActIdentity{}, nullptr, 0,
                           ws + gw.dzenc + (int64_t)g0 * L, L);                     // (the critic_z part of dZ: chain Z)
   __syncthreads();
   GEN_STAMP(10);
@@ -621,7 +621,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   {
     LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, 6 * ENC_H + 4, 16, 16, nullptr, 0,
                        ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, {}, {}, {}, {}, {}};
-    gemm_nt_packed_epi<1, true>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
+    gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
   }
   if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
   // chain Z (blockIdx.z == 2) goes to the neighbouring XCD: it reads only the encoder's weights and must not queue behind
   // chains G and R for the 32 CUs of theirs (batch 256: 16 tiles x 2 chains fill an XCD)
   if ((blockIdx.x & 7) != ((blockIdx.y + (blockIdx.z == 2 ? 1 : 0)) & 7)) return;
-  gen_body<HYPER, SC, LC, BC>(a, smem);
+  gen_body<HYPER, SC, LC, BC, true>(a, smem);        // (weights through sc1 buffer loads: tile_gemm.h WeightBlocks)
 }
 
 // ------------------------------------------------------------------------------------------------ dW + Adam
