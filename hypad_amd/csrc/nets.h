@@ -170,14 +170,20 @@ struct LstmCellBwdEpi {
   const float* gates_saved; int H; float* dGs; int ldg; int valid; int ps; const float* mask; int mask_ld;
   float* gout;               // global mirror [rows][6H] of the gate deltas (the weight-gradient kernel's operand rows), or null
   float gi[4], gg[4], go[4], tc[4], ms[4];
+  int vo_g;                  // this lane's byte offset into gout: row 4 q, column d 3H + unit
   __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
     const int nn = ok ? n : 0, d = nn >= H ? 1 : 0, jj = nn - d * H;
+    // (16 rows: prow is the identity; rows past `valid` read row 0 -- their deltas are zeroed below.  Buffer addressing: one
+    // lane offset, the row and the gate as scalar / constant offsets)
+    const GBuf sb(gates_saved), mb(mask);
+    const int vo_s = (4 * q * 8 * H + d * 4 * H + jj) * 4, vo_m = (4 * q * mask_ld + nn) * 4;
+    vo_g = (4 * q * 6 * H + d * 3 * H + jj) * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r;
-      const float* s = gates_saved + prow(row < valid ? row : 0, ps) * 8 * H + d * 4 * H + jj;
-      gi[r] = s[0]; gg[r] = s[H]; go[r] = s[2 * H]; tc[r] = s[3 * H];
-      ms[r] = mask ? mask[(size_t)row * mask_ld + nn] : 1.f;
+      const bool rv = 4 * q + r < valid;
+      const int vs = rv ? vo_s : (d * 4 * H + jj) * 4, so = rv ? r * 8 * H * 4 : 0;
+      gi[r] = sb.ld(vs, so); gg[r] = sb.ld(vs + H * 4, so); go[r] = sb.ld(vs + 2 * H * 4, so); tc[r] = sb.ld(vs + 3 * H * 4, so);
+      ms[r] = mask ? mb.ld(vo_m, r * mask_ld * 4) : 1.f;
     }
   }
   __device__ __forceinline__ void emit(int, int r, int row, int n, float v) {
@@ -192,7 +198,11 @@ struct LstmCellBwdEpi {
     }
     float* o = dGs + row * ldg + d * 3 * H;
     o[jj] = di; o[H + jj] = dg; o[2 * H + jj] = dov;
-    if (gout && row < valid) { float* w = gout + (size_t)row * 6 * H + d * 3 * H; w[jj] = di; w[H + jj] = dg; w[2 * H + jj] = dov; }
+    if (gout && row < valid) {
+      const GBuf gb(gout);
+      const int so = r * 6 * H * 4;
+      gb.st(di, vo_g, so); gb.st(dg, vo_g + H * 4, so); gb.st(dov, vo_g + 2 * H * 4, so);
+    }
   }
 };
 // dA[rows][K] = dG_fwd * W_ih_fwd + dG_rev * W_ih_rev  (compact gate columns -> PyTorch weight rows)
@@ -463,6 +473,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     LSTAMP(41);
     if (jj < H) {
       if constexpr (!PRE) { b_i = weight_scalar<SC1>(pb + jj); b_g = weight_scalar<SC1>(pb + Hp + jj); b_o = weight_scalar<SC1>(pb + 2 * Hp + jj); }      // (throughput callers: fewer live registers)
+      // saved rows through buffer addressing: the lane's offset (row 4 q, this unit) once, row and gate as scalar / constant offsets
+      const GBuf hb(h_out), gb(gates_save);
+      const int vo_h = (4 * q * 2 * H + d * H + jj) * 4, vo_g = (4 * q * 8 * H + d * 4 * H + jj) * 4;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -471,10 +484,11 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           const float gi = sigmoidf_(ai[m][r] + b_i), gg = tanhf_(ag[m][r] + b_g), go = sigmoidf_(ao[m][r] + b_o);
           const float tc = tanhf_(gi * gg);
           Hs[row * ldh + d * H + jj] = go * tc;
-          if (h_out && row < valid) h_out[prow(row, ps) * 2 * H + d * H + jj] = go * tc;
+          const int prs = m * ps + r;                      // prow(row, ps) = m ps + 4 q + r: the part that is not the lane's
+          if (h_out && row < valid) hb.st(go * tc, vo_h, prs * 2 * H * 4);
           if (gates_save && row < valid) {
-            float* sv = gates_save + prow(row, ps) * 8 * H + d * 4 * H + jj;
-            sv[0] = gi; sv[H] = gg; sv[2 * H] = go; sv[3 * H] = tc;
+            const int so = prs * 8 * H * 4;
+            gb.st(gi, vo_g, so); gb.st(gg, vo_g + H * 4, so); gb.st(go, vo_g + 2 * H * 4, so); gb.st(tc, vo_g + 3 * H * 4, so);
           }
         }
     }

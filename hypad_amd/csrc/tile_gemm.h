@@ -222,6 +222,15 @@ struct WeightBlocks {
     else return wp[(size_t)blk * 64];
   }
 };
+// Rows of a global fp32 array behind a buffer descriptor: a per-lane byte offset (computed once) + a scalar / constant offset per
+// access -- the epilogues of the latency-chain kernels store and fetch ~20 values per lane and stage, and as flat accesses each
+// one cost a 64-bit vector add on a SIMD whose fp32 MFMAs overlap with nothing.  (base: wave-uniform, may be null if unused)
+struct GBuf {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ explicit GBuf(const float* base) : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)) {}
+  __device__ __forceinline__ float ld(int vo, int so) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)); }
+  __device__ __forceinline__ void st(float v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
+};
 template <bool SC1>
 __device__ __forceinline__ float weight_scalar(const float* p) {            // one float of handed-off data (bias sums, ...)
   if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -308,16 +317,21 @@ struct PlainEpi {
   float* Ys; int ldy, ycol0; Act act; const float* escale; int es_ld;
   float* gout; int gld, gps; // global mirror of the result rows (row stride gld; gps != 0: row r lives at (r >> 4) * gps + (r & 15)), or null
   float es[MT][4];
+  int vo_g;                   // this lane's byte offset into gout: row 4 q, column n
   __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
+    vo_g = (4 * q * gld + n) * 4;
+    const GBuf eb(escale);
+    const int vo_e = (4 * q * es_ld + (ok ? n : 0)) * 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) es[m][r] = (escale && ok) ? escale[(size_t)(m * 16 + 4 * q + r) * es_ld + n] : 1.f;
+      for (int r = 0; r < 4; ++r) es[m][r] = (escale && ok) ? eb.ld(vo_e, ((m * 16 + r) * es_ld) * 4) : 1.f;
   }
   __device__ __forceinline__ void emit(int m, int r, int row, int n, float v) {
     const float o = act(v) * es[m][r];
     Ys[row * ldy + ycol0 + n] = o;
-    if (gout) gout[(size_t)(gps ? (row >> 4) * gps + (row & 15) : row) * gld + n] = o;
+    // (row = 16 m + 4 q + r: the lane part is vo_g, the rest a scalar)
+    if (gout) GBuf(gout).st(o, vo_g, ((gps ? m * gps : m * 16) + r) * gld * 4);
   }
 };
 template <int MT, bool PRE = false, class Act = ActIdentity, bool SC1 = false>

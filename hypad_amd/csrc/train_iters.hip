@@ -534,16 +534,18 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // requested before the reduction)
     {
       struct TanhBwdEpi {
-        float* Ys; int ldy; const float* E; int ldE; float* gout; float e[4];
+        float* Ys; int ldy; const float* E; int ldE; float* gout; float e[4]; int vo;
         __device__ __forceinline__ void prefetch(int n, int q, bool ok) {
+          vo = (4 * q * ldE + (ok ? n : 0)) * 4;                          // (buffer addressing: tile_gemm.h GBuf)
+          const GBuf eb(E);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) e[r] = ok ? E[(size_t)(4 * q + r) * ldE + n] : 0.f;
+          for (int r = 0; r < 4; ++r) e[r] = ok ? eb.ld(vo, r * ldE * 4) : 0.f;
         }
         __device__ __forceinline__ void emit(int, int r, int row, int n, float v) {
           const float o = v * (1.f - e[r] * e[r]);
-          Ys[row * ldy + n] = o; gout[(size_t)row * ldE + n] = o;        // LDS tile + the dW kernel's operand rows
+          Ys[row * ldy + n] = o; GBuf(gout).st(o, vo, r * ldE * 4);      // LDS tile + the dW kernel's operand rows
         }
-      } epi{R, ldS, ws + gw.ecat + prow0 * S, S, ws + gw.dpre2 + prow0 * S, {}};
+      } epi{R, ldS, ws + gw.ecat + prow0 * S, S, ws + gw.dpre2 + prow0 * S, {}, 0};
       gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
     }
     __syncthreads();
