@@ -910,6 +910,13 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
     }
   }
+#if HYPAD_DIAG
+  // development aid (scripts/diag_dw_items.py): wall-clock end of every wave of the generator's dW launch + its descriptor kind
+  if (a.stamps && tab.finalize == 1 && blockIdx.y == 0 && lane == 0 && item < 1024) {
+    a.stamps[3 * 48 * 8 + 64 + 2 * item] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[3 * 48 * 8 + 64 + 2 * item + 1] = item < tab.total_items ? d.kind * 1000 + d.net * 100 + (d.red_rows >> 4) : -1;
+  }
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (tab.finalize == 1) {        // generator losses (train.py:232-234, 243-244)
       const GenWs gw = gen_ws(B_, S_, L_);
