@@ -214,12 +214,11 @@ template <bool SC1>
 struct WeightBlocks {
   const float4* wp; __amdgpu_buffer_rsrc_t rs; int voff;
   __device__ __forceinline__ WeightBlocks(const float* W, int lane) {
-    if constexpr (SC1) { rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7fffffff, 0x00020000); voff = lane * 16; wp = nullptr; }
-    else { wp = reinterpret_cast<const float4*>(W) + lane; voff = 0; }
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7fffffff, 0x00020000); voff = lane * 16; wp = nullptr;
   }
   __device__ __forceinline__ float4 operator()(int blk) const {             // block index: wave-uniform
     if constexpr (SC1) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 16));
-    else return wp[(size_t)blk * 64];
+    else return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
   }
 };
 // Rows of a global fp32 array behind a buffer descriptor: a per-lane byte offset (computed once) + a scalar / constant offset per
