@@ -1106,7 +1106,7 @@ hipError_t allow_lds(const void* fn, size_t bytes) {
 // ------------------------------------------------------------------------------------------------ packed generator weights
 // Builds the MFMA-native copies (layout.h GenPack) from the parameter arenas: one thread per float4 of a packed block.
 struct PackDesc {
-  int kind;            // 0 W, 1 W with LSTM gate rows compacted, 2 W^T, 3 [W_fwd; W_rev]^T with compacted gate rows, 4 summed biases
+  int kind;            // 0 W, 1 W with LSTM gate rows compacted, 2 W^T, 3 [W_fwd; W_rev]^T with compacted gate rows, 4 summed biases, 5 critic_x padded image
   int net;             // HYPAD_NET_ENCODER / HYPAD_NET_DECODER
   int dst, nout, kred; // packed matrix: nout output rows, kred reduction columns
   int src0, src1, ld, H;
@@ -1119,9 +1119,25 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
   }
   const PackDesc d = tab.d[blockIdx.y];
   const int sig = blockIdx.z;
-  const float* P = d.net == HYPAD_NET_ENCODER ? a.P.enc + (int64_t)sig * a.pe : a.P.dec + (int64_t)sig * a.pd;
   float* pk = a.ws + sig * a.ws_sig_stride + a.pk_off + d.dst;
   const int u = blockIdx.x * 256 + threadIdx.x;
+  if (d.kind == 5) {                           // critic_x as the padded image of critic_mfma.h (stage_critic_padded's arithmetic, once)
+    const CriticLayout cl = cx_layout(a.S, a.L);
+    const CriticPad cp = critic_pad(a.S, a.L, 4);
+    if (u < cp.total) {
+      const float* C = a.P.cx + (int64_t)sig * a.pcx;
+      const int L = a.L, in_dim = cl.in_dim;
+      float v;
+      if (u < cp.wh) { const int n = u / cp.ldin, k = u - n * cp.ldin; v = k < in_dim ? C[cl.w[0] + n * in_dim + k] : (k == in_dim ? C[cl.b[0] + n] : 0.f); }
+      else if (u < cp.wl) {
+        const int i = u - cp.wh, li = 1 + i / (L * cp.LQ), rem = i - (li - 1) * L * cp.LQ, n = rem / cp.LQ, k = rem - n * cp.LQ;
+        v = k < L ? C[cl.w[li] + n * L + k] : (k == L ? C[cl.b[li] + n] : 0.f);
+      } else { const int k = u - cp.wl; v = k < L ? C[cl.w[cl.nh] + k] : (k == L ? C[cl.b[cl.nh]] : 0.f); }
+      pk[u] = v;
+    }
+    return;
+  }
+  const float* P = d.net == HYPAD_NET_ENCODER ? a.P.enc + (int64_t)sig * a.pe : a.P.dec + (int64_t)sig * a.pd;
   auto gate_row = [&](int n) { return n < d.H ? n : n + d.H; };           // compact [i|g|o] -> PyTorch [i,f,g,o] row
   const int Hp = (d.H + 15) & ~15;
   // forward gate matrices: packed row x * Hp + u (gate x of unit u; layout.h gate_rows) -> PyTorch row, or -1 for padding
@@ -1156,7 +1172,9 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
   }
   reinterpret_cast<float4*>(pk)[u] = make_float4(v[0], v[1], v[2], v[3]);
 }
-PackTable pack_table(const hypad_dims& dm) {
+// where the scoring kernel's padded critic_x image sits in its workspace: behind the packed generator weights, 16-byte aligned
+HD int score_critic_offset(int S, int L, int hyperbolic) { return (gen_pack(S, L, hyperbolic).total + 3) & ~3; }
+PackTable pack_table(const hypad_dims& dm, bool with_critic = false) {
   const int S = dm.signal_shape, L = dm.latent_dim;
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
@@ -1194,11 +1212,18 @@ PackTable pack_table(const hypad_dims& dm) {
   push(2, E, gp.enc_d_t, 2 * ENC_H, L, el.dense_w, -1, 2 * ENC_H, 0);
   push(2, D, gp.d2_t, 2 * DEC_H, S, dl.d2_w, -1, 2 * DEC_H, 0);
   push(2, D, gp.d1_t, L, DEC_D1, dl.d1_w, -1, L, 0);
+  if (with_critic) {                           // behind the generator's copies (hypad_score_workspace_bytes reserves it)
+    const int units = critic_pad(S, L, 4).total;
+    PackDesc d{5, HYPAD_NET_CRITIC_X, score_critic_offset(S, L, dm.hyperbolic), units, 0, 0, -1, 0, 0};
+    t.d[t.n++] = d;
+    if (units > t.max_units) t.max_units = units;
+  }
   return t;
 }
 // zero_ptr / zero_words: a block the next launches need zeroed (the critic phase's epoch words and flags), one word per thread
-int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned* zero_ptr = nullptr, int zero_words = 0, bool* zeroed = nullptr) {
-  const PackTable t = pack_table(dm);
+int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned* zero_ptr = nullptr, int zero_words = 0, bool* zeroed = nullptr,
+                bool with_critic = false) {
+  const PackTable t = pack_table(dm, with_critic);
   const dim3 grid((t.max_units + 255) / 256, t.n, dm.n_signals);
   const bool z = zero_ptr && zero_words > 0 && (int64_t)zero_words <= (int64_t)grid.x * grid.y * grid.z * 256;
   if (zeroed) *zeroed = z;
@@ -1212,7 +1237,7 @@ int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned
 // packed weights (no LDS re-shape), LSTM cells in the gate products' epilogues, the critic as LDS-resident MFMA layers, the
 // row-wise ball math four rows per wave.  79 KB of LDS: two workgroups per CU.
 struct ScoreArgs {
-  const float* pk; const float* cx; const float* head_b; const float* x; int64_t x_ld;
+  const float* pk; const float* cx; const float* cxpad; const float* head_b; const float* x; int64_t x_ld;      // cxpad: critic_x, padded image
   float* hyper; float* eucl; float* hyper_real; float* critic; float* rowdist;
   int64_t rows; int S, L, hyperbolic;
 };
@@ -1250,7 +1275,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (a.critic) {
     const CriticLayout clx = cx_layout(S, L);
     const CriticPad cpx = critic_pad(S, L, 4);
-    stage_critic_padded(cw, a.cx, clx, L, cpx);
+    stage_params(cw, a.cxpad, cpx.total);      // the padded image hypad_score_forward_packed's pack launch wrote (critic_mfma.h CriticPad)
     critic_tile_fwd(xs, ldS, cw, clx, L, cpx, bufA, outv);
     if (threadIdx.x < valid) a.critic[r0 + threadIdx.x] = outv[threadIdx.x];
   } else {
@@ -1536,7 +1561,7 @@ int hypad_pack_generator(const hypad_dims* d, const hypad_train_state* st, void*
 }
 size_t hypad_score_workspace_bytes(int S, int L, int hyperbolic) {
   if (S < 1 || S > MAX_S || L < 1 || L > MAX_L) return 0;
-  return (size_t)gen_pack(S, L, hyperbolic).total * sizeof(float);
+  return (size_t)(score_critic_offset(S, L, hyperbolic) + critic_pad(S, L, 4).total) * sizeof(float);      // packed generator + padded critic_x
 }
 int hypad_score_forward_packed(const float* enc, const float* dec, const float* cx, const float* x, int64_t x_row_stride, float* hyper,
                                float* eucl, float* hyper_real, float* critic, float* rowdist, int64_t rows, int S, int L,
@@ -1551,10 +1576,11 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   pa.P.enc = const_cast<float*>(enc); pa.P.dec = const_cast<float*>(dec);
   pa.pe = enc_layout(S, L).total; pa.pd = dec_layout(S, L, hyperbolic).total;
   pa.ws = (float*)workspace; pa.ws_sig_stride = 0; pa.pk_off = 0;
-  int rc = launch_pack(pa, d, (hipStream_t)s);
+  pa.P.cx = const_cast<float*>(cx); pa.pcx = cx_layout(S, L).total;
+  int rc = launch_pack(pa, d, (hipStream_t)s, nullptr, 0, nullptr, cx != nullptr);
   if (rc) return rc;
   ScoreArgs a;
-  a.pk = (const float*)workspace; a.cx = cx; a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
+  a.pk = (const float*)workspace; a.cx = cx; a.cxpad = (const float*)workspace + score_critic_offset(S, L, hyperbolic); a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
   a.x = x; a.x_ld = x_row_stride > 0 ? x_row_stride : S;
   a.hyper = hyper; a.eucl = eucl; a.hyper_real = hyper_real; a.critic = critic; a.rowdist = rowdist;
   a.rows = rows; a.S = S; a.L = L; a.hyperbolic = hyperbolic;
