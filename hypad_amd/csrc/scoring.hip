@@ -62,26 +62,25 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
     if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) v[cnt + lane] = __int_as_float(0x7f800000);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" and "equal" (two compare + add-carry
-    // pairs per value); only when some value occurs twice in this anti-diagonal is the ordered tie count needed.
-    int rank[EPL], same[EPL];
+    // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" only (one compare + add-carry per value).
+    // Without ties those counts are a permutation of 0 .. cnt-1, with ties two values share a count and the counts' sum falls
+    // short of cnt (cnt - 1) / 2: only then is the ordered tie count needed.  (The sum is exact in fp32: < 2^15 at window 256.)
+    int rank[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { rank[e] = 0; same[e] = 0; }
+    for (int e = 0; e < EPL; ++e) rank[e] = 0;
     for (int k0 = 0; k0 < cnt; k0 += 4) {
       const float4 q = *reinterpret_cast<const float4*>(v + k0);
       const float vk[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-          rank[e] += vk[u] < mine[e] ? 1 : 0;
-          same[e] += vk[u] == mine[e] ? 1 : 0;
-        }
+        for (int e = 0; e < EPL; ++e) rank[e] += vk[u] < mine[e] ? 1 : 0;
     }
-    bool ties = false;
+    float rsum = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) ties |= (lane + 64 * e < cnt) && same[e] > 1;
-    if (__any(ties)) {                               // wave-uniform
+    for (int e = 0; e < EPL; ++e) rsum += lane + 64 * e < cnt ? (float)rank[e] : 0.f;
+    const bool ties = hypad::wave_sum(rsum) != 0.5f * (float)cnt * (float)(cnt - 1);
+    if (ties) {                                      // wave-uniform
 #pragma unroll
       for (int e = 0; e < EPL; ++e) rank[e] = 0;
       for (int k = 0; k < cnt; ++k) {
