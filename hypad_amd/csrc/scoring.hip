@@ -256,7 +256,7 @@ constexpr int KDE_CB = 4;                    // candidates per pass-2 batch
 __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
                                                             int64_t n, int W) {
   __shared__ double vals[THREADS / 64][MAX_WINDOW];
-  __shared__ float vals32[THREADS / 64][MAX_WINDOW];
+  __shared__ __attribute__((aligned(16))) float vals32[THREADS / 64][MAX_WINDOW + 4];
   __shared__ double terms[THREADS / 64][KDE_CB * MAX_WINDOW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t T = n + W - 1;
@@ -284,25 +284,40 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
     double out;
     if (cnt > 1 && cov > 0.0 && cov == cov) {
       const double inv = 0.5 / cov;
-      // pass 1: fp32 densities of this lane's samples
-      const float invf = (float)inv * 1.44269504088896341f;                       // exp(-d^2 inv) = exp2(-d^2 inv log2 e)
-      float d32[KPL];
+      // pass 1: fp32 densities of this lane's samples.  exp(-d^2 inv) = exp2(-(c d)^2) with c = sqrt(inv log2 e): the samples are
+      // rescaled once (in place: pass 2 reads the fp64 copies), so a pair costs a subtract, a multiply, an exp2 and an add; the
+      // slab is padded with +inf to a multiple of four (a padded pair contributes exp2(-inf) = 0) and read four values at a
+      // time, every value once for all of the lane's samples.
+      const float cf = __builtin_amdgcn_sqrtf((float)inv * 1.44269504088896341f);
+      for (int k = lane; k < cnt; k += 64) vf[k] *= cf;
+      if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) vf[cnt + lane] = __int_as_float(0x7f800000);
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      float d32[KPL], xs[KPL];
+#pragma unroll
+      for (int u = 0; u < KPL; ++u) { const int k = lane + 64 * u; xs[u] = vf[k < cnt ? k : 0]; d32[u] = 0.f; }
+      const int nu = (cnt + 63) >> 6;                                             // sample slots in use (wave-uniform)
+      for (int m = 0; m < cnt; m += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(vf + m);
+        const float vm[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) {
+          if (u >= nu) continue;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const float d = xs[u] - vm[c]; d32[u] += __builtin_amdgcn_exp2f(-(d * d)); }
+        }
+      }
       float mx = -1.f;
 #pragma unroll
       for (int u = 0; u < KPL; ++u) {
-        const int k = lane + 64 * u;
-        d32[u] = -1.f;
-        if (k < cnt) {
-          const float xk = vf[k];
-          float dens = 0.f;
-          for (int m = 0; m < cnt; ++m) { const float d = xk - vf[m]; dens += __builtin_amdgcn_exp2f(-d * d * invf); }
-          d32[u] = dens;
-          mx = fmaxf(mx, dens);
-        }
+        if (lane + 64 * u >= cnt) d32[u] = -1.f;
+        mx = fmaxf(mx, d32[u]);
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
-      const float thr = mx * (1.f - 1e-3f);
+      // (error of an fp32 density: the exponent's argument carries ~4e-6 absolute at the terms that matter, the 100-term sum
+      // ~6e-6 relative: 1.5e-5 in all.  Everything within 2e-4 of the fp32 maximum goes to pass 2.)
+      const float thr = mx * (1.f - 2e-4f);
       // pass 2: fp64 densities of the candidates, in ascending sample order (the first maximum is kept); of every sample if
       // pass 1 produced no candidate (a bandwidth so small that its reciprocal leaves the fp32 range makes the screen NaN).
       // A wave pays for a sequential sum as if all 64 lanes ran it, so a candidate's sum is NOT given to one lane with its
@@ -312,6 +327,17 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
       double best = -1.0;
       int besti = 0x7fffffff;
       double* tm = terms[wave];
+      {
+        // one candidate only: the screen has decided (its margin is far above the fp32 pass's error), no fp64 sum is needed
+        int ncand = 0, first = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) {
+          const unsigned long long mk = __ballot(lane + 64 * u < cnt && d32[u] >= thr);
+          ncand += __builtin_popcountll(mk);
+          if (mk && first == 0x7fffffff) first = __builtin_ctzll(mk) + 64 * u;
+        }
+        if (ncand == 1) besti = first;
+      }
       for (int round = 0; round < 2 && besti == 0x7fffffff; ++round) {
 #pragma unroll
         for (int u = 0; u < KPL; ++u) {
@@ -336,7 +362,16 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
             double dens = -1.0;
             if (lane < nb) {
               dens = 0.0;
-              for (int m = 0; m < cnt; ++m) dens += tm[lane * MAX_WINDOW + m];
+              const double* tp = tm + lane * MAX_WINDOW;
+              int m = 0;
+              for (; m + 8 <= cnt; m += 8) {                 // (the terms of eight steps requested together; added in index order)
+                double t8[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) t8[x] = tp[m + x];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) dens += t8[x];
+              }
+              for (; m < cnt; ++m) dens += tp[m];
             }
 #pragma unroll
             for (int c = 0; c < KDE_CB; ++c) {
