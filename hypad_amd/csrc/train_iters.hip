@@ -329,6 +329,15 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   }
   float* part_out = ws + gw.partial + tile * 4;
   if (threadIdx.x == 0) part_out[2] = sum_crit;
+  if (tile == 0 && sig == 0 && threadIdx.x == 0) {
+    // optimizer step number and its bias corrections (double-precision powers): once per launch, for the dW + Adam launch --
+    // here, on the chain with slack
+    const int step = a.counters[a.opt] + 1;
+    a.counters[a.opt] = step;
+    const AdamCoef c0 = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
+    float* ac = a.ws + gw.adamc;
+    ac[0] = c0.bc1; ac[1] = c0.bc2; ac[2] = c0.sqrt_bc2;
+  }
 }
 
 // SC / LC / BC: window length, latent width, batch as compile-time constants (0 = from the arguments); see
@@ -356,14 +365,8 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   float* Ein = (HYPER && role == 1) ? smem + lp.hb : bufA;      // the Moebius head's input rows
   const uint32_t tick = (uint32_t)a.counters[3];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-    // optimizer step number and its bias corrections (double-precision powers): once, here, for the dW + Adam launch
-    const int step = a.counters[a.opt] + 1;
-    a.counters[a.opt] = step;
-    const AdamCoef c0 = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
-    float* ac = a.ws + gw.adamc;
-    ac[0] = c0.bc1; ac[1] = c0.bc2; ac[2] = c0.sqrt_bc2;
-  }
+  // (the optimizer step number and its bias corrections -- two double-precision powers on one lane, ~2 k cycles -- are taken by
+  // chain Z's first workgroup, which ends at 40 k of the kernel's 88 k cycles: gen_role_z)
   const int g0 = tile * 16;                 // first batch row of this tile
   const int pass = role;                    // decoder pass carried by this workgroup
   const int64_t prow0 = (int64_t)pass * B + g0;          // its first operand row in the pass-major workspace arrays
