@@ -436,6 +436,16 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # algorithmic memory-side bytes of ONE resident critic launch (the kernel table): every record written once by
+    # its producer and read once by its critic; every chunk's merged gradient share -- the valid accumulator quads of its critic:
+    # (Q (in + 1) + (nh - 1) Q (L + 1) + L + 1) x 16 bytes, Q = ceil(L / 4) -- written once and read by each of the B/16 chunks
+    traffic_algorithmic = None
+    if dom == "critic_persistent_kernel":
+        nchunks, q = B // 16, (L + 3) // 4
+        rec = sum(eng.epoch_records(N_BATCHES, N_CRITICS, c)[1].record_floats for c in (0, 1)) * 4 * nchunks
+        share = ((q * (S + 1) + 3 * q * (L + 1) + L + 1) + (q * (L + 1) + q * (L + 1) + L + 1)) * 16 * nchunks     # critic_x (4 hidden layers), critic_z (2)
+        traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + share * (1 + nchunks)))
+
     # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU
     secondary = None
     if spg == 1 and hyperbolic and not args.no_secondary:
@@ -484,6 +494,8 @@ def main():
                        "launch": "eager" if args.no_graph else "hipGraph replay of the captured epoch", "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_algorithmic": traffic_algorithmic,
+                         "traffic_ratio": (traffic / traffic_algorithmic) if traffic and traffic_algorithmic else None,
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
                          "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
                          "us_per_critic_iteration": 1e3 * kern_ms["critic_iteration"],

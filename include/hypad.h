@@ -259,7 +259,8 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_
  * 2 * n_signals * batch / 16 <= CUs of the device; HYPAD_CRITIC_PERSISTENT=0 in the environment selects the launches. */
 int hypad_critic_phase_persistent(const hypad_dims* dims);
 /* 1 when that resident launch also produces the phase's records itself (extra workgroups behind the resident ones: no separate
- * precompute launch) for a phase of n_iters = n_critics * n_batches iterations; HYPAD_CRITIC_PRODUCERS=0 turns it off. */
+ * precompute launch) for a phase of n_iters = n_critics * n_batches iterations: where the resident critics hold at most half of
+ * the device's CUs (the producers need the others); HYPAD_CRITIC_PRODUCERS=0 turns it off. */
 int hypad_critic_phase_producers(const hypad_dims* dims, int n_iters);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 
