@@ -743,16 +743,16 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 // (16 halves the registers and doubles the waves per SIMD; measured with 8 and 32 signals per GPU it changes nothing --
 // with many signals the launch moves ~9 MB per signal and sits at ~3.5 TB/s of HBM traffic.)
 template <class Table, int SC = 0, int LC = 0, int BC = 0, int KS = 48>
-__device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab) {
+__device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab, const int bx = (int)blockIdx.x) {      // bx: the workgroup's index in the launch's work (dw_adam_kernel: co-location)
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
-  const int item = blockIdx.x * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
+  const int item = bx * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
   // Every scalar fetch that hangs off the kernel arguments leaves in one batch -- the workgroup's descriptor, the step
   // counter, the generator's bias corrections -- instead of one memory round trip each.
-  const int di = (tab.block_desc[blockIdx.x >> 2] >> (8 * (blockIdx.x & 3))) & 0xff;
+  const int di = (tab.block_desc[bx >> 2] >> (8 * (bx & 3))) & 0xff;
   const DwDesc d = tab.d[di];                    // by value: one load group, not one load per field
   const int step = a.counters[a.opt];            // already incremented by the iteration's first kernel
   const float* ac = a.ws + (tab.finalize == 1 ? gen_ws(B_, S_, L_).adamc : 0);
@@ -920,7 +920,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     a.stamps[3 * 48 * 8 + 64 + 2 * item + 1] = item < tab.total_items ? d.kind * 1000 + d.net * 100 + (d.red_rows >> 4) : -1;
   }
 #endif
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bx == 0 && threadIdx.x == 0) {
     if (tab.finalize == 1) {        // generator losses (train.py:232-234, 243-244)
       const GenWs gw = gen_ws(B_, S_, L_);
       float aux = 0.f, fx = 0.f, fz = 0.f;
@@ -936,8 +936,18 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     if (blockIdx.y == 0 && a.tick_owner) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
-template <int SC, int LC, int BC, int KS>
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) { dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab); }
+// COLOC: blockIdx.x is stretched by 8 and only the blocks that land on XCD (signal mod 8) work (workgroups are dealt round-robin
+// over the 8 XCDs), so one model's weight tiles share an L2: its ~0.9 MB of operand rows are fetched from HBM once, not once per
+// XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
+template <int SC, int LC, int BC, int KS, bool COLOC = false>
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
+  if constexpr (COLOC) {
+    if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
+    dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab, (int)(blockIdx.x >> 3));
+  } else {
+    dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab);
+  }
+}
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
 __global__ __launch_bounds__(THREADS) void dw_adam_pair_kernel(IterArgs ax, DwTableS tx, IterArgs az, DwTableS tz) {
   if (blockIdx.z == 0) dw_adam_body(ax, tx); else dw_adam_body(az, tz);
@@ -1487,8 +1497,14 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
   const DwTable tab = gen_table(*d, with_decay);
-  const dim3 dgrid(dw_blocks(tab.total_items), d->n_signals);
-  if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+  const char* cenv = getenv("HYPAD_DW_COLOC");
+  const bool coloc = cenv ? cenv[0] == '1' : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
+  const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), d->n_signals);
+  if (coloc) {
+    if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+  } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   HYPAD_CHECK_LAUNCH();
