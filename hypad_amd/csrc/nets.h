@@ -176,13 +176,14 @@ struct LstmCellBwdEpi {
     // (16 rows: prow is the identity; rows past `valid` read row 0 -- their deltas are zeroed below.  Buffer addressing: one
     // lane offset, the row and the gate as scalar / constant offsets)
     const GBuf sb(gates_saved), mb(mask);
-    const int vo_s = (4 * q * 8 * H + d * 4 * H + jj) * 4, vo_m = (4 * q * mask_ld + nn) * 4;
+    const int vo_s = (4 * q * 8 * H + (d * H + jj) * 4) * 4, vo_m = (4 * q * mask_ld + nn) * 4;      // (lstm_layer_fwd_packed's layout)
     vo_g = (4 * q * 6 * H + d * 3 * H + jj) * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool rv = 4 * q + r < valid;
-      const int vs = rv ? vo_s : (d * 4 * H + jj) * 4, so = rv ? r * 8 * H * 4 : 0;
-      gi[r] = sb.ld(vs, so); gg[r] = sb.ld(vs + H * 4, so); go[r] = sb.ld(vs + 2 * H * 4, so); tc[r] = sb.ld(vs + 3 * H * 4, so);
+      const int vs = rv ? vo_s : (d * H + jj) * 16, so = rv ? r * 8 * H * 4 : 0;
+      const float4 g4 = sb.ld4(vs, so);
+      gi[r] = g4.x; gg[r] = g4.y; go[r] = g4.z; tc[r] = g4.w;
       ms[r] = mask ? mb.ld(vo_m, r * mask_ld * 4) : 1.f;
     }
   }
@@ -475,7 +476,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
       if constexpr (!PRE) { b_i = weight_scalar<SC1>(pb + jj); b_g = weight_scalar<SC1>(pb + Hp + jj); b_o = weight_scalar<SC1>(pb + 2 * Hp + jj); }      // (throughput callers: fewer live registers)
       // saved rows through buffer addressing: the lane's offset (row 4 q, this unit) once, row and gate as scalar / constant offsets
       const GBuf hb(h_out), gb(gates_save);
-      const int vo_h = (4 * q * 2 * H + d * H + jj) * 4, vo_g = (4 * q * 8 * H + d * 4 * H + jj) * 4;
+      // (saved gates of the packed path: [row][dir][unit][i, g, o, tanh c] -- one 16-byte store here, one 16-byte load in the
+      // cell backward's epilogue -- not the [dir][gate][unit] rows of the stand-alone LSTM entry points)
+      const int vo_h = (4 * q * 2 * H + d * H + jj) * 4, vo_g = (4 * q * 8 * H + (d * H + jj) * 4) * 4;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -487,8 +490,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           const int prs = m * ps + r;                      // prow(row, ps) = m ps + 4 q + r: the part that is not the lane's
           if (h_out && row < valid) hb.st(go * tc, vo_h, prs * 2 * H * 4);
           if (gates_save && row < valid) {
-            const int so = prs * 8 * H * 4;
-            gb.st(gi, vo_g, so); gb.st(gg, vo_g + H * 4, so); gb.st(go, vo_g + 2 * H * 4, so); gb.st(tc, vo_g + 3 * H * 4, so);
+            gb.st4(make_float4(gi, gg, go, tc), vo_g, prs * 8 * H * 4);
           }
         }
     }

@@ -229,6 +229,9 @@ struct GBuf {
   __device__ __forceinline__ explicit GBuf(const float* base) : rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000)) {}
   __device__ __forceinline__ float ld(int vo, int so) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)); }
   __device__ __forceinline__ void st(float v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
+  // (16 bytes: the whole vector is converted at once -- hipcc narrows an element-wise use of a b128 result to one dword)
+  __device__ __forceinline__ float4 ld4(int vo, int so) const { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)); }
+  __device__ __forceinline__ void st4(const float4& v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), rs, vo, so, 0); }
 };
 template <bool SC1>
 __device__ __forceinline__ float weight_scalar(const float* p) {            // one float of handed-off data (bias sums, ...)
