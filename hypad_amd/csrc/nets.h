@@ -490,7 +490,7 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
           const int prs = m * ps + r;                      // prow(row, ps) = m ps + 4 q + r: the part that is not the lane's
           if (h_out && row < valid) hb.st(go * tc, vo_h, prs * 2 * H * 4);
           if (gates_save && row < valid) {
-            gb.st4(make_float4(gi, gg, go, tc), vo_g, prs * 8 * H * 4);
+            gb.st4(make_float4(gi, gg, go, tc), vo_g + prs * 8 * H * 4);      // (row offset in the vector offset: see GBuf::st4)
           }
         }
     }

@@ -231,7 +231,11 @@ struct GBuf {
   __device__ __forceinline__ void st(float v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
   // (16 bytes: the whole vector is converted at once -- hipcc narrows an element-wise use of a b128 result to one dword)
   __device__ __forceinline__ float4 ld4(int vo, int so) const { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)); }
-  __device__ __forceinline__ void st4(const float4& v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), rs, vo, so, 0); }
+  // 16-byte stores take NO scalar offset: `buffer_store_dwordx4 ... s_off offen` with the data registers rewritten a few
+  // instructions later lost or mixed values intermittently on gfx950 / ROCm 7.2 (2-5 of 6 test runs; the compiler's `s_nop 1`
+  // behind the store was there); the same store with the offset folded into the vector offset, and the 4-byte stores and
+  // 16-byte LOADS with a scalar offset, never did (tests/test_gpu_parity.py::test_other_window_sizes_match_oracle, 12 runs each).
+  __device__ __forceinline__ void st4(const float4& v, int vo) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), rs, vo, 0, 0); }
 };
 template <bool SC1>
 __device__ __forceinline__ float weight_scalar(const float* p) {            // one float of handed-off data (bias sums, ...)
