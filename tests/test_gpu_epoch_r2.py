@@ -446,3 +446,30 @@ def test_hand_offs_hold_under_uneven_load(dev, monkeypatch):
         assert torch.equal(l, want_l), rep
         for k in ("cx", "cz", "enc", "dec"):
             assert torch.equal(e.params[k], want_p[k]), (rep, k)
+
+
+@pytest.mark.parametrize("S,B,hyper", [(100, 64, True), (51, 32, False), (150, 256, True)])
+def test_generator_step_is_repeatable(dev, S, B, hyper):
+    """One generator step from the same state, eight times over: losses, first moments (= the gradients) and weights must be
+    the same bits every time.  (A 16-byte buffer store with a scalar offset once corrupted saved LSTM gates intermittently on
+    this hardware: single runs of the parity tests passed more often than not -- only repetition showed it.)"""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    torch.manual_seed(S + B)
+    mods = dict(enc=ot.Encoder(S, 20).eval(), dec=ot.Decoder(S, 20, hyper).eval(), cx=ot.CriticX(S, 20).eval(), cz=ot.CriticZ(20).eval())
+    rng = np.random.default_rng(S)
+    xs = cu(rng.uniform(-1, 1, size=(B, S)).astype(np.float32)).reshape(1, B, S)
+    z = cu(rng.standard_normal((B, 20)).astype(np.float32))
+    outs = []
+    for rep in range(8):
+        eng = Engine(S, 20, B, hyper, lr=5e-4)
+        for k, m in mods.items():
+            eng.load_state_dict(k, m.state_dict())
+        l = eng.decoder_iteration(xs, None, z, train_mode=False)
+        torch.cuda.synchronize()
+        outs.append((l.clone(), {k: (eng.exp_avg[k].clone(), eng.params[k].clone()) for k in ("enc", "dec")}))
+    for rep in range(1, 8):
+        assert torch.equal(outs[rep][0], outs[0][0]), rep
+        for k in ("enc", "dec"):
+            assert torch.equal(outs[rep][1][k][0], outs[0][1][k][0]), (rep, k, "first moment")
+            assert torch.equal(outs[rep][1][k][1], outs[0][1][k][1]), (rep, k, "weights")
