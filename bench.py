@@ -81,6 +81,153 @@ def build_engine(spg, rank, hyperbolic, device):
     return eng, x
 
 
+def make_step(eng, x, spg, gen, device, graph=True):
+    """One timed step = one epoch.  Returns (step, losses): `step()` draws the DataLoader's shuffles -- a fresh permutation for
+    each of the 5 critic passes and the generator pass (argsort of uniform keys: six independent uniform permutations from one
+    batched sort instead of six randperm calls) -- into the STATIC int32 buffer whose address the captured epoch reads, then
+    replays the epoch's hipGraph (or launches it eagerly: same bits)."""
+    losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
+    perm_buf = torch.empty(N_CRITICS + 1, N_BATCHES * B, dtype=torch.int32, device=device)
+
+    def step():
+        perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
+        perm_buf.copy_(perm)
+        if graph:
+            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+        else:
+            eng.train_epoch(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+    return step, losses
+
+
+def profile_kernels(eng, x, spg, device, reps=24):
+    """Per-kernel launch durations of one epoch at `spg` signals, HIP events on the launch stream (hypad_profile_iteration):
+    kind 4 = the critic phase of one epoch (145 iterations) exactly as train_epoch launches it: ONE resident launch
+    (critic_persistent_kernel; reported per iteration and per launch; with its own record producers, or behind a precompute
+    launch) or, where that form cannot run, 145 per-iteration launches (the mean of the steady-state ones); kind 2 =
+    decoder_iteration (generator kernel, dW + Adam).  Returns per-launch ms, launches per epoch, epoch share and the
+    algorithmic FLOPs of one launch of each kernel (SURVEY.md §8d accounting)."""
+    persistent = eng.critic_phase_persistent()
+    names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 2: ["gen", "dw_gen"]}
+    acc = {n: [] for v in names.values() for n in v}
+    idx = torch.arange(B, device=device, dtype=torch.int32)
+    for rep in range(reps):
+        for kind in (4, 2):
+            ms = eng.profile_iteration(kind, x, idx, train_mode=True)
+            if rep >= 4:
+                for n, v in zip(names[kind], ms):
+                    acc[n].append(v)
+    kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_first_or_reinit"}
+    n_it = N_CRITICS * N_BATCHES
+    producers = persistent and eng.critic_phase_producers(n_it)      # the resident launch writes its own records: no precompute launch
+    if persistent:
+        per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
+        launches = {"critic_persistent_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+        if not producers:
+            per_launch["critic_phase_precompute_kernel"] = kern_ms["critic_precompute"]
+            launches["critic_phase_precompute_kernel"] = 1
+    else:
+        per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
+                      "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
+        launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+    epoch_share = {k: per_launch[k] * launches[k] for k in per_launch}
+    # (with producers the resident launch also does the precompute's work: both parts are its algorithmic FLOPs)
+    mac = {"critic_persistent_kernel": (MAC_PER_WINDOW["critic_iteration"] + (MAC_PER_WINDOW["critic_precompute"] if producers else 0)) * n_it,
+           "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
+           "critic_phase_precompute_kernel": MAC_PER_WINDOW["critic_precompute"] * n_it, "gen_kernel": MAC_PER_WINDOW["gen"],
+           "dw_adam_kernel": MAC_PER_WINDOW["dw_gen"]}
+    return {"persistent": persistent, "producers": producers, "kern_ms": kern_ms, "per_launch": per_launch, "launches": launches,
+            "epoch_share_ms": epoch_share, "dominant": max(epoch_share, key=epoch_share.get),
+            "flop_per_launch": {k: 2.0 * mac[k] * B * spg for k in per_launch}}
+
+
+EPOCH_FLOP_PER_SIGNAL = 2.0 * B * N_BATCHES * (N_CRITICS * (MAC_PER_WINDOW["critic_precompute"] + MAC_PER_WINDOW["critic_iteration"])
+                                                + MAC_PER_WINDOW["gen"] + MAC_PER_WINDOW["dw_gen"])
+
+
+def bench_signals(spg, rank, device, gen, warmup=5, steps=20):
+    """`spg` signals (models) per GPU, otherwise configs[1]: the epoch replayed as a captured hipGraph (static shuffle buffer),
+    `warmup` untimed + `steps` timed epochs; the same epochs launched eagerly (host-bound wherever ~61 launches of CPU enqueue
+    exceed the GPU time); per-kernel launch times at this signal count and the chip-level rate: all algorithmic FLOPs of an
+    epoch over the epoch's time, against the fp32-MFMA peak."""
+    eng, x = build_engine(spg, spg * rank, True, device)
+    out = {"workload": "configs[2] per-GPU share: %d signals (%d models) per GPU, otherwise as configs[1]" % (spg, spg),
+           "signals_per_gpu": spg, "steps": steps, "warmup": warmup, "unit": "windows/s (this GPU)",
+           "critic_phase_persistent": eng.critic_phase_persistent()}
+    for mode in ("graph", "eager"):
+        step, losses = make_step(eng, x, spg, gen, device, graph=mode == "graph")
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        eng.check_status()
+        assert bool(torch.isfinite(losses).all())
+        out[mode + "_ms_per_step"] = 1e3 * dt
+    out["launch"] = "hipGraph replay of the captured epoch"
+    out["ms_per_step"] = out["graph_ms_per_step"]
+    out["value"] = spg * N_BATCHES * B / (1e-3 * out["ms_per_step"])
+    prof = profile_kernels(eng, x, spg, device, reps=12)
+    tflops = spg * EPOCH_FLOP_PER_SIGNAL / (1e-3 * out["ms_per_step"]) / 1e12
+    dom = prof["dominant"]
+    out["roofline"] = {"bound": "mfma", "what": "chip level: every kernel's algorithmic FLOPs of one epoch / the epoch's time",
+                       "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
+                       "flop_per_step": spg * EPOCH_FLOP_PER_SIGNAL, "kernel_ms": prof["per_launch"], "launches_per_step": prof["launches"],
+                       "epoch_share_ms": prof["epoch_share_ms"], "dominant": dom,
+                       "dominant_achieved": prof["flop_per_launch"][dom] / (prof["per_launch"][dom] * 1e-3) / 1e12,
+                       "critic_phase": ("resident launch" + (" with its own record producers" if prof["producers"] else " behind a precompute launch"))
+                                       if prof["persistent"] else "one launch per iteration"}
+    del eng, x
+    return out
+
+
+def bench_drop_in(hyperbolic, device, passes=2):
+    """The reference's call surface at speed: `hypad_amd.train.{critic_x,critic_z,decoder}_iteration` driven by the reference's
+    own epoch loop (train.py:315-356) -- nn.Module views of the arenas, one (B, S, 1) float64 sample per call as the
+    DataLoader hands it over, z / alpha drawn on the host by NumPy / torch exactly where the reference draws them.  Times
+    `passes` epochs of 29 x (5 + 5 + 1) iterations after one warm-up epoch."""
+    from types import SimpleNamespace
+    from hypad_amd import train as ht
+    from hypad_amd.models import tadgan
+    P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=hyperbolic)
+    torch.manual_seed(0)
+    enc, dec, cx, cz = [m.to(device) for m in (tadgan.Encoder(S, L), tadgan.Decoder(S, L, hyperbolic), tadgan.CriticX(S, L), tadgan.CriticZ(L))]
+    opt = ht.make_optimizers(enc, dec, cx, cz, P)
+    data = torch.from_numpy(synth_windows(N_WINDOWS, S, 0)[: N_BATCHES * B, :, None])      # float64, like SignalDataset (dataloader.py:227-232)
+    np.random.seed(0)
+
+    def epoch(resident_samples):
+        n = 0
+        for _ in range(N_CRITICS):
+            for b in range(N_BATCHES):
+                sample = resident_samples[b]
+                ht.critic_x_iteration(sample, dec, cx, opt[0], P)
+                ht.critic_z_iteration(sample, enc, cz, opt[1], P)
+                n += 2
+        for b in range(N_BATCHES):
+            ht.decoder_iteration(resident_samples[b], enc, dec, cx, cz, opt[2], P)
+            n += 1
+        return n
+    out = {"what": "reference epoch loop (train.py:315-356) over hypad_amd.train's iteration functions: host NumPy/torch RNG, "
+                   "one call per iteration", "unit": "windows/s"}
+    for name, samples in (("host_samples", [data[b * B:(b + 1) * B] for b in range(N_BATCHES)]),
+                          ("device_samples", [data[b * B:(b + 1) * B].to(device) for b in range(N_BATCHES)])):
+        epoch(samples)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(passes):
+            n += epoch(samples)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": passes * N_BATCHES * B / dt, "us_per_iteration": 1e6 * dt / n, "ms_per_epoch": 1e3 * dt / passes}
+    out["value"] = out["device_samples"]["value"]
+    out["us_per_iteration"] = out["device_samples"]["us_per_iteration"]
+    return out
+
+
 def _cpu_rate(threads, hyperbolic, budget, max_batches):
     """(windows/s, minibatches, seconds) of the oracle's epoch body at `threads` intra-op threads."""
     from types import SimpleNamespace
@@ -138,6 +285,47 @@ def cpu_baseline(hyperbolic, budget_s=24.0):
     return best
 
 
+def cpu_scoring_baseline(n):
+    """The same scoring pass on the host: the oracle's networks (torch CPU, the reference's module structure) for the test-loop
+    forward and oracle/scoring.py (NumPy / SciPy / pandas restatement of utils/anomaly_detection_utils.py) for the numerics, on a
+    bounded sample of `n` windows.  The KDE critic smoothing -- scipy.stats.gaussian_kde once per timestep -- dominates."""
+    from oracle import scoring as osc
+    from oracle import tadgan as ot
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, 8)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    enc, dec, cx = ot.Encoder(S, L).eval(), ot.Decoder(S, L, True).eval(), ot.CriticX(S, L).eval()
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (n, S))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        hyper, eucl = dec(enc(xt.view(1, -1, S)))
+        critic = cx(xt.view(1, -1, S)).reshape(-1).numpy()
+        real = dec.hyperbolic_linear(xt.float()).numpy()
+        eucl = eucl.reshape(-1, S).numpy()
+        hyper = hyper.reshape(-1, S).numpy()
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    true = osc.unroll_true(x)
+    pred, _ = osc.unroll_predictions(eucl, False)
+    w = min(max(n // 100, 2), 200)
+    e1 = osc.zscore_clip(osc.rolling_mean_centered(osc.point_error(true, pred), w))
+    e2 = osc.zscore_clip(osc.rolling_mean_centered(osc.dtw_error(true, pred.astype(np.float64), 10), w))
+    t_num = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cs = osc.final_critic_scores(critic, n, S)
+    t_kde = time.perf_counter() - t0
+    assert np.isfinite(e1).all() and np.isfinite(e2).all() and np.isfinite(cs).all() and np.isfinite(hyper).all() and np.isfinite(real).all()
+    torch.set_num_threads(ncores)
+    tot = t_fwd + t_num + t_kde
+    return {"value": n / tot, "unit": "windows/s", "cores": threads, "host_cores": ncores, "kind": "port",
+            "sample": f"{n} windows of 100: forward {t_fwd:.2f} s (torch CPU, {threads} threads), numerics {t_num:.2f} s, KDE critic smoothing "
+                      f"{t_kde:.2f} s (NumPy / SciPy, 1 thread)",
+            "without_kde_value": n / (t_fwd + t_num)}
+
+
 def _event_ms(fn, reps):
     """Mean duration of fn's kernels, HIP events on the stream they are launched on (torch's current stream = _C.stream())."""
     fn()
@@ -154,7 +342,7 @@ def _event_ms(fn, reps):
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec; 6 290 measured for a float4 copy
 
 
-def bench_scoring(device, n=125_000, reps=5):
+def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
     """BASELINE.json's second metric, anomaly-score windows/s, on this GPU's share of configs[4] (10^6 windows over 8 GPUs): the
     test-loop forward with the hyperbolic row distance (anomaly_detection.py:67-113), then un-roll median + point and DTW errors +
     rolling mean + z-score (utils/anomaly_detection_utils.py:866-962, 516-524).  Returns (scoring, roofline_hbm, roofline_scoring):
@@ -196,10 +384,18 @@ def bench_scoring(device, n=125_000, reps=5):
         e2 = adu.rolling_mean(adu._dtw_error(true, pred, 10), 200)
         return adu.zscore_clip(e1), adu.zscore_clip(e2)
 
-    t_fwd, t_num = timed(forward), timed(numerics)
-    scoring = {"windows": n, "value": n / (t_fwd + t_num), "unit": "windows/s", "forward_windows_per_s": n / t_fwd,
-               "numerics_windows_per_s": n / t_num,
-               "numerics": "un-roll median, point + DTW(11) errors, rolling mean(200), z-score (host wall clock around the wrappers)"}
+    def critic_smoothing():         # final_critic_scores (utils/anomaly_detection_utils.py:365-404): KDE mode per timestep, trimmed z-score, rolling mean
+        return adu._compute_critic_score(adu.kde_modes(critic, S), n // 100)
+
+    t_fwd, t_num, t_kde = timed(forward), timed(numerics), timed(critic_smoothing)
+    scoring = {"windows": n, "value": n / (t_fwd + t_num + t_kde), "unit": "windows/s", "forward_windows_per_s": n / t_fwd,
+               "numerics_windows_per_s": n / t_num, "critic_smoothing_windows_per_s": n / t_kde,
+               "without_kde_value": n / (t_fwd + t_num),
+               "what": "value = test-loop forward + reconstruction numerics (un-roll median, point + DTW(11) errors, rolling mean(200), z-score) "
+                       "+ the KDE critic smoothing score_anomalies runs (utils/anomaly_detection_utils.py:470-506); host wall clock around "
+                       "the wrappers; without_kde_value = the first two only (the figure of rounds 1-2)"}
+    if cpu_sample:
+        scoring["cpu_baseline"] = cpu_scoring_baseline(cpu_sample)
 
     # ---- each scoring kernel on its own: pre-allocated outputs, HIP events
     T = n + S - 1
@@ -250,16 +446,26 @@ def bench_scoring(device, n=125_000, reps=5):
     return scoring, roofline_hbm, roofline_scoring
 
 
-def bench_scoring_sharded(device, world, rank, per_gpu=125_000, reps=3):
-    """configs[4] across the ranks (opt-in: --sharded-scoring): 125 000 windows per GPU of one long series.  Rank 0 holds the
-    trained weights; ONE RCCL broadcast of the parameter arenas (~1 MB) gives them to every rank (parallel.broadcast_weights);
-    every rank then scores its window range (+ halos) and all-gathers the per-window / per-timestep vectors.  Hyperbolic branch
-    (row-wise Poincare distance) and Euclidean branch (un-roll median + DTW): hypad_amd/parallel.py.  All ranks call this."""
+def bench_scoring_sharded(device, world, rank, per_gpu=125_000, reps=5):
+    """configs[4] across the ranks: 125 000 windows per GPU of one long series.  Rank 0 holds the trained weights; ONE RCCL
+    broadcast of the parameter arenas (~1 MB) gives them to every rank (parallel.broadcast_weights); every rank then scores its
+    window range (+ halos) and all-gathers the per-window / per-timestep vectors.  Hyperbolic branch (row-wise Poincare
+    distance) and Euclidean branch (un-roll median + DTW): hypad_amd/parallel.py.  All ranks call this.  At one GPU a
+    world-size-1 `nccl` group is created for the section, so the collectives really run through RCCL (communicator creation,
+    broadcast, all_gather_into_tensor, all_reduce) instead of being skipped."""
     import torch.distributed as dist
     from hypad_amd import parallel as par
     from hypad_amd.models import tadgan
-    out = {"rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
-           "backend": dist.get_backend() if dist.is_initialized() else None}
+    own_group = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+        own_group = True
+    out = {"rccl_world_size": dist.get_world_size(), "backend": dist.get_backend()}
     n = per_gpu * world
     g = torch.Generator(device=device).manual_seed(3)
     series = (torch.rand(n + S - 1, device=device, generator=g) * 2 - 1).contiguous()
@@ -269,29 +475,33 @@ def bench_scoring_sharded(device, world, rank, per_gpu=125_000, reps=3):
         out["broadcast_bytes"] = par.broadcast_weights(mods, src=0)       # ... and takes rank 0's
         enc, dec, cx = mods
         if hyperbolic:
-            fn = lambda: par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1)
+            fn = lambda t: par.score_windows_sharded(series, enc, dec, cx, S, "mult", x_row_stride=1, as_tensor=t)
             want = n
         else:
             y = series.unfold(0, S, 1)[:n].contiguous()                   # (N, S) window matrix for the un-roll
-            fn = lambda: par.score_anomalies_sharded(y, enc, dec, cx, S, rec_error_type="dtw", comb="mult")
+            fn = lambda t: par.score_anomalies_sharded(y, enc, dec, cx, S, rec_error_type="dtw", comb="mult", as_tensor=t)
             want = n + S - 1
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            scores = fn()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        rates = {}
+        for as_tensor in (True, False):                                   # device result (stays in HBM) / NumPy result (the reference's return type)
+            fn(as_tensor)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                scores = fn(as_tensor)
+            torch.cuda.synchronize()
+            rates[as_tensor] = n / ((time.perf_counter() - t0) / reps)
         assert scores.shape == (want,) and np.isfinite(scores).all()
-        if dist.is_initialized():                                         # every rank must hold the same scores
-            chk = torch.tensor([float(np.sum(scores))], device=device, dtype=torch.float64)
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            assert float(lo) == float(hi), "ranks disagree on the gathered scores"
-        out["hyperbolic" if hyperbolic else "euclidean_dtw"] = {"windows": n, "value": n / dt, "unit": "windows/s"}
+        chk = torch.tensor([float(np.sum(scores))], device=device, dtype=torch.float64)      # every rank must hold the same scores
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo) == float(hi), "ranks disagree on the gathered scores"
+        out["hyperbolic" if hyperbolic else "euclidean_dtw"] = {"windows": n, "value": rates[True], "unit": "windows/s",
+                                                                "numpy_result_value": rates[False]}
     out["what"] = ("hyperbolic: forward + row-wise Poincare distance + KDE critic modes by window range, all-gather, global steps on every "
                    "rank; euclidean_dtw: forward + un-roll median + DTW(11) + rolling mean by timestep range, all-gather, z-score + KDE critic "
-                   "scores + 'mult' on every rank")
+                   "scores + 'mult' on every rank; value = scores left on the device, numpy_result_value = returned as NumPy (D2H included)")
+    if own_group:
+        dist.destroy_process_group()
     return out
 
 
@@ -326,7 +536,10 @@ def main():
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
     ap.add_argument("--no-graph", action="store_true", help="launch every epoch eagerly instead of replaying its captured hipGraph")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
-    ap.add_argument("--sharded-scoring", action="store_true", help="also time configs[4]-style scoring sharded over all ranks")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip timing the reference-style loop over hypad_amd.train's iteration functions")
+    ap.add_argument("--no-sharded-scoring", action="store_true", help="skip configs[4]-style scoring sharded over all ranks (RCCL collectives; "
+                                                                      "a one-rank nccl group at --gpus 1)")
+    ap.add_argument("--sharded-scoring", action="store_true", help="run that section at --gpus > 1 too (it is on by default at one GPU)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -349,26 +562,13 @@ def main():
     spg = args.signals_per_gpu
     eng, x = build_engine(spg, rank, hyperbolic, device)
     gen = torch.Generator(device=device).manual_seed(100 + rank)
-    losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
-
-    perm_buf = torch.empty(N_CRITICS + 1, N_BATCHES * B, dtype=torch.int32, device=device)
-
-    def step():
-        # the DataLoader's shuffles: a fresh permutation for each of the 5 critic passes and the generator pass
-        # (argsort of uniform keys: six independent uniform permutations from one batched sort instead of six randperm calls),
-        # written into the buffer whose address the captured epoch reads
-        perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
-        perm_buf.copy_(perm)
-        if args.no_graph:
-            eng.train_epoch(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
-        else:       # the epoch's fixed launch sequence, captured once as a hipGraph and replayed (same bits as eager)
-            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    step, losses = make_step(eng, x, spg, gen, device, graph=not args.no_graph)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -381,58 +581,33 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    eng.check_status()              # (a resident critic launch that gave up would have raised here: the timed epochs were complete)
     last = losses.float().mean(dim=(0, 1)).cpu().tolist()
     assert all(np.isfinite(last)), "training diverged"
 
     # ---- per-kernel durations, HIP events on the launch stream (same workload, after the timed region)
-    # kind 4 = the critic phase of one epoch (145 iterations) exactly as train_epoch launches it: the precompute of the records,
-    # then ONE resident launch (critic_persistent_kernel; reported per iteration and per launch) or, where that form cannot run,
-    # 145 per-iteration launches (the mean of the steady-state ones); kind 2 = decoder_iteration (generator kernel, dW + Adam)
-    persistent = eng.critic_phase_persistent()
-    names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 2: ["gen", "dw_gen"]}
-    acc = {n: [] for v in names.values() for n in v}
-    idx = torch.arange(B, device=device, dtype=torch.int32)
-    for rep in range(24):
-        for kind in (4, 2):
-            ms = eng.profile_iteration(kind, x, idx, train_mode=True)
-            if rep >= 4:
-                for n, v in zip(names[kind], ms):
-                    acc[n].append(v)
-    kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_first_or_reinit"}
-    n_it = N_CRITICS * N_BATCHES
-    # launches per epoch and milliseconds per launch of each kernel
-    producers = persistent and eng.critic_phase_producers(n_it)      # the resident launch writes its own records: no precompute launch
-    if persistent:
-        per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
-        launches = {"critic_persistent_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
-        if not producers:
-            per_launch["critic_phase_precompute_kernel"] = kern_ms["critic_precompute"]
-            launches["critic_phase_precompute_kernel"] = 1
-    else:
-        per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
-                      "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
-        launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
-    share = {k: per_launch[k] * launches[k] for k in per_launch}
-    dom = max(share, key=share.get)
-    # (with producers the resident launch also does the precompute's work: both parts are its algorithmic FLOPs)
-    mac = {"critic_persistent_kernel": (MAC_PER_WINDOW["critic_iteration"] + (MAC_PER_WINDOW["critic_precompute"] if producers else 0)) * n_it,
-           "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
-           "critic_phase_precompute_kernel": MAC_PER_WINDOW["critic_precompute"] * n_it, "gen_kernel": MAC_PER_WINDOW["gen"],
-           "dw_adam_kernel": MAC_PER_WINDOW["dw_gen"]}
-    flop = 2.0 * mac[dom] * B * spg                      # algorithmic FLOPs of ONE launch of the dominant kernel
+    prof = profile_kernels(eng, x, spg, device)
+    per_launch, launches, epoch_share, dom = prof["per_launch"], prof["launches"], prof["epoch_share_ms"], prof["dominant"]
+    persistent, producers, n_it = prof["persistent"], prof["producers"], N_CRITICS * N_BATCHES
+    flop = prof["flop_per_launch"][dom]                  # algorithmic FLOPs of ONE launch of the dominant kernel
     achieved = flop / (per_launch[dom] * 1e-3) / 1e12
 
     # memory-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run, so this is the figure
-    # of the committed rocprofv3 --pmc passes of this same command (profiles/r02_pmc_traffic.json, gfx950 FETCH_SIZE correction
+    # of the committed rocprofv3 --pmc passes of this same command (profiles/r0N_pmc_traffic.json, gfx950 FETCH_SIZE correction
     # of MI355X_MICROARCH.md) -- but only while the kernel sources are the ones that profile was taken on (sha256 recorded in the
     # profile); null otherwise
     traffic, traffic_note = None, "no committed PMC profile matches these kernel sources"
     try:
         from hypad_amd.build import source_digest
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        if prof.get("source_sha256") == source_digest() and dom in prof["kernels"] and hyperbolic and spg == 1:
-            traffic = prof["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_note = "profiles/r02_pmc_traffic.json (same kernel sources: sha256 matches)"
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            pmc = json.load(open(path))
+            if pmc.get("source_sha256") == source_digest() and dom in pmc["kernels"] and hyperbolic and spg == 1:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_note = f"profiles/{name} (same kernel sources: sha256 matches)"
+                break
     except (OSError, KeyError, ValueError):
         pass
 
@@ -443,32 +618,31 @@ def main():
     if dom == "critic_persistent_kernel":
         nchunks, q = B // 16, (L + 3) // 4
         rec = sum(eng.epoch_records(N_BATCHES, N_CRITICS, c)[1].record_floats for c in (0, 1)) * 4 * nchunks
-        share = ((q * (S + 1) + 3 * q * (L + 1) + L + 1) + (q * (L + 1) + q * (L + 1) + L + 1)) * 16 * nchunks     # critic_x (4 hidden layers), critic_z (2)
-        traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + share * (1 + nchunks)))
+        share_bytes = ((q * (S + 1) + 3 * q * (L + 1) + L + 1) + (q * (L + 1) + q * (L + 1) + L + 1)) * 16 * nchunks     # critic_x (4 hidden layers), critic_z (2)
+        traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + share_bytes * (1 + nchunks)))
 
-    # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU
+    # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
+    # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
     secondary = None
     if spg == 1 and hyperbolic and not args.no_secondary:
-        eng8, x8 = build_engine(8, 8 * rank, True, device)
-        l8 = torch.empty(8, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
-        def step8():
-            perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
-            eng8.train_epoch(x8, perm.to(torch.int32).contiguous(), N_BATCHES, N_CRITICS, train_mode=True, losses=l8)
-        for _ in range(2):
-            step8()
-        torch.cuda.synchronize()
-        t8 = time.perf_counter()
-        for _ in range(8):
-            step8()
-        torch.cuda.synchronize()
-        t8 = (time.perf_counter() - t8) / 8
-        assert bool(torch.isfinite(l8).all())
-        secondary = {"workload": "configs[2] per-GPU share: 8 signals (8 models) per GPU, otherwise as configs[1]", "signals_per_gpu": 8,
-                     "ms_per_step": 1e3 * t8, "value": 8 * N_BATCHES * B / t8, "unit": "windows/s (this GPU)",
-                     "critic_phase_persistent": eng8.critic_phase_persistent()}
-        del eng8, x8
+        secondary = bench_signals(8, rank, device, gen)
 
-    sharded = bench_scoring_sharded(device, world, rank) if args.sharded_scoring else None
+    # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
+    # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
+    drop_in = None
+    if spg == 1 and rank == 0 and not args.no_drop_in:
+        drop_in = bench_drop_in(hyperbolic, device)
+
+    sharded = None
+    # (one GPU: on by default, through a one-rank RCCL group; several GPUs: only on request -- the multi-GPU collectives have never
+    # run on hardware in this pool, and the scaling run's headline line must not depend on them)
+    if not args.no_sharded_scoring and not args.no_scoring and (world == 1 or args.sharded_scoring):
+        try:
+            sharded = bench_scoring_sharded(device, world, rank)
+        except Exception as e:      # (an RCCL set-up problem on a box must not cost the run its headline line: reported, not hidden)
+            if world > 1:
+                raise
+            sharded = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         windows = world * spg * N_BATCHES * B * args.steps
         out = {
@@ -498,8 +672,8 @@ def main():
                          "traffic_ratio": (traffic / traffic_algorithmic) if traffic and traffic_algorithmic else None,
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
                          "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
-                         "us_per_critic_iteration": 1e3 * kern_ms["critic_iteration"],
-                         "kernel_ms": per_launch, "epoch_share_ms": share, "flop_per_launch": flop,
+                         "us_per_critic_iteration": 1e3 * prof["kern_ms"]["critic_iteration"],
+                         "kernel_ms": per_launch, "epoch_share_ms": epoch_share, "flop_per_launch": flop,
                          "flop_per_launch_parts": ({"critic_iterations": 2.0 * MAC_PER_WINDOW["critic_iteration"] * n_it * B * spg,
                                                     "record_producers": 2.0 * (MAC_PER_WINDOW["critic_precompute"] if producers else 0) * n_it * B * spg}
                                                    if dom == "critic_persistent_kernel" else None)},
@@ -507,8 +681,10 @@ def main():
         }
         if secondary is not None:
             out["secondary"] = secondary
+        if drop_in is not None:
+            out["drop_in"] = drop_in
         if not args.no_scoring:
-            out["scoring"], out["roofline_hbm"], out["roofline_scoring"] = bench_scoring(device)
+            out["scoring"], out["roofline_hbm"], out["roofline_scoring"] = bench_scoring(device, cpu_sample=0 if args.no_cpu_baseline else 40000)
         if sharded is not None:
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:

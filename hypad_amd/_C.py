@@ -20,12 +20,25 @@ class HypadError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise HypadError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -m hypad_amd.build). "
             "hypad_amd has no CPU fallback.")
-    return ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    # (an override -- HYPAD_LIB_PATH / HYPAD_DEV_LIB, A/B scripts -- may point at a stale build whose structs differ: refuse it
+    # before any symbol is bound or called)
+    try:
+        lib.hypad_abi_version.restype = c_int
+        got = lib.hypad_abi_version()
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise HypadError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it (python -m hypad_amd.build --force)")
+    return lib
 
 
 lib = _load()
@@ -67,7 +80,11 @@ class EpochNoise(Structure):
 class EpochIO(Structure):
     _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise))]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int)]
+
+
+EPOCH_PER_ITERATION = 1            # hypad_epoch_io.flags
+EPOCH_TEST_GIVE_UP_SHIFT = 8
 
 
 class RecordInfo(Structure):
@@ -122,6 +139,8 @@ _SIGS = {
     "hypad_critic_z_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
+    "hypad_epoch_status": (c_int, [POINTER(TrainState), POINTER(c_int), P]),
+    "hypad_epoch_restore": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, P]),
     "hypad_critic_phase_persistent": (c_int, [POINTER(Dims)]),
     "hypad_critic_phase_producers": (c_int, [POINTER(Dims), c_int]),
     "hypad_epoch_record_info": (c_int, [POINTER(Dims), c_int, c_int, c_int, POINTER(RecordInfo)]),

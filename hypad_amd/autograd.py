@@ -5,8 +5,14 @@ Each layer is a ``torch.autograd.Function`` over the library's forward / backwar
 ``hypad_linear_act_{fwd,bwd}``, ``hypad_lstm_bidir_{fwd,bwd}``, ``hypad_mobius_linear_{fwd,bwd}``), so the graph's arithmetic
 is the HIP kernels'; torch only chains them (and draws the dropout masks of train mode).  The fused iteration functions
 of ``hypad_amd.train`` remain the fast path: one launch group per iteration instead of ~20 layer launches.
+
+First-order only: every backward is ``once_differentiable`` -- a reference-style gradient penalty taken through these
+forwards with ``torch.autograd.grad(..., create_graph=True)`` (train.py:72-93) raises instead of silently returning a
+penalty whose second-order gradient is zero.  The WGAN-GP iterations, second-order chain included, are
+``hypad_amd.train.critic_{x,z}_iteration``.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _C
 
@@ -29,6 +35,7 @@ class _LinearAct(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         rows, k, n = x.shape[0], x.shape[1], w.shape[0]
@@ -59,6 +66,7 @@ class _LstmBidirT1(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, go):
         x, wf, wr, gates = ctx.saved_tensors
         rows, k, h = x.shape[0], x.shape[1], wf.shape[0] // 4

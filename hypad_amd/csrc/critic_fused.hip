@@ -139,6 +139,8 @@ struct PhaseArgs {
   // through, after the record's write-through stores have drained) by the workgroup that wrote it; null = the records come from
   // the precompute launch in front
   unsigned* rec_flags;                         // (2 critics, n_signals, n_iters, B/16)
+  int fault_it;                                // tests (HYPAD_EPOCH_TEST_GIVE_UP_SHIFT): > 0 = critic_x chunk 0 of signal 0 behaves as if its
+                                               // wait for the siblings' shares had timed out at that iteration
 };
 // (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
 // neither the stamps nor their setter)
@@ -1033,6 +1035,10 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   int* ctl = reinterpret_cast<int*>(xsc) + 3 * MAXCH;
   auto give_up = [&](unsigned code) __attribute__((always_inline)) {   // called by one lane: tell the workgroup and the siblings
     __hip_atomic_store(ph.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.guard) {                                                     // ... and the host: the first code sticks (hypad_epoch_status)
+      int expected = 0;
+      __hip_atomic_compare_exchange_strong(a.counters + 4, &expected, (int)code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     ctl[0] = 1;
   };
   // Records come from the precompute launch in front of this one, or (ph.rec_flags) from producer workgroups of THIS launch
@@ -1097,7 +1103,8 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       // ---- every chunk's share of iteration it - 1
       if (CHAIN && wave == 0) {
         bool ok = false;
-        for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const bool fault = IS_X && ph.fault_it > 0 && it == ph.fault_it && sig == 0 && chunk == 0;      // (tests: a timed-out wait)
+        for (unsigned spins = fault ? SPIN_LIMIT : 0u; spins < SPIN_LIMIT; ++spins) {
           const unsigned f = lane < nchunks ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)it;
           ok = __all((int)(f >= (unsigned)it));
           if (ok) break;
@@ -1558,6 +1565,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
 template <int SC, int LC, int BC>
 __global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (ax.guard && ax.counters[4] != 0) return;     // fail-stop: an earlier resident launch on this state gave up (hypad_epoch_status)
   if (blockIdx.z >= 2) {            // producer workgroups (ph.rec_flags): the records, in iteration order behind the resident critics
     precompute_body<true>(ax, az, ph, smem, blockIdx.x, blockIdx.y, (blockIdx.z - 2) >> 1, (blockIdx.z - 2) & 1, gridDim.y);
     return;
@@ -1610,21 +1618,47 @@ static int device_cus() {
   }
   return cus[dev] > 0 ? cus[dev] : 0;
 }
-bool critic_phase_persistent(const hypad_dims& d) {
+using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
+// compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
+static IterKernel phase_kernel(int S, int L, int B, bool persistent) {
+  const bool s100 = S == 100 && L == 20 && B == 64, s150 = S == 150 && L == 20 && B == 256;
+  return persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 0> : critic_persistent_kernel<0, 0, 0>)
+                    : (s100 ? critic_iteration_kernel<100, 20, 64> : s150 ? critic_iteration_kernel<150, 20, 0> : critic_iteration_kernel<0, 0, 0>);
+}
+// Does the runtime place at least one workgroup of the resident kernel on a CU (registers + the full LDS plan)?  Asked once
+// per kernel instantiation and device.  (Residency itself comes from the grid: workgroups <= CUs, one per CU.)
+static bool persistent_kernel_fits(int S, int L, int B, size_t lds) {
+  static int cache[64][3] = {{0}};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const int slot = (S == 100 && L == 20 && B == 64) ? 0 : (S == 150 && L == 20 && B == 256) ? 1 : 2;
+  if (cache[dev][slot] == 0 || slot == 2) {
+    const void* kfn = (const void*)phase_kernel(S, L, B, true);
+    int blocks = 0;
+    bool ok = true;
+    if (lds > 64 * 1024) ok = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (ok) ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kfn, FT, lds) == hipSuccess && blocks >= 1;
+    cache[dev][slot] = ok ? 1 : -1;
+  }
+  return cache[dev][slot] > 0;
+}
+bool critic_phase_persistent(const hypad_dims& d, int flags) {
   const char* env = getenv("HYPAD_CRITIC_PERSISTENT");
-  if (env && env[0] == '0') return false;
+  if ((env && env[0] == '0') || (flags & HYPAD_EPOCH_PER_ITERATION)) return false;
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
   const int nchunks = d.batch / 16;
   if (!persist_geom_supported(gx, nchunks) || !persist_geom_supported(gz, nchunks)) return false;
   const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
-  if ((size_t)((lx > lz ? lx : lz) + 3 * MAXCH + 4) * sizeof(float) > 160 * 1024) return false;
-  return (long long)nchunks * d.n_signals * 2 <= device_cus();       // all resident, one workgroup per CU
+  const size_t lds = (size_t)((lx > lz ? lx : lz) + 3 * MAXCH + 4) * sizeof(float);
+  if (lds > 160 * 1024) return false;
+  if ((long long)nchunks * d.n_signals * 2 > device_cus()) return false;       // all resident, one workgroup per CU
+  return persistent_kernel_fits(d.signal_shape, d.latent_dim, d.batch, lds);
 }
 
 // How a phase of n_iters iterations runs in `extra`: iterations per slice, and whether the resident launch carries its own record
 // producers (no precompute launch in front; HYPAD_CRITIC_PRODUCERS=0 turns it off: A/B timing and the equality test)
 struct PhasePlan { bool ok, persistent, fused; int cap; size_t fixed, per_iter; };
-static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iters) {
+static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iters, int flags = 0) {
   PhasePlan p{};
   p.fixed = critic_phase_fixed_floats(d); p.per_iter = critic_phase_floats_per_iter(d);
   if (!critic_phase_supported(d) || extra_floats < p.fixed + p.per_iter) return p;
@@ -1632,7 +1666,7 @@ static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iter
   p.cap = (int)((extra_floats - p.fixed) / p.per_iter);
   if (p.cap > n_iters) p.cap = n_iters;
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
-  p.persistent = critic_phase_persistent(d);
+  p.persistent = critic_phase_persistent(d, flags);
   const char* prod = getenv("HYPAD_CRITIC_PRODUCERS");
   // Producers share the chip with the resident critics, one workgroup per CU either way: they must find free CUs (every CU taken
   // by a critic that waits for its record would be a deadlock -- the bounded polls would end it with an error) and enough of
@@ -1657,9 +1691,9 @@ static size_t sync_block_bytes(const hypad_dims& d, const PhasePlan& p) {
   return b;
 }
 // What hypad_train_epoch's first launch (the weight pack) can zero for the phase: the first slice's block, or nothing
-void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words) {
+void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words, int flags) {
   *ptr = nullptr; *words = 0;
-  const PhasePlan p = plan_phase(d, extra_floats, n_iters);
+  const PhasePlan p = plan_phase(d, extra_floats, n_iters, flags);
   if (!p.ok || !p.persistent) return;
   *ptr = (unsigned*)(((uintptr_t)extra + 15) & ~(uintptr_t)15);
   *words = (int)(sync_block_bytes(d, p) / 4);
@@ -1667,10 +1701,10 @@ void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_flo
 
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
-                     const unsigned* zeroed) {
+                     const unsigned* zeroed, int flags) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
-  const PhasePlan plan = plan_phase(d, extra_floats, n_iters);
+  const PhasePlan plan = plan_phase(d, extra_floats, n_iters, flags);
   if (!plan.ok) return HYPAD_EWORKSPACE;
   const size_t fixed = plan.fixed;
   const int cap = plan.cap;
@@ -1692,17 +1726,14 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     const size_t need = (size_t)(pre_lds(ax.S).total + 4 + (gx.rec_floats > gz.rec_floats ? gx.rec_floats : gz.rec_floats)) * sizeof(float);
     if (need > lds) lds = need;
   }
-  // compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
-  using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
-  const bool s100 = ax.S == 100 && ax.L == 20 && ax.B == 64, s150 = ax.S == 150 && ax.L == 20 && ax.B == 256;
-  const IterKernel kern = persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 0> : critic_persistent_kernel<0, 0, 0>)
-                                     : (s100 ? critic_iteration_kernel<100, 20, 64> : s150 ? critic_iteration_kernel<150, 20, 0> : critic_iteration_kernel<0, 0, 0>);
+  const IterKernel kern = phase_kernel(ax.S, ax.L, ax.B, persistent);
   const void* kfn = (const void*)kern;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   PhaseArgs ph{};
+  ph.fault_it = (flags >> HYPAD_EPOCH_TEST_GIVE_UP_SHIFT) & 0xff;
   // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
   // persistent form's exchange buffers: [epoch words | error word] (zeroed before every launch), granules, merged shares
   float* p = extra;

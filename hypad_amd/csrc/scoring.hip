@@ -288,11 +288,13 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
     if (cnt > 1 && cov > 0.0 && cov == cov) {
       const double inv = 0.5 / cov;
       // pass 1: fp32 densities of this lane's samples.  exp(-d^2 inv) = exp2(-(c d)^2) with c = sqrt(inv log2 e): the samples are
-      // rescaled once (in place: pass 2 reads the fp64 copies), so a pair costs a subtract, a multiply, an exp2 and an add; the
+      // centred and rescaled once (pass 2 reads the fp64 copies), so a pair costs a subtract, a multiply, an exp2 and an add; the
       // slab is padded with +inf to a multiple of four (a padded pair contributes exp2(-inf) = 0) and read four values at a
       // time, every value once for all of the lane's samples.
-      const float cf = __builtin_amdgcn_sqrtf((float)inv * 1.44269504088896341f);
-      for (int k = lane; k < cnt; k += 64) vf[k] *= cf;
+      // The samples are CENTRED first, in fp64 (densities depend on differences only): rescaling the raw values would leave the
+      // fp32 copies with an absolute error of |value| 2^-24 c, which at |mean| / bandwidth beyond ~1e4 exceeds the screen's margin.
+      const double c64 = sqrt(inv * 1.44269504088896341);
+      for (int k = lane; k < cnt; k += 64) vf[k] = (float)((v[k] - mean) * c64);
       if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) vf[cnt + lane] = __int_as_float(0x7f800000);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);

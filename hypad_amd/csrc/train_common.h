@@ -91,6 +91,8 @@ struct IterArgs {
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
+  int guard;                       // 1 (hypad_train_epoch): a launch is a no-op while counters[4] -- the resident critic launch's
+                                   // status word -- is non-zero (fail-stop, see hypad_epoch_status in hypad.h)
   long long* stamps;               // development aid: shader-clock stamps [role][48 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null
 };
 #if HYPAD_DIAG
@@ -217,11 +219,11 @@ size_t critic_phase_fixed_floats(const hypad_dims& d);     // double-buffered op
 size_t critic_phase_floats_per_iter(const hypad_dims& d);  // precomputed records of one (critic_x || critic_z) iteration
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise = nullptr, int* persistent_used = nullptr,
-                     const unsigned* zeroed = nullptr);
+                     const unsigned* zeroed = nullptr, int flags = 0);
 // the block the resident form needs zero in front of its first launch (null: none) -- the caller's previous launch may zero it
-void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words);
+void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words, int flags = 0);
 bool critic_phase_producers(const hypad_dims& d, int n_iters);      // ... and that launch produces the records itself
-bool critic_phase_persistent(const hypad_dims& d);         // the phase runs as ONE resident launch (critic_persistent_kernel)
+bool critic_phase_persistent(const hypad_dims& d, int flags = 0);   // the phase runs as ONE resident launch (critic_persistent_kernel)
 int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad_record_info* out);
 
 }  // namespace train

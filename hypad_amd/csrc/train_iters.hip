@@ -662,6 +662,7 @@ __global__ __launch_bounds__(TB) void critic_gp_pair_kernel(IterArgs ax, IterArg
 template <bool HYPER, int SC, int LC, int BC>
 __global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.guard && a.counters[4] != 0) return;         // fail-stop behind a resident critic launch that gave up (hypad_epoch_status)
   // chain Z (blockIdx.z == 2) goes to the neighbouring XCD: it reads only the encoder's weights and must not queue behind
   // chains G and R for the 32 CUs of theirs (batch 256: 16 tiles x 2 chains fill an XCD)
   if ((blockIdx.x & 7) != ((blockIdx.y + (blockIdx.z == 2 ? 1 : 0)) & 7)) return;
@@ -941,6 +942,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
 // XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
 template <int SC, int LC, int BC, int KS, bool COLOC = false>
 __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
+  if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
     if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
     dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab, (int)(blockIdx.x >> 3));
@@ -1042,6 +1044,7 @@ DecayTable decay_table(const hypad_dims& dm) {
 // the last `nsteps` generator steps of the decay-only parameters; counters[opt] already holds the last step's number
 __global__ __launch_bounds__(256) void decay_steps_kernel(IterArgs a, DecayTable tab, int nsteps) {
   __shared__ float bc[2 * 64];
+  if (a.guard && a.counters[4] != 0) return;
   const int sig = blockIdx.y;
   const int last = a.counters[a.opt];
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1119,13 +1122,36 @@ hipError_t allow_lds(const void* fn, size_t bytes) {
 // ------------------------------------------------------------------------------------------------ packed generator weights
 // Builds the MFMA-native copies (layout.h GenPack) from the parameter arenas: one thread per float4 of a packed block.
 struct PackDesc {
-  int kind;            // 0 W, 1 W with LSTM gate rows compacted, 2 W^T, 3 [W_fwd; W_rev]^T with compacted gate rows, 4 summed biases, 5 critic_x padded image
+  int kind;            // 0 W, 1 W with LSTM gate rows compacted, 2 W^T, 3 [W_fwd; W_rev]^T with compacted gate rows, 4 summed biases, 5 critic_x padded image,
+                       // 6 snapshot of the critics' parameters, moments and the counters (hypad_epoch_restore)
   int net;             // HYPAD_NET_ENCODER / HYPAD_NET_DECODER
   int dst, nout, kred; // packed matrix: nout output rows, kred reduction columns
   int src0, src1, ld, H;
 };
 struct PackTable { int n; int max_units; PackDesc d[32]; };
-__global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab, unsigned* zero_ptr, int zero_words) {
+// Layout of the epoch snapshot (hypad_epoch_restore): per signal [P.cx | M.cx | V.cx | P.cz | M.cz | V.cz], then counters[0..3]
+HD int64_t snapshot_floats(int pcx, int pcz, int n_signals) { return (int64_t)n_signals * 3 * (pcx + pcz) + 4; }
+// one float4 of one signal's snapshot: to the snapshot (restore = false) or back to the arenas
+__device__ __forceinline__ void snapshot_move(const IterArgs& a, float* snap, int sig, int u, bool restore) {
+  const int qx = a.pcx / 4, qz = a.pcz / 4;
+  if (u >= 3 * (qx + qz)) return;
+  float4* sn = reinterpret_cast<float4*>(snap + (int64_t)sig * 3 * (a.pcx + a.pcz)) + u;
+  const bool is_x = u < 3 * qx;
+  const int v = is_x ? u : u - 3 * qx, q = is_x ? qx : qz;
+  const int which = v / q, e = v - which * q;
+  const hypad_nets& N = which == 0 ? a.P : (which == 1 ? a.M : a.V);
+  float4* ar = reinterpret_cast<float4*>(is_x ? N.cx + (int64_t)sig * a.pcx : N.cz + (int64_t)sig * a.pcz) + e;
+  if (restore) *ar = *sn; else *sn = *ar;
+}
+__global__ __launch_bounds__(256) void epoch_restore_kernel(IterArgs a, float* snap, int n_signals) {
+  snapshot_move(a, snap, blockIdx.y, blockIdx.x * 256 + threadIdx.x, true);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) {
+    const int32_t* saved = reinterpret_cast<const int32_t*>(snap + (int64_t)n_signals * 3 * (a.pcx + a.pcz));
+    a.counters[threadIdx.x] = threadIdx.x < 4 ? saved[threadIdx.x] : 0;
+  }
+}
+__global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab, unsigned* zero_ptr, int zero_words, float* snap) {
+  if (a.guard && a.counters[4] != 0) return;   // fail-stop: in particular the snapshot of the state the failed epoch began from stays
   if (zero_words) {                            // (launch_pack: one word per thread of the grid)
     const int64_t flat = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (flat < zero_words) zero_ptr[flat] = 0u;
@@ -1134,6 +1160,11 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
   const int sig = blockIdx.z;
   float* pk = a.ws + sig * a.ws_sig_stride + a.pk_off + d.dst;
   const int u = blockIdx.x * 256 + threadIdx.x;
+  if (d.kind == 6) {
+    snapshot_move(a, snap, sig, u, false);
+    if (u < 4 && sig == 0) reinterpret_cast<int32_t*>(snap + (int64_t)gridDim.z * 3 * (a.pcx + a.pcz))[u] = a.counters[u];
+    return;
+  }
   if (d.kind == 5) {                           // critic_x as the padded image of critic_mfma.h (stage_critic_padded's arithmetic, once)
     const CriticLayout cl = cx_layout(a.S, a.L);
     const CriticPad cp = critic_pad(a.S, a.L, 4);
@@ -1187,7 +1218,7 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
 }
 // where the scoring kernel's padded critic_x image sits in its workspace: behind the packed generator weights, 16-byte aligned
 HD int score_critic_offset(int S, int L, int hyperbolic) { return (gen_pack(S, L, hyperbolic).total + 3) & ~3; }
-PackTable pack_table(const hypad_dims& dm, bool with_critic = false) {
+PackTable pack_table(const hypad_dims& dm, bool with_critic = false, bool with_snapshot = false) {
   const int S = dm.signal_shape, L = dm.latent_dim;
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
@@ -1231,16 +1262,23 @@ PackTable pack_table(const hypad_dims& dm, bool with_critic = false) {
     t.d[t.n++] = d;
     if (units > t.max_units) t.max_units = units;
   }
+  if (with_snapshot) {
+    const int units = 3 * (cx_layout(S, L).total + cz_layout(L).total) / 4;
+    PackDesc d{6, HYPAD_NET_CRITIC_X, 0, units, 0, 0, -1, 0, 0};
+    t.d[t.n++] = d;
+    if (units > t.max_units) t.max_units = units;
+  }
   return t;
 }
 // zero_ptr / zero_words: a block the next launches need zeroed (the critic phase's epoch words and flags), one word per thread
+// snap: where to snapshot the critics' state for hypad_epoch_restore, or null
 int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned* zero_ptr = nullptr, int zero_words = 0, bool* zeroed = nullptr,
-                bool with_critic = false) {
-  const PackTable t = pack_table(dm, with_critic);
+                bool with_critic = false, float* snap = nullptr) {
+  const PackTable t = pack_table(dm, with_critic, snap != nullptr);
   const dim3 grid((t.max_units + 255) / 256, t.n, dm.n_signals);
   const bool z = zero_ptr && zero_words > 0 && (int64_t)zero_words <= (int64_t)grid.x * grid.y * grid.z * 256;
   if (zeroed) *zeroed = z;
-  hipLaunchKernelGGL(pack_generator_kernel, grid, dim3(256), 0, s, a, t, z ? zero_ptr : nullptr, z ? zero_words : 0);
+  hipLaunchKernelGGL(pack_generator_kernel, grid, dim3(256), 0, s, a, t, z ? zero_ptr : nullptr, z ? zero_words : 0, snap);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -1329,6 +1367,7 @@ struct IterCall {
   int train_mode; const float* masks; uint64_t seed;
   float* losses; int64_t loss_sig_stride;
   void* workspace; size_t workspace_bytes;
+  int guard = 0;
 };
 
 // opt: 0 critic_x, 1 critic_z, 2 generator
@@ -1353,7 +1392,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.ws_sig_stride = per;
   a.pk_off = ws_pack_offset(*d) - (opt == 1 ? ws_cz_offset(*d) : 0);       // a.ws is shifted for critic_z
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
-  a.opt = opt; a.tick_owner = 1; a.stamps = nullptr;
+  a.opt = opt; a.tick_owner = 1; a.stamps = nullptr; a.guard = io.guard;
 #if HYPAD_DIAG
   a.stamps = g_gen_stamps;
 #endif
@@ -1560,6 +1599,14 @@ extern "C" void hypad_diag_set_gen_stamps(long long* p) { g_gen_stamps = p; }
 
 extern "C" {
 
+// Floats in front of the hoisted critic phase's area in an epoch workspace: the per-signal iteration workspaces, then the snapshot
+// of the critics' state (hypad_epoch_restore), 64-byte aligned
+static size_t epoch_base_floats(const hypad_dims& d) {
+  const size_t snap = (size_t)snapshot_floats(cx_layout(d.signal_shape, d.latent_dim).total, cz_layout(d.latent_dim).total, d.n_signals);
+  return (size_t)ws_floats_per_signal(d) * d.n_signals + ((snap + 15) & ~(size_t)15);
+}
+static float* epoch_snapshot_ptr(const hypad_dims& d, void* workspace) { return (float*)workspace + (size_t)ws_floats_per_signal(d) * d.n_signals; }
+
 size_t hypad_train_workspace_bytes(const hypad_dims* d) {
   if (check_dims(d)) return 0;
   return (size_t)ws_floats_per_signal(*d) * d->n_signals * sizeof(float);
@@ -1670,7 +1717,7 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
     c.loss_sig_stride = 2 * PROF_ITERS * 4;
     rc = fill_args(ax, d, st, c, 0);
     if (!rc) rc = fill_args(az, d, st, c, 1);
-    const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
+    const size_t base = epoch_base_floats(*d);
     if (!rc && !critic_phase_supported(*d)) rc = HYPAD_EUNSUPPORTED;
     if (!rc && io->workspace_bytes < (base + critic_phase_fixed_floats(*d) + PROF_ITERS * critic_phase_floats_per_iter(*d)) * sizeof(float)) rc = HYPAD_EWORKSPACE;
     if (!rc) rc = launch_pack(ax, *d, (hipStream_t)s);      // the precompute reads the packed generator weights
@@ -1696,8 +1743,8 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* d, int n_batches, int n_cri
   if (check_dims(d) || n_batches <= 0 || n_critics < 0) return 0;
   int64_t n = (int64_t)n_batches * n_critics;
   if (n > 512) n = 512;
-  const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
-  if (!critic_phase_supported(*d) || n == 0) return base * sizeof(float);      // per-minibatch launch groups only
+  const size_t base = epoch_base_floats(*d);
+  if (!critic_phase_supported(*d) || n == 0) return (size_t)ws_floats_per_signal(*d) * d->n_signals * sizeof(float);      // per-minibatch launch groups only
   return (base + critic_phase_fixed_floats(*d) + (size_t)n * critic_phase_floats_per_iter(*d)) * sizeof(float);
 }
 
@@ -1712,11 +1759,12 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.x_row_stride = io->x_row_stride; c.z = nullptr; c.alpha = nullptr;
   c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
   c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
+  c.guard = 1;                                          // every launch of the epoch stops behind a resident critic launch that gave up
   const int iters = (2 * io->n_critics + 1) * io->n_batches;
   c.loss_sig_stride = (int64_t)iters * 4;
   int it = 0;
   const int64_t pass_rows = (int64_t)io->n_batches * d->batch;
-  const size_t base = (size_t)ws_floats_per_signal(*d) * d->n_signals;
+  const size_t base = epoch_base_floats(*d);
   const size_t have = io->workspace_bytes / sizeof(float);
   const int64_t B = d->batch, L = d->latent_dim, S = d->signal_shape, ns = d->n_signals;
   const int64_t mk_cx = 12 * B * L + B * 2 * DEC_H, mk_cz = 6 * B * L, mk_gen = 6 * B * L + 2 * B * 2 * DEC_H;   // hypad_iter_io.drop layouts
@@ -1726,12 +1774,14 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   unsigned* zero_ptr = nullptr;                        // the resident critic launch's epoch words / flags: zeroed by the pack launch
   int zero_words = 0;
   bool zeroed = false;
-  if (hoisted) critic_phase_zero_block(*d, (float*)io->workspace + base, have - base, io->n_critics * io->n_batches, &zero_ptr, &zero_words);
+  if (hoisted) critic_phase_zero_block(*d, (float*)io->workspace + base, have - base, io->n_critics * io->n_batches, &zero_ptr, &zero_words, io->flags);
+  // the resident critic launch can give up (bounded waits): the state it began from is kept for hypad_epoch_restore
+  float* snap = hoisted && critic_phase_persistent(*d, io->flags) ? epoch_snapshot_ptr(*d, io->workspace) : nullptr;
   {                                                    // packed generator weights: built once, then kept current by the dW kernel
     IterArgs ag;
     c.row_index = io->row_index; c.losses = io->losses;
     rc = fill_args(ag, d, st, c, 2);
-    if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s, zero_ptr, zero_words, &zeroed);
+    if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s, zero_ptr, zero_words, &zeroed, false, snap);
     if (rc) return rc;
   }
   if (hoisted) {                                       // train.py:315-328, generator forwards hoisted (critic_fused.hip)
@@ -1745,7 +1795,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
     if (rc) return rc;
     const int n = io->n_critics * io->n_batches;
     rc = run_critic_phase(ax, az, io->row_index, n, io->losses, (float*)io->workspace + base, have - base, d->n_signals,
-                          (hipStream_t)s, nullptr, nz, nullptr, zeroed ? zero_ptr : nullptr);
+                          (hipStream_t)s, nullptr, nz, nullptr, zeroed ? zero_ptr : nullptr, io->flags);
     if (rc) return rc;
     it = 2 * n;
   } else {
@@ -1798,7 +1848,33 @@ int hypad_epoch_record_info(const hypad_dims* d, int n_batches, int n_critics, i
   if (n > 512) return HYPAD_EUNSUPPORTED;
   int rc = critic_phase_record_info(*d, (int)n, critic, out);
   if (rc) return rc;
-  out->offset_floats += (int64_t)ws_floats_per_signal(*d) * d->n_signals;
+  out->offset_floats += (int64_t)epoch_base_floats(*d);
+  return HYPAD_OK;
+}
+
+int hypad_epoch_status(const hypad_train_state* st, int* status_host, hypad_stream_t s) {
+  if (!st || !st->counters || !status_host) return HYPAD_EINVAL;
+  int32_t v = 0;
+  hipError_t e = hipMemcpyAsync(&v, st->counters + 4, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)s);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)s);
+  if (e != hipSuccess) return (int)e;
+  *status_host = (int)v;
+  return HYPAD_OK;
+}
+
+int hypad_epoch_restore(const hypad_dims* d, const hypad_train_state* st, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!st || !st->counters || !st->params.cx || !st->params.cz || !st->exp_avg.cx || !st->exp_avg.cz || !st->exp_avg_sq.cx || !st->exp_avg_sq.cz)
+    return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < epoch_base_floats(*d) * sizeof(float)) return HYPAD_EWORKSPACE;
+  IterArgs a{};
+  a.P = st->params; a.M = st->exp_avg; a.V = st->exp_avg_sq; a.counters = st->counters;
+  a.pcx = cx_layout(d->signal_shape, d->latent_dim).total; a.pcz = cz_layout(d->latent_dim).total;
+  const int units = 3 * (a.pcx + a.pcz) / 4;
+  hipLaunchKernelGGL(epoch_restore_kernel, dim3((units + 255) / 256, d->n_signals), dim3(256), 0, (hipStream_t)s, a, epoch_snapshot_ptr(*d, workspace),
+                     d->n_signals);
+  HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
 

@@ -7,6 +7,7 @@ workspace, and exposes the three iterations and a whole epoch (train.py:299-356)
 stays resident in HBM.  ``hypad_amd.train`` wraps it with n_signals = 1 around user-visible nn.Modules.
 """
 import ctypes
+import logging
 
 import numpy as np
 import torch
@@ -32,7 +33,9 @@ class Engine:
         self.params = {k: z(k) for k in NETS}
         self.exp_avg = {k: z(k) for k in NETS}
         self.exp_avg_sq = {k: z(k) for k in NETS}
-        self.counters = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.counters = torch.zeros(8, dtype=torch.int32, device=self.device)    # [0..2] optimizer steps, [3] rng tick, [4] status word
+        self.epoch_flags = 0                     # hypad_epoch_io.flags of every epoch (EPOCH_PER_ITERATION after a recovery)
+        self._last_epoch = None                  # arguments of the last train_epoch / train_epoch_graph call (check_status re-runs it)
         self.dims = _C.Dims(self.S, self.L, self.B, int(self.hyperbolic), self.n)
         nbytes = _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims))
         if nbytes == 0:
@@ -44,6 +47,17 @@ class Engine:
         if nbytes > self._ws_bytes:
             self.workspace = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             self._ws_bytes = nbytes
+            self._drop_graphs()                  # captured epochs hold the old workspace's address
+
+    def _drop_graphs(self):
+        self.__dict__.pop("_graphs", None)
+
+    def _graph_state_key(self):
+        """Everything a captured epoch froze besides its call arguments: the arenas', moments', counters' and workspace's
+        addresses and the optimizer scalars (passed by value)."""
+        ptrs = tuple(d[k].data_ptr() for d in (self.params, self.exp_avg, self.exp_avg_sq) for k in NETS)
+        return ptrs + (self.counters.data_ptr(), self.workspace.data_ptr(), self._ws_bytes, self.lr, self.betas, self.eps, self.gen_wd,
+                       self.gen_stab, self.epoch_flags)
 
     # ---- weights in / out ------------------------------------------------------------------------------
     def catalogue(self, net):
@@ -69,6 +83,7 @@ class Engine:
             self.exp_avg[k] = t.view(1, -1)
         for k, t in (exp_avg_sq or {}).items():
             self.exp_avg_sq[k] = t.view(1, -1)
+        self._drop_graphs()
 
     # ---- C structs -------------------------------------------------------------------------------------
     def _nets(self, d):
@@ -169,27 +184,63 @@ class Engine:
             losses = getattr(self, "_graph_losses", None)
             if losses is None or losses.shape != (self.n, iters, 4):
                 losses = self._graph_losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
-        key = (x.data_ptr(), row_index.data_ptr(), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride), self.seed)
+        self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
+        key = (x.data_ptr(), row_index.data_ptr(), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride), self.seed,
+               self._graph_state_key())
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
-            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                    # (side stream: _C.stream() is torch's current stream inside the block)
                 self.train_epoch(x, row_index, n_batches, n_critics, train_mode, losses=losses, x_row_stride=x_row_stride)
-            graphs[key] = g
+            graphs[key] = (g, x, row_index, losses)      # (the buffers whose addresses the graph holds stay alive with it)
             # the capture itself did not execute anything
-        graphs[key].replay()
+        graphs[key][0].replay()
+        self._last_epoch = dict(x=x, row_index=row_index, n_batches=n_batches, n_critics=n_critics, train_mode=train_mode, losses=losses,
+                                x_row_stride=x_row_stride)
         return losses
 
+    # ---- status channel of the resident critic launch (include/hypad.h: hypad_epoch_status / hypad_epoch_restore) -------------
+    def status(self):
+        """counters[4] after everything enqueued so far (synchronises the stream): 0, or the code of the bounded wait that gave up."""
+        st = self._state()
+        out = ctypes.c_int(0)
+        _C.check(_C.lib.hypad_epoch_status(ctypes.byref(st), ctypes.byref(out), _C.stream()), "epoch_status")
+        return out.value
+
+    def check_status(self, recover=True):
+        """Call where the host reads an epoch's losses.  If the epoch's resident critic launch gave up (a withheld CU: CU mask,
+        partitioned or shared device), the launches behind it were no-ops; with ``recover`` the critics and counters are put
+        back to the state that epoch began from, the epoch is repeated with one launch per critic iteration (same random
+        streams: the bits the resident form would have produced) and every later epoch of this engine uses that form.
+        Returns the status code that was found (0 = nothing happened); raises without ``recover``."""
+        code = self.status()
+        if code == 0:
+            return 0
+        if not recover or self._last_epoch is None:
+            raise _C.HypadError(f"the resident critic launch gave up (status 0x{code:x}: a bounded wait for a sibling workgroup timed out)")
+        logging.getLogger("hypad_amd").warning(
+            "resident critic launch gave up (status 0x%x): restoring the critics and repeating the epoch with per-iteration launches", code)
+        st = self._state()
+        _C.check(_C.lib.hypad_epoch_restore(ctypes.byref(self.dims), ctypes.byref(st), self.workspace.data_ptr(), self._ws_bytes, _C.stream()),
+                 "epoch_restore")
+        self.epoch_flags = (self.epoch_flags & 0xff) | _C.EPOCH_PER_ITERATION      # (any test-hook bits above bit 7 go)
+        self._drop_graphs()
+        self.train_epoch(**self._last_epoch)
+        again = self.status()
+        if again:
+            raise _C.HypadError(f"status 0x{again:x} after the per-iteration re-run")
+        return code
+
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None,
-                    workspace_iters=None):
+                    workspace_iters=None, flags=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
         hoist=False keeps the per-minibatch launch groups for the critic phase (A/B checks).
         x_row_stride=1: x is the scaled series (SignalDataset.window_view), not a window matrix.
         workspace_iters: hand the library only the workspace of that many critic iterations (it then processes the phase in
         slices of that length: what it does on its own for phases longer than 512 iterations) -- tests.
         noise: optional dict of injected planes (hypad_epoch_noise: z_cx, alpha_cx, z_cz, alpha_cz, z_gen, masks_*; float32
-        device tensors, iteration-major) replacing the device Philox draws -- parity runs."""
+        device tensors, iteration-major) replacing the device Philox draws -- parity runs.
+        flags: hypad_epoch_io.flags for this call (default: the engine's ``epoch_flags``)."""
         x, stride = self._check_x(x, x_row_stride)
         if hoist:
             self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
@@ -206,7 +257,11 @@ class Engine:
                         losses.data_ptr(), self.workspace.data_ptr(),
                         (self._ws_bytes if workspace_iters is None else _C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), int(workspace_iters), 1))
                         if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
-                        ctypes.pointer(nz) if nz is not None else None)
+                        ctypes.pointer(nz) if nz is not None else None, int(self.epoch_flags if flags is None else flags))
         st = self._state()
         _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")
+        if not torch.cuda.is_current_stream_capturing():
+            self._last_epoch = dict(x=x, row_index=row_index, n_batches=n_batches, n_critics=n_critics,
+                                    train_mode=train_mode, losses=losses, hoist=hoist, x_row_stride=x_row_stride, noise=noise,
+                                    workspace_iters=workspace_iters)
         return losses

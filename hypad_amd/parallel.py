@@ -13,6 +13,13 @@ import torch
 import torch.distributed as dist
 
 
+def _group_active(group=None):
+    """True when a process group exists: the collectives below then RUN -- also at world size 1 (a one-GPU box still creates
+    the RCCL communicator and executes broadcast / all-gather / all-reduce, so the nccl branches are the code that is
+    tested, not dead code until an 8-GPU node shows up).  Without a process group they are no-ops."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def signals_of_rank(n_signals, world, rank):
     """Round-robin ownership of signals."""
     return list(range(rank, n_signals, world))
@@ -42,7 +49,7 @@ def timestep_range(n_windows, world, rank, window):
 def global_zscore_stats(local_sum, local_sumsq, local_count, group=None):
     """Mean and population std over all ranks from one all-reduce of (sum, sum sq, count) (stats.zscore, ddof=0)."""
     t = torch.tensor([local_sum, local_sumsq, local_count], dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized():
+    if _group_active(group):
         if dist.get_backend(group) == "nccl":
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -57,7 +64,7 @@ def broadcast_weights(modules, src=0, group=None):
     """One-time broadcast of the shared generator / critic weights for sharded scoring (~1 MB, RCCL
     broadcast over xGMI): every module's flat parameter arena is overwritten with rank ``src``'s.  A no-op without a
     process group.  Returns the number of bytes broadcast."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _group_active(group):
         return 0
     nbytes = 0
     for m in modules:
@@ -74,7 +81,7 @@ def broadcast_weights(modules, src=0, group=None):
 
 def gather_signal_metrics(local, group=None):
     """{signal_id: metrics} from every rank -> merged dict on every rank (end-of-run only; KB-sized)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _group_active(group):
         return dict(local)
     out = [None] * dist.get_world_size(group)
     dist.all_gather_object(out, dict(local), group=group)
@@ -88,7 +95,7 @@ def gather_signal_metrics(local, group=None):
 def _all_gather_ranges(local, total, ranges, group=None):
     """Every rank contributes the 1-D tensor `local` = its [begin, end) slice of a vector of `total` elements
     (`ranges[r]` = rank r's slice); returns the whole vector on every rank.  One all-gather of equal-sized (padded) pieces."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _group_active(group):
         return local
     world = dist.get_world_size(group)
     width = max(e - b for b, e in ranges)
@@ -120,7 +127,7 @@ def sharded_hyperbolic_scores(n_windows, window, evaluate, kde_modes, finish, ne
     * ``finish(rowdist, modes, norms)`` -> final scores: the global steps (quantile-trimmed z-score of the modes, rolling
       mean, combination) on the full vectors, exactly the unsharded code, so the result does not depend on the world size.
     """
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    world = dist.get_world_size(group) if _group_active(group) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     b, e = window_range(n_windows, world, rank)
     hb, he = window_range_with_halo(n_windows, world, rank, window)
@@ -143,34 +150,48 @@ def sharded_hyperbolic_scores(n_windows, window, evaluate, kde_modes, finish, ne
     return finish(rowdist, modes, norms)
 
 
+_WS_CACHE = {}
+
+
+def _score_workspace(device, S, L, hyperbolic):
+    """The fused forward's workspace (packed weights, rebuilt by every call of it), allocated once per (device, shape)."""
+    from . import _C
+    key = (str(device), S, L, int(hyperbolic))
+    if key not in _WS_CACHE:
+        nbytes = _C.lib.hypad_score_workspace_bytes(S, L, int(hyperbolic))
+        _WS_CACHE[key] = (torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=device), nbytes)
+    return _WS_CACHE[key]
+
+
 def score_windows_sharded(x, encoder, decoder, critic_x, signal_shape, combination="mult", group=None, x_row_stride=0,
-                          n_windows=None):
+                          n_windows=None, as_tensor=False):
     """``sharded_hyperbolic_scores`` on the device kernels: ``x`` is the (N, S) fp32 window matrix -- or, with
     ``x_row_stride=1``, the scaled series whose window n is x[n : n + S] -- resident on every rank, like the weights
-    (broadcast them once with ``torch.distributed.broadcast(module.arena(), 0)`` if the ranks did not load the same
-    checkpoint).  Returns the final scores, (N,) float64 NumPy, on every rank."""
+    (broadcast them once with ``broadcast_weights`` if the ranks did not load the same checkpoint).  Returns the final
+    scores, (N,) float64, on every rank: a NumPy array as the reference's functions return, or (``as_tensor``) the device
+    tensor.  Per window only its distance and critic value leave the fused forward (8 bytes; the reconstructions are
+    written only where a combination needs their norms)."""
     import math
     from . import _C
-    from .hyperspace import gmath
     from .utils import anomaly_detection_utils as adu
     if not decoder.hyperbolic:
         raise ValueError("score_windows_sharded is the hyperbolic branch; use score_anomalies_sharded for Euclidean models")
     S, L = signal_shape, encoder.latent_space_dim
     N = n_windows if n_windows is not None else (x.shape[0] if x_row_stride == 0 else x.numel() - S + 1)
     need_norms = "uncertainty" in combination
-    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 1)
-    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=x.device)
+    ws, ws_bytes = _score_workspace(x.device, S, L, 1)
     encoder.eval(); decoder.eval(); critic_x.eval()
 
     def evaluate(lo, hi):
         n = hi - lo
         new = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
-        hyper, eucl, hreal, critic, dist_ = new(n, S), new(n, S), new(n, S), new(n), new(n)
+        hyper = new(n, S) if need_norms else None
+        critic, dist_ = new(n), new(n)
         xs = x[lo:hi] if x_row_stride == 0 else x[lo * x_row_stride:]
         _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(encoder.arena()), _C.ptr(decoder.arena()), _C.ptr(critic_x.arena()), _C.ptr(xs),
-                                                   x_row_stride, _C.ptr(hyper), _C.ptr(eucl), _C.ptr(hreal), _C.ptr(critic), _C.ptr(dist_),
+                                                   x_row_stride, _C.ptr(hyper), None, None, _C.ptr(critic), _C.ptr(dist_),
                                                    n, S, L, 1, ws.data_ptr(), ws_bytes, _C.stream()), "score_forward_packed")
-        out = {"rowdist": gmath.poincare_rowdist(hreal, hyper), "critic": critic}
+        out = {"rowdist": dist_, "critic": critic}
         if need_norms:
             out["norms"] = adu.row_norms(hyper)
         return out
@@ -179,7 +200,7 @@ def score_windows_sharded(x, encoder, decoder, critic_x, signal_shape, combinati
         critic_scores = []
         if combination in ("mult", "uncertainty", "sum", "sum_uncertainty", "critic", "critic_uncertainty"):
             critic_scores = adu._compute_critic_score(modes, math.trunc(N * 0.01))[:N]
-        return adu.combine_scores(combination, critic_scores, rowdist, norms=norms)
+        return adu.combine_scores(combination, critic_scores, rowdist, norms=norms, as_tensor=as_tensor)
 
     return sharded_hyperbolic_scores(N, S, evaluate, adu.kde_modes, finish, need_norms, group)
 
@@ -220,7 +241,7 @@ def sharded_euclidean_scores(n_windows, window, smooth_window, evaluate, unroll_
     vectors on every rank: the scores do not depend on the world size.  ``zscore="allreduce"`` instead normalises each
     rank's errors with the global (sum, sum of squares, count) of ONE 24-byte all-reduce before the gather (``finish`` then
     receives z-scores; the summation order, hence the last bits, depend on the world size)."""
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    world = dist.get_world_size(group) if _group_active(group) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     T = n_windows + window - 1
     tb, te = timestep_range(n_windows, world, rank, window)
@@ -255,12 +276,12 @@ def sharded_euclidean_scores(n_windows, window, smooth_window, evaluate, unroll_
 
 
 def score_anomalies_sharded(y, encoder, decoder, critic_x, signal_shape, rec_error_type="point", comb="mult", score_window=10,
-                            group=None, zscore="gather"):
+                            group=None, zscore="gather", as_tensor=False):
     """``sharded_euclidean_scores`` on the device kernels: the Euclidean branch of the reference's scoring
     (``test_tadgan`` batch body anomaly_detection.py:67-113 -> ``score_anomalies`` utils/anomaly_detection_utils.py:407-576)
     for a window matrix ``y`` (N, S) -- float32 or float64, resident on every rank like the weights.  Returns the final
-    scores, (N + S - 1,) float64 NumPy, on every rank; equal bit for bit to ``utils.anomaly_detection_utils.score_anomalies``
-    on the un-sharded reconstructions (``zscore="gather"``)."""
+    scores, (N + S - 1,) float64 -- NumPy, or (``as_tensor``) the device tensor -- on every rank; equal bit for bit to
+    ``utils.anomaly_detection_utils.score_anomalies`` on the un-sharded reconstructions (``zscore="gather"``)."""
     import math
     from . import _C
     from .utils import anomaly_detection_utils as adu
@@ -273,13 +294,12 @@ def score_anomalies_sharded(y, encoder, decoder, critic_x, signal_shape, rec_err
     kind = rec_error_type.lower()
     if kind not in ("point", "area", "dtw"):
         raise ValueError(rec_error_type)
-    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 0)
-    ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=y.device)
+    ws, ws_bytes = _score_workspace(y.device, S, L, 0)
     encoder.eval(); decoder.eval(); critic_x.eval()
 
     def evaluate(lo, hi):
         n = hi - lo
-        xs = y[lo:hi].to(torch.float32).contiguous()
+        xs = y[lo:hi].to(torch.float32).contiguous()            # (no copy when the windows already are fp32)
         recon = torch.empty(n, S, device=y.device, dtype=torch.float32)
         critic = torch.empty(n, device=y.device, dtype=torch.float32)
         _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(encoder.arena()), _C.ptr(decoder.arena()), _C.ptr(critic_x.arena()), _C.ptr(xs), 0,
@@ -300,7 +320,7 @@ def score_anomalies_sharded(y, encoder, decoder, critic_x, signal_shape, rec_err
         else:
             rec_scores = torch.clamp(rec_scores, min=0) + 1
         critic_scores = adu._compute_critic_score(modes, w)
-        return adu.combine_euclidean(comb, critic_scores, rec_scores)
+        return adu.combine_euclidean(comb, critic_scores, rec_scores, as_tensor=as_tensor)
 
     return sharded_euclidean_scores(N, S, w, evaluate, lambda r: adu.unroll_predictions(r, False)[0], error_fn, adu.rolling_mean,
                                     adu.kde_modes, finish, score_window, group, zscore)

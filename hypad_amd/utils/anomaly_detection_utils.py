@@ -132,8 +132,9 @@ def row_norms(x):
     return out
 
 
-def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[], norms=None):
-    """:336-362.  ``norms``: the row norms of ``recons_signal`` when the caller already has them (sharded scoring)."""
+def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[], norms=None, as_tensor=False):
+    """:336-362.  ``norms``: the row norms of ``recons_signal`` when the caller already has them (sharded scoring);
+    ``as_tensor``: leave the result on the device instead of returning NumPy."""
     if combination not in ("sum", "mult", "uncertainty", "critic", "critic_uncertainty", "sum_uncertainty", "rec", "rec_uncertainty"):
         raise ValueError(combination)
     c = _f64(critic_scores) if len(critic_scores) else None
@@ -146,10 +147,10 @@ def combine_scores(combination, critic_scores=[], rec_scores=[], recons_signal=[
         c = c[:n].contiguous()
     out = torch.empty(n, device=_dev(), dtype=torch.float64)
     _C.check(_C.lib.hypad_combine_scores(_C.COMB[combination], _C.ptr(c), _C.ptr(r), _C.ptr(u), _C.ptr(out), n, _C.stream()), "combine")
-    return out.cpu().numpy()
+    return out if as_tensor else out.cpu().numpy()
 
 
-def combine_euclidean(comb, critic_scores, rec_scores):
+def combine_euclidean(comb, critic_scores, rec_scores, as_tensor=False):
     """Tail of score_anomalies (:553-570), lambda_rec = 0.5."""
     mode = {"mult": "eucl_mult", "sum": "eucl_sum", "rec": "rec", "critic": "critic"}.get(comb)
     if mode is None:
@@ -157,7 +158,7 @@ def combine_euclidean(comb, critic_scores, rec_scores):
     c, r = _f64(critic_scores), _f64(rec_scores)
     out = torch.empty_like(r)
     _C.check(_C.lib.hypad_combine_scores(_C.COMB[mode], _C.ptr(c), _C.ptr(r), None, _C.ptr(out), r.numel(), _C.stream()), "combine")
-    return out.cpu().numpy()
+    return out if as_tensor else out.cpu().numpy()
 
 
 def _compute_critic_score(critics, smooth_window):

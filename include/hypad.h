@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HYPAD_ABI_VERSION 2
+#define HYPAD_ABI_VERSION 3
 
 enum {
   HYPAD_OK = 0,
@@ -180,7 +180,9 @@ typedef struct hypad_train_state {
   hypad_nets params;       /* signal s of a net at base + s * hypad_param_count(net) */
   hypad_nets exp_avg;      /* Adam first moment, same layout */
   hypad_nets exp_avg_sq;   /* Adam second moment */
-  int32_t* counters;       /* device int32[4]: optimizer steps taken by {critic_x, critic_z, generator}, rng ticks */
+  int32_t* counters;       /* device int32[8]: [0..2] optimizer steps taken by {critic_x, critic_z, generator}, [3] rng ticks,
+                              [4] STATUS of hypad_train_epoch's resident critic launch (0 = fine; otherwise the code of the first
+                              bounded wait that gave up, see hypad_epoch_status), [5..7] reserved (zero) */
   float lr, beta1, beta2, eps;
   float gen_weight_decay;  /* hyperbolic generator optimizer: 1e-5 (train.py:286); ignored otherwise */
   int gen_stabilize;       /* 10 (train.py:287) */
@@ -247,7 +249,14 @@ typedef struct hypad_epoch_io {
   void* workspace; size_t workspace_bytes;   /* >= hypad_train_workspace_bytes(dims); with >= hypad_epoch_workspace_bytes(...)
                                                 the critic phase runs in its hoisted form (see below) */
   const hypad_epoch_noise* noise;            /* NULL: all randomness from device Philox(seed) */
+  int flags;                                 /* HYPAD_EPOCH_* bits, 0 = defaults */
 } hypad_epoch_io;
+enum {
+  HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits
+                                                (what HYPAD_CRITIC_PERSISTENT=0 in the environment selects for every call) */
+  HYPAD_EPOCH_TEST_GIVE_UP_SHIFT = 8         /* tests only: bits 8..15 = k > 0 makes the resident launch behave as if its wait for the
+                                                siblings' shares had timed out at critic iteration k (signal 0, critic_x) */
+};
 /* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
  * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up
  * to 512 iterations of precomputed rows (longer phases are processed in chunks).  Same random streams and the same
@@ -263,6 +272,22 @@ int hypad_critic_phase_persistent(const hypad_dims* dims);
  * the device's CUs (the producers need the others); HYPAD_CRITIC_PRODUCERS=0 turns it off. */
 int hypad_critic_phase_producers(const hypad_dims* dims, int n_iters);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
+
+/* Status channel of the resident critic launch.  That launch needs every one of its critic workgroups co-resident (one per CU:
+ * the launcher checks the grid against the device's CU count and the kernel's occupancy, but a CU mask, a partitioned or shared
+ * device can still withhold CUs) and all its waits are bounded: a wait that gives up stores its code -- 0x100 + it: a sibling's
+ * gradient share of critic iteration `it` never arrived; 0x200 + it: a sibling's scalars; 0x300 + it: a record -- into
+ * counters[4] (first code wins), writes NaN into that iteration's loss row, and the launch ends.  From then on every training
+ * launch of hypad_train_epoch on this state is a no-op (fail-stop: the generator is never stepped against half-updated
+ * critics, the snapshot below is never overwritten) until hypad_epoch_restore.
+ *   hypad_epoch_status : copies counters[4] to *status_host and SYNCHRONISES the stream (not capturable).
+ *   hypad_epoch_restore: puts both critics' parameters and moments and counters[0..3] back to what they were when the failed
+ *                        hypad_train_epoch call began (it snapshots them into its workspace first: 50 KB per signal) and clears
+ *                        counters[4]; the caller then repeats that epoch with HYPAD_EPOCH_PER_ITERATION -- same random streams,
+ *                        same bits as the resident form would have produced.  Capturable; workspace = the failed call's. */
+int hypad_epoch_status(const hypad_train_state* st, int* status_host, hypad_stream_t stream);
+int hypad_epoch_restore(const hypad_dims* dims, const hypad_train_state* st, void* workspace, size_t workspace_bytes,
+                        hypad_stream_t stream);
 
 /* Where hypad_train_epoch's hoisted critic phase left its precomputed records (tests and tools; valid after a call with
  * n_critics * n_batches <= 512 iterations): records of critic `critic` (0 = critic_x, 1 = critic_z) start `offset_floats` floats

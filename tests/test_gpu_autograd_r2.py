@@ -84,3 +84,20 @@ def test_custom_training_loop_outside_the_fused_iterations():
     with torch.no_grad():
         rec = dec.eval()(enc.eval()(x.view(1, 64, 100)))                       # fused inference kernels, same arena
     assert abs(float(torch.nn.functional.mse_loss(rec.view(64, 100), x)) - last) < 0.2 * first
+
+
+def test_double_backward_through_the_module_forwards_raises():
+    """The layer Functions are first-order (once_differentiable): a reference-style gradient penalty -- torch.autograd.grad(...,
+    create_graph=True) then backward through the gradient, train.py:72-93 -- must fail loudly, not return a penalty whose
+    second-order gradient is silently zero.  (The fused critic iterations carry the second-order chain themselves.)"""
+    from hypad_amd.hyperspace import gmath
+    o, h = _pair(100, True)
+    x = torch.rand(32, 100, device="cuda").requires_grad_(True)
+    out = h["cx"](x.view(1, 32, 100)).sum()
+    (g,) = torch.autograd.grad(out, x, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|not differentiable twice"):
+        g.norm().backward()
+    y = (0.3 * torch.rand(8, 100, device="cuda")).requires_grad_(True)
+    (gy,) = torch.autograd.grad(gmath.expmap0(y).sum(), y, create_graph=True)
+    with pytest.raises(RuntimeError):
+        gy.sum().backward()

@@ -276,7 +276,7 @@ def test_eight_signals_per_gpu_match_single_models(dev):
             eng8.load_state_dict(k, m.state_dict(), s)
     l8 = eng8.train_epoch(cu(x), cu(perm, torch.int32), nb, nc, False, noise={k: cu(v) for k, v in planes.items()})
     torch.cuda.synchronize()
-    assert eng8.counters.cpu().tolist() == [nb * nc, nb * nc, nb, nb * nc + nb]
+    assert eng8.counters[:4].cpu().tolist() == [nb * nc, nb * nc, nb, nb * nc + nb]
     for s in (0, 3, 7):
         e1 = _engine(mods[s], S, B, True)
         l1 = e1.train_epoch(cu(x[s:s + 1]), cu(perm, torch.int32), nb, nc, False, noise={k: cu(v[:, s:s + 1]) for k, v in planes.items()})
@@ -341,7 +341,7 @@ def test_epoch_as_hip_graph_equals_eager(dev):
         assert torch.equal(la, lb), e
     for net in ("enc", "dec", "cx", "cz"):
         assert torch.equal(ea.params[net], eb.params[net]), net
-    assert ea.counters.cpu().tolist() == eb.counters.cpu().tolist() == [3 * nb * nc, 3 * nb * nc, 3 * nb, 3 * (nb * nc + nb)]
+    assert ea.counters[:4].cpu().tolist() == eb.counters[:4].cpu().tolist() == [3 * nb * nc, 3 * nb * nc, 3 * nb, 3 * (nb * nc + nb)]
 
 
 @pytest.mark.parametrize("persistent", ["1", "0"])
@@ -365,7 +365,7 @@ def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
         assert e.critic_phase_persistent() == (persistent == "1")
         l = e.train_epoch(xs, perm, nb, nc, True, workspace_iters=wi)
         torch.cuda.synchronize()
-        outs.append((l.clone(), {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}, e.counters.cpu().tolist()))
+        outs.append((l.clone(), {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}, e.counters[:4].cpu().tolist()))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and o[2] == outs[0][2]
         for k in ("cx", "cz", "enc", "dec"):

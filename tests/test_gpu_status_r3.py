@@ -1,0 +1,132 @@
+"""Round 3: the status channel of the resident critic launch (include/hypad.h: counters[4], hypad_epoch_status,
+hypad_epoch_restore, HYPAD_EPOCH_PER_ITERATION) and the engine's graph cache.
+
+The resident launch (critic_persistent_kernel) needs all its critic workgroups co-resident and bounds every wait.  A wait
+that gives up must (a) reach the host, (b) stop the epoch's remaining launches (the generator must not be stepped against
+half-updated critics), and (c) be recoverable: critics + counters restored, the epoch repeated with one launch per critic
+iteration -- the same bits a healthy resident launch produces (train.py:299-356 is the schedule either way)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda", dtype).contiguous()
+
+
+def _setup(ns=1, seed=5, S=100, B=64, nb=3, nc=2, hyper=True):
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    rng = np.random.default_rng(seed)
+    N = nb * B
+    x = cu(np.clip(np.sin(np.arange(N)[None, :, None] / (9.0 + np.arange(ns)[:, None, None]) + np.arange(S)[None, None, :] / 7.0)
+                   + 0.05 * rng.standard_normal((ns, N, S)), -1, 1))
+    perms = [cu(np.stack([rng.permutation(N) for _ in range(nc + 1)]), torch.int32) for _ in range(3)]
+
+    def engine():
+        eng = Engine(S, 20, B, hyper, n_signals=ns, lr=5e-4, seed=99)
+        for s in range(ns):
+            torch.manual_seed(seed + s)
+            mods = dict(enc=ot.Encoder(S, 20), dec=ot.Decoder(S, 20, hyper), cx=ot.CriticX(S, 20), cz=ot.CriticZ(20))
+            for k, m in mods.items():
+                eng.load_state_dict(k, m.state_dict(), s)
+        return eng
+    return engine, x, perms, nb, nc
+
+
+def _snapshot(eng):
+    torch.cuda.synchronize()
+    return ({k: eng.params[k].clone() for k in eng.params}, {k: eng.exp_avg[k].clone() for k in eng.params},
+            {k: eng.exp_avg_sq[k].clone() for k in eng.params}, eng.counters.clone())
+
+
+def _same(a, b):
+    return all(torch.equal(a[i][k], b[i][k]) for i in range(3) for k in a[i]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("ns,graph", [(1, False), (3, False), (1, True)])
+def test_resident_launch_that_gives_up_is_reported_stops_the_epoch_and_is_recovered(ns, graph):
+    from hypad_amd import _C
+    engine, x, perms, nb, nc = _setup(ns)
+    good = engine()
+    assert good.critic_phase_persistent(), "this test is about the resident form"
+    run = (lambda e, p, **kw: e.train_epoch_graph(x, p, nb, nc, True, **kw)) if graph else (lambda e, p, **kw: e.train_epoch(x, p, nb, nc, True, **kw))
+    perm_buf = perms[0].clone()                    # (graph replays read the shuffles from one static buffer)
+    l_good = [run(good, perm_buf).clone()]
+    assert good.status() == 0
+    s_good = [_snapshot(good)]
+    perm_buf.copy_(perms[1])
+    l_good.append(run(good, perm_buf).clone())
+    s_good.append(_snapshot(good))
+
+    bad = engine()
+    start = _snapshot(bad)
+    bad.epoch_flags = 2 << _C.EPOCH_TEST_GIVE_UP_SHIFT          # critic_x chunk 0 of signal 0 "times out" at critic iteration 2
+    perm_buf.copy_(perms[0])
+    l_bad = run(bad, perm_buf).clone()
+    code = bad.status()
+    assert code == 0x100 + 2, hex(code)
+    after = _snapshot(bad)
+    # fail-stop: no generator step was taken (parameters, moments, step counter), the loss row of the failing iteration is NaN
+    for k in ("enc", "dec"):
+        assert torch.equal(after[0][k], start[0][k]) and torch.equal(after[1][k], start[1][k]), k
+    assert int(after[3][2]) == 0 and int(after[3][4]) == code
+    assert bool(torch.isnan(l_bad[0, 2 * 1, 0])) or bool(torch.isnan(l_bad[0, 2 * 2, 0]))
+    # a second epoch on the failed state changes nothing at all (its launches are no-ops; the snapshot is not overwritten)
+    run(bad, perm_buf)
+    assert _same(_snapshot(bad), after)
+    # without recovery the host gets an exception
+    with pytest.raises(_C.HypadError):
+        bad.check_status(recover=False)
+    # recovery: restore + the same epoch with one launch per critic iteration == the healthy resident epoch, bit for bit
+    assert bad.check_status() == code
+    assert bad.status() == 0 and bad.epoch_flags == _C.EPOCH_PER_ITERATION
+    assert torch.equal(bad._last_epoch["losses"], l_good[0])
+    assert _same(_snapshot(bad), s_good[0])
+    # ... and the engine goes on in that form, still bit-equal to the resident one
+    perm_buf.copy_(perms[1])
+    l2 = run(bad, perm_buf)
+    assert bad.check_status() == 0
+    assert torch.equal(l2, l_good[1]) and _same(_snapshot(bad), s_good[1])
+
+
+def test_epoch_status_entry_points_validate_their_arguments():
+    import ctypes
+    from hypad_amd import _C
+    engine, x, perms, nb, nc = _setup()
+    eng = engine()
+    st = eng._state()
+    out = ctypes.c_int(-1)
+    assert _C.lib.hypad_epoch_status(None, ctypes.byref(out), _C.stream()) == -1
+    assert _C.lib.hypad_epoch_status(ctypes.byref(st), None, _C.stream()) == -1
+    assert _C.lib.hypad_epoch_status(ctypes.byref(st), ctypes.byref(out), _C.stream()) == 0 and out.value == 0
+    assert _C.lib.hypad_epoch_restore(ctypes.byref(eng.dims), ctypes.byref(st), None, 0, _C.stream()) == -2
+    assert _C.lib.hypad_epoch_restore(ctypes.byref(eng.dims), ctypes.byref(st), eng.workspace.data_ptr(), 64, _C.stream()) == -2
+
+
+def test_captured_epoch_is_recaptured_when_what_it_froze_changes():
+    """the graph cache key must cover every address and by-value scalar the capture froze -- workspace, arenas,
+    moments, counters, lr / betas / eps / weight decay -- not only x / row_index / losses."""
+    engine, x, perms, nb, nc = _setup()
+    a, b = engine(), engine()
+    pa, pb = perms[0].clone(), perms[0].clone()
+    a.train_epoch_graph(x, pa, nb, nc, True)
+    b.train_epoch_graph(x, pb, nb, nc, True)
+    assert len(a._graphs) == 1
+    # a larger workspace (what profile_iteration or a longer epoch asks for) drops the captured epochs
+    a._grow_workspace(a._ws_bytes + (1 << 20))
+    assert "_graphs" not in a.__dict__
+    # a changed learning rate must take effect in the next replayed epoch: compare with an eager engine given the same change
+    for e in (a, b):
+        e.lr = 1e-3
+    la = a.train_epoch_graph(x, pa, nb, nc, True).clone()
+    lb = b.train_epoch(x, pb, nb, nc, True)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb)
+    for k in a.params:
+        assert torch.equal(a.params[k], b.params[k]), k
+    # adopting other arenas (hypad_amd.train binds module views this way) drops them too
+    a.adopt({k: v.clone().view(-1) for k, v in a.params.items()})
+    assert "_graphs" not in a.__dict__
