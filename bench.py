@@ -400,7 +400,10 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
     # ---- each scoring kernel on its own: pre-allocated outputs, HIP events
     T = n + S - 1
     true64, pred32 = adu.unroll_true(x), new(T)
-    err64, sm64, z64, modes64, stats = new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(4, dtype=torch.float64)
+    err64, sm64, z64, modes64 = new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64), new(T, dtype=torch.float64)
+    stats = torch.empty(_C.STATS_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    roll_bytes = _C.lib.hypad_rolling_workspace_bytes(T)
+    roll_ws = torch.empty(roll_bytes, dtype=torch.uint8, device=device)
     x64 = x.to(torch.float64)
     C = _C.lib
     kern = {
@@ -409,8 +412,9 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
         "unroll_true": (lambda: C.hypad_unroll_true(_C.ptr(x64), _C.ptr(true64), n, S, st()), "hbm", None, 16 * T),
         "point_error": (lambda: C.hypad_point_error(_C.ptr(true64), _C.ptr(pred32), _C.ptr(err64), T, st()), "hbm", None, 20 * T),
         "dtw_error_kernel<11>": (lambda: C.hypad_dtw_error(_C.ptr(true64), _C.ptr(pred32), _C.ptr(err64), T, 10, st()), "valu", 121.0 * T, 20 * T),
-        "rolling_mean_kernel(200)": (lambda: C.hypad_rolling_mean(_C.ptr(err64), _C.ptr(sm64), T, 200, st()), "hbm", None, 16 * T),
-        "zscore_clip": (lambda: C.hypad_zscore_clip(_C.ptr(sm64), _C.ptr(z64), T, _C.ptr(stats), 32, st()), "hbm", None, 24 * T),
+        "rolling_mean(200)": (lambda: C.hypad_rolling_mean(_C.ptr(err64), None, _C.ptr(sm64), T, 200, 0, roll_ws.data_ptr(), roll_bytes, st()), "hbm", None, 16 * T),
+        "rolling_mean(1250) of |true - pred|": (lambda: C.hypad_rolling_mean(_C.ptr(true64), _C.ptr(pred32), _C.ptr(sm64), T, n // 100, 0, roll_ws.data_ptr(), roll_bytes, st()), "hbm", None, 20 * T),
+        "zscore_clip": (lambda: C.hypad_zscore_clip(_C.ptr(sm64), _C.ptr(z64), T, stats.data_ptr(), _C.STATS_WORKSPACE_BYTES, st()), "hbm", None, 24 * T),
         "kde_mode_kernel": (lambda: C.hypad_kde_mode(_C.ptr(critic), _C.ptr(modes64), n, S, st()), "valu", float(S) * S * T, 4 * n + 8 * T),
     }
     roofline_scoring = {}
@@ -525,6 +529,15 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def _claim_stdout():
+    """stdout carries ONE JSON line.  Libraries write there too (RCCL prints a version banner from C when its first communicator
+    is created): point file descriptor 1 at stderr for the whole run and keep the real stdout for the JSON line."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -544,6 +557,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)
+    json_out = _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -689,7 +703,8 @@ def main():
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hyperbolic)
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

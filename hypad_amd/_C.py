@@ -83,6 +83,7 @@ class EpochIO(Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int)]
 
 
+STATS_WORKSPACE_BYTES = 256 * 5 * 8  # HYPAD_STATS_WORKSPACE_BYTES
 EPOCH_PER_ITERATION = 1            # hypad_epoch_io.flags
 EPOCH_TEST_GIVE_UP_SHIFT = 8
 
@@ -154,7 +155,8 @@ _SIGS = {
     "hypad_point_error": (c_int, [P, P, P, c_int64, P]),
     "hypad_area_error": (c_int, [P, P, P, c_int64, c_int, P]),
     "hypad_dtw_error": (c_int, [P, P, P, c_int64, c_int, P]),
-    "hypad_rolling_mean": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_rolling_workspace_bytes": (c_size_t, [c_int64]),
+    "hypad_rolling_mean": (c_int, [P, P, P, c_int64, c_int, c_int64, P, c_size_t, P]),
     "hypad_zscore_clip": (c_int, [P, P, c_int64, P, c_size_t, P]),
     "hypad_kde_mode": (c_int, [P, P, c_int64, c_int, P]),
     "hypad_critic_zscore": (c_int, [P, c_double, c_double, P, c_int64, P, c_size_t, P]),
@@ -166,6 +168,24 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here = the library does not match include/hypad.h
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def first_order_only(backward):
+    """Decorator for the backward of a torch.autograd.Function whose gradient kernels are not themselves differentiable.  Under
+    ``create_graph=True`` (grad mode is enabled while the engine runs backward) the returned gradients would be constants: a
+    reference-style gradient penalty built from them (train.py:72-93) would train with a zero second-order term and no error
+    anywhere.  Raise instead.  (``once_differentiable`` does not: with a constant incoming gradient it returns detached
+    tensors silently.)"""
+    import functools
+
+    @functools.wraps(backward)
+    def guarded(ctx, *grads):
+        if torch.is_grad_enabled():
+            raise HypadError("double backward (create_graph=True) through hypad_amd's layer functions is not supported: their gradient "
+                             "kernels are first-order.  The WGAN-GP iterations with the second-order chain are "
+                             "hypad_amd.train.critic_x_iteration / critic_z_iteration")
+        return backward(ctx, *grads)
+    return guarded
 
 
 def check(rc, what=""):

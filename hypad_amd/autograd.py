@@ -6,13 +6,12 @@ Each layer is a ``torch.autograd.Function`` over the library's forward / backwar
 is the HIP kernels'; torch only chains them (and draws the dropout masks of train mode).  The fused iteration functions
 of ``hypad_amd.train`` remain the fast path: one launch group per iteration instead of ~20 layer launches.
 
-First-order only: every backward is ``once_differentiable`` -- a reference-style gradient penalty taken through these
-forwards with ``torch.autograd.grad(..., create_graph=True)`` (train.py:72-93) raises instead of silently returning a
+First-order only: every backward is guarded by ``_C.first_order_only`` -- a reference-style gradient penalty taken through
+these forwards with ``torch.autograd.grad(..., create_graph=True)`` (train.py:72-93) raises instead of silently returning a
 penalty whose second-order gradient is zero.  The WGAN-GP iterations, second-order chain included, are
 ``hypad_amd.train.critic_{x,z}_iteration``.
 """
 import torch
-from torch.autograd.function import once_differentiable
 
 from . import _C
 
@@ -35,7 +34,7 @@ class _LinearAct(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         rows, k, n = x.shape[0], x.shape[1], w.shape[0]
@@ -66,7 +65,7 @@ class _LstmBidirT1(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, go):
         x, wf, wr, gates = ctx.saved_tensors
         rows, k, h = x.shape[0], x.shape[1], wf.shape[0] // 4

@@ -188,54 +188,138 @@ __global__ __launch_bounds__(THREADS) void dtw_error_kernel(const double* __rest
   }
 }
 
-__global__ __launch_bounds__(THREADS) void rolling_mean_kernel(const double* __restrict__ in, double* __restrict__ out, int64_t T, int w) {
+// ---- centred rolling mean (pandas rolling(w, center=True, min_periods=w/2).mean(), NaNs skipped).
+// A window's sum is O(w) additions per output if taken element by element: 1 250 per timestep at 125 000 windows (the reference's
+// smoothing window is 1 % of the windows), 10^4 at 10^6.  It is taken from two levels of pre-summed chunks instead -- 16 and 256
+// elements, aligned to the ABSOLUTE index (origin + local index) -- in one canonical order: the elements up to the next multiple of
+// 16, 16-chunks up to the next multiple of 256, 256-chunks, 16-chunks, the remaining elements; <= 30 + 30 + w/256 additions.
+// Canonical and absolute: a rank that smooths only a slice of the series (parallel.sharded_euclidean_scores passes the slice's
+// position as `origin`) performs exactly the additions the un-sharded pass performs for the same timestep -- same bits.
+// Windows up to 32 wide are summed directly (also position-independent).
+constexpr int RC1 = 16, RC2 = 256, ROLL_DIRECT_MAX = 32;
+struct RollSrc {                                   // element i of the smoothed series: in[i], or the point-wise error |in[i] - sub[i]| (:761-777) fused
+  const double* in; const float* sub;
+  __device__ __forceinline__ double operator()(int64_t i) const { const double v = in[i]; return sub ? fabs(v - (double)sub[i]) : v; }
+};
+struct RollWs { double* s1; double* s2; int* c1; int* c2; int64_t n1, n2; };
+__host__ __device__ inline void roll_counts(int64_t T, int64_t origin, int64_t& n1, int64_t& n2) {
+  n1 = ((origin + T - 1) >> 4) - (origin >> 4) + 1;
+  n2 = ((origin + T - 1) >> 8) - (origin >> 8) + 1;
+}
+// level 1: one thread per 16-chunk, ascending
+__global__ __launch_bounds__(THREADS) void roll_chunks1_kernel(RollSrc src, RollWs ws, int64_t T, int64_t origin) {
+  const int64_t c = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (c >= ws.n1) return;
+  const int64_t g0 = ((origin >> 4) + c) << 4;
+  double s = 0.0; int cnt = 0;
+#pragma unroll 4
+  for (int k = 0; k < RC1; ++k) {
+    const int64_t i = g0 + k - origin;
+    if (i >= 0 && i < T) { const double v = src(i); if (v == v) { s += v; ++cnt; } }
+  }
+  ws.s1[c] = s; ws.c1[c] = cnt;
+}
+// level 2: one thread per 256-chunk = 16 level-1 chunks, ascending
+__global__ __launch_bounds__(THREADS) void roll_chunks2_kernel(RollWs ws, int64_t origin) {
+  const int64_t c = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (c >= ws.n2) return;
+  const int64_t first1 = (((origin >> 8) + c) << 4) - (origin >> 4);      // level-1 slot of this chunk's first 16-chunk (may be < 0 at the left edge)
+  double s = 0.0; int cnt = 0;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int64_t j = first1 + k;
+    if (j >= 0 && j < ws.n1) { s += ws.s1[j]; cnt += ws.c1[j]; }
+  }
+  ws.s2[c] = s; ws.c2[c] = cnt;
+}
+template <bool CHUNKED>
+__global__ __launch_bounds__(THREADS) void rolling_mean_kernel(RollSrc src, RollWs ws, double* __restrict__ out, int64_t T, int w, int64_t origin) {
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS) {
     int64_t lo, hi;
     centred_window(i, w, T, lo, hi);
     int cnt = 0;
     double s = 0.0;
-    for (int64_t k = lo; k <= hi; ++k) {
-      double v = in[k];
-      if (v == v) { s += v; ++cnt; }            // pandas skips NaN
+    if constexpr (!CHUNKED) {
+      for (int64_t k = lo; k <= hi; ++k) {
+        const double v = src(k);
+        if (v == v) { s += v; ++cnt; }            // pandas skips NaN
+      }
+    } else {
+      const int64_t b1 = origin >> 4, b2 = origin >> 8, end = origin + hi + 1;
+      int64_t p = origin + lo;
+      auto elems = [&](int64_t to) { for (; p < to; ++p) { const double v = src(p - origin); if (v == v) { s += v; ++cnt; } } };
+      const int64_t a16 = (p + RC1 - 1) & ~(int64_t)(RC1 - 1);
+      elems(a16 < end ? a16 : end);
+      while (p + RC1 <= end && (p & (RC2 - 1))) { s += ws.s1[(p >> 4) - b1]; cnt += ws.c1[(p >> 4) - b1]; p += RC1; }
+      while (p + RC2 <= end) { s += ws.s2[(p >> 8) - b2]; cnt += ws.c2[(p >> 8) - b2]; p += RC2; }
+      while (p + RC1 <= end) { s += ws.s1[(p >> 4) - b1]; cnt += ws.c1[(p >> 4) - b1]; p += RC1; }
+      elems(end);
     }
     out[i] = cnt >= w / 2 && cnt > 0 ? s / (double)cnt : NAN;
   }
 }
 
-// stats[0] = mean, stats[1] = population std (scipy.stats.zscore, ddof = 0)
-__global__ __launch_bounds__(1024) void zscore_stats_kernel(const double* __restrict__ in, double* __restrict__ stats, int64_t T) {
-  __shared__ double part[16];
-  __shared__ double mean_s;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < T; i += 1024) s += in[i];
-  s = wave_sum(s);
-  if (lane == 0) part[wave] = s;
+// ---- z-score statistics in two levels (scipy.stats.zscore: mean, population std).  Level 1: up to STAT_G blocks, each over one
+// contiguous slice: (n, mean, M2 = sum (x - mean)^2) two-pass inside the slice; level 2: every block of the elementwise kernel
+// that follows merges the <= 256 partials itself with the pairwise update (Chan et al.) in one fixed tree order -- no third
+// launch, the same bits in every block.  (The one-block serial form took 41 us per 10^5 values: 1 % of the HBM rate.)
+constexpr int STAT_G = 256;
+struct StatPart { double n, mean, m2, rsum, rcnt; };          // rsum / rcnt: sum and count of the values inside [lo, hi] (critic score)
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {      // fixed order: wave butterflies, then the 4 wave sums ascending
+  v = wave_sum(v);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int k = 0; k < 16; ++k) t += part[k];
-    mean_s = t / (double)T;
-  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  const double mean = mean_s;
-  double q = 0.0;
-  for (int64_t i = threadIdx.x; i < T; i += 1024) { double d = in[i] - mean; q += d * d; }
-  q = wave_sum(q);
-  __syncthreads();
-  if (lane == 0) part[wave] = q;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int k = 0; k < 16; ++k) t += part[k];
-    stats[0] = mean;
-    stats[1] = sqrt(t / (double)T);
-  }
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ __launch_bounds__(THREADS) void zscore_apply_kernel(const double* __restrict__ in, const double* __restrict__ stats,
-                                                                double* __restrict__ out, int64_t T) {
-  const double mean = stats[0], sd = stats[1];
-  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS) {
+template <bool RANGE>
+__global__ __launch_bounds__(256) void stat_partials_kernel(const double* __restrict__ in, StatPart* __restrict__ parts, int64_t T, double lo, double hi) {
+  __shared__ double sh[4];
+  const int64_t len = (T + gridDim.x - 1) / gridDim.x;
+  const int64_t b = (int64_t)blockIdx.x * len, e = b + len < T ? b + len : T;
+  double s = 0.0, rs = 0.0, rc = 0.0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+    const double x = in[i];
+    s += x;
+    if (RANGE && x >= lo && x <= hi) { rs += x; rc += 1.0; }
+  }
+  const double n = e > b ? (double)(e - b) : 0.0;
+  const double mean = n > 0.0 ? block_sum_256(s, sh) / n : 0.0;
+  double q = 0.0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) { const double d = in[i] - mean; q += d * d; }
+  q = block_sum_256(q, sh);
+  if (RANGE) { rs = block_sum_256(rs, sh); rc = block_sum_256(rc, sh); }
+  if (threadIdx.x == 0) { StatPart p; p.n = n; p.mean = mean; p.m2 = q; p.rsum = rs; p.rcnt = rc; parts[blockIdx.x] = p; }
+}
+__device__ __forceinline__ StatPart stat_merge(const StatPart& a, const StatPart& b) {
+  if (b.n == 0.0) return a;
+  if (a.n == 0.0) return b;
+  StatPart r;
+  r.n = a.n + b.n;
+  const double d = b.mean - a.mean;
+  r.mean = a.mean + d * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / r.n);
+  r.rsum = a.rsum + b.rsum; r.rcnt = a.rcnt + b.rcnt;
+  return r;
+}
+// every thread of a 256-thread block gets the merged statistics of `g` partials (fixed binary tree over the slots)
+__device__ __forceinline__ StatPart stat_merge_all(const StatPart* __restrict__ parts, int g, StatPart* sh) {
+  StatPart p; p.n = 0.0; p.mean = 0.0; p.m2 = 0.0; p.rsum = 0.0; p.rcnt = 0.0;
+  if ((int)threadIdx.x < g) p = parts[threadIdx.x];
+  sh[threadIdx.x] = p;
+  __syncthreads();
+  for (int st = 1; st < STAT_G; st <<= 1) {
+    if ((threadIdx.x & (2 * st - 1)) == 0) sh[threadIdx.x] = stat_merge(sh[threadIdx.x], sh[threadIdx.x + st]);
+    __syncthreads();
+  }
+  return sh[0];
+}
+__global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restrict__ in, const StatPart* __restrict__ parts, int g,
+                                                            double* __restrict__ out, int64_t T) {
+  __shared__ StatPart sh[STAT_G];
+  const StatPart st = stat_merge_all(parts, g, sh);
+  const double mean = st.mean, sd = sqrt(st.m2 / st.n);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (int64_t)gridDim.x * 256) {
     double z = (in[i] - mean) / sd;
     out[i] = (z != z) ? z : fmax(z, 0.0) + 1.0;  // np.clip keeps NaN
   }
@@ -405,46 +489,14 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
   }
 }
 
-// _compute_critic_score :307-333 without the rolling mean: stats[0] = mean of the values inside [lo, hi],
-// stats[1] = population std of all values; out = |x - mean| / std + 1.
-__global__ __launch_bounds__(1024) void critic_stats_kernel(const double* __restrict__ in, double lo, double hi,
-                                                             double* __restrict__ stats, int64_t T) {
-  __shared__ double part[3][16];
-  __shared__ double mean_all;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double s = 0.0, sr = 0.0, cr = 0.0;
-  for (int64_t i = threadIdx.x; i < T; i += 1024) {
-    const double x = in[i];
-    s += x;
-    if (x >= lo && x <= hi) { sr += x; cr += 1.0; }
-  }
-  s = wave_sum(s); sr = wave_sum(sr); cr = wave_sum(cr);
-  if (lane == 0) { part[0][wave] = s; part[1][wave] = sr; part[2][wave] = cr; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int k = 0; k < 16; ++k) { a += part[0][k]; b += part[1][k]; c += part[2][k]; }
-    mean_all = a / (double)T;
-    stats[0] = b / c;
-  }
-  __syncthreads();
-  const double m = mean_all;
-  double q = 0.0;
-  for (int64_t i = threadIdx.x; i < T; i += 1024) { const double d = in[i] - m; q += d * d; }
-  q = wave_sum(q);
-  __syncthreads();
-  if (lane == 0) part[0][wave] = q;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0;
-    for (int k = 0; k < 16; ++k) a += part[0][k];
-    stats[1] = sqrt(a / (double)T);
-  }
-}
-__global__ __launch_bounds__(THREADS) void critic_apply_kernel(const double* __restrict__ in, const double* __restrict__ stats,
-                                                                double* __restrict__ out, int64_t T) {
-  const double mean = stats[0], sd = stats[1];
-  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < T; i += (int64_t)gridDim.x * THREADS)
+// _compute_critic_score :307-333 without the rolling mean: out = |x - mean of the values inside [lo, hi]| / population std of all
+// values + 1 (the statistics in two levels, as for the z-score above).
+__global__ __launch_bounds__(256) void critic_apply_kernel(const double* __restrict__ in, const StatPart* __restrict__ parts, int g,
+                                                            double* __restrict__ out, int64_t T) {
+  __shared__ StatPart sh[STAT_G];
+  const StatPart st = stat_merge_all(parts, g, sh);
+  const double mean = st.rsum / st.rcnt, sd = sqrt(st.m2 / st.n);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (int64_t)gridDim.x * 256)
     out[i] = fabs((in[i] - mean) / sd) + 1.0;
 }
 
@@ -529,19 +581,43 @@ int hypad_dtw_error(const double* y, const float* yh, double* out, int64_t t, in
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
-int hypad_rolling_mean(const double* in, double* out, int64_t t, int window, hypad_stream_t s) {
-  if (!in || !out || t < 0 || window < 1) return HYPAD_EINVAL;
+size_t hypad_rolling_workspace_bytes(int64_t t) {
+  if (t <= 0) return 0;
+  const int64_t n1 = t / RC1 + 3, n2 = t / RC2 + 3;               // (>= the chunk counts for any origin)
+  return (size_t)(n1 + n2) * (sizeof(double) + sizeof(int)) + 64;
+}
+int hypad_rolling_mean(const double* in, const float* sub, double* out, int64_t t, int window, int64_t origin, void* workspace,
+                       size_t workspace_bytes, hypad_stream_t s) {
+  if (!in || !out || t < 0 || window < 1 || origin < 0) return HYPAD_EINVAL;
   if (t == 0) return HYPAD_OK;
-  hipLaunchKernelGGL(rolling_mean_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, out, t, window);
+  RollSrc src{in, sub};
+  RollWs ws{};
+  if (window <= ROLL_DIRECT_MAX) {
+    hipLaunchKernelGGL(rolling_mean_kernel<false>, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, src, ws, out, t, window, origin);
+    HYPAD_CHECK_LAUNCH();
+    return HYPAD_OK;
+  }
+  if (!workspace || workspace_bytes < hypad_rolling_workspace_bytes(t)) return HYPAD_EWORKSPACE;
+  roll_counts(t, origin, ws.n1, ws.n2);
+  const int64_t cap1 = t / RC1 + 3, cap2 = t / RC2 + 3;
+  ws.s1 = (double*)workspace; ws.s2 = ws.s1 + cap1;
+  ws.c1 = (int*)(ws.s2 + cap2); ws.c2 = ws.c1 + cap1;
+  hipLaunchKernelGGL(roll_chunks1_kernel, dim3((unsigned)((ws.n1 + THREADS - 1) / THREADS)), dim3(THREADS), 0, (hipStream_t)s, src, ws, t, origin);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(roll_chunks2_kernel, dim3((unsigned)((ws.n2 + THREADS - 1) / THREADS)), dim3(THREADS), 0, (hipStream_t)s, ws, origin);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rolling_mean_kernel<true>, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, src, ws, out, t, window, origin);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
+static int stat_blocks(int64_t t) { int64_t g = (t + 1023) / 1024; return (int)(g < 1 ? 1 : (g > STAT_G ? STAT_G : g)); }
 int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
   if (!in || !out || t <= 0) return HYPAD_EINVAL;
-  if (!workspace || workspace_bytes < 4 * sizeof(double)) return HYPAD_EWORKSPACE;
-  hipLaunchKernelGGL(zscore_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, in, (double*)workspace, t);
+  if (!workspace || workspace_bytes < HYPAD_STATS_WORKSPACE_BYTES) return HYPAD_EWORKSPACE;
+  const int g = stat_blocks(t);
+  hipLaunchKernelGGL(stat_partials_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, 0.0, 0.0);
   HYPAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, (const double*)workspace, out, t);
+  hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(t, 1024)), dim3(256), 0, (hipStream_t)s, in, (const StatPart*)workspace, g, out, t);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -555,10 +631,11 @@ int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hy
 int hypad_critic_zscore(const double* in, double q25, double q75, double* out, int64_t t, void* workspace, size_t workspace_bytes,
                         hypad_stream_t s) {
   if (!in || !out || t <= 0) return HYPAD_EINVAL;
-  if (!workspace || workspace_bytes < 4 * sizeof(double)) return HYPAD_EWORKSPACE;
-  hipLaunchKernelGGL(critic_stats_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, in, q25, q75, (double*)workspace, t);
+  if (!workspace || workspace_bytes < HYPAD_STATS_WORKSPACE_BYTES) return HYPAD_EWORKSPACE;
+  const int g = stat_blocks(t);
+  hipLaunchKernelGGL(stat_partials_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, q25, q75);
   HYPAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(critic_apply_kernel, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, in, (const double*)workspace, out, t);
+  hipLaunchKernelGGL(critic_apply_kernel, dim3(grid_for(t, 1024)), dim3(256), 0, (hipStream_t)s, in, (const StatPart*)workspace, g, out, t);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

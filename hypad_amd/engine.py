@@ -211,7 +211,7 @@ class Engine:
         """Call where the host reads an epoch's losses.  If the epoch's resident critic launch gave up (a withheld CU: CU mask,
         partitioned or shared device), the launches behind it were no-ops; with ``recover`` the critics and counters are put
         back to the state that epoch began from, the epoch is repeated with one launch per critic iteration (same random
-        streams: the bits the resident form would have produced) and every later epoch of this engine uses that form.
+        streams: bit for bit a healthy epoch in that form) and every later epoch of this engine uses that form.
         Returns the status code that was found (0 = nothing happened); raises without ``recover``."""
         code = self.status()
         if code == 0:

@@ -6,7 +6,6 @@ logmap0 (:1267-1270), mobius_add (:536-555), project (:340-352), plus the inline
 train.py:226-230 and the hyperbolic loss of train.py:232.  Each is one HIP kernel forward and one backward.
 """
 import torch
-from torch.autograd.function import once_differentiable
 
 from .. import _C
 
@@ -35,7 +34,7 @@ class _Unary(torch.autograd.Function):
         return out.view(x.shape)
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, go):
         (x2,) = ctx.saved_tensors
         go2 = go.to(torch.float32).contiguous().reshape(x2.shape)
@@ -76,7 +75,7 @@ class _MobiusAdd(torch.autograd.Function):
         return out.view(x.shape)
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, go):
         x2, y2 = ctx.saved_tensors
         go2 = go.to(torch.float32).contiguous().reshape(x2.shape)
@@ -111,7 +110,7 @@ class _RowDist(torch.autograd.Function):
         return out.view(u.shape[:-1])
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, gd):
         u2, v2 = ctx.saved_tensors
         gd = gd.to(torch.float32).contiguous().reshape(-1)
@@ -138,7 +137,7 @@ class _HyperLoss(torch.autograd.Function):
         return out.view(())
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, g):
         u2, v2 = ctx.saved_tensors
         gu, gv = torch.empty_like(u2), torch.empty_like(v2)

@@ -6,7 +6,6 @@ non-linearity, k = -1, fp32 (models/tadgan.py:43-52).  Anything else raises.
 import math
 
 import torch
-from torch.autograd.function import once_differentiable
 from torch import nn
 
 from .. import _C
@@ -53,7 +52,7 @@ class _MobiusLinearFn(torch.autograd.Function):
         return out.view(*x.shape[:-1], n)
 
     @staticmethod
-    @once_differentiable
+    @_C.first_order_only
     def backward(ctx, go):
         x2, w, b, u = ctx.saved_tensors
         rows, k, n = x2.shape[0], x2.shape[1], w.shape[0]

@@ -235,7 +235,9 @@ def sharded_euclidean_scores(n_windows, window, smooth_window, evaluate, unroll_
       * ``unroll_median(recon)`` (:918-923), ``error_fn(true, pred)`` (point / area / DTW, :761-863) over the extended range
         as a series of its own -- only values whose whole footprint lies inside the range (or at a true end of the series,
         where the reference's own edge handling applies) are kept;
-      * ``rolling_mean(err, smooth_window)`` (:953-961) the same way;  ``kde_modes(critic, window)`` for its timesteps.
+      * ``rolling_mean(err, smooth_window, origin)`` (:953-961) the same way -- ``origin`` = position of ``err[0]`` in the whole
+        series: an implementation whose summation order depends on absolute positions (hypad_rolling_mean's chunked sums) then
+        gives a slice the bits of the whole;  ``kde_modes(critic, window)`` for its timesteps.
     Exchanged: one all-gather each of the (T,) smoothed errors and (T,) critic modes -- 16 MB at 10^6 windows -- then
     ``finish(err, modes)`` runs the global steps (z-score / clip, quantile-trimmed critic z-score, combination) on the full
     vectors on every rank: the scores do not depend on the world size.  ``zscore="allreduce"`` instead normalises each
@@ -255,7 +257,7 @@ def sharded_euclidean_scores(n_windows, window, smooth_window, evaluate, unroll_
         # keep what does not feel the artificial ends of the extended range
         h_err = error_halo(score_window)
         va, vb = (a + h_err if a > 0 else 0), (b - h_err if b < T else T)
-        sm = rolling_mean(err[va - a: vb - a].contiguous(), smooth_window)
+        sm = rolling_mean(err[va - a: vb - a].contiguous(), smooth_window, va)      # va: where the slice sits in the whole series
         mine = sm[tb - va: te - va]
         # critic modes of the owned timesteps (they see windows [tb - S + 1, te), a subset of the evaluated ones)
         modes = kde_modes(got["critic"], window)[tb - wlo: te - wlo]

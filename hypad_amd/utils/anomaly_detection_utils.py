@@ -73,14 +73,32 @@ def _dtw_error(y, y_hat, score_window=10):
     return out
 
 
-def rolling_mean(x, window):
+_SCRATCH = {}
+
+
+def _scratch(device, nbytes, tag):
+    """A per-device scratch buffer for the library calls' workspaces (grown, never shrunk; stream-ordered like everything here)."""
+    key = (str(device), tag)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _SCRATCH[key] = torch.empty(max(int(nbytes), 64), dtype=torch.uint8, device=device)
+    return buf
+
+
+def rolling_mean(x, window, origin=0, minus=None):
     """pandas ``rolling(window, center=True, min_periods=window // 2).mean()`` (:953-961, :325-330).  ``window == 0`` -- the
-    reference's ``math.trunc(n * 0.01)`` for fewer than 100 windows -- gives all-NaN, as pandas does."""
+    reference's ``math.trunc(n * 0.01)`` for fewer than 100 windows -- gives all-NaN, as pandas does.  ``minus``: smooth the
+    point-wise error ``|x - minus|`` (:761-777) without materialising it.  ``origin``: position of ``x[0]`` in the whole series
+    when ``x`` is a slice of it (the sums are taken in an order fixed by absolute positions: a slice gives the whole's bits)."""
     x = _f64(x)
     if int(window) == 0:
         return torch.full_like(x, float("nan"))
     out = torch.empty_like(x)
-    _C.check(_C.lib.hypad_rolling_mean(_C.ptr(x), _C.ptr(out), x.numel(), int(window), _C.stream()), "rolling_mean")
+    sub = None if minus is None else _f32(minus)
+    nbytes = _C.lib.hypad_rolling_workspace_bytes(x.numel())
+    ws = _scratch(x.device, nbytes, "roll")
+    _C.check(_C.lib.hypad_rolling_mean(_C.ptr(x), _C.ptr(sub), _C.ptr(out), x.numel(), int(window), int(origin), ws.data_ptr(), nbytes,
+                                       _C.stream()), "rolling_mean")
     return out
 
 
@@ -88,8 +106,8 @@ def zscore_clip(x):
     """stats.zscore(x) -> clip(min=0) + 1  (:523-524)."""
     x = _f64(x)
     out = torch.empty_like(x)
-    ws = torch.empty(4, device=x.device, dtype=torch.float64)
-    _C.check(_C.lib.hypad_zscore_clip(_C.ptr(x), _C.ptr(out), x.numel(), _C.ptr(ws), 32, _C.stream()), "zscore_clip")
+    ws = _scratch(x.device, _C.STATS_WORKSPACE_BYTES, "stats")
+    _C.check(_C.lib.hypad_zscore_clip(_C.ptr(x), _C.ptr(out), x.numel(), ws.data_ptr(), _C.STATS_WORKSPACE_BYTES, _C.stream()), "zscore_clip")
     return out
 
 
@@ -104,7 +122,10 @@ def reconstruction_errors(y, y_hat, step_size=1, score_window=10, smoothing_wind
     true = unroll_true(y)
     pred, summ = unroll_predictions(y_hat, with_summary)
     kind = rec_error_type.lower()
-    if kind == "point":
+    if kind == "point" and smooth and smoothing_window:
+        err = rolling_mean(true, smoothing_window, minus=pred)         # |true - pred| smoothed in one pass
+        smooth = False
+    elif kind == "point":
         err = _point_wise_error(true, pred)
     elif kind == "area":
         err = _area_error(true, pred, score_window)
@@ -167,8 +188,9 @@ def _compute_critic_score(critics, smooth_window):
     c = _f64(critics)
     q = torch.quantile(c, torch.tensor([0.25, 0.75], dtype=torch.float64, device=c.device))
     out = torch.empty_like(c)
-    ws = torch.empty(4, device=c.device, dtype=torch.float64)
-    _C.check(_C.lib.hypad_critic_zscore(_C.ptr(c), float(q[0]), float(q[1]), _C.ptr(out), c.numel(), _C.ptr(ws), 32, _C.stream()),
+    ws = _scratch(c.device, _C.STATS_WORKSPACE_BYTES, "stats")
+    lo, hi = q.tolist()                                        # (one device -> host read for both)
+    _C.check(_C.lib.hypad_critic_zscore(_C.ptr(c), lo, hi, _C.ptr(out), c.numel(), ws.data_ptr(), _C.STATS_WORKSPACE_BYTES, _C.stream()),
              "critic_zscore")
     return rolling_mean(out, smooth_window)
 

@@ -283,8 +283,9 @@ int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const
  *   hypad_epoch_status : copies counters[4] to *status_host and SYNCHRONISES the stream (not capturable).
  *   hypad_epoch_restore: puts both critics' parameters and moments and counters[0..3] back to what they were when the failed
  *                        hypad_train_epoch call began (it snapshots them into its workspace first: 50 KB per signal) and clears
- *                        counters[4]; the caller then repeats that epoch with HYPAD_EPOCH_PER_ITERATION -- same random streams,
- *                        same bits as the resident form would have produced.  Capturable; workspace = the failed call's. */
+ *                        counters[4]; the caller then repeats that epoch with HYPAD_EPOCH_PER_ITERATION -- same random streams:
+ *                        bit for bit the epoch a healthy run in that form produces (the two forms differ only in floating-point
+ *                        summation order).  Capturable; workspace = the failed call's. */
 int hypad_epoch_status(const hypad_train_state* st, int* status_host, hypad_stream_t stream);
 int hypad_epoch_restore(const hypad_dims* dims, const hypad_train_state* st, void* workspace, size_t workspace_bytes,
                         hypad_stream_t stream);
@@ -355,15 +356,24 @@ int hypad_point_error(const double* y, const float* y_hat, double* out, int64_t 
 int hypad_area_error(const double* y, const float* y_hat, double* out, int64_t t, int score_window, hypad_stream_t stream);
 /* _dtw_error :815-863 (pyts.metrics.dtw classic, squared cost, sqrt of the accumulated cost) */
 int hypad_dtw_error(const double* y, const float* y_hat, double* out, int64_t t, int score_window, hypad_stream_t stream);
-/* pandas rolling(window, center=True, min_periods=window/2).mean()  :953-961, :325-330 */
-int hypad_rolling_mean(const double* in, double* out, int64_t t, int window, hypad_stream_t stream);
-/* stats.zscore -> clip(min=0) + 1  :523-524,542-543.  workspace: 4 doubles */
+/* pandas rolling(window, center=True, min_periods=window/2).mean()  :953-961, :325-330 -- of in[], or, with sub != NULL, of the
+ * point-wise error |in[i] - sub[i]| (:761-777 fused).  Windows wider than 32 are summed from two levels of pre-summed chunks
+ * (16 and 256 elements) aligned to the absolute index origin + i, in one canonical order: O(60 + window / 256) additions per
+ * output instead of O(window), and a caller that smooths a slice [origin, origin + t) of a longer series gets, for every
+ * timestep whose window lies inside the slice, the bits the whole series gives (sharded scoring).
+ * workspace: hypad_rolling_workspace_bytes(t) (may be NULL for window <= 32). */
+size_t hypad_rolling_workspace_bytes(int64_t t);
+int hypad_rolling_mean(const double* in, const float* sub, double* out, int64_t t, int window, int64_t origin, void* workspace,
+                       size_t workspace_bytes, hypad_stream_t stream);
+/* workspace of hypad_zscore_clip / hypad_critic_zscore: the per-slice partial statistics of their first launch */
+#define HYPAD_STATS_WORKSPACE_BYTES (256 * 5 * 8)
+/* stats.zscore -> clip(min=0) + 1  :523-524,542-543.  workspace: HYPAD_STATS_WORKSPACE_BYTES */
 int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
 /* final_critic_scores :365-404 (also :470-504), KDE step: modes (n + window - 1) fp64 -- for every un-rolled timestep
  * the window-critic value at which scipy.stats.gaussian_kde of the covering windows' values peaks (median fallback). */
 int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hypad_stream_t stream);
 /* _compute_critic_score :307-322: out = |x - mean(x within [q25, q75])| / std(x) + 1 (quantiles supplied by the caller;
- * the rolling mean of :325-330 is hypad_rolling_mean).  workspace: 4 doubles */
+ * the rolling mean of :325-330 is hypad_rolling_mean).  workspace: HYPAD_STATS_WORKSPACE_BYTES */
 int hypad_critic_zscore(const double* in, double q25, double q75, double* out, int64_t t, void* workspace,
                         size_t workspace_bytes, hypad_stream_t stream);
 /* np.linalg.norm(recons, axis=1)  :341,347,350,359 */

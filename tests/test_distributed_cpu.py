@@ -139,7 +139,7 @@ def _eucl_ops(kind, y, y_hat, critic, n_windows, window, calls=None):
     unroll = lambda r: torch.from_numpy(scoring.unroll_predictions(r.numpy(), False)[0])
     err = {"point": scoring.point_error, "area": scoring.area_error, "dtw": scoring.dtw_error}[kind]
     error_fn = lambda t, p: torch.from_numpy(np.asarray(err(t.numpy(), p.numpy().astype(np.float64)), dtype=np.float64))
-    rolling = lambda e, ww: torch.from_numpy(_direct_rolling_mean(e.numpy(), ww))
+    rolling = lambda e, ww, origin=0: torch.from_numpy(_direct_rolling_mean(e.numpy(), ww))
 
     def kde_modes(c, ww):
         ext = np.repeat(c.numpy().astype(np.float64).reshape(-1, 1), ww, axis=1)

@@ -87,17 +87,22 @@ def test_custom_training_loop_outside_the_fused_iterations():
 
 
 def test_double_backward_through_the_module_forwards_raises():
-    """The layer Functions are first-order (once_differentiable): a reference-style gradient penalty -- torch.autograd.grad(...,
-    create_graph=True) then backward through the gradient, train.py:72-93 -- must fail loudly, not return a penalty whose
-    second-order gradient is silently zero.  (The fused critic iterations carry the second-order chain themselves.)"""
+    """The layer Functions are first-order: a reference-style gradient penalty -- torch.autograd.grad(..., create_graph=True),
+    train.py:72-93 -- must fail loudly instead of returning a constant whose second-order gradient is silently zero.  (The
+    fused critic iterations carry the second-order chain themselves.)  Plain first-order use keeps working."""
+    from hypad_amd import _C
     from hypad_amd.hyperspace import gmath
     o, h = _pair(100, True)
     x = torch.rand(32, 100, device="cuda").requires_grad_(True)
     out = h["cx"](x.view(1, 32, 100)).sum()
-    (g,) = torch.autograd.grad(out, x, create_graph=True)
-    with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|not differentiable twice"):
-        g.norm().backward()
+    with pytest.raises(_C.HypadError, match="create_graph"):
+        torch.autograd.grad(out, x, create_graph=True)
+    out = h["cx"](x.view(1, 32, 100)).sum()
+    (g,) = torch.autograd.grad(out, x)
+    assert g.shape == x.shape and bool(torch.isfinite(g).all())
     y = (0.3 * torch.rand(8, 100, device="cuda")).requires_grad_(True)
-    (gy,) = torch.autograd.grad(gmath.expmap0(y).sum(), y, create_graph=True)
-    with pytest.raises(RuntimeError):
-        gy.sum().backward()
+    with pytest.raises(_C.HypadError, match="create_graph"):
+        torch.autograd.grad(gmath.expmap0(y).sum(), y, create_graph=True)
+    with pytest.raises(_C.HypadError, match="create_graph"):
+        torch.autograd.grad(h["dec"](torch.randn(1, 8, 20, device="cuda").requires_grad_(True))[0].sum(), list(h["dec"].parameters())[:1],
+                            create_graph=True)

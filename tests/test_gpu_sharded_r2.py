@@ -67,7 +67,7 @@ def _rank_worker(rank, world, port, kind, n, S, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,n,S", [("dtw", 433, 100), ("point", 1000, 100)])
+@pytest.mark.parametrize("kind,n,S", [("dtw", 433, 100), ("point", 1000, 100), ("dtw", 4_100, 100), ("point", 30_000, 100)])
 def test_two_ranks_sharing_the_gpu_equal_one_rank(kind, n, S):
     import torch.multiprocessing as mp
     from hypad_amd import parallel as par
