@@ -39,6 +39,7 @@ class ArenaModule(nn.Module):
                 holder.register_parameter(leaf, param)
             self._slots[name] = (param, off, n, shape)
         self._arena = arena
+        self._arena_calls = 0
 
     def _holder_for(self, name):
         parts = name.split(".")
@@ -70,19 +71,34 @@ class ArenaModule(nn.Module):
             cur.data = view
             self._slots[name] = (cur, off, n, shape)
         self._arena = arena
+        self._glue_items = None
 
-    def _glued(self):
+    def _glued(self, spot=False):
         base = self._arena.data_ptr()
-        for name, (p, off, n, shape) in self._slots.items():
-            holder, leaf = self._holder_for(name)
-            cur = getattr(holder, leaf)
-            if cur is not p or cur.data_ptr() != base + 4 * off or cur.device != self._arena.device:
+        dev = self._arena.device
+        items = getattr(self, "_glue_items", None)
+        if items is None or len(items) != len(self._slots):      # (holder's parameter dict, leaf name) resolved once
+            items = self._glue_items = [(self._holder_for(name)[0]._parameters, self._holder_for(name)[1], name) for name in self._slots]
+        if spot:                                                  # first and last tensor only
+            items = (items[0], items[-1])
+        for params, leaf, name in items:
+            p, off, n, shape = self._slots[name]
+            cur = params.get(leaf)
+            if cur is not p or cur.data_ptr() != base + 4 * off or cur.device != dev:
                 return False
         return True
 
-    def arena(self):
-        """The flat device buffer (re-packed first if a parameter was re-assigned behind our back)."""
-        if not self._glued():
+    FULL_CHECK_EVERY = 32
+
+    def arena(self, fast=False):
+        """The flat device buffer, re-packed first if a parameter was re-assigned behind our back (``module.w = Parameter(..)``
+        or ``p.data = ..``; ``copy_`` / ``load_state_dict`` / ``.to()`` keep the views glued by themselves).  Verifying every
+        view costs ~1 us per tensor -- more than an iteration's launches for the decoder -- so the per-iteration callers
+        (``hypad_amd.train``, ``fast=True``) get the full verification on every 32nd call and a two-tensor spot check
+        otherwise; everyone else gets it on every call."""
+        self._arena_calls = getattr(self, "_arena_calls", 0) + 1
+        full = (not fast) or self._arena_calls % self.FULL_CHECK_EVERY == 1
+        if not self._glued(spot=not full):
             self._repack()
         if not self._arena.is_cuda:
             raise _C.HypadError("network parameters must live on the GPU: call .cuda() (hypad_amd has no CPU path)")

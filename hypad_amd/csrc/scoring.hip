@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "../../include/hypad.h"
 #include "device_utils.h"
@@ -30,90 +31,212 @@ __device__ __forceinline__ float np_lerp(float a, float b, float t) {
   if (t >= 0.5f) r = b - diff * (1.0f - t);
   return r;
 }
-// EPL: anti-diagonal values per lane (window <= 64 EPL); the rank-by-counting loop is the kernel's cost (window^2 / 64
+// EPL: anti-diagonal values per lane (window <= 64 EPL); the rank-by-counting loop is the kernel's arithmetic (window^2 / 64
 // compares per timestep and lane), so it is instantiated for the window class and reads the broadcast values four at a time.
-template <int EPL>
+//
+// Memory side: timestep t gathers y_hat[t - j][j] -- one 4-byte element from each of `window` rows, 4 of every 64-byte sector
+// (7.9x the algorithmic bytes when each wave gathered its own anti-diagonal).  A workgroup now owns UT consecutive timesteps and
+// stages their anti-diagonals through LDS: row r contributes the contiguous run j in [t0 - r, t0 + UT - r) to this tile, read
+// with lane-consecutive (coalesced) loads, every element of y_hat by exactly one workgroup; the element lands at
+// tile[t - t0][j - j0(t)], i.e. each timestep's values end up as one contiguous LDS row (row stride = window rounded up to a
+// multiple of 4, so consecutive j of one source row -- consecutive t -- fall into different banks: stride + 1 is odd).
+//
+// FILTER (median only, no summary): a full rank count is window^2 compares although only the middle is wanted.  Two pivots are
+// taken from the ranks of a 32-value sample (the 11th and 22nd smallest: the median of 100 lies between them in ~96 % of
+// draws), the values below / not above them are counted with two ballots per slot, and if the middle position(s) fall between
+// the pivots and at most 64 values do, only those candidates are ranked against each other (~33^2 compares).  Anything else --
+// pivots that miss, ties among the candidates, short edge diagonals -- takes the full count: the result is the exact order
+// statistic either way.
+constexpr int UT = 64;                       // timesteps per workgroup tile
+template <int EPL, bool FILTER>
 __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
                                                                  double* __restrict__ summary, int64_t n, int W) {
-  __shared__ __attribute__((aligned(16))) float vals[THREADS / 64][MAX_WINDOW];
-  __shared__ float sorted[THREADS / 64][MAX_WINDOW];
+  extern __shared__ __attribute__((aligned(16))) float usm[];
+  const int WS = (W + 3) & ~3;                              // tile row stride (floats)
+  float* tile = usm;                                        // [UT][WS]
+  float* sorted = usm + UT * WS;                            // [waves][MAX_WINDOW]   (summary / candidates)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int NWV = THREADS / 64;
   const int64_t T = n + W - 1;
-  float* v = vals[wave];
-  float* s = sorted[wave];
-  for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
-    const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
-    const int j1 = (int)(t + 1 < W ? t + 1 : W);
-    const int cnt = j1 - j0;
-    float mine[EPL];
+  float* s = sorted + wave * MAX_WINDOW;
+  const float INF = __int_as_float(0x7f800000);
+  for (int64_t t0 = (int64_t)blockIdx.x * UT; t0 < T; t0 += (int64_t)gridDim.x * UT) {
+    // ---- stage: rows r in [t0 - (W - 1), t0 + UT) (clipped to the matrix), their runs of this tile's timesteps
+    constexpr int RB = 8;                                    // rows in flight per wave
+    if (t0 >= W - 1 && t0 + UT <= n) {
+      // interior tile (all but the first and last two of a long series): no clipping, j0 == 0, 32-bit indices relative to the
+      // tile's first row, the row number a scalar -- ~9 vector instructions per row and lane instead of ~30 of 64-bit arithmetic
+      const float* base = y_hat + (t0 - (W - 1)) * W;
+      const int nrows = W + UT - 1;
+      for (int kb = wave_s * RB; kb < nrows; kb += NWV * RB) {
+        float val[RB];
+        int dst[RB];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      int i = lane + 64 * e;
-      mine[e] = 0.f;
-      if (i < cnt) {
-        int j = j0 + i;
-        mine[e] = y_hat[(t - j) * W + j];
-        v[i] = mine[e];
+        for (int u = 0; u < RB; ++u) {
+          const int k = kb + u;                              // (scalar) row of the tile's parallelogram
+          const int jb = W - 1 - k > 0 ? W - 1 - k : 0;
+          const int j = jb + lane, tt = k - (W - 1) + j;
+          const bool ok = k < nrows && j < W && tt < UT;
+          dst[u] = ok ? tt * WS + j : -1;
+          val[u] = ok ? base[k * W + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          if (dst[u] >= 0) tile[dst[u]] = val[u];
+      }
+    } else {
+      const int64_t r_lo = t0 - (W - 1) > 0 ? t0 - (W - 1) : 0;
+      const int64_t r_hi = t0 + UT < n ? t0 + UT : n;         // exclusive
+      for (int64_t rb = r_lo + wave * RB; rb < r_hi; rb += NWV * RB) {
+        float val[RB];
+        int dst[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int64_t r = rb + u;
+          int jb = (int)(t0 - r > 0 ? t0 - r : 0);             // first column of row r inside the tile
+          const int j = jb + lane;                             // (a run is at most UT = 64 columns: one element per lane)
+          const int64_t t = r + j;
+          dst[u] = -1; val[u] = 0.f;
+          if (r < r_hi && j < W && t < t0 + UT && t < T) {
+            const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
+            dst[u] = (int)(t - t0) * WS + (j - j0);
+            val[u] = y_hat[r * W + j];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+          if (dst[u] >= 0) tile[dst[u]] = val[u];
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave landed
-    // pad the slab to a multiple of 4 with +inf (never below or equal to a finite value)
-    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) v[cnt + lane] = __int_as_float(0x7f800000);
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" only (one compare + add-carry per value).
-    // Without ties those counts are a permutation of 0 .. cnt-1, with ties two values share a count and the counts' sum falls
-    // short of cnt (cnt - 1) / 2: only then is the ordered tie count needed.  (The sum is exact in fp32: < 2^15 at window 256.)
-    int rank[EPL];
+    __syncthreads();
+    for (int tt = wave; tt < UT; tt += NWV) {
+      const int64_t t = t0 + tt;
+      if (t >= T) break;
+      const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
+      const int j1 = (int)(t + 1 < W ? t + 1 : W);
+      const int cnt = j1 - j0;
+      float* v = tile + tt * WS;
+      // pad the row to a multiple of 4 with +inf (never below or equal to a finite value)
+      if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) v[cnt + lane] = INF;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave landed
+      float mine[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) rank[e] = 0;
-    for (int k0 = 0; k0 < cnt; k0 += 4) {
-      const float4 q = *reinterpret_cast<const float4*>(v + k0);
-      const float vk[4] = {q.x, q.y, q.z, q.w};
+      for (int e = 0; e < EPL; ++e) { const int i = lane + 64 * e; mine[e] = i < cnt ? v[i] : INF; }
+      const int m1 = (cnt - 1) >> 1, m2 = cnt >> 1;
+      float lo_med = 0.f, hi_med = 0.f;
+      bool done = false;
+      if (FILTER && !summary && cnt >= 64) {                 // wave-uniform
+        // ranks inside the sample v[0 .. 31] (lanes >= 32 idle along)
+        const float sv = v[lane & 31];
+        int less = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int k0 = 0; k0 < 32; k0 += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(v + k0);
+          less += (q.x < sv ? 1 : 0) + (q.y < sv ? 1 : 0) + (q.z < sv ? 1 : 0) + (q.w < sv ? 1 : 0);
+        }
+        float plo = less <= 10 ? sv : -INF, phi = less >= 21 ? sv : INF;     // 11th smallest (largest with <= 10 below), 22nd smallest
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) rank[e] += vk[u] < mine[e] ? 1 : 0;
-    }
-    float rsum = 0.f;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) rsum += lane + 64 * e < cnt ? (float)rank[e] : 0.f;
-    const bool ties = hypad::wave_sum(rsum) != 0.5f * (float)cnt * (float)(cnt - 1);
-    if (ties) {                                      // wave-uniform
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) rank[e] = 0;
-      for (int k = 0; k < cnt; ++k) {
-        const float vk = v[k];
+        for (int off = 16; off > 0; off >>= 1) { plo = fmaxf(plo, __shfl_xor(plo, off, WAVE)); phi = fminf(phi, __shfl_xor(phi, off, WAVE)); }
+        plo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(plo)));
+        phi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(phi)));
+        int c_lt = 0, c_le = 0;
+        unsigned long long cm[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const int i = lane + 64 * e;
-          rank[e] += (vk < mine[e]) || (vk == mine[e] && k < i);
+          const bool in = lane + 64 * e < cnt;
+          c_lt += __builtin_popcountll(__ballot(in && mine[e] < plo));
+          c_le += __builtin_popcountll(__ballot(in && mine[e] <= phi));
+          cm[e] = __ballot(in && mine[e] >= plo && mine[e] <= phi);
         }
-      }
-    }
+        const int nc = c_le - c_lt;
+        if (c_lt <= m1 && m2 < c_le && nc <= 64 && nc > 0) {
+          // compact the candidates into the wave's slab, rank them against each other
+          int base = 0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e)
-      if (lane + 64 * e < cnt) s[rank[e]] = mine[e];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    if (lane == 0) {
-      const float lo = s[(cnt - 1) >> 1], hi = s[cnt >> 1];
-      median[t] = (cnt & 1) ? lo : (lo + hi) * 0.5f;     // np.median of float32 stays float32
-      if (summary) {
-        double* o = summary + t * 5;
-        o[0] = (double)s[0];
-        const double qs[3] = {0.25, 0.5, 0.75};
-        for (int qi = 0; qi < 3; ++qi) {
-          double pos = qs[qi] * (double)(cnt - 1);
-          int a = (int)floor(pos);
-          int b = a + 1 < cnt ? a + 1 : cnt - 1;
-          o[1 + qi] = (double)np_lerp(s[a], s[b], (float)(pos - (double)a));
+          for (int e = 0; e < EPL; ++e) {
+            const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm[e], 0u));
+            if ((cm[e] >> lane) & 1ull) s[pos] = mine[e];
+            base += __builtin_popcountll(cm[e]);
+          }
+          if (lane < 4 && nc + lane < ((nc + 3) & ~3)) s[nc + lane] = INF;
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          const float c = lane < nc ? s[lane] : INF;
+          int rk = 0;
+          for (int k0 = 0; k0 < nc; k0 += 4) {
+            const float4 q = *reinterpret_cast<const float4*>(s + k0);
+            rk += (q.x < c ? 1 : 0) + (q.y < c ? 1 : 0) + (q.z < c ? 1 : 0) + (q.w < c ? 1 : 0);
+          }
+          // without ties the "less" counts are a permutation of 0 .. nc - 1 (their sum tells): then the lanes holding local ranks
+          // m1 - c_lt and m2 - c_lt hold the two middle values
+          const float rsum = hypad::wave_sum(lane < nc ? (float)rk : 0.f);
+          if (rsum == 0.5f * (float)nc * (float)(nc - 1)) {
+            const unsigned long long k1 = __ballot(lane < nc && rk == m1 - c_lt), k2 = __ballot(lane < nc && rk == m2 - c_lt);
+            lo_med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), (int)__builtin_ctzll(k1)));
+            hi_med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), (int)__builtin_ctzll(k2)));
+            done = true;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        o[4] = (double)s[cnt - 1];
       }
+      if (!done) {
+        // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" only (one compare + add-carry per value).
+        // Without ties those counts are a permutation of 0 .. cnt-1, with ties two values share a count and the counts' sum falls
+        // short of cnt (cnt - 1) / 2: only then is the ordered tie count needed.  (The sum is exact in fp32: < 2^15 at window 256.)
+        int rank[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) rank[e] = 0;
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+          const float4 q = *reinterpret_cast<const float4*>(v + k0);
+          const float vk[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) rank[e] += vk[u] < mine[e] ? 1 : 0;
+        }
+        float rsum = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) rsum += lane + 64 * e < cnt ? (float)rank[e] : 0.f;
+        const bool ties = hypad::wave_sum(rsum) != 0.5f * (float)cnt * (float)(cnt - 1);
+        if (ties) {                                      // wave-uniform
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) rank[e] = 0;
+          for (int k = 0; k < cnt; ++k) {
+            const float vk = v[k];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              const int i = lane + 64 * e;
+              rank[e] += (vk < mine[e]) || (vk == mine[e] && k < i);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          if (lane + 64 * e < cnt) s[rank[e]] = mine[e];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        lo_med = s[m1]; hi_med = s[m2];
+      }
+      if (lane == 0) {
+        median[t] = (cnt & 1) ? lo_med : (lo_med + hi_med) * 0.5f;     // np.median of float32 stays float32
+        if (summary) {
+          double* o = summary + t * 5;
+          o[0] = (double)s[0];
+          const double qs[3] = {0.25, 0.5, 0.75};
+          for (int qi = 0; qi < 3; ++qi) {
+            double pos = qs[qi] * (double)(cnt - 1);
+            int a = (int)floor(pos);
+            int b = a + 1 < cnt ? a + 1 : cnt - 1;
+            o[1 + qi] = (double)np_lerp(s[a], s[b], (float)(pos - (double)a));
+          }
+          o[4] = (double)s[cnt - 1];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
@@ -379,6 +502,9 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
       // fp32 copies with an absolute error of |value| 2^-24 c, which at |mean| / bandwidth beyond ~1e4 exceeds the screen's margin.
       const double c64 = sqrt(inv * 1.44269504088896341);
       for (int k = lane; k < cnt; k += 64) vf[k] = (float)((v[k] - mean) * c64);
+      // (Measured and dropped in round 3: using the kernel matrix's symmetry -- each unordered pair once, the partner's share
+      // delivered with ds_add_f32 -- halves the exponentials but the LDS float adds cost far more than they save: 3.28 ms
+      // against 0.42 ms for 125 000 windows.)
       if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) vf[cnt + lane] = __int_as_float(0x7f800000);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -538,9 +664,19 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   if (!y_hat || !median || n <= 0 || window <= 0) return HYPAD_EINVAL;
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
   const int64_t T = n + window - 1;
-  if (window <= 64) hipLaunchKernelGGL(unroll_median_kernel<1>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
-  else if (window <= 128) hipLaunchKernelGGL(unroll_median_kernel<2>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
-  else hipLaunchKernelGGL(unroll_median_kernel<4>, dim3(grid_for(T, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, y_hat, median, summary, n, window);
+  const size_t lds = (size_t)(UT * ((window + 3) & ~3) + (THREADS / 64) * MAX_WINDOW) * sizeof(float);      // <= 68 KB at window 256
+  const char* fenv = getenv("HYPAD_UNROLL_FILTER");
+  const bool filter = !(fenv && fenv[0] == '0');
+  const dim3 grid(grid_for(T, UT)), block(THREADS);
+#define HYPAD_UNROLL(EPL)                                                                                                      \
+  do {                                                                                                                        \
+    auto kf = filter ? unroll_median_kernel<EPL, true> : unroll_median_kernel<EPL, false>;                                      \
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return HYPAD_EUNSUPPORTED;                                                                                               \
+    hipLaunchKernelGGL(kf, grid, block, lds, (hipStream_t)s, y_hat, median, summary, n, window);                               \
+  } while (0)
+  if (window <= 64) HYPAD_UNROLL(1); else if (window <= 128) HYPAD_UNROLL(2); else HYPAD_UNROLL(4);
+#undef HYPAD_UNROLL
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

@@ -83,6 +83,7 @@ class Engine:
             self.exp_avg[k] = t.view(1, -1)
         for k, t in (exp_avg_sq or {}).items():
             self.exp_avg_sq[k] = t.view(1, -1)
+        self._st = None
         self._drop_graphs()
 
     # ---- C structs -------------------------------------------------------------------------------------
@@ -90,8 +91,14 @@ class Engine:
         return _C.Nets(*(d[k].data_ptr() for k in NETS))
 
     def _state(self):
-        return _C.TrainState(self._nets(self.params), self._nets(self.exp_avg), self._nets(self.exp_avg_sq),
-                             self.counters.data_ptr(), self.lr, self.betas[0], self.betas[1], self.eps, self.gen_wd, self.gen_stab)
+        """hypad_train_state for the next call.  The pointer part is rebuilt only after adopt() (the arenas, moments and counters
+        are allocated once and updated in place); the scalars are refreshed on every call."""
+        st = self.__dict__.get("_st")
+        if st is None:
+            st = self._st = _C.TrainState(self._nets(self.params), self._nets(self.exp_avg), self._nets(self.exp_avg_sq),
+                                          self.counters.data_ptr(), 0.0, 0.0, 0.0, 0.0, 0.0, 0)
+        st.lr, st.beta1, st.beta2, st.eps, st.gen_weight_decay, st.gen_stabilize = self.lr, self.betas[0], self.betas[1], self.eps, self.gen_wd, self.gen_stab
+        return st
 
     def _check_x(self, x, x_row_stride=0):
         """x: (n_signals, n_windows, S) window matrices, or -- with x_row_stride=1 -- (n_signals, T) scaled series whose

@@ -27,6 +27,36 @@ from .optim import Adam, RiemannianAdam
 _NET_OF = {tadgan.Encoder: "enc", tadgan.Decoder: "dec", tadgan.CriticX: "cx", tadgan.CriticZ: "cz"}
 
 
+class _NoiseStage:
+    """Host-drawn noise of one iteration -> device in ONE copy: a ring of pinned host rows [z | alpha] and device rows of the
+    same shape.  NumPy / torch CPU write their draws straight into the pinned row; one non-blocking H2D follows; an event
+    per slot guards the pinned row against being refilled while its copy is still in flight (the device row is protected by
+    stream order: the kernels that read it precede the next copy into it)."""
+    SLOTS = 8
+
+    def __init__(self, device, floats):
+        self.floats = floats
+        self.host = torch.empty(self.SLOTS, floats, dtype=torch.float32).pin_memory()
+        self.host_np = self.host.numpy()
+        self.dev = torch.empty(self.SLOTS, floats, dtype=torch.float32, device=device)
+        self.events = [None] * self.SLOTS
+        self.k = 0
+
+    def slot(self):
+        k = self.k = (self.k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        return k
+
+    def upload(self, k):
+        self.dev[k].copy_(self.host[k], non_blocking=True)
+        ev = self.events[k]
+        if ev is None:
+            ev = self.events[k] = torch.cuda.Event()
+        ev.record()
+        return self.dev[k]
+
+
 class _Fused:
     """Flat Adam moments + device counters attached to one optimizer."""
 
@@ -45,26 +75,54 @@ class _Fused:
                              gen_weight_decay=g.get("weight_decay", 0.0), gen_stabilize=g.get("stabilize") or 0,
                              seed=torch.initial_seed() + salt)
         self.steps = 0
+        self.step_tensor = torch.tensor(0.0)   # ONE tensor shared by every parameter's state["step"]: one fill per step, not one per tensor
         for k, m in modules.items():          # expose the moments the way torch optimizers do
             for name, (p, off, n, shape) in m._slots.items():
-                optim.state[p] = {"step": torch.tensor(0.0), "exp_avg": self.exp_avg[k][off:off + n].view(shape),
+                optim.state[p] = {"step": self.step_tensor, "exp_avg": self.exp_avg[k][off:off + n].view(shape),
                                   "exp_avg_sq": self.exp_avg_sq[k][off:off + n].view(shape)}
         self.optim = optim
+        self.noise = None
+        self._bound = None
 
     def bind(self, others):
-        arenas = {k: m.arena() for k, m in {**others, **self.modules}.items()}
-        for k in ("enc", "dec", "cx", "cz"):   # the ABI wants four valid pointers; untouched nets borrow one
-            arenas.setdefault(k, next(iter(arenas.values())))
-        self.engine.adopt(arenas, self.exp_avg, self.exp_avg_sq)
-        g = self.optim.param_groups[0]
-        self.engine.lr = float(g["lr"])
+        """The engine pointed at the current arenas of the stepped and the frozen networks.  Re-adopting (new views, dropped
+        graphs) only when a module or one of its arenas changed since the last call."""
+        mods = {**others, **self.modules}
+        sig = tuple((k, id(m), m.arena(fast=True).data_ptr()) for k, m in mods.items())
+        if sig != self._bound:
+            arenas = {k: m.arena() for k, m in mods.items()}
+            for k in ("enc", "dec", "cx", "cz"):   # the ABI wants four valid pointers; untouched nets borrow one
+                arenas.setdefault(k, next(iter(arenas.values())))
+            self.engine.adopt(arenas, self.exp_avg, self.exp_avg_sq)
+            self._bound = sig
+        lr = float(self.optim.param_groups[0]["lr"])
+        if lr != self.engine.lr:
+            self.engine.lr = lr
         return self.engine
+
+    def stage(self, B, L, alpha_width, z, alpha, device):
+        """(z, alpha) on the device for one iteration, drawn where the reference draws them (z: NumPy's global generator,
+        train.py:24,118,205; alpha: torch's CPU generator, train.py:64,149 -- in that order) unless given."""
+        nz, na = B * L, B * alpha_width
+        if self.noise is None or self.noise.floats != nz + na:
+            self.noise = _NoiseStage(device, nz + na)
+        st = self.noise
+        k = st.slot()
+        if z is None:
+            z = np.random.normal(size=(1, B, L))
+        st.host_np[k, :nz] = np.asarray(z, dtype=np.float64).reshape(-1)          # (cast to float32 on assignment)
+        if na:
+            row = st.host[k, nz:]
+            if alpha is None:
+                torch.rand((1, B, alpha_width), out=row.view(1, B, alpha_width))
+            else:
+                row.copy_(torch.as_tensor(alpha, dtype=torch.float32).reshape(-1))
+        d = st.upload(k)
+        return d[:nz].view(1, B, L), (d[nz:].view(1, B, alpha_width) if na else None)
 
     def stepped(self):
         self.steps += 1
-        for st in self.optim.state.values():
-            if isinstance(st.get("step"), torch.Tensor):
-                st["step"].fill_(self.steps)
+        self.step_tensor.fill_(self.steps)
 
 
 def _resume_salt(resume_epoch):
@@ -106,27 +164,23 @@ def _fused(optim, modules, params, hyperbolic):
         optim._hypad = f
     elif f.key != _fused_key(modules, dims):
         raise _C.HypadError("this optimizer is already bound to other modules / dimensions (signal_shape, latent_space_dim, "
-                            "batch_size, hyperbolic): its Adam moments cannot be carried over -- create a new optimizer")
+                            "batch_size, hyperbolic): its Adam moments cannot be carried over -- create a new optimizer.  (A last, "
+                            "smaller minibatch does this too: build the DataLoader with drop_last=True, as main.py:38 does.)")
     return f
 
 
 def _sample(sample, params):
-    x = sample.reshape(params.batch_size, params.signal_shape)
+    try:
+        x = sample.reshape(1, params.batch_size, params.signal_shape)
+    except RuntimeError as e:
+        raise _C.HypadError(f"a minibatch must hold batch_size x signal_shape = {params.batch_size} x {params.signal_shape} values, got "
+                            f"{tuple(sample.shape)}: build the DataLoader with drop_last=True (main.py:38) -- the fused iterations are "
+                            "bound to one batch size") from e
     if not x.is_cuda:
         x = x.cuda()
-    return x.to(torch.float32).contiguous().unsqueeze(0)
-
-
-def _draw_z(params, z, device):
-    if z is None:
-        z = np.random.normal(size=(1, params.batch_size, params.latent_space_dim))       # train.py:24,118,205
-    return torch.as_tensor(np.asarray(z), dtype=torch.float32).reshape(1, params.batch_size, -1).contiguous().to(device)
-
-
-def _draw_alpha(shape, alpha, device):
-    if alpha is None:
-        alpha = torch.rand(shape)                                                         # train.py:64,149 (CPU generator)
-    return torch.as_tensor(alpha, dtype=torch.float32).reshape(shape).contiguous().to(device)
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)
+    return x if x.is_contiguous() else x.contiguous()
 
 
 def _train_flag(*mods):
@@ -141,11 +195,10 @@ def critic_x_iteration(sample, decoder, critic_x, optim_cx, params, z=None, alph
     x = _sample(sample, params)
     f = _fused(optim_cx, {"cx": critic_x}, params, decoder.hyperbolic)
     eng = f.bind({"dec": decoder})
-    B, S = params.batch_size, params.signal_shape
-    losses = eng.critic_x_iteration(x, None, _draw_z(params, z, x.device), _draw_alpha((1, B, S), alpha, x.device),
-                                    _train_flag(decoder, critic_x), dropout_masks)
+    zd, ad = f.stage(params.batch_size, params.latent_space_dim, params.signal_shape, z, alpha, x.device)
+    losses = eng.critic_x_iteration(x, None, zd, ad, _train_flag(decoder, critic_x), dropout_masks)
     f.stepped()
-    return losses[0, 0].to(torch.float64)
+    return losses.view(-1)[0].to(torch.float64)
 
 
 def critic_z_iteration(sample, encoder, critic_z, optim_cz, params, z=None, alpha=None, dropout_masks=None):
@@ -153,11 +206,10 @@ def critic_z_iteration(sample, encoder, critic_z, optim_cz, params, z=None, alph
     x = _sample(sample, params)
     f = _fused(optim_cz, {"cz": critic_z}, params, False)
     eng = f.bind({"enc": encoder})
-    B, L = params.batch_size, params.latent_space_dim
-    losses = eng.critic_z_iteration(x, None, _draw_z(params, z, x.device), _draw_alpha((1, B, L), alpha, x.device),
-                                    _train_flag(encoder, critic_z), dropout_masks)
+    zd, ad = f.stage(params.batch_size, params.latent_space_dim, params.latent_space_dim, z, alpha, x.device)
+    losses = eng.critic_z_iteration(x, None, zd, ad, _train_flag(encoder, critic_z), dropout_masks)
     f.stepped()
-    return losses[0, 0].clone()
+    return losses.view(-1)[0]
 
 
 def decoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_dec, params, err_loss=None, z=None,
@@ -171,12 +223,13 @@ def decoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_dec, p
     if decoder.hyperbolic and not getattr(optim_dec, "riemannian", False) and "stabilize" not in optim_dec.param_groups[0]:
         raise _C.HypadError("hyperbolic decoder_iteration needs a RiemannianAdam optimizer (train.py:282-288)")
     eng = f.bind({"cx": critic_x, "cz": critic_z})
-    losses = eng.decoder_iteration(x, None, _draw_z(params, z, x.device), _train_flag(encoder, decoder, critic_x, critic_z),
-                                   dropout_masks)
+    zd, _ = f.stage(params.batch_size, params.latent_space_dim, 0, z, None, x.device)
+    losses = eng.decoder_iteration(x, None, zd, _train_flag(encoder, decoder, critic_x, critic_z), dropout_masks)
     f.stepped()
+    flat = losses.view(-1)                       # (a fresh (1, 4) tensor per call: views of it are the caller's to keep)
     if decoder.hyperbolic:
-        return losses[0, 0].clone(), losses[0, 1].clone(), torch.Tensor([0])
-    return losses[0, 0].clone(), 0, losses[0, 1].clone()
+        return flat[0], flat[1], torch.Tensor([0])
+    return flat[0], 0, flat[1]
 
 
 def encoder_iteration(sample, encoder, decoder, critic_x, critic_z, optim_enc, params, err_loss=None, z=None, dropout_masks=None):

@@ -73,7 +73,7 @@ def _worker(rank, port, ret):
         x32 = yd.to(torch.float32).contiguous()
         res = score_batches([yd[: n // 3], yd[n // 3:]], enc, dec, cx, S)
         for comb in ("mult", "sum_uncertainty"):
-            want = adu.hyperbolic_scores(res["recons"], res["hyper_real"], res["critic"], S, comb)
+            want = adu.hyperbolic_scores(res["recons"].cpu().numpy(), res["hyper_real"].cpu().numpy(), res["critic"].cpu().numpy(), S, comb)
             got_m = par.score_windows_sharded(x32, enc, dec, cx, S, comb)
             got_s = par.score_windows_sharded(torch.from_numpy(series).cuda().float().contiguous(), enc, dec, cx, S, comb, x_row_stride=1)
             # (the sharded scorer takes the distance the fused forward computed; hyperbolic_scores re-computes it from the written
