@@ -139,6 +139,8 @@ struct PhaseArgs {
   // through, after the record's write-through stores have drained) by the workgroup that wrote it; null = the records come from
   // the precompute launch in front
   unsigned* rec_flags;                         // (2 critics, n_signals, n_iters, B/16)
+  int n_signals;
+  int xcd_stretch;                             // 1: the critics' workgroup ids are stretched by 8 (one critic's chunks on one XCD); 0: dealt in id order
   int fault_it;                                // tests (HYPAD_EPOCH_TEST_GIVE_UP_SHIFT): > 0 = critic_x chunk 0 of signal 0 behaves as if its
                                                // wait for the siblings' shares had timed out at that iteration
 };
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterA
 // Residency: one workgroup per CU (the launcher asks for the full LDS plan for both critics and checks
 // workgroups <= CUs before choosing this form; otherwise the per-iteration launches run).
 #if HYPAD_DIAG
-#define PSTAMP(k) do { if (ph.stamps && it == 5 && (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == 0) ph.stamps[(blockIdx.z * 32 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAMP(k) do { if (ph.stamps && it == 5 && (threadIdx.x & 63) == 0 && chunk == 0 && sig == 0) ph.stamps[(((IS_X ? 0 : 1)) * 32 + (k)) * 8 + (threadIdx.x >> 6)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PSTAMP(k) do { } while (0)
 #endif
@@ -926,9 +928,10 @@ HD int persist_items(const CritGeom& g) {
 }
 
 template <bool IS_X, int SC, int LC, int BC>
-__device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const PhaseArgs& ph, float* smem) {
+__device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const PhaseArgs& ph, float* smem, const int sig, const int chunk,
+                                                       const int n_signals) {
   const int L = LC ? LC : a.L, B = BC ? BC : a.B, S = SC ? SC : a.S;
-  const int sig = blockIdx.y, chunk = blockIdx.x, nchunks = B / 16;
+  const int nchunks = B / 16;
   constexpr int nh = IS_X ? 4 : 2;
   // weight-gradient tiles per wave (seven waves share them): exact at the compile-time shapes, MAXT otherwise
   constexpr int TPW = (SC && LC) ? (persist_tiles(IS_X ? SC : LC, LC, nh) + NW - 2) / (NW - 1) : MAXT;
@@ -965,9 +968,17 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   const int slabf = nitems * 4;
   float* xslab = (IS_X ? ph.xslab_x : ph.xslab_z) + (int64_t)sig * 2 * nchunks * slabf;
   unsigned long long* gran = (IS_X ? ph.gran_x : ph.gran_z) + (int64_t)sig * 2 * nchunks * 4;
-  unsigned* flags = ph.flags + ((int64_t)(IS_X ? 0 : 1) * gridDim.y + sig) * nchunks;
+  unsigned* flags = ph.flags + ((int64_t)(IS_X ? 0 : 1) * n_signals + sig) * nchunks;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xslab, 0, 0x7fffffff, 0x00020000);
   float* lo_base = ph.losses + sig * a.loss_sig_stride + (IS_X ? 0 : 4);
+  // Which XCD this workgroup runs on (MI355X_MICROARCH.md, dispatch: a hardware register, not an assumption about placement).  It
+  // travels in the top byte of the chunk's epoch word; once a chunk has seen that ALL chunks of its critic share its XCD -- the
+  // launcher deals them that way, see critic_persistent_kernel -- their exchange stays inside that XCD's L2: shares, granules and
+  // epoch words are stored WITHOUT the write-through bit (the line stays in L2; every sibling reads it there with the sc1 --
+  // L1-bypassing -- loads it uses anyway) instead of being pushed to the memory side and fetched back from there by every
+  // sibling.  Any other placement keeps the write-through forms: correctness never depends on where a workgroup landed.
+  const unsigned my_xcc = (__builtin_amdgcn_s_getreg(6164) & 0xfu) + 1u;            // hwreg(HW_REG_XCC_ID, 0, 4) + 1
+  bool same_xcd = false;                                                            // decided at the first wait (iteration 1)
 
   auto tile_desc = [&](int t, int& li, int& n0, int& k0) __attribute__((always_inline)) {
     if (t < g.tiles0) { li = 0; n0 = (t / g.tk0) * 16; k0 = (t % g.tk0) * 16; return; }
@@ -1047,7 +1058,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   // joins.  Every record load is a 16-byte sc1 buffer load either way (Guideline 16 R1).
   auto await_record = [&](int it) __attribute__((always_inline)) {     // one wave calls it; a workgroup barrier follows
     if (!ph.rec_flags) return;
-    const unsigned* f = ph.rec_flags + ((((int64_t)(IS_X ? 0 : 1) * gridDim.y + sig) * n_iters + it) * nchunks + chunk);
+    const unsigned* f = ph.rec_flags + ((((int64_t)(IS_X ? 0 : 1) * n_signals + sig) * n_iters + it) * nchunks + chunk);
     bool ok = false;
     for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
       ok = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -1105,9 +1116,13 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         bool ok = false;
         const bool fault = IS_X && ph.fault_it > 0 && it == ph.fault_it && sig == 0 && chunk == 0;      // (tests: a timed-out wait)
         for (unsigned spins = fault ? SPIN_LIMIT : 0u; spins < SPIN_LIMIT; ++spins) {
-          const unsigned f = lane < nchunks ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)it;
-          ok = __all((int)(f >= (unsigned)it));
-          if (ok) break;
+          const unsigned f = lane < nchunks ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)it | (my_xcc << 24);
+          ok = __all((int)((f & 0xffffffu) >= (unsigned)it));
+          if (ok) {
+            const bool together = __all((int)((f >> 24) == my_xcc));             // every chunk of this critic on this workgroup's XCD
+            if (it == 1 && lane == 0) ctl[1] = together ? 1 : 0;
+            break;
+          }
           if ((spins & 1023) == 1023 && __hip_atomic_load(ph.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
           __builtin_amdgcn_s_sleep(2);
         }
@@ -1115,6 +1130,11 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       }
       __syncthreads();
       if (ctl[0]) { if (writer && threadIdx.x == 0 && it <= n_iters) lo_base[(int64_t)(2 * (it - 1)) * 4] = __builtin_nanf(""); return; }
+      if (it == 1) {
+        same_xcd = ctl[1] != 0;
+        // (observability: counters[5] = critics of this launch whose chunks all share an XCD -- zeroed by the epoch's first launch)
+        if (same_xcd && a.guard && chunk == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(a.counters + 5, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       PSTAMP(1);                                                         // siblings' shares are there
       obase = ppar * nchunks * slabf;
       // the first four chunks' shares of this thread's layer-0 quads: requested together, before anything is waited for (clamped
@@ -1188,7 +1208,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     };
     if (fin) {
       if (!CHAIN) phase_b();
-      if (IS_X && ph.advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {      // step counters and rng tick: nobody reads
+      if (IS_X && ph.advance && chunk == 0 && sig == 0 && threadIdx.x == 0) {      // step counters and rng tick: nobody reads
         a.counters[0] += n_iters; a.counters[1] += n_iters; a.counters[3] += n_iters;           // them inside this launch
       }
       if (writer) {                                                   // the phase's last state -> arenas
@@ -1491,8 +1511,9 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       float v;
       if (threadIdx.x == 0) { v = 0.f; for (int w = 0; w < NW; ++w) v += red[w]; }
       else v = red[31 + threadIdx.x];
-      __hip_atomic_store(gr + chunk * 4 + threadIdx.x, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long word = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+      if (same_xcd) __hip_atomic_store(gr + chunk * 4 + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in this XCD's L2
+      else __hip_atomic_store(gr + chunk * 4 + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (it + 1 < n_iters) request_record(it + 1);         // lands during the tiles below and the waits that follow
     if (!(CHAIN && wave == 2)) {
@@ -1546,7 +1567,8 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc_rf[i][r] + coef * acc_gp[i][r];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, (obase + e * 4) * 4, 0, 16);
+            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, (obase + e * 4) * 4, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, (obase + e * 4) * 4, 0, 16);
           }
         }
       }
@@ -1554,7 +1576,10 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     PSTAMP(14);                                                          // share stored
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
     __syncthreads();                                      // ... before ONE lane signals for all of them
-    if (threadIdx.x == 0) __hip_atomic_store(flags + chunk, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      if (same_xcd) __hip_atomic_store(flags + chunk, epoch | (my_xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(flags + chunk, epoch | (my_xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     PSTAMP(15);                                                          // drained, epoch word out
     PSTAMP(16);
   }
@@ -1562,15 +1587,33 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   if (wave < BW0) run(std::true_type{}); else run(std::false_type{});
 }
 
+// Placement.  The grid is one-dimensional.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, dispatch), so the
+// critic part of the grid is stretched by 8: id = 8 * slot + x runs on the XCD group x, and critic c = 2 * signal + {0: critic_x,
+// 1: critic_z} takes x = c mod 8 with slots (c / 8) * nchunks + chunk -- ALL chunk workgroups of one critic on one XCD (they
+// exchange a gradient share with each other every iteration; critic_x and critic_z of a signal on neighbouring XCDs), at most
+// 32 of them per XCD for any signal count the resident form accepts.  Ids whose (x, slot) names no critic exit at once.  The
+// record producers follow in iteration order.  A speed matter only: the body reads the XCD it really runs on from the
+// hardware and picks its store flavour from that (see `same_xcd`).
 template <int SC, int LC, int BC>
 __global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (ax.guard && ax.counters[4] != 0) return;     // fail-stop: an earlier resident launch on this state gave up (hypad_epoch_status)
-  if (blockIdx.z >= 2) {            // producer workgroups (ph.rec_flags): the records, in iteration order behind the resident critics
-    precompute_body<true>(ax, az, ph, smem, blockIdx.x, blockIdx.y, (blockIdx.z - 2) >> 1, (blockIdx.z - 2) & 1, gridDim.y);
+  const int nchunks = (BC ? BC : ax.B) / 16, ns = ph.n_signals;
+  const int crit_ids = ph.xcd_stretch ? 8 * nchunks * ((2 * ns + 7) >> 3) : 2 * ns * nchunks;
+  const int id = blockIdx.x;
+  if (id >= crit_ids) {             // producer workgroups (ph.rec_flags): the records, in iteration order behind the resident critics
+    const int q = id - crit_ids;
+    const int tile = q % nchunks, rest = q / nchunks;
+    const int sig = rest % ns, zz = rest / ns;
+    precompute_body<true>(ax, az, ph, smem, tile, sig, zz >> 1, zz & 1, ns);
     return;
   }
-  if (blockIdx.z == 0) critic_persistent_body<true, SC, LC, BC>(ax, ph, smem); else critic_persistent_body<false, SC, LC, BC>(az, ph, smem);
+  int c, chunk;
+  if (ph.xcd_stretch) { const int slot = id >> 3; c = (slot / nchunks) * 8 + (id & 7); chunk = slot % nchunks; }
+  else { chunk = id % nchunks; const int r = id / nchunks; c = 2 * (r % ns) + r / ns; }      // (HYPAD_CRITIC_XCD=0: the round-2 order)
+  if (c >= 2 * ns) return;
+  if ((c & 1) == 0) critic_persistent_body<true, SC, LC, BC>(ax, ph, smem, c >> 1, chunk, ns);
+  else critic_persistent_body<false, SC, LC, BC>(az, ph, smem, c >> 1, chunk, ns);
 }
 
 __global__ void advance_counters_kernel(int32_t* counters, int n) {
@@ -1734,6 +1777,8 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   }
   PhaseArgs ph{};
   ph.fault_it = (flags >> HYPAD_EPOCH_TEST_GIVE_UP_SHIFT) & 0xff;
+  ph.n_signals = n_signals;
+  { const char* xenv = getenv("HYPAD_CRITIC_XCD"); ph.xcd_stretch = (xenv && xenv[0] == '0') ? 0 : 1; }
   // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
   // persistent form's exchange buffers: [epoch words | error word] (zeroed before every launch), granules, merged shares
   float* p = extra;
@@ -1804,7 +1849,9 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
         if (e != hipSuccess) return (int)e;
       }
       if (ev) (void)hipEventRecord(ev[2], s);
-      hipLaunchKernelGGL(kern, dim3(nchunks, n_signals, fused ? 2 + 2 * n : 2), dim3(FT), lds, s, ax, az, ph);
+      // (one-dimensional grid: the critics' ids stretched by 8 for XCD placement, then the producers -- critic_persistent_kernel)
+      const unsigned crit_ids = ph.xcd_stretch ? 8u * nchunks * ((2u * n_signals + 7u) >> 3) : 2u * n_signals * nchunks;
+      hipLaunchKernelGGL(kern, dim3(crit_ids + (fused ? 2u * n * nchunks * n_signals : 0u)), dim3(FT), lds, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
       if (ev) (void)hipEventRecord(ev[3], s);
     } else {

@@ -422,3 +422,71 @@ extern "C" int hypad_diag_tile(const float* W, int mode, int threads, long long*
   }
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------- store16: 16-byte buffer stores vs rewriting
+// their data registers.  Round 2 met intermittently lost / mixed values behind `buffer_store_dwordx4 ... s_off offen` whose data
+// registers were rewritten a few instructions later (tile_gemm.h GBuf::st4).  This isolates it: a wave stores four registers
+// holding a known pattern and overwrites those registers NOPS wait states later, all inside one asm block so that no compiler
+// scheduling or hazard handling takes part; a second kernel counts the 16-byte slots that do not hold the pattern.
+//   FORM 0: row offset in a scalar register (`s_off offen`)        FORM 1: offset folded into the vector offset (`0 offen`)
+//   FORM 2: FORM 0 with the scalar register written by s_mov right before the store (SGPR written by SALU -> VMEM read)
+//   NOPS 0: the overwrite is the next instruction; k > 0: `s_nop k-1` in between.
+namespace {
+__device__ __forceinline__ unsigned store16_pattern(unsigned slot, unsigned e) { return (slot * 2654435761u) ^ (0x9e3779b9u * (e + 1u)); }
+
+template <int FORM, int NOPS>
+__global__ __launch_bounds__(256) void diag_store16_kernel(unsigned* __restrict__ buf, int iters) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 0x7fffffff, 0x00020000);
+  const unsigned tid = blockIdx.x * 256 + threadIdx.x;
+  const unsigned per_iter = gridDim.x * 256 * 16;                            // bytes of one iteration's slots
+  for (int it = 0; it < iters; ++it) {
+    const unsigned slot = (unsigned)it * (gridDim.x * 256) + tid;
+    const unsigned a = store16_pattern(slot, 0), b = store16_pattern(slot, 1), c = store16_pattern(slot, 2), d = store16_pattern(slot, 3);
+    const unsigned so = (unsigned)it * per_iter;                             // wave-uniform row offset
+    const unsigned vo_lane = tid * 16, vo_full = vo_lane + so;
+    const unsigned junk = ~a;
+#define ST16_NOP(N) "s_nop " #N "\n\t"
+#define ST16_BODY(STORE, NOPSTR)                                                                                             \
+    asm volatile("v_mov_b32 v28, %[a]\n\tv_mov_b32 v29, %[b]\n\tv_mov_b32 v30, %[c]\n\tv_mov_b32 v31, %[d]\n\t"             \
+                 "s_nop 4\n\t" STORE NOPSTR                                                                                   \
+                 "v_mov_b32 v28, %[j]\n\tv_mov_b32 v29, %[j]\n\tv_mov_b32 v30, %[j]\n\tv_mov_b32 v31, %[j]\n\t"             \
+                 : : [a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d), [j] "v"(junk), [vl] "v"(vo_lane), [vf] "v"(vo_full), [rs] "s"(rs), [so] "s"(so) \
+                 : "v28", "v29", "v30", "v31", "s33", "memory")
+#define ST16_FORM(NOPSTR)                                                                                                    \
+    do {                                                                                                                     \
+      if constexpr (FORM == 0) ST16_BODY("buffer_store_dwordx4 v[28:31], %[vl], %[rs], %[so] offen\n\t", NOPSTR);          \
+      else if constexpr (FORM == 1) ST16_BODY("buffer_store_dwordx4 v[28:31], %[vf], %[rs], 0 offen\n\t", NOPSTR);          \
+      else ST16_BODY("s_mov_b32 s33, %[so]\n\tbuffer_store_dwordx4 v[28:31], %[vl], %[rs], s33 offen\n\t", NOPSTR);        \
+    } while (0)
+    if constexpr (NOPS == 0) ST16_FORM("");
+    else if constexpr (NOPS == 1) ST16_FORM(ST16_NOP(0));
+    else if constexpr (NOPS == 2) ST16_FORM(ST16_NOP(1));
+    else if constexpr (NOPS == 3) ST16_FORM(ST16_NOP(2));
+    else ST16_FORM(ST16_NOP(4));
+#undef ST16_FORM
+#undef ST16_BODY
+#undef ST16_NOP
+  }
+}
+__global__ __launch_bounds__(256) void diag_store16_check_kernel(const unsigned* __restrict__ buf, unsigned slots, unsigned long long* bad) {
+  unsigned n = 0;
+  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s < slots; s += gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(buf)[s];
+    if (v.x != store16_pattern(s, 0) || v.y != store16_pattern(s, 1) || v.z != store16_pattern(s, 2) || v.w != store16_pattern(s, 3)) ++n;
+  }
+  if (n) atomicAdd(bad, (unsigned long long)n);
+}
+}  // namespace
+
+// buf: blocks * 256 * iters * 16 bytes (<= 2 GB); bad: device counter, zeroed by the caller.  Returns 0 or a HIP error.
+extern "C" int hypad_diag_store16(int form, int nops, int blocks, int iters, unsigned* buf, unsigned long long* bad, hypad_stream_t s) {
+  if (form < 0 || form > 2 || nops < 0 || nops > 4 || blocks < 1 || iters < 1 || (long long)blocks * 256 * iters * 16 > 0x7fffffffLL) return HYPAD_EINVAL;
+#define ST16_LAUNCH(F, N) hipLaunchKernelGGL((diag_store16_kernel<F, N>), dim3(blocks), dim3(256), 0, (hipStream_t)s, buf, iters)
+#define ST16_N(F) do { switch (nops) { case 0: ST16_LAUNCH(F, 0); break; case 1: ST16_LAUNCH(F, 1); break; case 2: ST16_LAUNCH(F, 2); break; \
+                                       case 3: ST16_LAUNCH(F, 3); break; default: ST16_LAUNCH(F, 4); } } while (0)
+  if (form == 0) ST16_N(0); else if (form == 1) ST16_N(1); else ST16_N(2);
+#undef ST16_N
+#undef ST16_LAUNCH
+  hipLaunchKernelGGL(diag_store16_check_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, buf, (unsigned)(blocks * 256 * iters), bad);
+  return (int)hipGetLastError();
+}

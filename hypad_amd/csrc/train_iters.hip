@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(256) void epoch_restore_kernel(IterArgs a, float* s
 }
 __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTable tab, unsigned* zero_ptr, int zero_words, float* snap) {
   if (a.guard && a.counters[4] != 0) return;   // fail-stop: in particular the snapshot of the state the failed epoch began from stays
+  if (a.guard && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.counters[5] = 0;      // (placement census of the resident launch)
   if (zero_words) {                            // (launch_pack: one word per thread of the grid)
     const int64_t flat = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (flat < zero_words) zero_ptr[flat] = 0u;

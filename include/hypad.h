@@ -182,7 +182,8 @@ typedef struct hypad_train_state {
   hypad_nets exp_avg_sq;   /* Adam second moment */
   int32_t* counters;       /* device int32[8]: [0..2] optimizer steps taken by {critic_x, critic_z, generator}, [3] rng ticks,
                               [4] STATUS of hypad_train_epoch's resident critic launch (0 = fine; otherwise the code of the first
-                              bounded wait that gave up, see hypad_epoch_status), [5..7] reserved (zero) */
+                              bounded wait that gave up, see hypad_epoch_status), [5] how many critics of the last hypad_train_epoch's resident
+                              launch had all their chunk workgroups on one XCD (a speed matter only), [6..7] reserved (zero) */
   float lr, beta1, beta2, eps;
   float gen_weight_decay;  /* hyperbolic generator optimizer: 1e-5 (train.py:286); ignored otherwise */
   int gen_stabilize;       /* 10 (train.py:287) */

@@ -135,3 +135,49 @@ def test_captured_epoch_is_recaptured_when_what_it_froze_changes():
     # adopting other arenas (hypad_amd.train binds module views this way) drops them too
     a.adopt({k: v.clone().view(-1) for k, v in a.params.items()})
     assert "_graphs" not in a.__dict__
+
+
+# ------------------------------------------------------------------------------------------------ XCD placement of the resident launch
+@pytest.mark.parametrize("ns,S,B", [(1, 100, 64), (5, 100, 64), (8, 100, 64), (1, 150, 256)])
+def test_chunks_of_a_critic_share_an_xcd_and_the_epoch_keeps_its_bits(ns, S, B, monkeypatch):
+    """critic_persistent_kernel deals the chunk workgroups of one critic to one XCD (ids stretched by 8) and, having read from
+    the hardware that they really share it, keeps their exchange -- gradient shares, scalar granules, epoch words -- in that
+    XCD's L2 (stores without the write-through bit).  HYPAD_CRITIC_XCD=0 deals them in id order (the round-2 placement: a
+    critic's chunks on different XCDs -> the write-through forms).  Placement and store flavour are speed matters only: both
+    epochs must agree bit for bit -- losses, all four networks, moments, counters -- also with the chip busy on a side stream;
+    and the census word (counters[5]) must say which form ran."""
+    nb, nc = 4, 3
+    engine, x, perms, _, _ = _setup(ns, seed=7, S=S, B=B, nb=nb, nc=nc)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HYPAD_CRITIC_XCD", mode)
+        e = engine()
+        assert e.critic_phase_persistent()
+        l = e.train_epoch(x, perms[0], nb, nc, True).clone()
+        l2 = e.train_epoch(x, perms[1], nb, nc, True).clone()
+        assert e.status() == 0
+        outs[mode] = (l, l2, _snapshot(e))
+    census = {m: int(outs[m][2][3][5]) for m in outs}
+    print("critics whose chunks share an XCD: stretched ids", census["1"], "of", 2 * ns, "; id order", census["0"])
+    assert census["1"] == 2 * ns, census            # (what the dispatcher is observed to do; the kernel would be correct without it)
+    assert census["0"] == 0 or B // 16 == 1, census
+    a, b = outs["1"], outs["0"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(a[2][i][k], b[2][i][k]) for i in range(3) for k in a[2][i]) and torch.equal(a[2][3][:5], b[2][3][:5])
+    # the same under an uneven background load, several times
+    monkeypatch.setenv("HYPAD_CRITIC_XCD", "1")
+    side = torch.cuda.Stream()
+    src = torch.empty(32 << 20, dtype=torch.float32, device="cuda")
+    dst = torch.empty_like(src)
+    for rep in range(6):
+        e = engine()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                dst.copy_(src)
+        l = e.train_epoch(x, perms[0], nb, nc, True)
+        l2 = e.train_epoch(x, perms[1], nb, nc, True)
+        torch.cuda.synchronize()
+        assert torch.equal(l, a[0]) and torch.equal(l2, a[1]), rep
+        snap = _snapshot(e)
+        assert all(torch.equal(snap[i][k], a[2][i][k]) for i in range(3) for k in snap[i]), rep
