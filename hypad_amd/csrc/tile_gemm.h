@@ -231,10 +231,14 @@ struct GBuf {
   __device__ __forceinline__ void st(float v, int vo, int so) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
   // (16 bytes: the whole vector is converted at once -- hipcc narrows an element-wise use of a b128 result to one dword)
   __device__ __forceinline__ float4 ld4(int vo, int so) const { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0)); }
-  // 16-byte stores take NO scalar offset: `buffer_store_dwordx4 ... s_off offen` with the data registers rewritten a few
-  // instructions later lost or mixed values intermittently on gfx950 / ROCm 7.2 (2-5 of 6 test runs; the compiler's `s_nop 1`
-  // behind the store was there); the same store with the offset folded into the vector offset, and the 4-byte stores and
-  // 16-byte LOADS with a scalar offset, never did (tests/test_gpu_parity.py::test_other_window_sizes_match_oracle, 12 runs each).
+  // 16-byte stores take NO scalar offset.  Hardware hazard (gfx950, isolated in round 3: csrc/diag.hip hypad_diag_store16,
+  // scripts/diag_store16.py, profiles/r03_store16_hazard.txt): a VALU write of the data registers of a `buffer_store_dwordx4`
+  // needs wait states behind the store -- ONE with the row offset in a scalar register (`s_off offen`: 1.1 % of the stores
+  // carried the overwriting values with none, 0 of 1.3e8 with one), TWO with an immediate offset (`0 offen`: 24 % / 1.1 % / 0).
+  // hipcc (ROCm 7.2) pads the immediate form (`s_nop 1`) but treats the scalar-offset form as hazard-free and pads nothing:
+  // whenever its scheduler put the next writer of those registers right behind such a store, values were lost -- the
+  // intermittent gradients of round 2 (2-5 of 6 test runs).  With the offset folded into the vector offset the compiler's own
+  // padding covers it.  tests/test_cabi_and_host.py keeps every 16-byte buffer store of the sources on the immediate form.
   __device__ __forceinline__ void st4(const float4& v, int vo) const { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), rs, vo, 0, 0); }
 };
 template <bool SC1>

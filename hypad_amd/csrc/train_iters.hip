@@ -740,6 +740,10 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 
 // SC / LC / BC: compile-time dims of the reference configuration (0 = run-time), which fold the layout arithmetic of
 // shadow_ref() and gen_ws() into constants.
+// (Measured and dropped in round 3: 32 x 32 weight tiles -- four accumulators per wave, half the operand loads per MFMA and per
+// parameter -- for the many-signal launches: 157 registers (2 waves per SIMD instead of 3) and three round trips per item made
+// the launch SLOWER at 8 / 16 / 32 signals per GPU: 33 -> 42, 56 -> 64, 101 -> 110 us.  The operand re-reads of the 16 x 16 tiles
+// are L2 hits once a model's tiles share an XCD (COLOC); what the launch waits for is its scattered 64-byte store segments.)
 // KS: k-steps (groups of four reduction rows) a weight item keeps in flight: 48 covers B <= 64 in one memory round trip.
 // (16 halves the registers and doubles the waves per SIMD; measured with 8 and 32 signals per GPU it changes nothing --
 // with many signals the launch moves ~9 MB per signal and sits at ~3.5 TB/s of HBM traffic.)

@@ -123,3 +123,35 @@ def test_train_module_keeps_the_reference_call_surface():
     assert lead(ht.encoder_iteration, 5) == ["sample", "encoder", "decoder", "critic_x", "critic_z"]
     assert lead(ht.train_tadgan, 8) == ["train_loader", "encoder", "decoder", "critic_x", "critic_z", "n_epochs", "params", "path"]
     assert lead(ht.train, 3) == ["train_loader", "params", "config_path"]
+
+
+def test_wide_buffer_stores_keep_their_offset_out_of_scalar_registers():
+    """gfx950 needs a wait state between `buffer_store_dwordx4 ..., s_off offen` and a VALU write of its data registers, and
+    hipcc (ROCm 7.2) inserts none for that form (profiles/r03_store16_hazard.txt; csrc/tile_gemm.h GBuf::st4): every 12- / 16-byte
+    raw buffer store of the kernel sources must pass the literal 0 as its scalar offset (the compiler pads the immediate form)."""
+    import glob
+    pat = re.compile(r"__builtin_amdgcn_raw_buffer_store_b(?:96|128)\s*\(")
+    found = 0
+    for path in glob.glob(os.path.join(ROOT, "hypad_amd", "csrc", "*")):
+        if path.endswith("diag.hip"):
+            continue                                   # (the reproducer writes the hazardous form on purpose, in inline assembly)
+        src = open(path).read()
+        for m in pat.finditer(src):
+            depth, i, args, cur = 1, m.end(), [], ""
+            while depth:
+                c = src[i]
+                if c == "(":
+                    depth += 1
+                elif c == ")":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                if c == "," and depth == 1:
+                    args.append(cur.strip()); cur = ""
+                else:
+                    cur += c
+                i += 1
+            args.append(cur.strip())
+            assert len(args) == 5 and args[3] == "0", (os.path.basename(path), args)
+            found += 1
+    assert found >= 3
