@@ -34,6 +34,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (a + b) + (c + d);
 }
+// Maximum / minimum over the 64 lanes, result in every lane (same DPP butterfly; six ds_bpermute hops as shuffles)
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_move_<0xB1>(v));
+  v = fmaxf(v, dpp_move_<0x4E>(v));
+  v = fmaxf(v, dpp_move_<0x141>(v));
+  v = fmaxf(v, dpp_move_<0x140>(v));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 // Sum over each aligned group of 16 lanes (one DPP row), result in every lane of the group: the first four steps above.
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_move_<0xB1>(v);

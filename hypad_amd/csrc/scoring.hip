@@ -48,9 +48,17 @@ __device__ __forceinline__ float np_lerp(float a, float b, float t) {
 // pivots that miss, ties among the candidates, short edge diagonals -- takes the full count: the result is the exact order
 // statistic either way.
 constexpr int UT = 64;                       // timesteps per workgroup tile
+#if HYPAD_DIAG
+long long* g_unroll_stamps = nullptr;        // development aid (dev library): [0..3] shader-clock stamps of one workgroup's first tile, [8] filter hits, [9] full counts
+#define USTAMP(k) do { if (stamps && blockIdx.x == 37 && threadIdx.x == 0 && t0 == (int64_t)blockIdx.x * UT) stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define UCOUNT(k) do { if (ucount && lane == 0) atomicAdd((unsigned long long*)stamps + (k), 1ull); } while (0)
+#else
+#define USTAMP(k) do { } while (0)
+#define UCOUNT(k) do { } while (0)
+#endif
 template <int EPL, bool FILTER>
 __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
-                                                                 double* __restrict__ summary, int64_t n, int W) {
+                                                                 double* __restrict__ summary, int64_t n, int W, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float usm[];
   const int WS = (W + 3) & ~3;                              // tile row stride (floats)
   float* tile = usm;                                        // [UT][WS]
@@ -61,7 +69,11 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
   const int64_t T = n + W - 1;
   float* s = sorted + wave * MAX_WINDOW;
   const float INF = __int_as_float(0x7f800000);
+#if HYPAD_DIAG
+  const bool ucount = stamps && stamps[14] != 0;             // (counting costs one contended atomic per timestep: a run of its own)
+#endif
   for (int64_t t0 = (int64_t)blockIdx.x * UT; t0 < T; t0 += (int64_t)gridDim.x * UT) {
+    USTAMP(0);
     // ---- stage: rows r in [t0 - (W - 1), t0 + UT) (clipped to the matrix), their runs of this tile's timesteps
     constexpr int RB = 8;                                    // rows in flight per wave
     if (t0 >= W - 1 && t0 + UT <= n) {
@@ -109,7 +121,9 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
           if (dst[u] >= 0) tile[dst[u]] = val[u];
       }
     }
+    USTAMP(1);
     __syncthreads();
+    USTAMP(2);
     for (int tt = wave; tt < UT; tt += NWV) {
       const int64_t t = t0 + tt;
       if (t >= T) break;
@@ -137,10 +151,7 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
           less += (q.x < sv ? 1 : 0) + (q.y < sv ? 1 : 0) + (q.z < sv ? 1 : 0) + (q.w < sv ? 1 : 0);
         }
         float plo = less <= 10 ? sv : -INF, phi = less >= 21 ? sv : INF;     // 11th smallest (largest with <= 10 below), 22nd smallest
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) { plo = fmaxf(plo, __shfl_xor(plo, off, WAVE)); phi = fminf(phi, __shfl_xor(phi, off, WAVE)); }
-        plo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(plo)));
-        phi = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(phi)));
+        plo = hypad::wave_max(plo); phi = hypad::wave_min(phi);                // (DPP butterflies: no LDS round trips on this chain)
         int c_lt = 0, c_le = 0;
         unsigned long long cm[EPL];
 #pragma unroll
@@ -177,11 +188,13 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
             lo_med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), (int)__builtin_ctzll(k1)));
             hi_med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), (int)__builtin_ctzll(k2)));
             done = true;
+            UCOUNT(8);
           }
           __builtin_amdgcn_wave_barrier();
         }
       }
       if (!done) {
+        UCOUNT(9);
         // rank = #{k : v[k] < mine} + #{k < i : v[k] == mine}.  Fast pass: count "less" only (one compare + add-carry per value).
         // Without ties those counts are a permutation of 0 .. cnt-1, with ties two values share a count and the counts' sum falls
         // short of cnt (cnt - 1) / 2: only then is the ordered tie count needed.  (The sum is exact in fp32: < 2^15 at window 256.)
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
       }
       __builtin_amdgcn_wave_barrier();
     }
+    USTAMP(3);
     __syncthreads();
   }
 }
@@ -668,12 +682,16 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   const char* fenv = getenv("HYPAD_UNROLL_FILTER");
   const bool filter = !(fenv && fenv[0] == '0');
   const dim3 grid(grid_for(T, UT)), block(THREADS);
+  long long* stamps = nullptr;
+#if HYPAD_DIAG
+  stamps = g_unroll_stamps;
+#endif
 #define HYPAD_UNROLL(EPL)                                                                                                      \
   do {                                                                                                                        \
     auto kf = filter ? unroll_median_kernel<EPL, true> : unroll_median_kernel<EPL, false>;                                      \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return HYPAD_EUNSUPPORTED;                                                                                               \
-    hipLaunchKernelGGL(kf, grid, block, lds, (hipStream_t)s, y_hat, median, summary, n, window);                               \
+    hipLaunchKernelGGL(kf, grid, block, lds, (hipStream_t)s, y_hat, median, summary, n, window, stamps);                       \
   } while (0)
   if (window <= 64) HYPAD_UNROLL(1); else if (window <= 128) HYPAD_UNROLL(2); else HYPAD_UNROLL(4);
 #undef HYPAD_UNROLL
@@ -791,3 +809,7 @@ int hypad_combine_scores(int mode, const double* c, const double* r, const doubl
 }
 
 }  // extern "C"
+
+#if HYPAD_DIAG
+extern "C" void hypad_diag_set_unroll_stamps(long long* p) { g_unroll_stamps = p; }
+#endif

@@ -4,9 +4,13 @@ Same function names and argument meaning as the reference for the numerics on th
 (SURVEY.md §8a rows S1-S6); inputs may be NumPy arrays (as the reference passes) or device tensors, results
 come back as NumPy arrays like the reference's.  Interval extraction and the overlap-segment metrics
  are host-side NumPy in ``hypad_amd.utils.intervals`` and re-exported here under the reference's
-names; file caches and plotting are not part of this module.
+names.  The reference's cached artefacts are kept under their names and formats -- ``critic_scores.pickle``,
+``point.pickle`` / ``area.pickle`` / ``dtw.pickle`` (:229-235, :470-550), ``anomalies.csv`` (:94-95) and the results table
+``./results/<params.filename>`` (:115-126) -- whenever a ``path`` is given; plotting is not part of this module.
 """
 import math
+import os
+import pickle
 
 import numpy as np
 import torch
@@ -210,29 +214,90 @@ def final_critic_scores(critic_score, true_signal):
     return _compute_critic_score(kde_modes(critic_score, w), math.trunc(n * 0.01)).cpu().numpy()
 
 
+def _load_pickle(file):
+    with open(file, "rb") as handle:
+        return pickle.load(handle)
+
+
+def _dump_pickle(obj, file):
+    with open(file, "wb") as handle:
+        pickle.dump(obj, handle, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+def compute_critic_scores(rec_scores, critic_score, true_signal, params, path):
+    """:225-238 -- the smoothed KDE critic scores of the hyperbolic / multivariate branches, cached as
+    ``path + "critic_scores.pickle"`` (read back only when ``params.load`` is set, always re-written otherwise)."""
+    file = (path or "") + "critic_scores.pickle"
+    if path and getattr(params, "load", False) and os.path.exists(file):
+        critic_scores = np.asarray(_load_pickle(file))
+    else:
+        ts = np.asarray(true_signal)
+        critic_scores = final_critic_scores(critic_score, ts.reshape(len(ts), -1))
+        if path:
+            _dump_pickle(critic_scores, file)
+    return critic_scores[: len(rec_scores)]
+
+
 def score_anomalies(y, y_hat, critic, index=None, score_window=10, critic_smooth_window=None, error_smooth_window=None,
                     smooth=True, rec_error_type="point", comb="mult", lambda_rec=0.5, path=None, samples_num="0"):
-    """:407-576 without the pickle caches (``path`` is ignored).  Returns (final_scores, true_index, true, predictions)."""
+    """:407-576.  Returns (final_scores, true_index, true, predictions).  With a ``path`` the reference's caches are kept:
+    ``critic_scores.pickle`` is read if present (else computed and written); the z-scored reconstruction scores of all three
+    error types are written as ``point.pickle`` / ``area.pickle`` / ``dtw.pickle`` when missing, and the requested one is read
+    back if it was there already (``predictions`` is then empty, as in the reference)."""
     if lambda_rec != 0.5:
         raise NotImplementedError("lambda_rec != 0.5")
     n = y.shape[0]
     critic_smooth_window = critic_smooth_window or math.trunc(n * 0.01)
     error_smooth_window = error_smooth_window or math.trunc(n * 0.01)
-    critic_scores = _compute_critic_score(kde_modes(critic, y_hat.shape[1]), critic_smooth_window)
-    rec, predictions = reconstruction_errors(y, y_hat, 1, score_window, error_smooth_window, smooth, rec_error_type)
-    rec_scores = zscore_clip(rec)
+    cfile = (path or "") + "critic_scores.pickle"
+    if path and os.path.exists(cfile):
+        critic_scores = np.asarray(_load_pickle(cfile))
+    else:
+        critic_scores = _compute_critic_score(kde_modes(critic, y_hat.shape[1]), critic_smooth_window)
+        if path:
+            _dump_pickle(critic_scores.cpu().numpy(), cfile)
+
+    def rec_scores_of(kind):
+        rec, predictions = reconstruction_errors(y, y_hat, 1, score_window, error_smooth_window, smooth, kind)
+        return zscore_clip(rec), predictions
+
+    had_requested = bool(path) and os.path.exists(path + rec_error_type + ".pickle")
+    if path:
+        for kind in ("point", "area", "dtw"):
+            if not os.path.exists(path + kind + ".pickle"):
+                _dump_pickle(rec_scores_of(kind)[0].cpu().numpy(), path + kind + ".pickle")
+    if had_requested:
+        rec_scores, predictions = np.asarray(_load_pickle(path + rec_error_type + ".pickle")), []
+    else:
+        rec_scores, predictions = rec_scores_of(rec_error_type)
+        if path:
+            _dump_pickle(rec_scores.cpu().numpy(), path + rec_error_type + ".pickle")
     final = combine_euclidean(comb, critic_scores, rec_scores)
     true = [[float(t)] for t in unroll_true(y).cpu().numpy()]
     return final, index, true, predictions
 
 
-def hyperbolic_scores(recons_signal, true_signal, critic_score, signal_shape, combination="mult"):
-    """The hyperbolic branch of univariate_anomaly_detection (:54-86) up to final_scores."""
+def hyperbolic_scores(recons_signal, true_signal, critic_score, signal_shape, combination="mult", params=None, path=None):
+    """The hyperbolic branch of univariate_anomaly_detection (:54-86) up to final_scores (``params`` / ``path``: the
+    ``critic_scores.pickle`` cache of compute_critic_scores)."""
     rec = hyperbolic_rec_scores(recons_signal, true_signal, signal_shape)
     critic_scores = []
     if combination in ("mult", "uncertainty", "sum", "sum_uncertainty", "critic", "critic_uncertainty"):
-        critic_scores = final_critic_scores(critic_score, np.asarray(true_signal).reshape(len(true_signal), -1))[: rec.shape[0]]
+        critic_scores = compute_critic_scores(rec, critic_score, true_signal, params, path)
     return combine_scores(combination, critic_scores, rec, recons_signal)
+
+
+def save_result(params, signal, out):
+    """:112-126 -- one row [signal, tn, fp, fn, tp] appended to ``./results/<params.filename>`` unless ``params.signal`` already
+    has one (the reference's check), the table created with its header when missing."""
+    import pandas as pd
+    file_place = "./results/{}".format(params.filename)
+    os.makedirs(os.path.dirname(file_place), exist_ok=True)
+    res = pd.read_csv(file_place) if os.path.isfile(file_place) else pd.DataFrame(columns=["signal", "tn", "fp", "fn", "tp"])
+    if params.signal not in list(res["signal"]):
+        res.loc[len(res)] = [signal] + list(out)
+        res.to_csv(file_place, index=False)
+    return file_place
 
 
 def univariate_anomaly_detection(recons_signal, true_signal, params, combination, critic_score, path=None, read_path=None,
@@ -240,9 +305,10 @@ def univariate_anomaly_detection(recons_signal, true_signal, params, combination
                                  signal_shape=None):
     """:21-127 end to end: window scores on the device, interval extraction and overlap-segment counts on the host.
 
-    Differences from the reference, all outside the numerics: nothing is written (``path`` / ``params.save_result`` /
-    ``read_path`` are accepted and ignored -- the CSV is only read there for its timestamp range, which the overlap
-    form does not use), and the result is returned instead of printed:
+    The reference's artefacts are written when ``path`` is given -- the score caches (score_anomalies / compute_critic_scores),
+    ``path + "anomalies.csv"`` with the predicted intervals, and, with ``params.save_result``, the results table
+    (``save_result``).  ``read_path`` is accepted and ignored (the reference reads that CSV only for its timestamp range,
+    which the overlap form of the metrics does not use).  The result is returned instead of printed:
         dict(final_scores, intervals (n, 3) [start, end, score], confusion [tn, fp, fn, tp] or [0, 0, 0, 0] when no
         interval was predicted (the reference's except branch), metrics or None)
     """
@@ -250,7 +316,7 @@ def univariate_anomaly_detection(recons_signal, true_signal, params, combination
         final_scores, true_index, _, _ = score_anomalies(true_signal, recons_signal, critic_score, true_index,
                                                          rec_error_type=rec_error_type, comb=combination, path=path)
     else:
-        final_scores = hyperbolic_scores(recons_signal, true_signal, critic_score, params.signal_shape, combination)
+        final_scores = hyperbolic_scores(recons_signal, true_signal, critic_score, params.signal_shape, combination, params, path)
     final_scores = np.asarray(final_scores, dtype=np.float64).reshape(-1)
     if true_index is None:
         true_index = np.arange(final_scores.size)
@@ -258,10 +324,15 @@ def univariate_anomaly_detection(recons_signal, true_signal, params, combination
                                fixed_threshold=True)
     out = dict(final_scores=final_scores, intervals=np.asarray(intervals, dtype=np.float64).reshape(-1, 3), confusion=[0, 0, 0, 0],
                metrics=None)
+    if path:
+        import pandas as pd
+        pd.DataFrame(out["intervals"], columns=["start", "end", "score"]).to_csv(path + "anomalies.csv")
     if known_anomalies is not None and out["intervals"].shape[0] > 0:
         pred = [(r[0], r[1]) for r in out["intervals"]]
         out["confusion"] = list(contextual_confusion_matrix(known_anomalies, pred, weighted=False))
         out["metrics"] = compute_metrics(known_anomalies, pred, verbose=False)
+    if getattr(params, "save_result", False):
+        out["results_file"] = save_result(params, signal, [int(v) for v in out["confusion"]])
     return out
 
 

@@ -68,3 +68,48 @@ def test_two_level_zscore_statistics(n):
     assert np.allclose(c, ref, rtol=0, atol=1e-10, equal_nan=True) and q[0] <= q[1]
     y = x.copy(); y[n // 2] = np.nan
     assert np.isnan(adu.zscore_clip(y).cpu().numpy()).all()                 # scipy propagates NaN
+
+
+def test_score_caches_and_result_table_follow_the_reference(tmp_path, monkeypatch):
+    """utils/anomaly_detection_utils.py:470-550 / :225-238 / :112-126 -- with a path the scoring functions leave and re-use the
+    reference's artefacts: critic_scores.pickle, point/area/dtw.pickle (z-scored reconstruction scores of ALL three error types),
+    anomalies.csv and the results table; a second call reads them back and returns the same scores with empty predictions."""
+    import os
+    import pickle
+    from types import SimpleNamespace
+    import pandas as pd
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    from helpers import load
+    fx = load("score.npz")
+    y, y_hat, critic = fx["y"], fx["y_hat"], fx["critic"]
+    path = str(tmp_path) + "/"
+    plain, _, true0, pred0 = adu.score_anomalies(y, y_hat, critic, None, rec_error_type="dtw", comb="mult")
+    first, _, _, pred1 = adu.score_anomalies(y, y_hat, critic, None, rec_error_type="dtw", comb="mult", path=path)
+    assert np.array_equal(first, plain, equal_nan=True) and len(pred1) == len(pred0)
+    assert sorted(os.listdir(path)) == ["area.pickle", "critic_scores.pickle", "dtw.pickle", "point.pickle"]
+    again, _, _, pred2 = adu.score_anomalies(y, y_hat, critic, None, rec_error_type="dtw", comb="mult", path=path)
+    assert np.array_equal(again, plain, equal_nan=True) and len(pred2) == 0
+    point = pickle.load(open(path + "point.pickle", "rb"))
+    rec, _ = adu.reconstruction_errors(y, y_hat, 1, 10, len(y) // 100, True, "point", with_summary=False)
+    assert np.array_equal(point, adu.zscore_clip(rec).cpu().numpy(), equal_nan=True)
+    # the cache is trusted, as in the reference: a doctored critic_scores.pickle shows up in the scores
+    cs = pickle.load(open(path + "critic_scores.pickle", "rb"))
+    pickle.dump(np.asarray(cs) * 2.0, open(path + "critic_scores.pickle", "wb"))
+    doubled, _, _, _ = adu.score_anomalies(y, y_hat, critic, None, rec_error_type="dtw", comb="mult", path=path)
+    assert np.allclose(doubled, 2.0 * plain, rtol=1e-12, equal_nan=True)
+    # hyperbolic branch: compute_critic_scores re-reads only with params.load; univariate_anomaly_detection writes anomalies.csv + results
+    hp = str(tmp_path / "hyper") + "/"
+    os.makedirs(hp)
+    monkeypatch.chdir(tmp_path)
+    P = SimpleNamespace(hyperbolic=True, signal_shape=100, load=False, save_result=True, filename="res.csv", signal="sigA", dataset="synthetic")
+    out = adu.univariate_anomaly_detection(fx["ball_recons"], fx["ball_real"], P, "mult", critic, hp, None, signal="sigA", signal_shape=100)
+    assert os.path.exists(hp + "critic_scores.pickle") and os.path.exists(hp + "anomalies.csv")
+    table = pd.read_csv(tmp_path / "results" / "res.csv")
+    assert list(table.columns) == ["signal", "tn", "fp", "fn", "tp"] and list(table["signal"]) == ["sigA"]
+    adu.univariate_anomaly_detection(fx["ball_recons"], fx["ball_real"], P, "mult", critic, hp, None, signal="sigA", signal_shape=100)
+    assert len(pd.read_csv(tmp_path / "results" / "res.csv")) == 1                      # one row per signal
+    pickle.dump(np.full(len(critic) + 99, 3.0), open(hp + "critic_scores.pickle", "wb"))
+    P.load = True
+    out2 = adu.univariate_anomaly_detection(fx["ball_recons"], fx["ball_real"], P, "mult", critic, hp, None, signal="sigA", signal_shape=100)
+    want = 3.0 * adu.hyperbolic_rec_scores(fx["ball_recons"], fx["ball_real"], 100).cpu().numpy().astype(np.float64)
+    assert np.allclose(out2["final_scores"], want, rtol=1e-12) and not np.allclose(out["final_scores"], want, rtol=1e-3)
