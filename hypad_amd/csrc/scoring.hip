@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/hypad.h"
 #include "device_utils.h"
@@ -47,7 +48,6 @@ __device__ __forceinline__ float np_lerp(float a, float b, float t) {
 // the pivots and at most 64 values do, only those candidates are ranked against each other (~33^2 compares).  Anything else --
 // pivots that miss, ties among the candidates, short edge diagonals -- takes the full count: the result is the exact order
 // statistic either way.
-constexpr int UT = 64;                       // timesteps per workgroup tile
 #if HYPAD_DIAG
 long long* g_unroll_stamps = nullptr;        // development aid (dev library): [0..3] shader-clock stamps of one workgroup's first tile, [8] filter hits, [9] full counts
 #define USTAMP(k) do { if (stamps && blockIdx.x == 37 && threadIdx.x == 0 && t0 == (int64_t)blockIdx.x * UT) stamps[k] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -56,9 +56,13 @@ long long* g_unroll_stamps = nullptr;        // development aid (dev library): [
 #define USTAMP(k) do { } while (0)
 #define UCOUNT(k) do { } while (0)
 #endif
-template <int EPL, bool FILTER>
-__global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
-                                                                 double* __restrict__ summary, int64_t n, int W, long long* stamps) {
+// UT: timesteps per workgroup tile, one wave per 16 of them (UT = 64: 256 threads, 128: 512).  A longer tile reads longer runs
+// of every source row (fewer partly used 128-byte lines at the runs' ends: the tile's triangle rows) for twice the LDS.
+template <int EPL, bool FILTER, int UT>
+__global__ __launch_bounds__(UT * 4) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
+                                                                double* __restrict__ summary, int64_t n, int W, long long* stamps) {
+  constexpr int THREADS = UT * 4;                           // (shadows the file's 256: this kernel's block size follows its tile)
+  constexpr int RUN = UT / 64;                               // elements per lane of one source row's run
   extern __shared__ __attribute__((aligned(16))) float usm[];
   const int WS = (W + 3) & ~3;                              // tile row stride (floats)
   float* tile = usm;                                        // [UT][WS]
@@ -75,50 +79,60 @@ __global__ __launch_bounds__(THREADS) void unroll_median_kernel(const float* __r
   for (int64_t t0 = (int64_t)blockIdx.x * UT; t0 < T; t0 += (int64_t)gridDim.x * UT) {
     USTAMP(0);
     // ---- stage: rows r in [t0 - (W - 1), t0 + UT) (clipped to the matrix), their runs of this tile's timesteps
-    constexpr int RB = 8;                                    // rows in flight per wave
+    constexpr int RB = 8 / RUN;                              // rows in flight per wave (8 loads per lane either way)
     if (t0 >= W - 1 && t0 + UT <= n) {
       // interior tile (all but the first and last two of a long series): no clipping, j0 == 0, 32-bit indices relative to the
       // tile's first row, the row number a scalar -- ~9 vector instructions per row and lane instead of ~30 of 64-bit arithmetic
       const float* base = y_hat + (t0 - (W - 1)) * W;
       const int nrows = W + UT - 1;
       for (int kb = wave_s * RB; kb < nrows; kb += NWV * RB) {
-        float val[RB];
-        int dst[RB];
+        float val[RB][RUN];
+        int dst[RB][RUN];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
           const int k = kb + u;                              // (scalar) row of the tile's parallelogram
           const int jb = W - 1 - k > 0 ? W - 1 - k : 0;
-          const int j = jb + lane, tt = k - (W - 1) + j;
-          const bool ok = k < nrows && j < W && tt < UT;
-          dst[u] = ok ? tt * WS + j : -1;
-          val[u] = ok ? base[k * W + j] : 0.f;
+#pragma unroll
+          for (int h = 0; h < RUN; ++h) {
+            const int j = jb + lane + 64 * h, tt = k - (W - 1) + j;
+            const bool ok = k < nrows && j < W && tt < UT;
+            dst[u][h] = ok ? tt * WS + j : -1;
+            val[u][h] = ok ? base[k * W + j] : 0.f;
+          }
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u)
-          if (dst[u] >= 0) tile[dst[u]] = val[u];
+#pragma unroll
+          for (int h = 0; h < RUN; ++h)
+            if (dst[u][h] >= 0) tile[dst[u][h]] = val[u][h];
       }
     } else {
       const int64_t r_lo = t0 - (W - 1) > 0 ? t0 - (W - 1) : 0;
       const int64_t r_hi = t0 + UT < n ? t0 + UT : n;         // exclusive
       for (int64_t rb = r_lo + wave * RB; rb < r_hi; rb += NWV * RB) {
-        float val[RB];
-        int dst[RB];
+        float val[RB][RUN];
+        int dst[RB][RUN];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
           const int64_t r = rb + u;
-          int jb = (int)(t0 - r > 0 ? t0 - r : 0);             // first column of row r inside the tile
-          const int j = jb + lane;                             // (a run is at most UT = 64 columns: one element per lane)
-          const int64_t t = r + j;
-          dst[u] = -1; val[u] = 0.f;
-          if (r < r_hi && j < W && t < t0 + UT && t < T) {
-            const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
-            dst[u] = (int)(t - t0) * WS + (j - j0);
-            val[u] = y_hat[r * W + j];
+          const int jb = (int)(t0 - r > 0 ? t0 - r : 0);       // first column of row r inside the tile
+#pragma unroll
+          for (int h = 0; h < RUN; ++h) {
+            const int j = jb + lane + 64 * h;                  // (a run is at most UT columns: RUN elements per lane)
+            const int64_t t = r + j;
+            dst[u][h] = -1; val[u][h] = 0.f;
+            if (r < r_hi && j < W && t < t0 + UT && t < T) {
+              const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
+              dst[u][h] = (int)(t - t0) * WS + (j - j0);
+              val[u][h] = y_hat[r * W + j];
+            }
           }
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u)
-          if (dst[u] >= 0) tile[dst[u]] = val[u];
+#pragma unroll
+          for (int h = 0; h < RUN; ++h)
+            if (dst[u][h] >= 0) tile[dst[u][h]] = val[u][h];
       }
     }
     USTAMP(1);
@@ -516,9 +530,11 @@ __global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restri
       // fp32 copies with an absolute error of |value| 2^-24 c, which at |mean| / bandwidth beyond ~1e4 exceeds the screen's margin.
       const double c64 = sqrt(inv * 1.44269504088896341);
       for (int k = lane; k < cnt; k += 64) vf[k] = (float)((v[k] - mean) * c64);
-      // (Measured and dropped in round 3: using the kernel matrix's symmetry -- each unordered pair once, the partner's share
-      // delivered with ds_add_f32 -- halves the exponentials but the LDS float adds cost far more than they save: 3.28 ms
-      // against 0.42 ms for 125 000 windows.)
+      // (Measured and dropped in round 3, twice: using the kernel matrix's symmetry -- each unordered pair evaluated once.  With the
+      // partner's share delivered by ds_add_f32: 3.28 ms against 0.42 ms for 125 000 windows (LDS float atomics).  With the values
+      // parked in a small LDS matrix in chunks of eight steps and collected by the partners after a wave barrier (no atomics,
+      // conflict-free strides, immediate offsets): 0.69 ms -- three per-lane LDS operations per pair cost more issue time than the
+      // quarter-rate exponential they save; the broadcast form below reads each value once for all 64 lanes.)
       if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) vf[cnt + lane] = __int_as_float(0x7f800000);
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -678,23 +694,31 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   if (!y_hat || !median || n <= 0 || window <= 0) return HYPAD_EINVAL;
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
   const int64_t T = n + window - 1;
-  const size_t lds = (size_t)(UT * ((window + 3) & ~3) + (THREADS / 64) * MAX_WINDOW) * sizeof(float);      // <= 68 KB at window 256
   const char* fenv = getenv("HYPAD_UNROLL_FILTER");
   const bool filter = !(fenv && fenv[0] == '0');
-  const dim3 grid(grid_for(T, UT)), block(THREADS);
+  const char* tenv = getenv("HYPAD_UNROLL_TILE");
+  const int ut = tenv && atoi(tenv) == 64 ? 64 : 128;
+  const size_t lds = (size_t)(ut * ((window + 3) & ~3) + (ut / 16) * MAX_WINDOW) * sizeof(float);      // 59 KB at window 100, 139 KB at 256
+  const dim3 grid(grid_for(T, ut)), block(ut * 4);
   long long* stamps = nullptr;
 #if HYPAD_DIAG
   stamps = g_unroll_stamps;
 #endif
-#define HYPAD_UNROLL(EPL)                                                                                                      \
+#define HYPAD_UNROLL2(EPL, F, U)                                                                                               \
   do {                                                                                                                        \
-    auto kf = filter ? unroll_median_kernel<EPL, true> : unroll_median_kernel<EPL, false>;                                      \
+    auto kf = unroll_median_kernel<EPL, F, U>;                                                                                 \
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
       return HYPAD_EUNSUPPORTED;                                                                                               \
     hipLaunchKernelGGL(kf, grid, block, lds, (hipStream_t)s, y_hat, median, summary, n, window, stamps);                       \
   } while (0)
+#define HYPAD_UNROLL(EPL)                                                                                                      \
+  do {                                                                                                                        \
+    if (ut == 64) { if (filter) HYPAD_UNROLL2(EPL, true, 64); else HYPAD_UNROLL2(EPL, false, 64); }                            \
+    else { if (filter) HYPAD_UNROLL2(EPL, true, 128); else HYPAD_UNROLL2(EPL, false, 128); }                                    \
+  } while (0)
   if (window <= 64) HYPAD_UNROLL(1); else if (window <= 128) HYPAD_UNROLL(2); else HYPAD_UNROLL(4);
 #undef HYPAD_UNROLL
+#undef HYPAD_UNROLL2
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

@@ -12,8 +12,9 @@ g = torch.Generator(device="cuda").manual_seed(3)
 y = torch.randn(n, S, device="cuda", generator=g).contiguous()
 med = torch.empty(n + S - 1, device="cuda")
 st = torch.zeros(16, dtype=torch.int64, device="cuda")
-for filt in ("1", "0"):
+for filt, tile in (("1", "128"), ("1", "64"), ("0", "128"), ("0", "64")):
     os.environ["HYPAD_UNROLL_FILTER"] = filt
+    os.environ["HYPAD_UNROLL_TILE"] = tile
     setp(None)
     for _ in range(3):
         _C.lib.hypad_unroll_median(_C.ptr(y), _C.ptr(med), None, n, S, _C.stream())
@@ -31,5 +32,5 @@ for filt in ("1", "0"):
     _C.lib.hypad_unroll_median(_C.ptr(y), _C.ptr(med), None, n, S, _C.stream())          # counts only (contended atomics: not timed)
     torch.cuda.synchronize()
     s[8:10] = st.cpu().tolist()[8:10]
-    print(f"filter={filt}: {a.elapsed_time(b) / 10 * 1e3:.1f} us per launch; tile of workgroup 37: stage {s[1] - s[0]} cycles, barrier {s[2] - s[1]}, "
+    print(f"filter={filt} tile={tile}: {a.elapsed_time(b) / 10 * 1e3:.1f} us per launch; tile of workgroup 37: stage {s[1] - s[0]} cycles, barrier {s[2] - s[1]}, "
           f"16 timesteps of wave 0 {s[3] - s[2]} ({(s[3] - s[2]) / 16:.0f} each); filter decided {s[8]} timesteps, full count {s[9]}")
