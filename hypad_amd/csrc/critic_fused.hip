@@ -140,6 +140,10 @@ struct PhaseArgs {
   // the precompute launch in front
   unsigned* rec_flags;                         // (2 critics, n_signals, n_iters, B/16)
   int n_signals;
+  int clear_each;                              // 1: zero the activation / delta tiles after every iteration (round 2; HYPAD_CRITIC_CLEAR=1).  Every element
+                                               // an iteration reads is written by that iteration first (the chains' epilogues store whole 16-column
+                                               // groups incl. the ones column and zero padding, the record fills in0 / dm, d loss / d out is set per
+                                               // iteration), so the sweep -- 62 KB of LDS stores, ~1 k cycles -- is only needed once, before the loop
   int xcd_stretch;                             // 1: the critics' workgroup ids are stretched by 8 (one critic's chunks on one XCD); 0: dealt in id order
   int fault_it;                                // tests (HYPAD_EPOCH_TEST_GIVE_UP_SHIFT): > 0 = critic_x chunk 0 of signal 0 behaves as if its
                                                // wait for the siblings' shares had timed out at that iteration
@@ -1145,6 +1149,8 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       for (int u = 0; u < PS; ++u)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
+          // (measured and dropped in round 3: the helper waves requesting their other-layer quads here too, so that phase B starts
+          // with its shares in registers -- the chains wait 1.8 k cycles for phase B: +28 spilled registers, epoch +0.015 ms)
           if (u >= NA) continue;                                         // (compile-time for the reference shapes: NA is)
           x0[u][w] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (obase + (w < nchunks ? w : 0) * slabf + (i_e[u] < 0 ? 0 : i_e[u]) * 4) * 4, 0, 16);
         }
@@ -1160,17 +1166,18 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     auto finish = [&](int u) __attribute__((always_inline)) {
       const int li = i_li[u];
       f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+      const bool pre = u < NA;                                                       // the first four chunks' shares are in x0 already
       if (it > 0) {
-        if (u < NA) {
+        if (pre) {
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
             const float on = w < nchunks ? 1.f : 0.f;
-            const f32x4 xf = __builtin_bit_cast(f32x4, x0[u < NA ? u : 0][w]);
+            const f32x4 xf = __builtin_bit_cast(f32x4, x0[pre ? u : 0][w]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) gsum[r] += on * xf[r];
           }
         }
-        for (int w0c = u < NA ? 4 : 0; w0c < nchunks; w0c += 4) {                     // batches above 64 rows: four more chunks at a time
+        for (int w0c = pre ? 4 : 0; w0c < nchunks; w0c += 4) {                        // batches above 64 rows: four more chunks at a time
           u32x4_t x[4];
 #pragma unroll
           for (int w = 0; w < 4; ++w)
@@ -1538,7 +1545,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     __syncthreads();
     if (ctl[0]) { if (writer && threadIdx.x == 0) lo_base[(int64_t)(2 * it) * 4] = __builtin_nanf(""); return; }
     PSTAMP(13);                                                          // siblings' scalars are there
-    clear_tiles();                                        // (every read of this iteration's tiles is behind the barrier above; one
+    if (ph.clear_each) clear_tiles();                     // (every read of this iteration's tiles is behind the barrier above; one
                                                           // wave -- wave 2 has no share to store -- clearing alone took 5 k cycles)
     float gs = 0.f, sreal = 0.f, sfake = 0.f;
     for (int w = 0; w < nchunks; ++w) { gs += xsc[w]; sreal += xsc[MAXCH + w]; sfake += xsc[2 * MAXCH + w]; }   // fixed order
@@ -1779,6 +1786,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   ph.fault_it = (flags >> HYPAD_EPOCH_TEST_GIVE_UP_SHIFT) & 0xff;
   ph.n_signals = n_signals;
   { const char* xenv = getenv("HYPAD_CRITIC_XCD"); ph.xcd_stretch = (xenv && xenv[0] == '0') ? 0 : 1; }
+  { const char* cenv = getenv("HYPAD_CRITIC_CLEAR"); ph.clear_each = (cenv && cenv[0] == '1') ? 1 : 0; }
   // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
   // persistent form's exchange buffers: [epoch words | error word] (zeroed before every launch), granules, merged shares
   float* p = extra;

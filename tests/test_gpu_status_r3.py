@@ -164,6 +164,16 @@ def test_chunks_of_a_critic_share_an_xcd_and_the_epoch_keeps_its_bits(ns, S, B, 
     a, b = outs["1"], outs["0"]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert all(torch.equal(a[2][i][k], b[2][i][k]) for i in range(3) for k in a[2][i]) and torch.equal(a[2][3][:5], b[2][3][:5])
+    # round 3 also stopped zeroing the activation / delta tiles after every iteration (every element read is written first):
+    # HYPAD_CRITIC_CLEAR=1 brings the sweep back -- same bits
+    monkeypatch.setenv("HYPAD_CRITIC_XCD", "1")
+    monkeypatch.setenv("HYPAD_CRITIC_CLEAR", "1")
+    e = engine()
+    l = e.train_epoch(x, perms[0], nb, nc, True).clone()
+    l2 = e.train_epoch(x, perms[1], nb, nc, True).clone()
+    snap = _snapshot(e)
+    assert torch.equal(l, a[0]) and torch.equal(l2, a[1]) and all(torch.equal(snap[i][k], a[2][i][k]) for i in range(3) for k in snap[i])
+    monkeypatch.delenv("HYPAD_CRITIC_CLEAR")
     # the same under an uneven background load, several times
     monkeypatch.setenv("HYPAD_CRITIC_XCD", "1")
     side = torch.cuda.Stream()
