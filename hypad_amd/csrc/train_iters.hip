@@ -659,6 +659,10 @@ __global__ __launch_bounds__(TB) void critic_gp_pair_kernel(IterArgs ax, IterArg
 // only the blocks that land on XCD (signal mod 8) work, so the 2 * B/16 workgroups of one model share an L2 -- each
 // generator weight is fetched from HBM once per launch instead of once per workgroup.  Placement is a speed matter
 // only: results do not depend on it.
+// (Measured and dropped in round 3: four extra workgroups per XCD that read the packed weights once, in the chains' order, to leave
+// them in that XCD's L2 ahead of the chains' sc1 loads -- the weights were rewritten a launch ago on other XCDs.  No change:
+// 40.14 vs 40.17 us per launch.  The chains' weight fetches are already hidden behind the previous stage; what a chain's 88 k
+// cycles consist of is MFMA issue plus the epilogues' vector instructions, which do not overlap on one SIMD: DESIGN.md §4.)
 template <bool HYPER, int SC, int LC, int BC>
 __global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
