@@ -124,6 +124,8 @@ _SIGS = {
     "hypad_linear_act_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, P]),
     "hypad_lstm_bidir_fwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "hypad_lstm_bidir_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "hypad_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "hypad_lstm_bidir_seq_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_int, c_void_p, c_size_t, P]),
     "hypad_encoder_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "hypad_decoder_fwd": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, POINTER(Dropout), P]),
     "hypad_critic_x_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, POINTER(Dropout), P]),

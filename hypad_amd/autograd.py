@@ -135,3 +135,30 @@ def critic_forward(m, x, n_hidden, p_drop):                  # models/tadgan.py:
         h = torch.nn.functional.dropout(h, p=p_drop, training=m.training)
     d = getattr(m, f"dense{n_hidden + 1}")
     return linear_act(h, d.weight, d.bias)
+
+
+def lstm_seq_forward(x, lstm, layer=0, hx=None):
+    """One bidirectional layer of a ``torch.nn.LSTM``-shaped parameter holder over a whole sequence (inference): ``x`` (T, rows, in)
+    -> ``(out (T, rows, 2H), (h_n, c_n) each (2, rows, H))`` as ``nn.LSTM(in, H, bidirectional=True)(x, hx)`` returns them.  The
+    reference's modules (models/tadgan.py:15-20, :35-38) are such layers driven with T = 1; this is the general-T
+    form: one MFMA GEMM for the input projections of all steps + a persistent recurrence kernel (csrc/lstm_seq.hip)."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in lstm.parameters())):
+        raise _C.HypadError("lstm_seq_forward is inference only (the reference never back-propagates through time: T = 1); "
+                            "wrap the call in torch.no_grad()")
+    x = _f32c(x, "input")
+    T, rows, k = x.shape
+    g = lambda n: _f32c(getattr(lstm, n + f"_l{layer}").detach(), n)
+    r = lambda n: _f32c(getattr(lstm, n + f"_l{layer}_reverse").detach(), n)
+    H = g("weight_hh").shape[1]
+    out = torch.empty(T, rows, 2 * H, device=x.device, dtype=torch.float32)
+    hn, cn = torch.empty(2, rows, H, device=x.device), torch.empty(2, rows, H, device=x.device)
+    h0 = c0 = None
+    if hx is not None:
+        h0, c0 = _f32c(hx[0], "h0"), _f32c(hx[1], "c0")
+    nbytes = _C.lib.hypad_lstm_seq_workspace_bytes(T, rows, H)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    _C.check(_C.lib.hypad_lstm_bidir_seq_fwd(_C.ptr(x), _C.ptr(g("weight_ih")), _C.ptr(g("weight_hh")), _C.ptr(g("bias_ih")), _C.ptr(g("bias_hh")),
+                                             _C.ptr(r("weight_ih")), _C.ptr(r("weight_hh")), _C.ptr(r("bias_ih")), _C.ptr(r("bias_hh")),
+                                             _C.ptr(h0), _C.ptr(c0), _C.ptr(out), _C.ptr(hn), _C.ptr(cn), T, rows, k, H, ws.data_ptr(), nbytes,
+                                             _C.stream()), "lstm_bidir_seq_fwd")
+    return out, (hn, cn)

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libhypad_hip.so")
 DEV_LIB = os.path.join(LIB_DIR, "libhypad_hip_dev.so")
-SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip"]
+SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "lstm_seq.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip"]
 DEV_SOURCES = SOURCES + ["diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 

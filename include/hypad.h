@@ -122,6 +122,20 @@ int hypad_lstm_bidir_fwd(const float* x, const float* w_ih_f, const float* b_ih_
 int hypad_lstm_bidir_bwd(const float* w_ih_f, const float* w_ih_r, const float* gates_saved, const float* grad_out,
                          float* grad_gates, float* grad_x, int64_t rows, int in_dim, int hidden, hypad_stream_t stream);
 
+/* The same layer over seq_len time steps -- torch.nn.LSTM(in_dim, hidden, num_layers=1, bidirectional=True) on a (seq_len, rows,
+ * in_dim) input, with W_hh and optional initial states (the module models/tadgan.py:15-20, :35-38 builds; the reference itself
+ * always feeds it seq_len = 1, where hypad_lstm_bidir_fwd is the faster form).  x (seq_len, rows, in_dim); w_ih_* (4*hidden,
+ * in_dim), w_hh_* (4*hidden, hidden), biases (4*hidden), PyTorch gate order [i,f,g,o]; h0 / c0 (2, rows, hidden) or NULL = zeros;
+ * out (seq_len, rows, 2*hidden) = [h_fwd(t) | h_rev(t)]; hn / cn (2, rows, hidden) final states, may be NULL.  The input
+ * projections of all steps run as one MFMA GEMM; the recurrence is a persistent kernel per (16-row tile, direction): W_hh in
+ * LDS, h_t in LDS, c_t in registers, the four gates of a unit on one lane, one barrier per step.  hidden <= 64.  Forward only.
+ * workspace: hypad_lstm_seq_workspace_bytes(seq_len, rows, hidden). */
+size_t hypad_lstm_seq_workspace_bytes(int seq_len, int64_t rows, int hidden);
+int hypad_lstm_bidir_seq_fwd(const float* x, const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                             const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                             const float* h0, const float* c0, float* out, float* hn, float* cn, int seq_len, int64_t rows,
+                             int in_dim, int hidden, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Networks, forward (eval or train-mode dropout).  `params` = arena of that network.
  * ---------------------------------------------------------------------------------------------- */
