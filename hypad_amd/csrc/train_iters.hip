@@ -748,6 +748,10 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 // parameter -- for the many-signal launches: 157 registers (2 waves per SIMD instead of 3) and three round trips per item made
 // the launch SLOWER at 8 / 16 / 32 signals per GPU: 33 -> 42, 56 -> 64, 101 -> 110 us.  The operand re-reads of the 16 x 16 tiles
 // are L2 hits once a model's tiles share an XCD (COLOC); what the launch waits for is its scattered 64-byte store segments.)
+// What the launch's time consists of at 32 signals per GPU (round 3 what-if builds, 85.6 us): without the packed copies' stores
+// 69 us, without the moments' stores 83, without the operand loads 62, without the optimiser-state loads 74 -- i.e. bytes, not
+// instructions: writing the packed copies as 16-byte stores (transposed copy as is, forward copy after a DPP quad transpose)
+// instead of eight scattered 4-byte stores per lane changed nothing (84.5 us; 11.5 at one signal) and was dropped.
 // KS: k-steps (groups of four reduction rows) a weight item keeps in flight: 48 covers B <= 64 in one memory round trip.
 // (16 halves the registers and doubles the waves per SIMD; measured with 8 and 32 signals per GPU it changes nothing --
 // with many signals the launch moves ~9 MB per signal and sits at ~3.5 TB/s of HBM traffic.)
