@@ -625,6 +625,21 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # matrix-pipe utilisation by counter (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the dispatch, scripts/profile_r03.sh): the
+    # committed rocprofv3 --pmc pass, under the same source-digest rule as `traffic`
+    roofline_mfma = None
+    try:
+        path = os.path.join(ROOT, "profiles", "r03_mfma_util.json")
+        mf = json.load(open(path))
+        same = mf.get("source_sha256") == source_digest()
+        roofline_mfma = {"source": "profiles/r03_mfma_util.json" + (" (same kernel sources: sha256 matches)" if same else
+                                                                     " (kernel sources changed since: indicative only)"),
+                         "formula": mf.get("formula"),
+                         "kernels": {k: {"mfma_util": v.get("mfma_util"), "algorithmic_util": v.get("algorithmic_util"),
+                                         "issued_over_algorithmic": v.get("issued_over_algorithmic")} for k, v in mf["kernels"].items()}}
+    except (OSError, KeyError, ValueError, NameError):
+        pass
+
     # algorithmic memory-side bytes of ONE resident critic launch (the kernel table): every record written once by
     # its producer and read once by its critic; every chunk's merged gradient share -- the valid accumulator quads of its critic:
     # (Q (in + 1) + (nh - 1) Q (L + 1) + L + 1) x 16 bytes, Q = ceil(L / 4) -- written once and read by each of the B/16 chunks
@@ -633,7 +648,10 @@ def main():
         nchunks, q = B // 16, (L + 3) // 4
         rec = sum(eng.epoch_records(N_BATCHES, N_CRITICS, c)[1].record_floats for c in (0, 1)) * 4 * nchunks
         share_bytes = ((q * (S + 1) + 3 * q * (L + 1) + L + 1) + (q * (L + 1) + q * (L + 1) + L + 1)) * 16 * nchunks     # critic_x (4 hidden layers), critic_z (2)
-        traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + share_bytes * (1 + nchunks)))
+        # (where every critic's chunks share an XCD -- counters[5], read from the hardware by the kernel -- the shares never leave that
+        # XCD's L2: the memory side then sees the records only)
+        shares_in_l2 = int(eng.counters[5]) == 2 * spg
+        traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + (0 if shares_in_l2 else share_bytes * (1 + nchunks))))
 
     # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
     # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
@@ -693,6 +711,9 @@ def main():
                                                    if dom == "critic_persistent_kernel" else None)},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
+        if roofline_mfma is not None:
+            out["roofline_mfma"] = roofline_mfma
+        out["config"]["critics_on_one_xcd"] = int(eng.counters[5])          # placement census of the last resident critic launch (of 2 per signal)
         if secondary is not None:
             out["secondary"] = secondary
         if drop_in is not None:
