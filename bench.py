@@ -81,20 +81,24 @@ def build_engine(spg, rank, hyperbolic, device):
     return eng, x
 
 
-def make_step(eng, x, spg, gen, device, graph=True):
-    """One timed step = one epoch.  Returns (step, losses): `step()` draws the DataLoader's shuffles -- a fresh permutation for
-    each of the 5 critic passes and the generator pass (argsort of uniform keys: six independent uniform permutations from one
-    batched sort instead of six randperm calls) -- into the STATIC int32 buffer whose address the captured epoch reads, then
-    replays the epoch's hipGraph (or launches it eagerly: same bits)."""
+def make_step(eng, x, spg, gen, device, graph=True, host_shuffle=False):
+    """One timed step = one epoch.  Returns (step, losses).  The DataLoader's shuffles -- a fresh uniform permutation for each of
+    the 5 critic passes and the generator pass -- are drawn on the device by the library (hypad_epoch_shuffles: argsort of Philox
+    keys in LDS, keyed by the rng tick) as the first node of the captured epoch, so a step is ONE graph replay with no host work
+    and no torch kernel; `host_shuffle` draws them with torch instead (rand + argsort into the static buffer the epoch reads:
+    what rounds 1-2 timed).  Eager launches: same bits as the replay."""
     losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
     perm_buf = torch.empty(N_CRITICS + 1, N_BATCHES * B, dtype=torch.int32, device=device)
 
     def step():
-        perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
-        perm_buf.copy_(perm)
+        if host_shuffle:
+            perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
+            perm_buf.copy_(perm)
         if graph:
-            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses, shuffle_windows=0 if host_shuffle else N_WINDOWS)
         else:
+            if not host_shuffle:
+                eng.draw_shuffles(perm_buf, N_WINDOWS)
             eng.train_epoch(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
     return step, losses
 
@@ -548,6 +552,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
     ap.add_argument("--no-graph", action="store_true", help="launch every epoch eagerly instead of replaying its captured hipGraph")
+    ap.add_argument("--host-shuffle", action="store_true", help="draw the epoch's shuffles with torch (rand + argsort) instead of inside the captured epoch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
     ap.add_argument("--no-drop-in", action="store_true", help="skip timing the reference-style loop over hypad_amd.train's iteration functions")
     ap.add_argument("--no-sharded-scoring", action="store_true", help="skip configs[4]-style scoring sharded over all ranks (RCCL collectives; "
@@ -582,7 +587,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step, losses = make_step(eng, x, spg, gen, device, graph=not args.no_graph)
+    step, losses = make_step(eng, x, spg, gen, device, graph=not args.no_graph, host_shuffle=args.host_shuffle)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -697,7 +702,9 @@ def main():
                        "iteration_windows_per_s": windows * (2 * N_CRITICS + 1) / elapsed,
                        "critic_phase": ("one resident launch per epoch (critic_persistent_kernel)" + (", records produced by that launch's own "
                                         "producer workgroups" if producers else " behind a precompute launch")) if persistent else "one launch per iteration",
-                       "launch": "eager" if args.no_graph else "hipGraph replay of the captured epoch", "rccl_world_size": world},
+                       "launch": "eager" if args.no_graph else "hipGraph replay of the captured epoch",
+                       "shuffles": "torch rand + argsort per epoch (host-driven)" if args.host_shuffle else
+                                   "drawn inside the epoch's launch sequence (hypad_epoch_shuffles)", "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                          "traffic_algorithmic": traffic_algorithmic,

@@ -142,6 +142,7 @@ _SIGS = {
     "hypad_critic_z_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
+    "hypad_epoch_shuffles": (c_int, [P, c_int, c_int, c_int, c_uint64, P, P]),
     "hypad_epoch_status": (c_int, [POINTER(TrainState), POINTER(c_int), P]),
     "hypad_epoch_restore": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, P]),
     "hypad_critic_phase_persistent": (c_int, [POINTER(Dims)]),

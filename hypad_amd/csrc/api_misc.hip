@@ -86,9 +86,53 @@ __global__ void rng_fill_kernel(int kind, uint64_t seed, uint32_t tick, uint32_t
   }
 }
 
+// hypad_epoch_shuffles: the DataLoader's shuffle (main.py:38 shuffle=True, drop_last=True) of every pass of an epoch, on the device
+// and capturable: pass p = the first `take` entries of a uniform random permutation of [0, n_windows) -- argsort of independent
+// Philox keys (64-bit key << 32 | index: no ties), one workgroup per pass, bitonic sort in LDS.  Keyed by (seed, tick, pass) with
+// the tick read from the device counters, so a replayed graph draws fresh permutations every epoch.
+constexpr int SHUF_MAX = 4096, SHUF_THREADS = 1024, RS_SHUFFLE = 5;
+__global__ __launch_bounds__(SHUF_THREADS) void epoch_shuffle_kernel(int32_t* __restrict__ out, int take, int n, int npow2, uint64_t seed,
+                                                                     const int32_t* __restrict__ counters) {
+  __shared__ unsigned long long keys[SHUF_MAX];
+  const uint32_t tick = counters ? (uint32_t)counters[3] : 0u;
+  const Philox ph(seed);
+  for (int i = threadIdx.x; i < npow2; i += SHUF_THREADS) {
+    unsigned long long k = ~0ull;                                        // padding sorts last
+    if (i < n) {
+      const uint4 r = ph((uint32_t)i >> 2, (uint32_t)RS_SHUFFLE, tick, (uint32_t)blockIdx.x);
+      k = ((unsigned long long)pick(r, i & 3) << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < npow2 / 2; t += SHUF_THREADS) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;     // the pair (lo, lo + stride) of this compare-exchange
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < take; i += SHUF_THREADS) out[(int64_t)blockIdx.x * take + i] = (int32_t)(unsigned)keys[i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int hypad_epoch_shuffles(int32_t* row_index, int n_passes, int take, int n_windows, uint64_t seed, const int32_t* counters,
+                         hypad_stream_t stream) {
+  if (!row_index || n_passes <= 0 || take <= 0 || n_windows < take) return HYPAD_EINVAL;
+  if (n_windows > SHUF_MAX) return HYPAD_EUNSUPPORTED;
+  int npow2 = 2;
+  while (npow2 < n_windows) npow2 <<= 1;
+  hipLaunchKernelGGL(epoch_shuffle_kernel, dim3(n_passes), dim3(SHUF_THREADS), 0, (hipStream_t)stream, row_index, take, n_windows, npow2, seed,
+                     counters);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
 
 int hypad_rng_fill(int kind, uint64_t seed, uint32_t tick, uint32_t rng_stream, uint32_t signal, float p_drop, float* out, int64_t n,
                    hypad_stream_t stream) {

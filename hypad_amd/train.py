@@ -384,11 +384,20 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
         n_epochs = n_epochs - params.resume_epoch
         actual_epoch = params.resume_epoch + 1
     for epoch in range(n_epochs):
-        # one uniform permutation per pass (argsort of uniform keys: one batched sort instead of six randperm calls)
-        perm = torch.rand(n_critics + 1, n_windows, device=dev, generator=gen).argsort(dim=1)[:, : n_batches * B]
-        perm_buf.copy_(perm)
+        # one uniform permutation per pass: drawn by the library inside the captured epoch where it can (<= 4096 windows:
+        # hypad_epoch_shuffles), else by one batched torch sort (argsort of uniform keys) into the buffer the epoch reads
+        in_graph = n_windows <= eng.SHUFFLE_MAX_WINDOWS
+        if not in_graph:
+            perm = torch.rand(n_critics + 1, n_windows, device=dev, generator=gen).argsort(dim=1)[:, : n_batches * B]
+            perm_buf.copy_(perm)
         # the epoch is a fixed launch sequence: captured once as a hipGraph, replayed every epoch (Engine.train_epoch_graph)
-        losses = eng.train_epoch_graph(x, perm_buf, n_batches, n_critics, True, x_row_stride=stride)[0]
+        losses = eng.train_epoch_graph(x, perm_buf, n_batches, n_critics, True, x_row_stride=stride, shuffle_windows=n_windows if in_graph else 0)
+        # the host reads the losses next (a synchronisation anyway): did the epoch's resident critic launch complete?  If one of
+        # its bounded waits gave up (a CU withheld by a CU mask / a shared device), the epoch's remaining launches were no-ops;
+        # check_status restores the critics and repeats the epoch with one launch per critic iteration, for good
+        if eng.check_status():
+            losses = eng._last_epoch["losses"]
+        losses = losses[0]
         crit = losses[: 2 * n_critics * n_batches, 0].reshape(n_critics * n_batches, 2).mean(0)
         gl = losses[2 * n_critics * n_batches:].mean(0)
         history.cx.append(float(crit[0])); history.cz.append(float(crit[1])); history.dec.append(float(gl[0]))

@@ -272,6 +272,15 @@ enum {
   HYPAD_EPOCH_TEST_GIVE_UP_SHIFT = 8         /* tests only: bits 8..15 = k > 0 makes the resident launch behave as if its wait for the
                                                 siblings' shares had timed out at critic iteration k (signal 0, critic_x) */
 };
+/* The DataLoader's shuffles of one epoch (main.py:38: shuffle=True, drop_last=True; train.py:315-351 iterates the loader once per
+ * pass) drawn on the device: row_index (n_passes, take) int32 <- for every pass the first `take` = n_batches * batch entries of an
+ * independent uniform random permutation of [0, n_windows) (argsort of Philox keys, keyed by seed, pass and the rng tick
+ * counters[3] -- NULL: tick 0 -- so every epoch of a replayed graph is shuffled afresh).  Capturable: an epoch including its
+ * shuffles is then a fixed launch sequence with no host work at all.  n_windows <= 4096 (one workgroup sorts a pass in LDS);
+ * HYPAD_EUNSUPPORTED beyond: draw the permutations with any other generator and pass them to hypad_train_epoch as before. */
+int hypad_epoch_shuffles(int32_t* row_index, int n_passes, int take, int n_windows, uint64_t seed, const int32_t* counters,
+                         hypad_stream_t stream);
+
 /* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
  * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up
  * to 512 iterations of precomputed rows (longer phases are processed in chunks).  Same random streams and the same

@@ -191,3 +191,54 @@ def test_chunks_of_a_critic_share_an_xcd_and_the_epoch_keeps_its_bits(ns, S, B, 
         assert torch.equal(l, a[0]) and torch.equal(l2, a[1]), rep
         snap = _snapshot(e)
         assert all(torch.equal(snap[i][k], a[2][i][k]) for i in range(3) for k in snap[i]), rep
+
+
+# ------------------------------------------------------------------------------------------------ device-side shuffles
+def test_epoch_shuffles_are_uniform_permutations_and_replay_afresh():
+    """hypad_epoch_shuffles stands in for the DataLoader's shuffle=True, drop_last=True (main.py:38): every pass the head of a
+    fresh permutation of the windows; captured into the epoch's graph it must draw NEW permutations at every replay (the key
+    includes the device rng tick) and the epoch must equal the one that is handed the same permutations explicitly."""
+    from hypad_amd import _C
+    engine, x, perms, nb, nc = _setup(ns=1, nb=3, nc=2)
+    n_windows, take = x.shape[1], nb * 64
+    e = engine()
+    buf = torch.empty(nc + 1, take, dtype=torch.int32, device="cuda")
+    draws = []
+    for tick in range(40):
+        e.counters[3] = tick
+        draws.append(e.draw_shuffles(buf, n_windows).clone())
+    d = torch.stack(draws).cpu().numpy()                       # (40, passes, take)
+    assert d.min() >= 0 and d.max() < n_windows
+    for t in range(40):
+        for p in range(nc + 1):
+            assert len(set(d[t, p].tolist())) == take          # no index twice
+    assert not np.array_equal(d[0, 0], d[0, 1]) and not np.array_equal(d[0], d[1])
+    e.counters[3] = 0
+    assert torch.equal(e.draw_shuffles(buf, n_windows), draws[0])           # keyed, not stateful
+    # uniformity: over 120 permutation heads every window should be drawn ~ take / n of the time, at a mean position ~ take / 2
+    big = Engine_draws(e, 2000, 1536, 400)
+    freq = np.bincount(big.reshape(-1), minlength=2000) / big.shape[0]
+    assert abs(freq.mean() - 1536 / 2000) < 1e-9 and freq.std() < 3.5 * np.sqrt(0.768 * 0.232 / big.shape[0])
+    assert 0.35 < (big[:, 0] < 1000).mean() < 0.65
+    # in-graph shuffles == the same permutations handed over explicitly, and a second replay uses other permutations
+    a, b = engine(), engine()
+    pa = torch.empty(nc + 1, take, dtype=torch.int32, device="cuda")
+    la = a.train_epoch_graph(x, pa, nb, nc, True, shuffle_windows=n_windows).clone()
+    first = pa.clone()
+    lb = b.train_epoch(x, b.draw_shuffles(torch.empty_like(pa), n_windows), nb, nc, True)
+    torch.cuda.synchronize()
+    assert torch.equal(la, lb) and all(torch.equal(a.params[k], b.params[k]) for k in a.params)
+    a.train_epoch_graph(x, pa, nb, nc, True, shuffle_windows=n_windows)
+    torch.cuda.synchronize()
+    assert not torch.equal(pa, first)
+    assert _C.lib.hypad_epoch_shuffles(pa.data_ptr(), 3, take, 5000, 1, None, _C.stream()) == -3       # > 4096 windows: caller's generator
+
+
+def Engine_draws(e, n_windows, take, reps):
+    buf = torch.empty(1, take, dtype=torch.int32, device="cuda")
+    out = []
+    for t in range(reps):
+        e.counters[3] = 1000 + t
+        out.append(e.draw_shuffles(buf, n_windows)[0].clone())
+    e.counters[3] = 0
+    return torch.stack(out).cpu().numpy()
