@@ -1558,6 +1558,9 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
     }
     // ---- merged share -> compact valid quads, write-through; then the epoch word
+    // (measured and dropped in round 3: publishing dW(real, fake) and dW(penalty rows) as two unscaled parts the moment each exists --
+    // the consumers apply the coefficient -- so that the epoch word need not wait for the siblings' scalars: twice the share
+    // stores and loads cost more than the shorter dependency saves, 2.86 -> 3.03 ms per epoch)
     {
       const int obase = ((it & 1) * nchunks + chunk) * slabf;
 #pragma unroll

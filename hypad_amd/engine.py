@@ -120,10 +120,13 @@ class Engine:
     def _iter(self, fn, x, row_index, z, alpha, train_mode, masks, x_row_stride=0):
         x, stride = self._check_x(x, x_row_stride)
         losses = torch.empty(self.n, 4, dtype=torch.float32, device=self.device)
-        drop = _C.Dropout(int(train_mode), None if masks is None else masks.data_ptr(), self.seed, 0)
-        io = _C.IterIO(x.data_ptr(), stride, int(x_row_stride), None if row_index is None else row_index.data_ptr(),
-                       None if z is None else z.data_ptr(), None if alpha is None else alpha.data_ptr(), drop,
-                       losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes)
+        io = self.__dict__.get("_iter_io")              # one struct per engine, refilled per call (the drop-in loop calls this 319 times per epoch)
+        if io is None:
+            io = self._iter_io = _C.IterIO()
+        p = lambda t: None if t is None else t.data_ptr()
+        io.x, io.x_signal_stride, io.x_row_stride, io.row_index, io.z, io.alpha = x.data_ptr(), stride, int(x_row_stride), p(row_index), p(z), p(alpha)
+        io.drop.train_mode, io.drop.masks, io.drop.seed, io.drop.offset = int(train_mode), p(masks), self.seed, 0
+        io.losses, io.workspace, io.workspace_bytes = losses.data_ptr(), self.workspace.data_ptr(), self._ws_bytes
         st = self._state()
         _C.check(fn(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), fn.__name__)
         return losses

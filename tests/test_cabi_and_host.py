@@ -155,3 +155,19 @@ def test_wide_buffer_stores_keep_their_offset_out_of_scalar_registers():
             assert len(args) == 5 and args[3] == "0", (os.path.basename(path), args)
             found += 1
     assert found >= 3
+
+
+def test_results_table_follows_the_reference(tmp_path, monkeypatch):
+    """utils/anomaly_detection_utils.py:112-126 (host-only part of the mirror): one [signal, tn, fp, fn, tp] row per signal in
+    ./results/<params.filename>, created with its header, never duplicated for a signal already present."""
+    from types import SimpleNamespace
+    import pandas as pd
+    adu = pytest.importorskip("hypad_amd.utils.anomaly_detection_utils")
+    monkeypatch.chdir(tmp_path)
+    P = SimpleNamespace(filename="out.csv", signal="a")
+    f = adu.save_result(P, "a", [5, 1, 2, 7])
+    adu.save_result(P, "a", [9, 9, 9, 9])                                       # same signal: kept as it was
+    P.signal = "b"
+    adu.save_result(P, "b", [0, 0, 0, 0])
+    t = pd.read_csv(f)
+    assert list(t.columns) == ["signal", "tn", "fp", "fn", "tp"] and t.values.tolist() == [["a", 5, 1, 2, 7], ["b", 0, 0, 0, 0]]
