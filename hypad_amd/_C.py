@@ -203,7 +203,12 @@ def ptr(t):
 
 
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream on the current device as a hipStream_t (the raw C getters: torch.cuda.current_stream() builds a Stream
+    object behind three layers of Python per call, ~5 us of the drop-in iteration functions' ~40 us of host time)."""
+    try:
+        return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:                                   # (a torch without the raw getters)
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def require_cuda(t, name="tensor", dtype=torch.float32):

@@ -755,6 +755,13 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 // KS: k-steps (groups of four reduction rows) a weight item keeps in flight: 48 covers B <= 64 in one memory round trip.
 // (16 halves the registers and doubles the waves per SIMD; measured with 8 and 32 signals per GPU it changes nothing --
 // with many signals the launch moves ~9 MB per signal and sits at ~3.5 TB/s of HBM traffic.)
+#ifndef HYPAD_DW_KS_MANY
+#define HYPAD_DW_KS_MANY 16                  // k-steps in flight in the many-signal (co-located) form of the dW + Adam launch: 61 registers, seven waves
+                                             // per SIMD instead of three (126 registers at 48).  Round 3, same box, launch time at 8 / 16 / 32 signals
+                                             // per GPU: 48 -> 30.5 / 49.0 / 86.4 us, 32 -> 29.4 / 45.2 / 77.7, 24 -> 27.2 / 41.7 / 70.3, 16 -> 26.7 / 41.1 /
+                                             // 68.1 (same accumulation order: same bits).  The one-signal launch keeps 48: it is as long as its slowest
+                                             // item, and an item with all its operand rows in flight makes ONE memory round trip
+#endif
 template <class Table, int SC = 0, int LC = 0, int BC = 0, int KS = 48>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab, const int bx = (int)blockIdx.x) {      // bx: the workgroup's index in the launch's work (dw_adam_kernel: co-location)
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
@@ -1553,9 +1560,9 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const bool coloc = cenv ? cenv[0] == '1' : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), d->n_signals);
   if (coloc) {
-    if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
   } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
   else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
