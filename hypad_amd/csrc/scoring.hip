@@ -59,7 +59,7 @@ long long* g_unroll_stamps = nullptr;        // development aid (dev library): [
 // UT: timesteps per workgroup tile, one wave per 16 of them (UT = 64: 256 threads, 128: 512).  A longer tile reads longer runs
 // of every source row (fewer partly used 128-byte lines at the runs' ends: the tile's triangle rows) for twice the LDS.
 template <int EPL, bool FILTER, int UT>
-__global__ __launch_bounds__(UT * 4) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
+__global__ __launch_bounds__(UT * 4) __attribute__((amdgpu_waves_per_eu(HYPAD_UNROLL_WPE, HYPAD_UNROLL_WPE))) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
                                                                 double* __restrict__ summary, int64_t n, int W, long long* stamps) {
   constexpr int THREADS = UT * 4;                           // (shadows the file's 256: this kernel's block size follows its tile)
   constexpr int RUN = UT / 64;                               // elements per lane of one source row's run
@@ -480,7 +480,17 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restr
 // windows covering it, critic[t - j] for the valid j (each window's score repeated along the window, un-rolled along
 // anti-diagonals).  Its score is the sample at which a Scott-bandwidth Gaussian KDE of those values is largest
 // (scipy.stats.gaussian_kde(v)(v), first arg-max), the median when fewer than two values or a singular covariance.
-constexpr int KDE_CB = 4;                    // candidates per pass-2 batch
+#ifndef HYPAD_KDE_CB
+#define HYPAD_KDE_CB 2
+#endif
+#ifndef HYPAD_KDE_WPE
+#define HYPAD_KDE_WPE 5
+#endif
+#ifndef HYPAD_UNROLL_WPE
+#define HYPAD_UNROLL_WPE 4
+#endif
+constexpr int KDE_CB = HYPAD_KDE_CB;         // candidates per pass-2 batch.  Its term buffer is the kernel's largest LDS array (4 KB per wave at 2): with 2
+                                             // and five waves per SIMD (96 registers) the kernel takes 0.354 ms per 125 000 windows; 0.438 at 4 / three waves
 //
 // Selection in two passes.  The result is a SAMPLE (the arg-max's value), so only the arg-max must be exact, not the densities:
 // pass 1 evaluates every density in fp32 (v_exp_f32: cnt^2 = 10^4 exponentials per timestep at window 100 -- in fp64 this pass
@@ -488,7 +498,7 @@ constexpr int KDE_CB = 4;                    // candidates per pass-2 batch
 // fp32 density lies within 1e-3 of the fp32 maximum -- a superset of the true arg-max set (the fp32 density's relative error is
 // below 3e-5: arguments carry <= 4 ulp, |argument| < 88 wherever the term is not 0, v_exp_f32 adds 2 ulp) -- with the same
 // first-maximum tie rule.  Clustered samples (many near-equal densities) simply put more candidates into pass 2.
-__global__ __launch_bounds__(THREADS) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_KDE_WPE, HYPAD_KDE_WPE))) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
                                                             int64_t n, int W) {
   __shared__ double vals[THREADS / 64][MAX_WINDOW];
   __shared__ __attribute__((aligned(16))) float vals32[THREADS / 64][MAX_WINDOW + 4];
