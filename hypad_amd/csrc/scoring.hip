@@ -13,6 +13,11 @@ using namespace hypad;
 
 namespace {
 
+// Build-time occupancy switches (waves per SIMD the register allocator is asked to fit).
+#ifndef HYPAD_UNROLL_WPE
+#define HYPAD_UNROLL_WPE 4
+#endif
+
 constexpr int THREADS = 256;
 constexpr int MAX_WINDOW = 256;
 
@@ -485,9 +490,6 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restr
 #endif
 #ifndef HYPAD_KDE_WPE
 #define HYPAD_KDE_WPE 5
-#endif
-#ifndef HYPAD_UNROLL_WPE
-#define HYPAD_UNROLL_WPE 4
 #endif
 constexpr int KDE_CB = HYPAD_KDE_CB;         // candidates per pass-2 batch.  Its term buffer is the kernel's largest LDS array (4 KB per wave at 2): with 2
                                              // and five waves per SIMD (96 registers) the kernel takes 0.354 ms per 125 000 windows; 0.438 at 4 / three waves
