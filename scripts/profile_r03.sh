@@ -30,4 +30,4 @@ cp $OUT/bench_trace.json $OUT/r03_bench_under_rocprof.json
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 ls -la $OUT
-tail -2 $OUT/bench_trace.err $OUT/mfma_target.err $OUT/mfma_util.err
+for f in $OUT/bench_trace.err $OUT/mfma_target.err $OUT/mfma_util.err; do tail -n 2 $f; done
