@@ -163,6 +163,10 @@ _SIGS = {
     "hypad_zscore_clip": (c_int, [P, P, c_int64, P, c_size_t, P]),
     "hypad_kde_mode": (c_int, [P, P, c_int64, c_int, P]),
     "hypad_critic_zscore": (c_int, [P, c_double, c_double, P, c_int64, P, c_size_t, P]),
+    "hypad_quantile_workspace_bytes": (c_size_t, []),
+    "hypad_quantiles": (c_int, [P, c_int64, P, c_int, P, P, c_size_t, P]),
+    "hypad_critic_score_workspace_bytes": (c_size_t, []),
+    "hypad_critic_score": (c_int, [P, P, c_int64, P, c_size_t, P]),
     "hypad_row_norms": (c_int, [P, P, c_int64, c_int, P]),
     "hypad_combine_scores": (c_int, [c_int, P, P, P, P, c_int64, P]),
 }

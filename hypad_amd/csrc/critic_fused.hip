@@ -322,7 +322,10 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
                          __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
+#ifndef HYPAD_PRE_WPE
+#define HYPAD_PRE_WPE 4
+#endif
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WPE, HYPAD_PRE_WPE))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   precompute_body<false>(ax, az, ph, smem, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, gridDim.y);
 }

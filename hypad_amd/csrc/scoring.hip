@@ -32,6 +32,7 @@ inline int grid_for(int64_t n, int per_block) {
 // by counting (ties broken by position), scatter into sorted order in LDS, read the order statistics.
 __device__ __forceinline__ float np_lerp(float a, float b, float t) {
   // numpy.lib._function_base_impl._lerp, evaluated in the data's precision (float32) as NumPy does
+#pragma clang fp contract(off)                   // numpy rounds the product before the sum: no fused multiply-add here
   float diff = b - a;
   float r = a + diff * t;
   if (t >= 0.5f) r = b - diff * (1.0f - t);
@@ -429,8 +430,10 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {      // 
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 template <bool RANGE>
-__global__ __launch_bounds__(256) void stat_partials_kernel(const double* __restrict__ in, StatPart* __restrict__ parts, int64_t T, double lo, double hi) {
+__global__ __launch_bounds__(256) void stat_partials_kernel(const double* __restrict__ in, StatPart* __restrict__ parts, int64_t T, double lo, double hi,
+                                                              const double* __restrict__ range_dev = nullptr) {      // range_dev: [lo, hi] left on the device by hypad_quantiles
   __shared__ double sh[4];
+  if (RANGE && range_dev) { lo = range_dev[0]; hi = range_dev[1]; }
   const int64_t len = (T + gridDim.x - 1) / gridDim.x;
   const int64_t b = (int64_t)blockIdx.x * len, e = b + len < T ? b + len : T;
   double s = 0.0, rs = 0.0, rc = 0.0;
@@ -488,6 +491,9 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restr
 #ifndef HYPAD_KDE_CB
 #define HYPAD_KDE_CB 2
 #endif
+#ifndef HYPAD_KDE_EXP
+#define HYPAD_KDE_EXP 0        // development what-ifs: 1 skips the fp32 screen's pair loop, 2 the fp64 pass (wrong results, timing only)
+#endif
 #ifndef HYPAD_KDE_WPE
 #define HYPAD_KDE_WPE 5
 #endif
@@ -497,9 +503,8 @@ constexpr int KDE_CB = HYPAD_KDE_CB;         // candidates per pass-2 batch.  It
 // Selection in two passes.  The result is a SAMPLE (the arg-max's value), so only the arg-max must be exact, not the densities:
 // pass 1 evaluates every density in fp32 (v_exp_f32: cnt^2 = 10^4 exponentials per timestep at window 100 -- in fp64 this pass
 // was 97 % of the kernel, 1.7 ms for 125 000 windows); pass 2 re-evaluates in fp64, exactly as before, only the samples whose
-// fp32 density lies within 1e-3 of the fp32 maximum -- a superset of the true arg-max set (the fp32 density's relative error is
-// below 3e-5: arguments carry <= 4 ulp, |argument| < 88 wherever the term is not 0, v_exp_f32 adds 2 ulp) -- with the same
-// first-maximum tie rule.  Clustered samples (many near-equal densities) simply put more candidates into pass 2.
+// fp32 density lies within 4e-5 of the fp32 maximum -- a superset of the true arg-max set (the fp32 density's relative error is
+// below 7.1e-6: the budget is written out at the threshold below) -- with the same first-maximum tie rule.  Clustered samples (many near-equal densities) simply put more candidates into pass 2.
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_KDE_WPE, HYPAD_KDE_WPE))) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
                                                             int64_t n, int W) {
   __shared__ double vals[THREADS / 64][MAX_WINDOW];
@@ -551,8 +556,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);
       float d32[KPL], xs[KPL];
+      float acc[KPL][4];                                   // one accumulator per position in the group of four: <= ceil(cnt / 4) terms each
 #pragma unroll
-      for (int u = 0; u < KPL; ++u) { const int k = lane + 64 * u; xs[u] = vf[k < cnt ? k : 0]; d32[u] = 0.f; }
+      for (int u = 0; u < KPL; ++u) {
+        const int k = lane + 64 * u;
+        xs[u] = vf[k < cnt ? k : 0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[u][c] = 0.f;
+      }
       const int nu = (cnt + 63) >> 6;                                             // sample slots in use (wave-uniform)
       for (int m = 0; m < cnt; m += 4) {
         const float4 q4 = *reinterpret_cast<const float4*>(vf + m);
@@ -561,9 +572,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
         for (int u = 0; u < KPL; ++u) {
           if (u >= nu) continue;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { const float d = xs[u] - vm[c]; d32[u] += __builtin_amdgcn_exp2f(-(d * d)); }
+          for (int c = 0; c < 4; ++c) { const float d = xs[u] - vm[c]; acc[u][c] += __builtin_amdgcn_exp2f(-(d * d)); }
         }
       }
+#pragma unroll
+      for (int u = 0; u < KPL; ++u) d32[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
       float mx = -1.f;
 #pragma unroll
       for (int u = 0; u < KPL; ++u) {
@@ -572,9 +585,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
-      // (error of an fp32 density: the exponent's argument carries ~4e-6 absolute at the terms that matter, the 100-term sum
-      // ~6e-6 relative: 1.5e-5 in all.  Everything within 2e-4 of the fp32 maximum goes to pass 2.)
-      const float thr = mx * (1.f - 2e-4f);
+      // Relative error of an fp32 density D~ against the exact D, all terms positive:
+      //  * arguments: a centred, rescaled sample y carries 2^-24 |y| <= 1e-6 (|y| < 32 for every pair that contributes: two of <= 256
+      //    samples within a few units of each other lie at most 2.6 sqrt(255 / 2) = 29 units from the mean; a lone outlier beyond that
+      //    sees only its own term, exactly 1), a difference d twice that, d^2 an absolute 2 |d| 2e-6 (+ 2^-24 d^2 from the product);
+      //    a term's relative error is ln 2 times that, and weighted by the terms themselves (|d| 2^(-d^2) <= 0.52, the self term is 1)
+      //    the sum's is <= 3e-6;
+      //  * v_exp_f32: 1 ulp = 1.2e-7;
+      //  * accumulation: four partial sums of <= 64 terms, each add 2^-24 of a partial sum that never exceeds the result: 3.8e-6, + 1.2e-7
+      //    for the two combining adds
+      // -> eps <= 7.1e-6 at window 256 (4.8e-6 at 100).  If k* is the true arg-max, D~[k*] >= (1 - eps) D[k*] >= (1 - eps) D[j] >=
+      // (1 - eps) / (1 + eps) D~[j] for every j: the screen keeps k* as long as its margin exceeds 2 eps = 1.5e-5.  Margin 4e-5
+      // (rounds 2-3 used 2e-4 with one accumulator per sample: 1.7 fp64 evaluations per timestep on random-normal values, 0.6 now).
+      const float thr = mx * (1.f - 4e-5f);
       // pass 2: fp64 densities of the candidates, in ascending sample order (the first maximum is kept); of every sample if
       // pass 1 produced no candidate (a bandwidth so small that its reciprocal leaves the fp32 range makes the screen NaN).
       // A wave pays for a sequential sum as if all 64 lanes ran it, so a candidate's sum is NOT given to one lane with its
@@ -595,7 +618,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
         }
         if (ncand == 1) besti = first;
       }
-      for (int round = 0; round < 2 && besti == 0x7fffffff; ++round) {
+      for (int round = 0; round < (HYPAD_KDE_EXP == 2 ? 0 : 2) && besti == 0x7fffffff; ++round) {
 #pragma unroll
         for (int u = 0; u < KPL; ++u) {
           const int ku = lane + 64 * u;
@@ -666,6 +689,151 @@ __global__ __launch_bounds__(256) void critic_apply_kernel(const double* __restr
   const double mean = st.rsum / st.rcnt, sd = sqrt(st.m2 / st.n);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < T; i += (int64_t)gridDim.x * 256)
     out[i] = fabs((in[i] - mean) / sd) + 1.0;
+}
+
+// ---- np.quantile (method "linear") of an fp64 vector without a sort: exact order statistics by radix selection on the keys.
+// _compute_critic_score :307-322 needs the 25 % and 75 % quantiles of the (T,) critic modes; torch.quantile sorted them (a device
+// radix sort + seven merge passes + ~15 elementwise launches, ~0.15 ms per 125 000 values, and the two results went through the
+// host).  Here: a double maps to a 64-bit key whose unsigned order is the numeric order; the key of the element of rank k is
+// fixed 11 bits at a time -- one pass over the data per level histograms the next digit of the elements that still match the
+// prefix (LDS histogram per workgroup, non-empty bins added to the level's global histogram), the next level's launch starts by
+// scanning that histogram for the bin that holds the rank.  Up to four ranks at once (floor and floor + 1 of two quantiles;
+// wave s of a workgroup scans for rank s).  Six levels (11 + 11 + 11 + 11 + 11 + 9 bits), then one workgroup interpolates as
+// numpy does.  Any NaN makes every quantile NaN (numpy).  Nothing returns to the host.
+constexpr int QS_BITS = 11, QS_BINS = 1 << QS_BITS, QS_LEVELS = 6, QS_SEL = 4;
+struct QsState { unsigned long long prefix; long long rank; };
+struct QsWs {                       // layout of the workspace (hypad_quantile_workspace_bytes)
+  unsigned int* hist;               // [QS_LEVELS][QS_SEL][QS_BINS], zeroed by the call's memset
+  QsState* state;                   // [QS_LEVELS + 1][QS_SEL]
+  unsigned int* nan_count;          // [1] (inside the zeroed region)
+};
+constexpr size_t QS_HIST_BYTES = (size_t)QS_LEVELS * QS_SEL * QS_BINS * sizeof(unsigned int);
+constexpr size_t QS_ZERO_BYTES = QS_HIST_BYTES + 64;
+constexpr size_t QS_WS_BYTES = QS_ZERO_BYTES + (QS_LEVELS + 1) * QS_SEL * sizeof(QsState) + 64;
+__host__ __device__ inline int qs_shift(int level) { const int sh = 64 - QS_BITS * (level + 1); return sh < 0 ? 0 : sh; }
+__host__ __device__ inline int qs_bins(int level) { return level == QS_LEVELS - 1 ? 1 << (64 - QS_BITS * (QS_LEVELS - 1)) : QS_BINS; }
+__device__ __forceinline__ unsigned long long qs_key(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double qs_value(unsigned long long k) {
+  const unsigned long long b = k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull);
+  return __longlong_as_double((long long)b);
+}
+// Wave `sel` of the block: which bin of hist[level][sel] holds rank st.rank?  Every lane returns the new state.
+__device__ __forceinline__ QsState qs_descend(const unsigned int* __restrict__ hist, int level, const QsState st) {
+  const int lane = threadIdx.x & 63, bins = qs_bins(level), per = bins / 64;       // 32 (or 8) consecutive bins per lane
+  unsigned long long mine = 0;
+  for (int i = 0; i < per; ++i) mine += hist[lane * per + i];
+  unsigned long long incl = mine;                                                   // inclusive wave scan
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(incl, off, WAVE); if (lane >= off) incl += o; }
+  const unsigned long long before = incl - mine, r = (unsigned long long)st.rank;
+  const bool here = r >= before && r < incl;                                        // exactly one lane (the ranks are < n)
+  int bin = 0; unsigned long long cum = 0;
+  if (here) {
+    cum = before;
+    for (int i = 0; i < per; ++i) { const unsigned int c = hist[lane * per + i]; if (r < cum + c) { bin = lane * per + i; break; } cum += c; }
+  }
+  const unsigned long long mask = __ballot(here);
+  const int src = mask ? __builtin_ctzll(mask) : 0;
+  bin = __shfl(bin, src, WAVE); cum = __shfl(cum, src, WAVE);
+  QsState nx; nx.prefix = st.prefix | ((unsigned long long)bin << qs_shift(level)); nx.rank = (long long)(r - cum);
+  return nx;
+}
+__global__ __launch_bounds__(256) void qs_level_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int level, int nsel,
+                                                         long long r0, long long r1, long long r2, long long r3) {
+  __shared__ unsigned int h[QS_SEL][QS_BINS];
+  __shared__ QsState cur[QS_SEL];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < nsel) {
+    QsState st;
+    if (level == 0) { st.prefix = 0; st.rank = wave == 0 ? r0 : wave == 1 ? r1 : wave == 2 ? r2 : r3; }
+    else st = qs_descend(ws.hist + ((size_t)(level - 1) * QS_SEL + wave) * QS_BINS, level - 1, ws.state[(level - 1) * QS_SEL + wave]);
+    if (lane == 0) { cur[wave] = st; if (blockIdx.x == 0) ws.state[level * QS_SEL + wave] = st; }
+  }
+  for (int i = threadIdx.x; i < QS_SEL * QS_BINS; i += 256) (&h[0][0])[i] = 0u;
+  __syncthreads();
+  const int sh = qs_shift(level), bins = qs_bins(level);
+  const int hi_sh = sh + (level == QS_LEVELS - 1 ? 64 - QS_BITS * (QS_LEVELS - 1) : QS_BITS);     // bits above the digit
+  unsigned long long pre[QS_SEL];
+  for (int s2 = 0; s2 < QS_SEL; ++s2) pre[s2] = s2 < nsel ? cur[s2].prefix : 0;
+  const int64_t len = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b = (int64_t)blockIdx.x * len, e = b + len < n ? b + len : n;
+  unsigned int nans = 0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+    const double x = in[i];
+    if (level == 0 && x != x) ++nans;
+    const unsigned long long k = qs_key(x);
+    const unsigned int digit = (unsigned int)(k >> sh) & (unsigned int)(bins - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < QS_SEL; ++s2)
+      if (s2 < nsel && (hi_sh >= 64 || ((k ^ pre[s2]) >> hi_sh) == 0)) atomicAdd(&h[s2][digit], 1u);
+  }
+  if (level == 0 && nans) atomicAdd(ws.nan_count, nans);
+  __syncthreads();
+  unsigned int* g = ws.hist + (size_t)level * QS_SEL * QS_BINS;
+  for (int i = threadIdx.x; i < nsel * QS_BINS; i += 256) {
+    const unsigned int c = (&h[0][0])[i];
+    if (c) atomicAdd(g + i, c);
+  }
+}
+__device__ __forceinline__ double np_lerp64(double a, double b, double t) {     // numpy.lib._function_base_impl._lerp
+#pragma clang fp contract(off)                   // numpy rounds the product before the sum: no fused multiply-add here
+  const double diff = b - a;
+  double r = a + diff * t;
+  if (t >= 0.5) r = b - diff * (1.0 - t);
+  return r;
+}
+// one workgroup: the last digits, then out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
+__global__ __launch_bounds__(256) void qs_final_kernel(QsWs ws, int nsel, double t0, double t1, double* __restrict__ out) {
+  __shared__ unsigned long long keys[QS_SEL];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave < nsel) {
+    const QsState st = qs_descend(ws.hist + ((size_t)(QS_LEVELS - 1) * QS_SEL + wave) * QS_BINS, QS_LEVELS - 1, ws.state[(QS_LEVELS - 1) * QS_SEL + wave]);
+    if (lane == 0) keys[wave] = st.prefix;
+  }
+  __syncthreads();
+  if (threadIdx.x < nsel / 2) {
+    const int j = threadIdx.x;
+    double r = np_lerp64(qs_value(keys[2 * j]), qs_value(keys[2 * j + 1]), j == 0 ? t0 : t1);
+    if (*ws.nan_count) r = __longlong_as_double(0x7ff8000000000000ll);
+    out[j] = r;
+  }
+}
+QsWs qs_ws(void* workspace) {
+  QsWs w; char* p = (char*)workspace;
+  w.hist = (unsigned int*)p; w.nan_count = (unsigned int*)(p + QS_HIST_BYTES); w.state = (QsState*)(p + QS_ZERO_BYTES);
+  return w;
+}
+// numpy (_function_base_impl._quantile, method "linear"): virtual index (n - 1) q, neighbours floor and floor + 1 (both the last
+// element once the index reaches n - 1), weight = index - floor
+inline void qs_position(int64_t n, double q, long long* lo, long long* hi, double* frac) {
+  const double pos = (double)(n - 1) * q;
+  const double f = floor(pos);
+  long long l = (long long)f;
+  *frac = pos - f;
+  if (pos >= (double)(n - 1)) { *lo = n - 1; *hi = n - 1; return; }
+  if (l < 0) l = 0;
+  *lo = l; *hi = l + 1 > n - 1 ? n - 1 : l + 1;
+}
+int launch_quantiles(const double* in, int64_t n, const double* q, int nq, double* out, void* workspace, hipStream_t s) {
+  const QsWs ws = qs_ws(workspace);
+  hipError_t e = hipMemsetAsync(workspace, 0, QS_ZERO_BYTES, s);
+  if (e != hipSuccess) return (int)e;
+  long long r[QS_SEL] = {0, 0, 0, 0};
+  double t[2] = {0.0, 0.0};
+  for (int j = 0; j < nq; ++j) qs_position(n, q[j], &r[2 * j], &r[2 * j + 1], &t[j]);
+  const int nsel = 2 * nq;
+  int64_t g = (n + 2047) / 2048;
+  g = g < 1 ? 1 : (g > 256 ? 256 : g);
+  for (int level = 0; level < QS_LEVELS; ++level) {
+    hipLaunchKernelGGL(qs_level_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, level, nsel, r[0], r[1], r[2], r[3]);
+    HYPAD_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(256), 0, s, ws, nsel, t[0], t[1], out);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
 }
 
 __global__ __launch_bounds__(THREADS) void row_norms_kernel(const float* __restrict__ x, double* __restrict__ out, int64_t rows, int dim) {
@@ -805,7 +973,7 @@ int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace,
   if (!in || !out || t <= 0) return HYPAD_EINVAL;
   if (!workspace || workspace_bytes < HYPAD_STATS_WORKSPACE_BYTES) return HYPAD_EWORKSPACE;
   const int g = stat_blocks(t);
-  hipLaunchKernelGGL(stat_partials_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, 0.0, 0.0);
+  hipLaunchKernelGGL(stat_partials_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, 0.0, 0.0, (const double*)nullptr);
   HYPAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(zscore_apply_kernel, dim3(grid_for(t, 1024)), dim3(256), 0, (hipStream_t)s, in, (const StatPart*)workspace, g, out, t);
   HYPAD_CHECK_LAUNCH();
@@ -823,12 +991,38 @@ int hypad_critic_zscore(const double* in, double q25, double q75, double* out, i
   if (!in || !out || t <= 0) return HYPAD_EINVAL;
   if (!workspace || workspace_bytes < HYPAD_STATS_WORKSPACE_BYTES) return HYPAD_EWORKSPACE;
   const int g = stat_blocks(t);
-  hipLaunchKernelGGL(stat_partials_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, q25, q75);
+  hipLaunchKernelGGL(stat_partials_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)workspace, t, q25, q75, (const double*)nullptr);
   HYPAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(critic_apply_kernel, dim3(grid_for(t, 1024)), dim3(256), 0, (hipStream_t)s, in, (const StatPart*)workspace, g, out, t);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
+size_t hypad_quantile_workspace_bytes(void) { return QS_WS_BYTES; }
+int hypad_quantiles(const double* in, int64_t n, const double* q, int nq, double* out, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  if (!in || !q || !out || n <= 0 || nq < 1) return HYPAD_EINVAL;
+  if (nq > 2 || n > ((int64_t)1 << 31)) return HYPAD_EUNSUPPORTED;
+  for (int j = 0; j < nq; ++j) if (!(q[j] >= 0.0 && q[j] <= 1.0)) return HYPAD_EINVAL;
+  if (!workspace || workspace_bytes < QS_WS_BYTES) return HYPAD_EWORKSPACE;
+  return launch_quantiles(in, n, q, nq, out, workspace, (hipStream_t)s);
+}
+int hypad_critic_score(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
+  if (!in || !out || t <= 0) return HYPAD_EINVAL;
+  if (t > ((int64_t)1 << 31)) return HYPAD_EUNSUPPORTED;
+  if (!workspace || workspace_bytes < hypad_critic_score_workspace_bytes()) return HYPAD_EWORKSPACE;
+  char* p = (char*)workspace;
+  double* range = (double*)p;                                     // [q25, q75]
+  void* stats = p + 64; void* qws = p + 64 + HYPAD_STATS_WORKSPACE_BYTES;
+  const double q[2] = {0.25, 0.75};
+  const int rc = launch_quantiles(in, t, q, 2, range, qws, (hipStream_t)s);
+  if (rc) return rc;
+  const int g = stat_blocks(t);
+  hipLaunchKernelGGL(stat_partials_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)s, in, (StatPart*)stats, t, 0.0, 0.0, (const double*)range);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(critic_apply_kernel, dim3(grid_for(t, 1024)), dim3(256), 0, (hipStream_t)s, in, (const StatPart*)stats, g, out, t);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+size_t hypad_critic_score_workspace_bytes(void) { return 64 + HYPAD_STATS_WORKSPACE_BYTES + QS_WS_BYTES; }
 int hypad_row_norms(const float* x, double* out, int64_t rows, int dim, hypad_stream_t s) {
   if (!x || !out || rows < 0 || dim <= 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;

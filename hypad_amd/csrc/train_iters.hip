@@ -1313,6 +1313,9 @@ struct ScoreArgs {
   int64_t rows; int S, L, hyperbolic;
 };
 struct ScoreLds { int xs, zs, bufA, bufB, cw, small, total, ldS; };
+#ifndef HYPAD_SCORE_WPE
+#define HYPAD_SCORE_WPE 4
+#endif
 HD ScoreLds score_lds(int S, int L) {
   ScoreLds p; int o = 0;
   p.ldS = pad4(S) + 4;
@@ -1322,7 +1325,7 @@ HD ScoreLds score_lds(int S, int L) {
   if (2 * buf < crit) buf = (crit + 1) / 2;
   buf = (buf + 3) & ~3;
   p.xs = o; o += 16 * p.ldS;
-  p.zs = o; o += 32 * LP;
+  p.zs = o; o += 16 * LP;
   p.bufA = o; o += buf;
   p.bufB = o; o += buf;
   p.cw = o; o += cp.total;
@@ -1331,7 +1334,7 @@ HD ScoreLds score_lds(int S, int L) {
   return p;
 }
 template <int SC, int LC>
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void score_forward_packed_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_SCORE_WPE, HYPAD_SCORE_WPE))) void score_forward_packed_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = SC ? SC : a.S, L = LC ? LC : a.L;
   const ScoreLds lp = score_lds(S, L);

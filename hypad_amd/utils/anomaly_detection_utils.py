@@ -8,6 +8,7 @@ names.  The reference's cached artefacts are kept under their names and formats 
 ``point.pickle`` / ``area.pickle`` / ``dtw.pickle`` (:229-235, :470-550), ``anomalies.csv`` (:94-95) and the results table
 ``./results/<params.filename>`` (:115-126) -- whenever a ``path`` is given; plotting is not part of this module.
 """
+import ctypes
 import math
 import os
 import pickle
@@ -186,16 +187,27 @@ def combine_euclidean(comb, critic_scores, rec_scores, as_tensor=False):
     return out if as_tensor else out.cpu().numpy()
 
 
+def quantiles(x, q):
+    """``np.quantile(x, q)`` (method "linear") of a device vector for one or two ``q``: exact order statistics by radix
+    selection (hypad_quantiles), the result stays on the device -- (len(q),) float64."""
+    c = _f64(x).reshape(-1)
+    q = [float(v) for v in np.atleast_1d(q)]
+    qa = (ctypes.c_double * len(q))(*q)
+    out = torch.empty(len(q), dtype=torch.float64, device=c.device)
+    nbytes = _C.lib.hypad_quantile_workspace_bytes()
+    ws = _scratch(c.device, nbytes, "quantiles")
+    _C.check(_C.lib.hypad_quantiles(_C.ptr(c), c.numel(), qa, len(q), _C.ptr(out), ws.data_ptr(), nbytes, _C.stream()), "quantiles")
+    return out
+
+
 def _compute_critic_score(critics, smooth_window):
-    """:307-333 -- quantile-trimmed mean, |z| + 1, centred rolling mean.  The two quantiles are the only step left to
-    torch (a device sort); everything else is one reduction kernel + one elementwise kernel + the rolling mean."""
+    """:307-333 -- quantile-trimmed mean, |z| + 1, centred rolling mean.  All on the device: the two quantiles by radix
+    selection (no sort), one reduction kernel, one elementwise kernel, the rolling mean; nothing passes through the host."""
     c = _f64(critics)
-    q = torch.quantile(c, torch.tensor([0.25, 0.75], dtype=torch.float64, device=c.device))
     out = torch.empty_like(c)
-    ws = _scratch(c.device, _C.STATS_WORKSPACE_BYTES, "stats")
-    lo, hi = q.tolist()                                        # (one device -> host read for both)
-    _C.check(_C.lib.hypad_critic_zscore(_C.ptr(c), lo, hi, _C.ptr(out), c.numel(), ws.data_ptr(), _C.STATS_WORKSPACE_BYTES, _C.stream()),
-             "critic_zscore")
+    nbytes = _C.lib.hypad_critic_score_workspace_bytes()
+    ws = _scratch(c.device, nbytes, "critic_score")
+    _C.check(_C.lib.hypad_critic_score(_C.ptr(c), _C.ptr(out), c.numel(), ws.data_ptr(), nbytes, _C.stream()), "critic_score")
     return rolling_mean(out, smooth_window)
 
 

@@ -400,6 +400,16 @@ int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hy
  * the rolling mean of :325-330 is hypad_rolling_mean).  workspace: HYPAD_STATS_WORKSPACE_BYTES */
 int hypad_critic_zscore(const double* in, double q25, double q75, double* out, int64_t t, void* workspace,
                         size_t workspace_bytes, hypad_stream_t stream);
+/* np.quantile(in, q) (method "linear") for nq <= 2 quantiles of n fp64 values, out (nq) fp64 ON THE DEVICE: exact order
+ * statistics by radix selection on the keys (no sort, no host round trip), numpy's interpolation; any NaN -> NaN.
+ * :319-320 (`np.quantile(critics, 0.25)`, `np.quantile(critics, 0.75)`).  workspace: hypad_quantile_workspace_bytes() */
+size_t hypad_quantile_workspace_bytes(void);
+int hypad_quantiles(const double* in, int64_t n, const double* q, int nq, double* out, void* workspace, size_t workspace_bytes,
+                    hypad_stream_t stream);
+/* _compute_critic_score :307-322 with the two quantiles taken on the device (hypad_quantiles), then as hypad_critic_zscore.
+ * workspace: hypad_critic_score_workspace_bytes() */
+size_t hypad_critic_score_workspace_bytes(void);
+int hypad_critic_score(const double* in, double* out, int64_t t, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
 /* np.linalg.norm(recons, axis=1)  :341,347,350,359 */
 int hypad_row_norms(const float* x, double* out, int64_t rows, int dim, hypad_stream_t stream);
 /* combine_scores :336-362 */

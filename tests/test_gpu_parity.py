@@ -688,8 +688,8 @@ def _assert_same_modes_up_to_fp64_ties(critic, w, got, ref):
 
 def test_kde_mode_selection_pins(dev):
     """Selections the fp32 screening pass of kde_mode_kernel cannot decide by itself -- they must come out of its fp64 pass equal
-    to scipy's: (a) two clusters whose peak densities differ by ~1e-4 relative (inside the screen's 2e-4 margin, far above fp64
-    rounding); (b) a large common offset with a small spread (|mean| / std = 1e5: the screen works on centred samples);
+    to scipy's: (a) two clusters whose peak densities differ by ~8e-5, ~1.6e-5 and ~1.6e-6 relative (around and inside the screen's 4e-5
+    margin, the last below the fp32 pass's own error; all far above fp64 rounding); (b) a large common offset with a small spread (|mean| / std = 1e5: the screen works on centred samples);
     (c) the same values in reversed window order (the first maximum in SAMPLE order wins a tie)."""
     from hypad_amd.utils import anomaly_detection_utils as adu
     from oracle import scoring as osc
@@ -711,10 +711,12 @@ def test_kde_mode_selection_pins(dev):
     # Laid out so that every full window holds the same multiset.
     base = 0.05 * rng.standard_normal(50)
     block = np.empty(100)
-    block[0::2] = -1.0 + base
+    for squeeze in (5e-3, 1e-3, 1e-4):           # ~8e-5 (outside the round-3 margin of 4e-5: the screen decides), ~1.6e-5 (inside it), ~1.6e-6 (below the fp32 error)
+        block[0::2] = -1.0 + base
+        block[1::2] = 1.0 - base * (1.0 - squeeze)
+        got, ref = check(np.tile(block, 4), exact=True)
+        assert np.all(ref[150:250] > 0), squeeze     # the squeezed cluster wins in fp64 ...
     block[1::2] = 1.0 - base * (1.0 - 5e-3)
-    got, ref = check(np.tile(block, 4), exact=True)
-    assert np.all(ref[150:250] > 0)              # the squeezed cluster wins in fp64 ...
     # (b) large offset, small spread
     got, ref = check(3.0e4 + 0.3 * rng.standard_normal(500))
     got, ref = check(-1.0e5 + rng.standard_normal(500))

@@ -113,3 +113,55 @@ def test_score_caches_and_result_table_follow_the_reference(tmp_path, monkeypatc
     out2 = adu.univariate_anomaly_detection(fx["ball_recons"], fx["ball_real"], P, "mult", critic, hp, None, signal="sigA", signal_shape=100)
     want = 3.0 * adu.hyperbolic_rec_scores(fx["ball_recons"], fx["ball_real"], 100).cpu().numpy().astype(np.float64)
     assert np.allclose(out2["final_scores"], want, rtol=1e-12) and not np.allclose(out["final_scores"], want, rtol=1e-3)
+
+
+def _quantile_cases():
+    rng = np.random.default_rng(11)
+    yield "normal", rng.standard_normal(125_099)
+    yield "fp32 origin", rng.standard_normal(50_001).astype(np.float32).astype(np.float64)
+    yield "narrow band", 0.3 + 1e-9 * rng.standard_normal(70_000)
+    yield "heavy ties", rng.integers(0, 4, 40_000).astype(np.float64)
+    yield "all equal", np.full(9_999, -2.5)
+    yield "signed zeros", np.concatenate([np.zeros(500), -np.zeros(500), rng.standard_normal(31) * 1e-300])
+    yield "infinities", np.concatenate([rng.standard_normal(1000), [np.inf] * 400, [-np.inf] * 700])
+    yield "wide exponents", rng.standard_normal(30_000) * 10.0 ** rng.integers(-200, 200, 30_000)
+    yield "subnormals", rng.standard_normal(3_000) * 5e-324 * 1000
+    yield "million", rng.standard_normal(1_000_003)
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 2047, 2049):
+        yield "n=%d" % n, rng.standard_normal(n)
+
+
+def test_device_quantiles_equal_numpy():
+    """hypad_quantiles (radix selection on the fp64 keys + numpy's interpolation) against np.quantile: equal bit for bit --
+    the quantiles of _compute_critic_score (utils/anomaly_detection_utils.py:319-320) and arbitrary ones."""
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    for name, x in _quantile_cases():
+        for q in ((0.25, 0.75), (0.0, 1.0), (0.5,), (0.1, 0.9), (1.0 / 3.0, 0.999), (0.75, 0.25)):
+            got = adu.quantiles(torch.from_numpy(x).cuda(), q).cpu().numpy()
+            ref = np.quantile(x, q)
+            assert np.array_equal(got, ref, equal_nan=True), (name, q, got, ref)
+    x = np.random.default_rng(5).standard_normal(10_000)
+    x[1234] = np.nan
+    assert np.all(np.isnan(adu.quantiles(x, (0.25, 0.75)).cpu().numpy()))            # numpy: any NaN -> NaN
+
+
+def test_critic_score_with_device_quantiles_has_the_bits_of_the_host_quantile_form():
+    """hypad_critic_score (quantiles taken on the device, read from device memory by the statistics launch) against
+    hypad_critic_zscore fed with np.quantile's values: the same bits; and against the NumPy restatement."""
+    from hypad_amd import _C
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    from oracle import scoring as osc
+    rng = np.random.default_rng(8)
+    for n in (5, 1_000, 125_099):
+        modes = rng.standard_normal(n).astype(np.float32).astype(np.float64)
+        c = torch.from_numpy(modes).cuda()
+        w = max(2, n // 100)
+        got = adu._compute_critic_score(c, w).cpu().numpy()
+        lo, hi = np.quantile(modes, 0.25), np.quantile(modes, 0.75)
+        out = torch.empty_like(c)
+        ws = torch.empty(_C.STATS_WORKSPACE_BYTES, dtype=torch.uint8, device="cuda")
+        _C.check(_C.lib.hypad_critic_zscore(_C.ptr(c), float(lo), float(hi), _C.ptr(out), n, ws.data_ptr(), _C.STATS_WORKSPACE_BYTES, _C.stream()), "critic_zscore")
+        want = adu.rolling_mean(out, w).cpu().numpy()
+        assert np.array_equal(got, want, equal_nan=True), n
+        ref = osc.compute_critic_score(modes, w)
+        assert np.allclose(got, ref, rtol=0, atol=1e-9, equal_nan=True), n
