@@ -155,6 +155,7 @@ _SIGS = {
     "hypad_radam_step": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, P]),
     "hypad_unroll_median": (c_int, [P, P, P, c_int64, c_int, P]),
     "hypad_unroll_true": (c_int, [P, P, c_int64, c_int, P]),
+    "hypad_unroll_true_f32": (c_int, [P, c_int64, P, c_int64, c_int, P]),
     "hypad_point_error": (c_int, [P, P, P, c_int64, P]),
     "hypad_area_error": (c_int, [P, P, P, c_int64, c_int, P]),
     "hypad_dtw_error": (c_int, [P, P, P, c_int64, c_int, P]),

@@ -274,10 +274,11 @@ __global__ __launch_bounds__(UT * 4) __attribute__((amdgpu_waves_per_eu(HYPAD_UN
   }
 }
 
-__global__ __launch_bounds__(THREADS) void unroll_true_kernel(const double* __restrict__ y, double* __restrict__ out, int64_t n, int W) {
+template <class TIn>
+__global__ __launch_bounds__(THREADS) void unroll_true_kernel(const TIn* __restrict__ y, int64_t ld, double* __restrict__ out, int64_t n, int W) {
   const int64_t T = n + W - 1;
   for (int64_t t = (int64_t)blockIdx.x * THREADS + threadIdx.x; t < T; t += (int64_t)gridDim.x * THREADS)
-    out[t] = t < n ? y[t * W] : y[(n - 1) * W + (t - n + 1)];
+    out[t] = (double)(t < n ? y[t * ld] : y[(n - 1) * ld + (t - n + 1)]);
 }
 
 __global__ __launch_bounds__(THREADS) void point_error_kernel(const double* __restrict__ y, const float* __restrict__ yh,
@@ -492,7 +493,10 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restr
 #define HYPAD_KDE_CB 2
 #endif
 #ifndef HYPAD_KDE_EXP
-#define HYPAD_KDE_EXP 0        // development what-ifs: 1 skips the fp32 screen's pair loop, 2 the fp64 pass (wrong results, timing only)
+#define HYPAD_KDE_EXP 0        // development what-ifs: 1 skips the fp32 screen's pair loop (and leaves one candidate), 2 the fp64 pass (wrong results, timing only)
+#endif
+#ifndef HYPAD_KDE_FACTORED
+#define HYPAD_KDE_FACTORED 1
 #endif
 #ifndef HYPAD_KDE_WPE
 #define HYPAD_KDE_WPE 5
@@ -505,17 +509,22 @@ constexpr int KDE_CB = HYPAD_KDE_CB;         // candidates per pass-2 batch.  It
 // was 97 % of the kernel, 1.7 ms for 125 000 windows); pass 2 re-evaluates in fp64, exactly as before, only the samples whose
 // fp32 density lies within 4e-5 of the fp32 maximum -- a superset of the true arg-max set (the fp32 density's relative error is
 // below 7.1e-6: the budget is written out at the threshold below) -- with the same first-maximum tie rule.  Clustered samples (many near-equal densities) simply put more candidates into pass 2.
+// KPL: sample slots of 64 per lane = ceil(window / 64), a template parameter: the fp32 pass keeps four partial sums per slot.
+template <int KPL>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_KDE_WPE, HYPAD_KDE_WPE))) void kde_mode_kernel(const float* __restrict__ critic, double* __restrict__ modes,
                                                             int64_t n, int W) {
-  __shared__ double vals[THREADS / 64][MAX_WINDOW];
-  __shared__ __attribute__((aligned(16))) float vals32[THREADS / 64][MAX_WINDOW + 4];
-  __shared__ double terms[THREADS / 64][KDE_CB * MAX_WINDOW];
+  constexpr int WMAX = 64 * KPL;                            // the window class: 9 KB of LDS per workgroup and slot, 18 KB at window 100
+  __shared__ double vals[THREADS / 64][WMAX];
+  __shared__ __attribute__((aligned(16))) float vals32[THREADS / 64][WMAX + 4];      // + the padding the fp32 pass reads past the end
+  __shared__ __attribute__((aligned(16))) float nsq32[THREADS / 64][WMAX + 4];       // -(value^2) for the factored form of the fp32 pass
+  __shared__ double terms[THREADS / 64][KDE_CB * WMAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t T = n + W - 1;
   double* v = vals[wave];
   float* vf = vals32[wave];
-  constexpr int KPL = MAX_WINDOW / 64;                     // samples per lane
+  float* nf = nsq32[wave];
   const double scottW = pow((double)W, -0.4);
+  const double rW1 = W > 1 ? 1.0 / (double)(W - 1) : 0.0;
   for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
     const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
     const int j1 = (int)(t + 1 < W ? t + 1 : W);
@@ -532,29 +541,46 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
     const double mean = wave_sum(s) / (double)cnt;
     double q = 0.0;
     for (int k = lane; k < cnt; k += 64) { const double d = v[k] - mean; q += d * d; }
-    const double var = cnt > 1 ? wave_sum(q) / (double)(cnt - 1) : 0.0;          // np.cov: ddof = 1
+    const double var = cnt > 1 ? wave_sum(q) * (cnt == W ? rW1 : 1.0 / (double)(cnt - 1)) : 0.0;      // np.cov: ddof = 1, `c *= 1 / fact`
     // Scott: factor = n^(-1/5), squared.  (All but the 2 (W - 1) edge timesteps have cnt == W: that power is taken once per
     // thread, not once per timestep -- a double-precision pow is ~200 instructions.)
     const double cov = var * (cnt == W ? scottW : pow((double)cnt, -0.4));
     double out;
     if (cnt > 1 && cov > 0.0 && cov == cov) {
-      const double inv = 0.5 / cov;
       // pass 1: fp32 densities of this lane's samples.  exp(-d^2 inv) = exp2(-(c d)^2) with c = sqrt(inv log2 e): the samples are
       // centred and rescaled once (pass 2 reads the fp64 copies), so a pair costs a subtract, a multiply, an exp2 and an add; the
       // slab is padded with +inf to a multiple of four (a padded pair contributes exp2(-inf) = 0) and read four values at a
       // time, every value once for all of the lane's samples.
       // The samples are CENTRED first, in fp64 (densities depend on differences only): rescaling the raw values would leave the
       // fp32 copies with an absolute error of |value| 2^-24 c, which at |mean| / bandwidth beyond ~1e4 exceeds the screen's margin.
-      const double c64 = sqrt(inv * 1.44269504088896341);
-      for (int k = lane; k < cnt; k += 64) vf[k] = (float)((v[k] - mean) * c64);
+      // The scale itself only has to be good to fp32 (an error in it is a slightly different bandwidth for every sample alike: 2e-7
+      // relative in the densities): one v_rsq_f32 instead of an fp64 division and square root per timestep; the fp64 1 / (2 cov) that
+      // pass 2 uses is taken only when pass 2 runs.  (A covariance outside the fp32 range makes the screen all-NaN or all-equal: pass 2
+      // then sees every sample, as before.)
+      const double c64 = (double)__builtin_amdgcn_rsqf((float)cov * 1.3862943611198906f);     // sqrt(log2 e / (2 cov))
+      float amax = 0.f;
+      for (int k = lane; k < cnt; k += 64) {
+        const float y = (float)((v[k] - mean) * c64);
+        vf[k] = y; nf[k] = -(y * y);
+        amax = fmaxf(amax, fabsf(y));
+      }
+      amax = wave_max(amax);
       // (Measured and dropped in round 3, twice: using the kernel matrix's symmetry -- each unordered pair evaluated once.  With the
       // partner's share delivered by ds_add_f32: 3.28 ms against 0.42 ms for 125 000 windows (LDS float atomics).  With the values
       // parked in a small LDS matrix in chunks of eight steps and collected by the partners after a wave barrier (no atomics,
       // conflict-free strides, immediate offsets): 0.69 ms -- three per-lane LDS operations per pair cost more issue time than the
       // quarter-rate exponential they save; the broadcast form below reads each value once for all 64 lanes.)
-      if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) vf[cnt + lane] = __int_as_float(0x7f800000);
+      const bool factored = amax <= 8.f;                   // (wave-uniform; NaN -> the direct form)
+      if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {      // padding to a multiple of four: a pair that contributes exp2(-inf) = 0 in either form
+        vf[cnt + lane] = factored && HYPAD_KDE_FACTORED ? 0.f : __int_as_float(0x7f800000);
+        nf[cnt + lane] = __int_as_float(0xff800000);
+      }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);
+      // (Measured and dropped in round 3: giving the cnt % 64 samples of the last slot 64 / b lanes each -- groups of b = 32, 16, ..
+      // samples by the binary digits of the remainder, each lane a share of the values, shares added by xor shuffles: 25 + 13 + 2 steps
+      // of four values per lane at window 100 instead of 25 + 25, 20 % fewer exponentials by counter, and no faster: 0.292 against
+      // 0.287 ms.  Per-lane LDS addresses and the shuffles cost what the idle lanes did.)
       float d32[KPL], xs[KPL];
       float acc[KPL][4];                                   // one accumulator per position in the group of four: <= ceil(cnt / 4) terms each
 #pragma unroll
@@ -565,18 +591,42 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
         for (int c = 0; c < 4; ++c) acc[u][c] = 0.f;
       }
       const int nu = (cnt + 63) >> 6;                                             // sample slots in use (wave-uniform)
-      for (int m = 0; m < cnt; m += 4) {
-        const float4 q4 = *reinterpret_cast<const float4*>(vf + m);
-        const float vm[4] = {q4.x, q4.y, q4.z, q4.w};
+      if (factored && HYPAD_KDE_FACTORED) {
+        // exp2(-(x - v)^2) = exp2(-x^2) exp2(2 x v - v^2): the pair costs a fused multiply-add (2 x in a register, v and -v^2 from
+        // LDS), an exp2 and an add -- three issue slots instead of four -- and exp2(-x^2) multiplies the finished sum once.
+        // |x|, |v| <= 8 keeps 2 x v - v^2 <= x^2 <= 64 inside the fp32 exponent range and its rounding (the product's and
+        // -v^2's: 2^-24 x 64 each at the very worst) inside the budget written out at the threshold below.
+        float x2[KPL];
 #pragma unroll
-        for (int u = 0; u < KPL; ++u) {
-          if (u >= nu) continue;
+        for (int u = 0; u < KPL; ++u) x2[u] = 2.f * xs[u];
+        for (int m = 0; m < (HYPAD_KDE_EXP == 1 ? 0 : cnt); m += 4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(vf + m);
+          const float4 n4 = *reinterpret_cast<const float4*>(nf + m);
+          const float vm[4] = {q4.x, q4.y, q4.z, q4.w}, nm[4] = {n4.x, n4.y, n4.z, n4.w};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { const float d = xs[u] - vm[c]; acc[u][c] += __builtin_amdgcn_exp2f(-(d * d)); }
+          for (int u = 0; u < KPL; ++u) {
+            if (u >= nu) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[u][c] += __builtin_amdgcn_exp2f(__builtin_fmaf(x2[u], vm[c], nm[c]));
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < KPL; ++u) d32[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+        for (int u = 0; u < KPL; ++u) d32[u] = ((acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3])) * __builtin_amdgcn_exp2f(-(xs[u] * xs[u]));
+      } else {
+        for (int m = 0; m < (HYPAD_KDE_EXP == 1 ? 0 : cnt); m += 4) {
+          const float4 q4 = *reinterpret_cast<const float4*>(vf + m);
+          const float vm[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+          for (int u = 0; u < KPL; ++u) {
+            if (u >= nu) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const float d = xs[u] - vm[c]; acc[u][c] += __builtin_amdgcn_exp2f(-(d * d)); }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < KPL; ++u) d32[u] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+      }
+      if (HYPAD_KDE_EXP == 1) d32[0] = lane == 0 ? 1.f : 0.f;
       float mx = -1.f;
 #pragma unroll
       for (int u = 0; u < KPL; ++u) {
@@ -585,7 +635,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
-      // Relative error of an fp32 density D~ against the exact D, all terms positive:
+      // Relative error of an fp32 density D~ against the exact D, all terms positive.  Direct form, exp2(-(x - v)^2):
       //  * arguments: a centred, rescaled sample y carries 2^-24 |y| <= 1e-6 (|y| < 32 for every pair that contributes: two of <= 256
       //    samples within a few units of each other lie at most 2.6 sqrt(255 / 2) = 29 units from the mean; a lone outlier beyond that
       //    sees only its own term, exactly 1), a difference d twice that, d^2 an absolute 2 |d| 2e-6 (+ 2^-24 d^2 from the product);
@@ -594,9 +644,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
       //  * v_exp_f32: 1 ulp = 1.2e-7;
       //  * accumulation: four partial sums of <= 64 terms, each add 2^-24 of a partial sum that never exceeds the result: 3.8e-6, + 1.2e-7
       //    for the two combining adds
-      // -> eps <= 7.1e-6 at window 256 (4.8e-6 at 100).  If k* is the true arg-max, D~[k*] >= (1 - eps) D[k*] >= (1 - eps) D[j] >=
-      // (1 - eps) / (1 + eps) D~[j] for every j: the screen keeps k* as long as its margin exceeds 2 eps = 1.5e-5.  Margin 4e-5
-      // (rounds 2-3 used 2e-4 with one accumulator per sample: 1.7 fp64 evaluations per timestep on random-normal values, 0.6 now).
+      // -> eps <= 7.1e-6 at window 256 (4.8e-6 at 100).  Factored form (all |y| <= 8), exp2(-x^2) exp2(2 x v - v^2):
+      //  * the samples' own rounding (|y| <= 8: 2^-24 x 8): 0.7e-6 by the same weighting;
+      //  * the argument 2 x v - v^2 (|.| <= 64): -v^2 rounded once, the fused multiply-add once, 2^-24 x 64 = 3.8e-6 absolute together
+      //    at the very worst -> ln 2 x 3.8e-6 = 2.6e-6;  exp2(-x^2): x^2 rounded (1.9e-6 absolute -> 1.3e-6) + 1 ulp;
+      //  * v_exp_f32 1.2e-7, accumulation 3.9e-6 as above, the closing product 6e-8
+      // -> eps <= 8.8e-6.  If k* is the true arg-max, D~[k*] >= (1 - eps) D[k*] >= (1 - eps) D[j] >= (1 - eps) / (1 + eps) D~[j] for
+      // every j: the screen keeps k* as long as its margin exceeds 2 eps = 1.8e-5.  Margin 4e-5 (rounds 2-3 used 2e-4 with one
+      // accumulator per sample: 1.7 fp64 evaluations per timestep on random-normal values, 0.6 now).
       const float thr = mx * (1.f - 4e-5f);
       // pass 2: fp64 densities of the candidates, in ascending sample order (the first maximum is kept); of every sample if
       // pass 1 produced no candidate (a bandwidth so small that its reciprocal leaves the fp32 range makes the screen NaN).
@@ -618,6 +673,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
         }
         if (ncand == 1) besti = first;
       }
+      double inv = 0.0;
+      if (__builtin_amdgcn_readfirstlane(besti) == 0x7fffffff) inv = 0.5 / cov;          // (only the fp64 pass needs it)
       for (int round = 0; round < (HYPAD_KDE_EXP == 2 ? 0 : 2) && besti == 0x7fffffff; ++round) {
 #pragma unroll
         for (int u = 0; u < KPL; ++u) {
@@ -635,14 +692,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
             for (int c = 0; c < KDE_CB; ++c) {
               if (kc[c] < 0) continue;
               const double xk = v[kc[c]];
-              for (int m = lane; m < cnt; m += 64) { const double d = xk - v[m]; tm[c * MAX_WINDOW + m] = exp(-d * d * inv); }
+              for (int m = lane; m < cnt; m += 64) { const double d = xk - v[m]; tm[c * WMAX + m] = exp(-d * d * inv); }
             }
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0xc07f);
             double dens = -1.0;
             if (lane < nb) {
               dens = 0.0;
-              const double* tp = tm + lane * MAX_WINDOW;
+              const double* tp = tm + lane * WMAX;
               int m = 0;
               for (; m + 8 <= cnt; m += 8) {                 // (the terms of eight steps requested together; added in index order)
                 double t8[8];
@@ -720,11 +777,16 @@ __device__ __forceinline__ double qs_value(unsigned long long k) {
   const unsigned long long b = k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull);
   return __longlong_as_double((long long)b);
 }
-// Wave `sel` of the block: which bin of hist[level][sel] holds rank st.rank?  Every lane returns the new state.
-__device__ __forceinline__ QsState qs_descend(const unsigned int* __restrict__ hist, int level, const QsState st) {
+// Wave `sel` of the block: which bin of hist[level][sel] holds rank st.rank?  The histogram row is first copied to LDS (`stage`,
+// >= qs_bins(level) words, private to the wave) with lane-consecutive loads that leave together -- walking it in global memory
+// cost one dependent L2 round trip per bin.  Every lane returns the new state.
+__device__ __forceinline__ QsState qs_descend(const unsigned int* __restrict__ hist, int level, const QsState st, unsigned int* stage) {
   const int lane = threadIdx.x & 63, bins = qs_bins(level), per = bins / 64;       // 32 (or 8) consecutive bins per lane
+  for (int i = lane; i < bins; i += 64) stage[i] = hist[i];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   unsigned long long mine = 0;
-  for (int i = 0; i < per; ++i) mine += hist[lane * per + i];
+  for (int i = 0; i < per; ++i) mine += stage[lane * per + i];
   unsigned long long incl = mine;                                                   // inclusive wave scan
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(incl, off, WAVE); if (lane >= off) incl += o; }
@@ -733,7 +795,7 @@ __device__ __forceinline__ QsState qs_descend(const unsigned int* __restrict__ h
   int bin = 0; unsigned long long cum = 0;
   if (here) {
     cum = before;
-    for (int i = 0; i < per; ++i) { const unsigned int c = hist[lane * per + i]; if (r < cum + c) { bin = lane * per + i; break; } cum += c; }
+    for (int i = 0; i < per; ++i) { const unsigned int c = stage[lane * per + i]; if (r < cum + c) { bin = lane * per + i; break; } cum += c; }
   }
   const unsigned long long mask = __ballot(here);
   const int src = mask ? __builtin_ctzll(mask) : 0;
@@ -746,29 +808,41 @@ __global__ __launch_bounds__(256) void qs_level_kernel(const double* __restrict_
   __shared__ unsigned int h[QS_SEL][QS_BINS];
   __shared__ QsState cur[QS_SEL];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // The kernel is a chain of dependent memory round trips (previous state -> previous histogram -> data -> histogram update), about a
+  // microsecond each; the first round's values do not depend on the scan, so they are requested before it.
+  constexpr int PER = 4;                                  // values per thread and round: requested together, then filed
+  double x[PER];
+  int64_t base = (int64_t)blockIdx.x * (256 * PER);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { const int64_t i = base + u * 256 + threadIdx.x; x[u] = i < n ? in[i] : 0.0; }
   if (wave < nsel) {
     QsState st;
     if (level == 0) { st.prefix = 0; st.rank = wave == 0 ? r0 : wave == 1 ? r1 : wave == 2 ? r2 : r3; }
-    else st = qs_descend(ws.hist + ((size_t)(level - 1) * QS_SEL + wave) * QS_BINS, level - 1, ws.state[(level - 1) * QS_SEL + wave]);
+    else st = qs_descend(ws.hist + ((size_t)(level - 1) * QS_SEL + wave) * QS_BINS, level - 1, ws.state[(level - 1) * QS_SEL + wave], h[wave]);
     if (lane == 0) { cur[wave] = st; if (blockIdx.x == 0) ws.state[level * QS_SEL + wave] = st; }
   }
+  __syncthreads();                                                                  // (h doubled as the scan's staging rows)
   for (int i = threadIdx.x; i < QS_SEL * QS_BINS; i += 256) (&h[0][0])[i] = 0u;
   __syncthreads();
   const int sh = qs_shift(level), bins = qs_bins(level);
   const int hi_sh = sh + (level == QS_LEVELS - 1 ? 64 - QS_BITS * (QS_LEVELS - 1) : QS_BITS);     // bits above the digit
   unsigned long long pre[QS_SEL];
   for (int s2 = 0; s2 < QS_SEL; ++s2) pre[s2] = s2 < nsel ? cur[s2].prefix : 0;
-  const int64_t len = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t b = (int64_t)blockIdx.x * len, e = b + len < n ? b + len : n;
   unsigned int nans = 0;
-  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
-    const double x = in[i];
-    if (level == 0 && x != x) ++nans;
-    const unsigned long long k = qs_key(x);
-    const unsigned int digit = (unsigned int)(k >> sh) & (unsigned int)(bins - 1);
+  for (; base < n; base += (int64_t)gridDim.x * (256 * PER)) {
 #pragma unroll
-    for (int s2 = 0; s2 < QS_SEL; ++s2)
-      if (s2 < nsel && (hi_sh >= 64 || ((k ^ pre[s2]) >> hi_sh) == 0)) atomicAdd(&h[s2][digit], 1u);
+    for (int u = 0; u < PER; ++u) {
+      if (base + u * 256 + threadIdx.x >= n) continue;
+      if (level == 0 && x[u] != x[u]) ++nans;
+      const unsigned long long k = qs_key(x[u]);
+      const unsigned int digit = (unsigned int)(k >> sh) & (unsigned int)(bins - 1);
+#pragma unroll
+      for (int s2 = 0; s2 < QS_SEL; ++s2)
+        if (s2 < nsel && (hi_sh >= 64 || ((k ^ pre[s2]) >> hi_sh) == 0)) atomicAdd(&h[s2][digit], 1u);
+    }
+    const int64_t nb = base + (int64_t)gridDim.x * (256 * PER);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int64_t i = nb + u * 256 + threadIdx.x; x[u] = i < n ? in[i] : 0.0; }
   }
   if (level == 0 && nans) atomicAdd(ws.nan_count, nans);
   __syncthreads();
@@ -788,9 +862,10 @@ __device__ __forceinline__ double np_lerp64(double a, double b, double t) {     
 // one workgroup: the last digits, then out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
 __global__ __launch_bounds__(256) void qs_final_kernel(QsWs ws, int nsel, double t0, double t1, double* __restrict__ out) {
   __shared__ unsigned long long keys[QS_SEL];
+  __shared__ unsigned int stage[QS_SEL][QS_BINS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < nsel) {
-    const QsState st = qs_descend(ws.hist + ((size_t)(QS_LEVELS - 1) * QS_SEL + wave) * QS_BINS, QS_LEVELS - 1, ws.state[(QS_LEVELS - 1) * QS_SEL + wave]);
+    const QsState st = qs_descend(ws.hist + ((size_t)(QS_LEVELS - 1) * QS_SEL + wave) * QS_BINS, QS_LEVELS - 1, ws.state[(QS_LEVELS - 1) * QS_SEL + wave], stage[wave]);
     if (lane == 0) keys[wave] = st.prefix;
   }
   __syncthreads();
@@ -825,8 +900,8 @@ int launch_quantiles(const double* in, int64_t n, const double* q, int nq, doubl
   double t[2] = {0.0, 0.0};
   for (int j = 0; j < nq; ++j) qs_position(n, q[j], &r[2 * j], &r[2 * j + 1], &t[j]);
   const int nsel = 2 * nq;
-  int64_t g = (n + 2047) / 2048;
-  g = g < 1 ? 1 : (g > 256 ? 256 : g);
+  int64_t g = (n + 1023) / 1024;
+  g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
   for (int level = 0; level < QS_LEVELS; ++level) {
     hipLaunchKernelGGL(qs_level_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, level, nsel, r[0], r[1], r[2], r[3]);
     HYPAD_CHECK_LAUNCH();
@@ -904,7 +979,13 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
 }
 int hypad_unroll_true(const double* y, double* out, int64_t n, int window, hypad_stream_t s) {
   if (!y || !out || n <= 0 || window <= 0) return HYPAD_EINVAL;
-  hipLaunchKernelGGL(unroll_true_kernel, dim3(grid_for(n + window - 1, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, out, n, window);
+  hipLaunchKernelGGL(unroll_true_kernel<double>, dim3(grid_for(n + window - 1, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, (int64_t)window, out, n, window);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+int hypad_unroll_true_f32(const float* y, int64_t row_stride, double* out, int64_t n, int window, hypad_stream_t s) {
+  if (!y || !out || n <= 0 || window <= 0 || row_stride < 1) return HYPAD_EINVAL;
+  hipLaunchKernelGGL(unroll_true_kernel<float>, dim3(grid_for(n + window - 1, THREADS)), dim3(THREADS), 0, (hipStream_t)s, y, row_stride, out, n, window);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
@@ -982,7 +1063,18 @@ int hypad_zscore_clip(const double* in, double* out, int64_t t, void* workspace,
 int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hypad_stream_t s) {
   if (!critic || !modes || n <= 0 || window <= 0) return HYPAD_EINVAL;
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
-  hipLaunchKernelGGL(kde_mode_kernel, dim3(grid_for(n + window - 1, THREADS / 64)), dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window);
+  // (A resident grid -- 256 x HYPAD_KDE_WPE workgroups whose waves stride over ~100 timesteps each -- was measured and dropped: 0.33 ms
+  // against 0.30 ms for 8 192 workgroups of ~4 timesteps per wave at 125 000 windows; HYPAD_KDE_GRID caps the grid for such trials.)
+  static const int kde_grid = getenv("HYPAD_KDE_GRID") ? atoi(getenv("HYPAD_KDE_GRID")) : 8192;
+  int gw = grid_for(n + window - 1, THREADS / 64);
+  if (gw > kde_grid) gw = kde_grid;
+  const dim3 grid(gw);
+  switch ((window + 63) / 64) {
+    case 1: hipLaunchKernelGGL(kde_mode_kernel<1>, grid, dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window); break;
+    case 2: hipLaunchKernelGGL(kde_mode_kernel<2>, grid, dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window); break;
+    case 3: hipLaunchKernelGGL(kde_mode_kernel<3>, grid, dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window); break;
+    default: hipLaunchKernelGGL(kde_mode_kernel<4>, grid, dim3(THREADS), 0, (hipStream_t)s, critic, modes, n, window); break;
+  }
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

@@ -374,6 +374,9 @@ int hypad_radam_step(float* params, const float* grads, float* exp_avg, float* e
 int hypad_unroll_median(const float* y_hat, float* median, double* summary, int64_t n, int window, hypad_stream_t stream);
 /* :908-910 -- true[t] = y[t][0] (t < n), y[n-1][t-n+1] otherwise; y (n, S) fp64 */
 int hypad_unroll_true(const double* y, double* out, int64_t n, int window, hypad_stream_t stream);
+/* the same from the fp32 window matrix the forward reads (row n at y + n * row_stride: row_stride = S for a matrix, 1 for the
+ * scaled series itself) -- no fp64 copy of the (n, S) matrix for the sake of n + S - 1 of its values */
+int hypad_unroll_true_f32(const float* y, int64_t row_stride, double* out, int64_t n, int window, hypad_stream_t stream);
 /* _point_wise_error :761-777 */
 int hypad_point_error(const double* y, const float* y_hat, double* out, int64_t t, hypad_stream_t stream);
 /* _area_error :780-812 (centred rolling trapezoid, window score_window, min_periods score_window/2) */

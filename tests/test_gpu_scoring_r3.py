@@ -165,3 +165,19 @@ def test_critic_score_with_device_quantiles_has_the_bits_of_the_host_quantile_fo
         assert np.array_equal(got, want, equal_nan=True), n
         ref = osc.compute_critic_score(modes, w)
         assert np.allclose(got, ref, rtol=0, atol=1e-9, equal_nan=True), n
+
+
+def test_unroll_true_from_the_fp32_matrix():
+    """hypad_unroll_true_f32 (first column + last row straight from the fp32 window matrix) == the fp64 form."""
+    from hypad_amd import _C
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    rng = np.random.default_rng(2)
+    for n, w in ((1, 100), (7, 3), (5_000, 100), (130, 256)):
+        y = rng.standard_normal((n, w)).astype(np.float32)
+        got = adu.unroll_true(torch.from_numpy(y).cuda()).cpu().numpy()            # fp32 device tensor: the new entry point
+        want = adu.unroll_true(y.astype(np.float64)).cpu().numpy()                  # fp64 path
+        assert np.array_equal(got, want) and np.array_equal(got, np.concatenate([y[:, 0], y[-1, 1:]]).astype(np.float64)), (n, w)
+    series = torch.from_numpy(rng.standard_normal(1_099).astype(np.float32)).cuda()  # row_stride 1: windows of a series
+    out = torch.empty(1_099, dtype=torch.float64, device="cuda")
+    _C.check(_C.lib.hypad_unroll_true_f32(_C.ptr(series), 1, _C.ptr(out), 1_000, 100, _C.stream()), "unroll_true_f32")
+    assert torch.equal(out, series.double())
