@@ -157,19 +157,23 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20):
     out = {"workload": "configs[2] per-GPU share: %d signals (%d models) per GPU, otherwise as configs[1]" % (spg, spg),
            "signals_per_gpu": spg, "steps": steps, "warmup": warmup, "unit": "windows/s (this GPU)",
            "critic_phase_persistent": eng.critic_phase_persistent()}
-    for mode in ("graph", "eager"):
-        step, losses = make_step(eng, x, spg, gen, device, graph=mode == "graph")
-        for _ in range(warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        eng.check_status()
-        assert bool(torch.isfinite(losses).all())
-        out[mode + "_ms_per_step"] = 1e3 * dt
+    runs = {"graph": [], "eager": []}
+    fns = {mode: make_step(eng, x, spg, gen, device, graph=mode == "graph") for mode in runs}
+    for _ in range(2):                                # the two launch modes alternately, twice: every run is reported, the faster one counts
+        for mode, (step, losses) in fns.items():      # (a replay measured right after other GPU processes once came out 15 % slower than the
+            for _ in range(warmup):                   # eager launches of the same epoch next to it; it does not reproduce in isolation)
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            runs[mode].append(1e3 * (time.perf_counter() - t0) / steps)
+            eng.check_status()
+            assert bool(torch.isfinite(losses).all())
+    for mode, v in runs.items():
+        out[mode + "_ms_per_step"] = min(v)
+        out[mode + "_ms_per_step_runs"] = v
     out["launch"] = "hipGraph replay of the captured epoch"
     out["ms_per_step"] = out["graph_ms_per_step"]
     out["value"] = spg * N_BATCHES * B / (1e-3 * out["ms_per_step"])

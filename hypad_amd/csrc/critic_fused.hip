@@ -235,10 +235,13 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
 // One (iteration, critic, signal, 16-row tile) of the critic phase's critic-independent work -> its record.  FUSED: the workgroup
 // is a producer inside the resident launch -- the record is assembled in LDS, leaves as 16-byte write-through stores, and its
 // flag word follows once every storing wave has drained (cdna_hip_programming.md Guideline 16 R1: the consumer loads it sc1).
-template <bool FUSED>
+// SC / LC: window length and latent width as compile-time constants (0 = read them from the arguments), as for the iteration
+// kernels below: with run-time dimensions the tile functions' loops and index arithmetic cost 9.9 vector instructions per MFMA
+// (SQ counters, profiles/r03_sq_counters.json), with the reference configuration folded in 2.9 (the scorers' forward).
+template <bool FUSED, int SC = 0, int LC = 0>
 __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterArgs& az, const PhaseArgs& ph, float* smem, int tile, int sig, int it,
                                                 int role, int n_signals) {
-  const int S = ax.S, L = ax.L, B = ax.B;
+  const int S = SC ? SC : ax.S, L = LC ? LC : ax.L, B = ax.B;
   const PreLds lp = pre_lds(S);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   const uint32_t tick = (uint32_t)ax.counters[3] + (uint32_t)it;
@@ -325,9 +328,14 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
 #ifndef HYPAD_PRE_WPE
 #define HYPAD_PRE_WPE 4
 #endif
+template <int SC, int LC>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WPE, HYPAD_PRE_WPE))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  precompute_body<false>(ax, az, ph, smem, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, gridDim.y);
+  precompute_body<false, SC, LC>(ax, az, ph, smem, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, gridDim.y);
+}
+typedef void (*PreKernel)(IterArgs, IterArgs, PhaseArgs);
+inline PreKernel precompute_kernel(int S, int L) {
+  return S == 100 && L == 20 ? critic_phase_precompute_kernel<100, 20> : critic_phase_precompute_kernel<0, 0>;
 }
 
 // ---------------------------------------------------------------------------------------------- iteration kernel
@@ -1618,7 +1626,7 @@ __global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, Iter
     const int q = id - crit_ids;
     const int tile = q % nchunks, rest = q / nchunks;
     const int sig = rest % ns, zz = rest / ns;
-    precompute_body<true>(ax, az, ph, smem, tile, sig, zz >> 1, zz & 1, ns);
+    precompute_body<true, SC, LC>(ax, az, ph, smem, tile, sig, zz >> 1, zz & 1, ns);
     return;
   }
   int c, chunk;
@@ -1772,7 +1780,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   az.seed = ax.seed ^ CRITIC_Z_SEED_XOR;
   const size_t lds_pre = (size_t)pre_lds(ax.S).total * sizeof(float);
   if (lds_pre > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)critic_phase_precompute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
+    hipError_t e = hipFuncSetAttribute((const void*)precompute_kernel(ax.S, ax.L), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
     if (e != hipSuccess) return (int)e;
   }
   const int lx = iter_lds(gx).total, lz = iter_lds(gz).total;
@@ -1853,7 +1861,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     const bool fold = persistent && !fused && sync_bytes / 4 <= (size_t)nchunks * n_signals * 2 * n * TB;
     ph.zero_ptr = fold ? ph.flags : nullptr; ph.zero_words = fold ? (int)(sync_bytes / 4) : 0; ph.advance = persistent ? 1 : 0;
     if (!fused) {
-      hipLaunchKernelGGL(critic_phase_precompute_kernel, dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
+      hipLaunchKernelGGL(precompute_kernel(ax.S, ax.L), dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
     }
     if (ev) (void)hipEventRecord(ev[1], s);

@@ -99,8 +99,11 @@ def _all_gather_ranges(local, total, ranges, group=None):
         return local
     world = dist.get_world_size(group)
     width = max(e - b for b, e in ranges)
-    piece = torch.zeros(width, dtype=local.dtype, device=local.device)
-    piece[: local.numel()] = local
+    if local.numel() == width:                                              # (no padding needed: the slice itself is the piece)
+        piece = local.contiguous()
+    else:
+        piece = torch.zeros(width, dtype=local.dtype, device=local.device)
+        piece[: local.numel()] = local
     if dist.get_backend(group) == "nccl":                                   # RCCL: device buffers, one collective
         out = torch.empty(world * width, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, piece, group=group)
@@ -109,7 +112,10 @@ def _all_gather_ranges(local, total, ranges, group=None):
         parts = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(parts, host, group=group)
         out = torch.cat(parts).to(local.device)
-    full = torch.cat([out[r * width: r * width + (e - b)] for r, (b, e) in enumerate(ranges)])
+    if all(b == r * width and (e - b == width or r == world - 1) for r, (b, e) in enumerate(ranges)):
+        full = out[:total]                                                  # equal pieces back to back, only the last one short: already the vector
+    else:
+        full = torch.cat([out[r * width: r * width + (e - b)] for r, (b, e) in enumerate(ranges)])
     assert full.numel() == total
     return full
 

@@ -9,4 +9,5 @@ cp gpurun_out/repeat_suite/summary.txt $O/repeat_suite_summary.txt
 python scripts/bench_multivariate.py > $O/bench_multivariate.log 2>&1; echo "multivariate rc=$?" >> $O/summary.txt
 python bench.py --euclidean --no-cpu-baseline --no-scoring --no-drop-in > $O/bench_euclidean.json 2> $O/bench_euclidean.err; echo "euclidean rc=$?" >> $O/summary.txt
 bash scripts/profile_r03.sh > $O/profile.log 2>&1; echo "profile rc=$?" >> $O/summary.txt
+bash scripts/sq_profile.sh > $O/sq_profile.log 2>&1; echo "sq counters rc=$?" >> $O/summary.txt
 cat $O/summary.txt $O/repeat_suite_summary.txt $O/bench_default.time; tail -n 3 $O/smoke.log; tail -n 4 $O/bench_multivariate.log
