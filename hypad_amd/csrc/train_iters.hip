@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_SCORE_
   decoder_trunk_fwd_tile_packed<1>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
   if (a.eucl) tile_store(a.eucl + r0 * S, S, bufA, ldS, 16, S, valid);
   if (a.hyperbolic) {
-    for (int i = threadIdx.x; i < 16 * ldS; i += TB) bufA[16 * ldS + i] = xs[i];      // rows 16-31: the real windows
+    for (int i = threadIdx.x; i < 16 * ldS; i += blockDim.x) bufA[16 * ldS + i] = xs[i];      // rows 16-31: the real windows
     __syncthreads();
     gemm_nt_packed<2>(bufA, ldS, S, S, a.pk + gp.head, nullptr, bufB, ldS, 0);
     __syncthreads();
@@ -1680,7 +1680,8 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   if (S == 100 && L == 20) {
     hipError_t e = allow_lds((const void*)score_forward_packed_kernel<100, 20>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((score_forward_packed_kernel<100, 20>), dim3((unsigned)tiles), dim3(TB), lds, (hipStream_t)s, a);
+    static const int score_threads = getenv("HYPAD_SCORE_THREADS") ? atoi(getenv("HYPAD_SCORE_THREADS")) : TB;      // (development switch)
+    hipLaunchKernelGGL((score_forward_packed_kernel<100, 20>), dim3((unsigned)tiles), dim3(score_threads), lds, (hipStream_t)s, a);
   } else {
     hipError_t e = allow_lds((const void*)score_forward_packed_kernel<0, 0>, lds);
     if (e != hipSuccess) return (int)e;
