@@ -20,7 +20,7 @@ class HypadError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
+ABI_VERSION = 4            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
 
 
 def _load():
@@ -80,7 +80,8 @@ class EpochNoise(Structure):
 class EpochIO(Structure):
     _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
-                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int),
+                ("aux_streams", POINTER(c_void_p)), ("n_aux_streams", c_int)]      # ABI 4: streams for the generator phase's model groups
 
 
 STATS_WORKSPACE_BYTES = 256 * 5 * 8  # HYPAD_STATS_WORKSPACE_BYTES

@@ -57,7 +57,7 @@ HD GenWs gen_ws(int B, int S, int L) {
   w.dzenc = o; o += pad4(2 * B * L);
   w.dgenc = o; o += pad4(2 * B * 6 * ENC_H);
   w.partial = o; o += pad4((B / 16) * 4);
-  w.adamc = o; o += 4;                              // Adam bias corrections of this step {1 - b1^t, 1 - b2^t, sqrt(1 - b2^t)} (signal 0's workspace)
+  w.adamc = o; o += 4;                              // Adam bias corrections of this step {1 - b1^t, 1 - b2^t, sqrt(1 - b2^t)} (the launch's first model's workspace)
   w.total = o;
   return w;
 }
@@ -91,6 +91,11 @@ struct IterArgs {
   float lr, b1, b2, eps, wd; int stabilize; int riemannian;
   int opt;                         // counters index of the optimizer stepped by this iteration
   int tick_owner;                  // 1: this iteration's dW kernel advances the rng tick (one owner per launch group)
+  int sig0;                        // first model of this launch (blockIdx.y + sig0 = the model's index): the generator phase of an epoch may run
+                                   // the models in groups, one chain of launches per group on a stream of its own (hypad_epoch_io.aux_streams)
+  int step_add;                    // < 0: the launch reads the step / rng tick counters and advances them (one launch group at a time on one
+                                   // stream); >= 0: it belongs to generator iteration `step_add` of an epoch -- step = counters[opt] + step_add + 1,
+                                   // tick = counters[3] + step_add, nothing is advanced (one closing launch adds the epoch's iterations)
   int guard;                       // 1 (hypad_train_epoch): a launch is a no-op while counters[4] -- the resident critic launch's
                                    // status word -- is non-zero (fail-stop, see hypad_epoch_status in hypad.h)
   long long* stamps;               // development aid: shader-clock stamps [role][48 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null

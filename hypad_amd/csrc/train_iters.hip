@@ -289,7 +289,7 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 template <int SC, int LC, int BC, bool WSC1 = false>
 __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = blockIdx.y, tile = blockIdx.x >> 3;
+  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3;
   const GenLds lp = gen_lds(S, L, a.hyperbolic, 2);
   const int ldS = lp.ldS;
   const GenWs gw = gen_ws(B, S, L);
@@ -299,7 +299,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
   float* dzc = smem + lp.small;             // [16][LP] gradient of -mean(critic_z) w.r.t. the encoder output
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
-  const uint32_t tick = (uint32_t)a.counters[3];
+  const uint32_t tick = (uint32_t)a.counters[3] + (uint32_t)(a.step_add > 0 ? a.step_add : 0);
   const int g0 = tile * 16;
   const float* mbase = a.masks ? a.masks + sig * a.mask_sig_stride : nullptr;
   const CriticLayout clz = cz_layout(L);
@@ -329,13 +329,13 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   }
   float* part_out = ws + gw.partial + tile * 4;
   if (threadIdx.x == 0) part_out[2] = sum_crit;
-  if (tile == 0 && sig == 0 && threadIdx.x == 0) {
+  if (tile == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     // optimizer step number and its bias corrections (double-precision powers): once per launch, for the dW + Adam launch --
-    // here, on the chain with slack
-    const int step = a.counters[a.opt] + 1;
-    a.counters[a.opt] = step;
+    // here, on the chain with slack; they go to the workspace of the launch's first model (IterArgs.sig0)
+    const int step = a.counters[a.opt] + 1 + (a.step_add > 0 ? a.step_add : 0);
+    if (a.step_add < 0) a.counters[a.opt] = step;
     const AdamCoef c0 = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, step);
-    float* ac = a.ws + gw.adamc;
+    float* ac = a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gw.adamc;
     ac[0] = c0.bc1; ac[1] = c0.bc2; ac[2] = c0.sqrt_bc2;
   }
 }
@@ -346,7 +346,7 @@ static_assert(TB == 512, "gen_body deals rows over 8 waves");
 template <bool HYPER, int SC, int LC, int BC, bool WSC1 = false>
 __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = blockIdx.y, tile = blockIdx.x >> 3, role = blockIdx.z;
+  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3, role = blockIdx.z;
   __builtin_amdgcn_s_setprio(2);            // (tile_gemm.h mfma_prio_*: the MFMA loops run below everything else)
   if (role == 2) { gen_role_z<SC, LC, BC, WSC1>(a, smem); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* red = small + 3 * 16 * LP;
   float* cw = smem + lp.cw; float* ct = smem + lp.ct;
   float* Ein = (HYPER && role == 1) ? smem + lp.hb : bufA;      // the Moebius head's input rows
-  const uint32_t tick = (uint32_t)a.counters[3];
+  const uint32_t tick = (uint32_t)a.counters[3] + (uint32_t)(a.step_add > 0 ? a.step_add : 0);
   // (the optimizer step number and its bias corrections -- two double-precision powers on one lane, ~2 k cycles -- are taken by
   // chain Z's first workgroup, which ends at 40 k of the kernel's 88 k cycles: gen_role_z)
   const int g0 = tile * 16;                 // first batch row of this tile
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(TB) void gen_kernel(IterArgs a) {
   if (a.guard && a.counters[4] != 0) return;         // fail-stop behind a resident critic launch that gave up (hypad_epoch_status)
   // chain Z (blockIdx.z == 2) goes to the neighbouring XCD: it reads only the encoder's weights and must not queue behind
   // chains G and R for the 32 CUs of theirs (batch 256: 16 tiles x 2 chains fill an XCD)
-  if ((blockIdx.x & 7) != ((blockIdx.y + (blockIdx.z == 2 ? 1 : 0)) & 7)) return;
+  if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0 + (blockIdx.z == 2 ? 1 : 0)) & 7)) return;
   gen_body<HYPER, SC, LC, BC, true>(a, smem);        // (weights through sc1 buffer loads: tile_gemm.h WeightBlocks)
 }
 
@@ -765,7 +765,7 @@ __device__ __forceinline__ ShadowRef shadow_ref(int net, int p_off, int S, int L
 template <class Table, int SC = 0, int LC = 0, int BC = 0, int KS = 48>
 __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab, const int bx = (int)blockIdx.x) {      // bx: the workgroup's index in the launch's work (dw_adam_kernel: co-location)
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
-  const int sig = blockIdx.y;
+  const int sig = blockIdx.y + a.sig0;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
@@ -774,8 +774,8 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
   // counter, the generator's bias corrections -- instead of one memory round trip each.
   const int di = (tab.block_desc[bx >> 2] >> (8 * (bx & 3))) & 0xff;
   const DwDesc d = tab.d[di];                    // by value: one load group, not one load per field
-  const int step = a.counters[a.opt];            // already incremented by the iteration's first kernel
-  const float* ac = a.ws + (tab.finalize == 1 ? gen_ws(B_, S_, L_).adamc : 0);
+  const int step = a.counters[a.opt] + (a.step_add >= 0 ? a.step_add + 1 : 0);      // (step_add < 0: already incremented by the iteration's first kernel)
+  const float* ac = a.ws + (tab.finalize == 1 ? (int64_t)a.sig0 * a.ws_sig_stride + gen_ws(B_, S_, L_).adamc : 0);
   const float ac0 = ac[0], ac1 = ac[1], ac2 = ac[2];
   AdamCoef co;
   if (tab.finalize == 1) {                     // generator: the first kernel left the bias corrections in the workspace
@@ -953,7 +953,7 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
       lo[0] = 10.f * aux - fx / a.B - fz / a.B;
       lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
     }
-    if (blockIdx.y == 0 && a.tick_owner) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
+    if (blockIdx.y == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
 // COLOC: blockIdx.x is stretched by 8 and only the blocks that land on XCD (signal mod 8) work (workgroups are dealt round-robin
@@ -963,7 +963,7 @@ template <int SC, int LC, int BC, int KS, bool COLOC = false>
 __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
   if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
-    if ((blockIdx.x & 7) != (blockIdx.y & 7)) return;
+    if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;
     dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab, (int)(blockIdx.x >> 3));
   } else {
     dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab);
@@ -1415,7 +1415,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.ws_sig_stride = per;
   a.pk_off = ws_pack_offset(*d) - (opt == 1 ? ws_cz_offset(*d) : 0);       // a.ws is shifted for critic_z
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
-  a.opt = opt; a.tick_owner = 1; a.stamps = nullptr; a.guard = io.guard;
+  a.opt = opt; a.tick_owner = 1; a.stamps = nullptr; a.guard = io.guard; a.sig0 = 0; a.step_add = -1;
 #if HYPAD_DIAG
   a.stamps = g_gen_stamps;
 #endif
@@ -1531,12 +1531,16 @@ int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const Iter
 }
 
 // with_decay = false: the decay-only parameters are left alone (the caller advances them with run_decay_steps)
+// sig0 / nsig / step_add: the models [sig0, sig0 + nsig) only, as generator iteration `step_add` of an epoch (IterArgs.step_add);
+// defaults: all models, counters read and advanced by the launches themselves.
 int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr, bool pack = true,
-            bool with_decay = true) {
+            bool with_decay = true, int sig0 = 0, int nsig = -1, int step_add = -1) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
-  dim3 grid(8 * (a.B / 16), d->n_signals, 3);            // blockIdx.x >> 3: tile (see gen_kernel); blockIdx.z: role G / R / Z
+  if (nsig < 0) nsig = d->n_signals;
+  a.sig0 = sig0; a.step_add = step_add;
+  dim3 grid(8 * (a.B / 16), nsig, 3);                    // blockIdx.x >> 3: tile (see gen_kernel); blockIdx.z: role G / R / Z
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
@@ -1561,7 +1565,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const DwTable tab = gen_table(*d, with_decay);
   const char* cenv = getenv("HYPAD_DW_COLOC");
   const bool coloc = cenv ? cenv[0] == '1' : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
-  const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), d->n_signals);
+  const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), nsig);
   if (coloc) {
     if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
     else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
@@ -1772,6 +1776,27 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* d, int n_batches, int n_cri
   return (base + critic_phase_fixed_floats(*d) + (size_t)n * critic_phase_floats_per_iter(*d)) * sizeof(float);
 }
 
+namespace {
+// Fork / join events of the generator phase's model groups (hypad_epoch_io.aux_streams): created once per process on first use.
+// (Event creation is not a stream operation: legal while a stream is being captured.  One epoch call at a time per process uses them.)
+struct GenFork { hipEvent_t forked; hipEvent_t joined[7]; };
+GenFork* gen_fork_events() {
+  static GenFork f;
+  static int state = 0;                    // 0 not tried, 1 ready, -1 failed
+  if (state == 0) {
+    bool ok = hipEventCreateWithFlags(&f.forked, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 7 && ok; ++i) ok = hipEventCreateWithFlags(&f.joined[i], hipEventDisableTiming) == hipSuccess;
+    state = ok ? 1 : -1;
+  }
+  return state == 1 ? &f : nullptr;
+}
+__global__ void advance_counters_kernel(int32_t* counters, int opt, int n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (counters[4] != 0) return;          // fail-stop (hypad_epoch_status): the launches before this one were no-ops
+    counters[opt] += n; counters[3] += n;
+  }
+}
+} // namespace
 int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t s) {
   if (!io || !io->row_index || io->n_batches <= 0 || io->n_critics < 0) return HYPAD_EINVAL;
   int rc = check_dims(d);
@@ -1841,15 +1866,49 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
     }
     c.z = nullptr; c.alpha = nullptr; c.masks = nullptr;
   }
-  for (int b = 0; b < io->n_batches; ++b) {            // train.py:347-352
-    c.row_index = io->row_index + io->n_critics * pass_rows + (int64_t)b * d->batch;
-    c.losses = io->losses + (int64_t)(it++) * 4;
-    if (nz) {
-      c.z = nz->z_gen ? nz->z_gen + (int64_t)b * ns * B * L : nullptr;
-      c.masks = inj_masks ? nz->masks_gen + (int64_t)b * ns * mk_gen : nullptr;
+  // train.py:347-352.  The models are independent of each other: with auxiliary streams they run in groups, one chain of
+  // (generator launch, dW + Adam launch) x n_batches per group and stream, so a group's optimizer launch overlaps another group's
+  // generator launch (a generator launch keeps 12 workgroups per model busy for ~37 us, the optimizer launch that follows is
+  // latency- or bandwidth-bound: in lock step the chip idles through both).  Every launch then carries its own step number and
+  // rng tick (IterArgs.step_add) and nobody advances the counters until the groups have joined.
+  int groups = 1 + (io->aux_streams ? (io->n_aux_streams < 0 ? 0 : io->n_aux_streams > 7 ? 7 : io->n_aux_streams) : 0);
+  if (groups > d->n_signals) groups = d->n_signals;
+  if (io->n_batches < 1) groups = 1;
+  GenFork* fork = nullptr;
+  if (groups > 1) {
+    fork = gen_fork_events();
+    if (!fork) groups = 1;
+  }
+  if (groups > 1) {
+    hipError_t e = hipEventRecord(fork->forked, (hipStream_t)s);
+    for (int g = 1; g < groups && e == hipSuccess; ++g) e = hipStreamWaitEvent((hipStream_t)io->aux_streams[g - 1], fork->forked, 0);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int it_gen0 = it;
+  for (int g = 0; g < groups; ++g) {
+    const int s0 = (int)((int64_t)d->n_signals * g / groups), s1 = (int)((int64_t)d->n_signals * (g + 1) / groups);
+    hipStream_t gs = g == 0 ? (hipStream_t)s : (hipStream_t)io->aux_streams[g - 1];
+    for (int b = 0; b < io->n_batches; ++b) {
+      c.row_index = io->row_index + io->n_critics * pass_rows + (int64_t)b * d->batch;
+      c.losses = io->losses + (int64_t)(it_gen0 + b) * 4;
+      if (nz) {
+        c.z = nz->z_gen ? nz->z_gen + (int64_t)b * ns * B * L : nullptr;
+        c.masks = inj_masks ? nz->masks_gen + (int64_t)b * ns * mk_gen : nullptr;
+      }
+      rc = run_gen(d, st, c, gs, nullptr, false, false, s0, s1 - s0, groups > 1 ? b : -1);
+      if (rc) return rc;
     }
-    rc = run_gen(d, st, c, (hipStream_t)s, nullptr, false, false);
-    if (rc) return rc;
+  }
+  it = it_gen0 + io->n_batches;
+  if (groups > 1) {
+    hipError_t e = hipSuccess;
+    for (int g = 1; g < groups && e == hipSuccess; ++g) {
+      e = hipEventRecord(fork->joined[g - 1], (hipStream_t)io->aux_streams[g - 1]);
+      if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)s, fork->joined[g - 1], 0);
+    }
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, st->counters, 2, io->n_batches);      // generator steps (counters[2]) and rng ticks
+    HYPAD_CHECK_LAUNCH();
   }
   // W_hh and the f-gate rows: all of the epoch's weight-decay steps at once (see decay_table)
   c.losses = io->losses;

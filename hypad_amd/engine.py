@@ -7,6 +7,7 @@ workspace, and exposes the three iterations and a whole epoch (train.py:299-356)
 stays resident in HBM.  ``hypad_amd.train`` wraps it with n_signals = 1 around user-visible nn.Modules.
 """
 import ctypes
+import os
 import logging
 
 import numpy as np
@@ -49,6 +50,34 @@ class Engine:
             self._ws_bytes = nbytes
             self._drop_graphs()                  # captured epochs hold the old workspace's address
 
+    MAX_AUX_STREAMS = 7
+
+    def _aux_streams_wanted(self):
+        """``self.aux_streams`` if set, else HYPAD_AUX_STREAMS, else the measured default: one auxiliary stream (two groups) from 28
+        models per GPU on, none below.  Measured on MI355X, epoch ms with 0 / 1 / 2 / 3 / 7 auxiliary streams: 8 models 3.33 / 3.49 /
+        - / 3.57 / 5.49; 12: 3.66 / 3.58 / 3.86; 16: 4.22 / 4.09 / 4.43; 24: 5.22 / 5.49 / 5.13; 32: 6.47 / 5.97 / 6.69 / 6.13 / 8.69 --
+        a second hardware queue costs ~7 us per dependent launch, which only the 32-model launches (58 us generator launches that
+        fill the chip's CUs, 54 us optimizer launches that fill its memory pipes) earn back."""
+        if hasattr(self, "aux_streams"):
+            return int(self.aux_streams)
+        if "HYPAD_AUX_STREAMS" in os.environ:
+            return int(os.environ["HYPAD_AUX_STREAMS"])
+        return 1 if self.n >= 28 else 0
+
+    def _aux_stream_args(self):
+        """(array of raw stream handles, count) for hypad_epoch_io: with several signals (models) per GPU the generator phase runs
+        them in groups on side streams, a group's optimizer launch overlapping another group's generator launch (include/hypad.h,
+        ABI 4).  0 (or one signal) keeps everything on the caller's stream; same bits either way."""
+        want = min(self.MAX_AUX_STREAMS, self.n - 1, self._aux_streams_wanted())
+        if want <= 0:
+            return None, 0
+        pool = self.__dict__.setdefault("_aux_pool", [])
+        while len(pool) < want:
+            pool.append(torch.cuda.Stream(device=self.device))
+        arr = (ctypes.c_void_p * want)(*(s.cuda_stream for s in pool[:want]))
+        self._aux_arr = arr                       # (kept alive for the duration of the call)
+        return ctypes.cast(arr, ctypes.POINTER(ctypes.c_void_p)), want
+
     def _drop_graphs(self):
         self.__dict__.pop("_graphs", None)
 
@@ -57,7 +86,7 @@ class Engine:
         addresses and the optimizer scalars (passed by value)."""
         ptrs = tuple(d[k].data_ptr() for d in (self.params, self.exp_avg, self.exp_avg_sq) for k in NETS)
         return ptrs + (self.counters.data_ptr(), self.workspace.data_ptr(), self._ws_bytes, self.lr, self.betas, self.eps, self.gen_wd,
-                       self.gen_stab, self.epoch_flags)
+                       self.gen_stab, self.epoch_flags, self._aux_streams_wanted())
 
     # ---- weights in / out ------------------------------------------------------------------------------
     def catalogue(self, net):
@@ -281,7 +310,8 @@ class Engine:
                         losses.data_ptr(), self.workspace.data_ptr(),
                         (self._ws_bytes if workspace_iters is None else _C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), int(workspace_iters), 1))
                         if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
-                        ctypes.pointer(nz) if nz is not None else None, int(self.epoch_flags if flags is None else flags))
+                        ctypes.pointer(nz) if nz is not None else None, int(self.epoch_flags if flags is None else flags),
+                        *self._aux_stream_args())
         st = self._state()
         _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")
         if not torch.cuda.is_current_stream_capturing():

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HYPAD_ABI_VERSION 3
+#define HYPAD_ABI_VERSION 4
 
 enum {
   HYPAD_OK = 0,
@@ -265,6 +265,14 @@ typedef struct hypad_epoch_io {
                                                 the critic phase runs in its hoisted form (see below) */
   const hypad_epoch_noise* noise;            /* NULL: all randomness from device Philox(seed) */
   int flags;                                 /* HYPAD_EPOCH_* bits, 0 = defaults */
+  /* ABI 4.  Optional: n_aux_streams (<= 7) further streams of the same device.  With more than one signal (model) per call the
+   * generator phase (train.py:347-352: 29 x [decoder_iteration, its optimizer step] per model, the models independent of each other)
+   * then runs the models in n_aux_streams + 1 groups, each group's chain of launches on a stream of its own -- forked from `stream`
+   * by an event after the critic phase, joined into it before the call returns its last launches -- so one group's optimizer
+   * launch overlaps another group's generator launch.  Results are the same bits with any number of streams (the step number and
+   * rng tick of every launch are its own arguments; the counters advance once, after the join).  Capturable like everything else:
+   * the groups become parallel branches of the captured graph.  NULL / 0: everything on `stream`. */
+  hypad_stream_t const* aux_streams; int n_aux_streams;
 } hypad_epoch_io;
 enum {
   HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits

@@ -242,3 +242,35 @@ def Engine_draws(e, n_windows, take, reps):
         out.append(e.draw_shuffles(buf, n_windows)[0].clone())
     e.counters[3] = 0
     return torch.stack(out).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ generator phase in model groups
+@pytest.mark.parametrize("ns,graph", [(2, False), (5, False), (8, True), (11, False)])
+def test_generator_phase_in_model_groups_keeps_the_bits(ns, graph):
+    """hypad_epoch_io.aux_streams (ABI 4): with several models per GPU the generator phase (train.py:347-352) runs them in groups,
+    each group's chain of launches on a stream of its own; every launch carries its step number and rng tick, the counters advance
+    once after the groups joined.  Two epochs on 0, 1, 3 and 7 auxiliary streams -- eagerly and as a replayed graph -- must agree
+    bit for bit: losses, all four networks, moments, counters; and the injected-noise planes must reach the right model."""
+    nb, nc = 3, 2
+    engine, x, perms, _, _ = _setup(ns, seed=21, nb=nb, nc=nc)
+    outs = {}
+    for aux in (0, 1, 3, 7):
+        e = engine()
+        e.aux_streams = aux
+        run = e.train_epoch_graph if graph else e.train_epoch
+        l = run(x, perms[0], nb, nc, True).clone()
+        l2 = run(x, perms[1], nb, nc, True).clone()
+        assert e.status() == 0
+        outs[aux] = (l, l2, _snapshot(e))
+    ref = outs[0]
+    assert int(ref[2][3][2]) == 2 * nb                       # generator steps counted once per iteration
+    for aux in (1, 3, 7):
+        got = outs[aux]
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), aux
+        assert _same(got[2], ref[2]), aux
+    # the models differ from each other (a group reading another group's rows would still be "consistent" across aux counts
+    # only if it did so in every run: compare with single-model engines)
+    e1 = engine()
+    e1.aux_streams = 7
+    l_all = e1.train_epoch(x, perms[0], nb, nc, True).clone()
+    assert not torch.equal(l_all[0], l_all[ns - 1])
