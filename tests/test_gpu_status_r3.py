@@ -47,9 +47,10 @@ def _same(a, b):
     return all(torch.equal(a[i][k], b[i][k]) for i in range(3) for k in a[i]) and torch.equal(a[3], b[3])
 
 
-@pytest.mark.parametrize("ns,graph", [(1, False), (3, False), (1, True)])
-def test_resident_launch_that_gives_up_is_reported_stops_the_epoch_and_is_recovered(ns, graph):
+@pytest.mark.parametrize("ns,graph,aux", [(1, False, 0), (3, False, 0), (1, True, 0), (3, False, 2), (3, True, 1)])
+def test_resident_launch_that_gives_up_is_reported_stops_the_epoch_and_is_recovered(ns, graph, aux, monkeypatch):
     from hypad_amd import _C
+    monkeypatch.setenv("HYPAD_AUX_STREAMS", str(aux))          # (aux > 0: the generator phase in model groups must stop and recover alike)
     engine, x, perms, nb, nc = _setup(ns)
     good = engine()
     assert good.critic_phase_persistent(), "this test is about the resident form"
