@@ -666,6 +666,13 @@ def test_critic_kde_smoothing_and_full_score_paths(dev):
     ext = np.repeat(cr.astype(np.float64).reshape(-1, 1), 100, axis=1)
     ref = np.array([osc.kde_mode(osc.antidiagonal(ext, i)) for i in range(799)])
     _assert_same_modes_up_to_fp64_ties(cr, 100, got, ref)
+    # every window class of the kernel (one to four sample slots of 64 per lane), heavy tails included (the direct form of the screen)
+    for w, n, heavy in ((7, 60, False), (64, 200, False), (65, 200, True), (130, 300, False), (192, 250, True), (256, 300, False)):
+        cr = (rng.standard_t(2, n) if heavy else rng.standard_normal(n)).astype(np.float32)
+        got = adu.kde_modes(cr, w).cpu().numpy()
+        ext = np.repeat(cr.astype(np.float64).reshape(-1, 1), w, axis=1)
+        ref = np.array([osc.kde_mode(osc.antidiagonal(ext, i)) for i in range(n + w - 1)])
+        _assert_same_modes_up_to_fp64_ties(cr, w, got, ref)
 
 
 def _assert_same_modes_up_to_fp64_ties(critic, w, got, ref):
