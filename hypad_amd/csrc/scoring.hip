@@ -365,30 +365,36 @@ __host__ __device__ inline void roll_counts(int64_t T, int64_t origin, int64_t& 
   n2 = ((origin + T - 1) >> 8) - (origin >> 8) + 1;
 }
 // level 1: one thread per 16-chunk, ascending
-__global__ __launch_bounds__(THREADS) void roll_chunks1_kernel(RollSrc src, RollWs ws, int64_t T, int64_t origin) {
-  const int64_t c = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  if (c >= ws.n1) return;
-  const int64_t g0 = ((origin >> 4) + c) << 4;
+// (one launch for both levels: a workgroup owns 16 consecutive 256-chunks and the 256 16-chunks they consist of -- the slots are
+// counted from the level-2 chunk's own first 16-chunk, so no 256-chunk straddles two workgroups; level 2 adds its 16 level-1 sums in
+// ascending order out of LDS: the additions of the two-launch form, hence its bits)
+__global__ __launch_bounds__(THREADS) void roll_chunks_kernel(RollSrc src, RollWs ws, int64_t T, int64_t origin) {
+  __shared__ double sh_s[THREADS];
+  __shared__ int sh_c[THREADS];
+  const int64_t c2_0 = (int64_t)blockIdx.x * 16;                                     // this workgroup's first 256-chunk
+  const int64_t first1 = (((origin >> 8) + c2_0) << 4) - (origin >> 4);             // level-1 slot of its first 16-chunk (may be < 0 at the left edge)
+  const int64_t j = first1 + threadIdx.x;
   double s = 0.0; int cnt = 0;
+  if (j >= 0 && j < ws.n1) {
+    const int64_t g0 = ((origin >> 4) + j) << 4;
 #pragma unroll 4
-  for (int k = 0; k < RC1; ++k) {
-    const int64_t i = g0 + k - origin;
-    if (i >= 0 && i < T) { const double v = src(i); if (v == v) { s += v; ++cnt; } }
+    for (int k = 0; k < RC1; ++k) {
+      const int64_t i = g0 + k - origin;
+      if (i >= 0 && i < T) { const double v = src(i); if (v == v) { s += v; ++cnt; } }
+    }
+    ws.s1[j] = s; ws.c1[j] = cnt;
   }
-  ws.s1[c] = s; ws.c1[c] = cnt;
-}
-// level 2: one thread per 256-chunk = 16 level-1 chunks, ascending
-__global__ __launch_bounds__(THREADS) void roll_chunks2_kernel(RollWs ws, int64_t origin) {
-  const int64_t c = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  if (c >= ws.n2) return;
-  const int64_t first1 = (((origin >> 8) + c) << 4) - (origin >> 4);      // level-1 slot of this chunk's first 16-chunk (may be < 0 at the left edge)
-  double s = 0.0; int cnt = 0;
+  sh_s[threadIdx.x] = s; sh_c[threadIdx.x] = cnt;
+  __syncthreads();
+  if (threadIdx.x < 16 && c2_0 + threadIdx.x < ws.n2) {
+    double s2 = 0.0; int c2 = 0;
 #pragma unroll 4
-  for (int k = 0; k < 16; ++k) {
-    const int64_t j = first1 + k;
-    if (j >= 0 && j < ws.n1) { s += ws.s1[j]; cnt += ws.c1[j]; }
+    for (int k = 0; k < 16; ++k) {
+      const int64_t jj = first1 + 16 * threadIdx.x + k;
+      if (jj >= 0 && jj < ws.n1) { s2 += sh_s[16 * threadIdx.x + k]; c2 += sh_c[16 * threadIdx.x + k]; }
+    }
+    ws.s2[c2_0 + threadIdx.x] = s2; ws.c2[c2_0 + threadIdx.x] = c2;
   }
-  ws.s2[c] = s; ws.c2[c] = cnt;
 }
 template <bool CHUNKED>
 __global__ __launch_bounds__(THREADS) void rolling_mean_kernel(RollSrc src, RollWs ws, double* __restrict__ out, int64_t T, int w, int64_t origin) {
@@ -633,8 +639,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
         if (lane + 64 * u >= cnt) d32[u] = -1.f;
         mx = fmaxf(mx, d32[u]);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+      mx = wave_max(mx);
       // Relative error of an fp32 density D~ against the exact D, all terms positive.  Direct form, exp2(-(x - v)^2):
       //  * arguments: a centred, rescaled sample y carries 2^-24 |y| <= 1e-6 (|y| < 32 for every pair that contributes: two of <= 256
       //    samples within a few units of each other lie at most 2.6 sqrt(255 / 2) = 29 units from the mean; a lone outlier beyond that
@@ -1041,9 +1046,7 @@ int hypad_rolling_mean(const double* in, const float* sub, double* out, int64_t 
   const int64_t cap1 = t / RC1 + 3, cap2 = t / RC2 + 3;
   ws.s1 = (double*)workspace; ws.s2 = ws.s1 + cap1;
   ws.c1 = (int*)(ws.s2 + cap2); ws.c2 = ws.c1 + cap1;
-  hipLaunchKernelGGL(roll_chunks1_kernel, dim3((unsigned)((ws.n1 + THREADS - 1) / THREADS)), dim3(THREADS), 0, (hipStream_t)s, src, ws, t, origin);
-  HYPAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(roll_chunks2_kernel, dim3((unsigned)((ws.n2 + THREADS - 1) / THREADS)), dim3(THREADS), 0, (hipStream_t)s, ws, origin);
+  hipLaunchKernelGGL(roll_chunks_kernel, dim3((unsigned)((ws.n2 + 15) / 16)), dim3(THREADS), 0, (hipStream_t)s, src, ws, t, origin);
   HYPAD_CHECK_LAUNCH();
   hipLaunchKernelGGL(rolling_mean_kernel<true>, dim3(grid_for(t, THREADS)), dim3(THREADS), 0, (hipStream_t)s, src, ws, out, t, window, origin);
   HYPAD_CHECK_LAUNCH();
