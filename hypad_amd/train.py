@@ -29,31 +29,35 @@ _NET_OF = {tadgan.Encoder: "enc", tadgan.Decoder: "dec", tadgan.CriticX: "cx", t
 
 class _NoiseStage:
     """Host-drawn noise of one iteration -> device in ONE copy: a ring of pinned host rows [z | alpha] and device rows of the
-    same shape.  NumPy / torch CPU write their draws straight into the pinned row; one non-blocking H2D follows; an event
-    per slot guards the pinned row against being refilled while its copy is still in flight (the device row is protected by
-    stream order: the kernels that read it precede the next copy into it)."""
-    SLOTS = 8
+    same shape.  NumPy / torch CPU write their draws straight into the pinned row; one non-blocking H2D follows.  A pinned row
+    must not be refilled while its copy is still in flight: the ring is walked in groups of GROUP slots, ONE event is recorded
+    behind a group's last copy and awaited before the group's first slot is refilled a lap later (an event per copy cost ~15 us
+    of host time per iteration: torch's record() looks the current stream up every time).  The device row is protected by
+    stream order: the kernels that read it precede the next copy into it."""
+    SLOTS, GROUP = 32, 8
 
     def __init__(self, device, floats):
         self.floats = floats
         self.host = torch.empty(self.SLOTS, floats, dtype=torch.float32).pin_memory()
         self.host_np = self.host.numpy()
         self.dev = torch.empty(self.SLOTS, floats, dtype=torch.float32, device=device)
-        self.events = [None] * self.SLOTS
-        self.k = 0
+        self.events = [None] * (self.SLOTS // self.GROUP)
+        self.k = self.SLOTS - 1
 
     def slot(self):
         k = self.k = (self.k + 1) % self.SLOTS
-        if self.events[k] is not None:
-            self.events[k].synchronize()
+        if k % self.GROUP == 0 and self.events[k // self.GROUP] is not None:
+            self.events[k // self.GROUP].synchronize()
         return k
 
     def upload(self, k):
         self.dev[k].copy_(self.host[k], non_blocking=True)
-        ev = self.events[k]
-        if ev is None:
-            ev = self.events[k] = torch.cuda.Event()
-        ev.record()
+        if k % self.GROUP == self.GROUP - 1:
+            g = k // self.GROUP
+            ev = self.events[g]
+            if ev is None:
+                ev = self.events[g] = torch.cuda.Event()
+            ev.record()
         return self.dev[k]
 
 
