@@ -136,6 +136,114 @@ __global__ __launch_bounds__(THREADS) void lstm_fwd_kernel(const float* __restri
   tile_store(out + r0 * 2 * H, 2 * H, hs, ldh, 16, 2 * H, valid);
 }
 
+// ---- the same layer for MANY rows (round 3): weights stationary in LDS.  lstm_fwd_kernel above re-reads the layer's weights from L2
+// for every 16-row tile and re-shapes them through a wave-private LDS slab (gemm_nt: 25-28 % of the SIMD-cycles are matrix-pipe
+// cycles by counter, profiles/r03_mfma_util.json).  Here a 512-thread workgroup owns ONE direction: its three gate blocks of W_ih
+// (i, g, o: the f gate meets c0 = 0) sit in LDS for the workgroup's lifetime -- [gate][unit][k], row stride kpad + 4 (= 4 x odd:
+// the 16 lanes of a ds_read_b128 phase hit 16 different 4-bank groups) -- and every wave walks its own 16-row tiles: the tile's x
+// rows go straight from global memory into the MFMA A layout (lane (row, kq) holds x[row][16 g + 4 kq .. + 3]; the four MFMAs of a
+// k-group use the components in turn, so A and B agree on a permuted k order), one 16-unit block at a time takes its three
+// accumulators through the whole K, and the cell runs on the accumulators (lane (unit, q), register r = row 4 q + r: the three
+// gates of a unit on one lane).  No barrier after the weights are staged.
+#ifndef HYPAD_LSTM_EXP
+#define HYPAD_LSTM_EXP 0        // development what-if: 1 folds the saved gates of all tiles onto 1 024 rows (same instructions, no HBM writes)
+#endif
+template <int KG>                      // k-groups of 16: in_dim <= 16 KG
+__global__ __launch_bounds__(512) void lstm_fwd_lds_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
+                                                            const float* wr, const float* bir, const float* bhr, float* __restrict__ out,
+                                                            float* __restrict__ gates_save, int64_t rows, int K, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int dir = blockIdx.x & 1, slice = blockIdx.x >> 1, nslices = gridDim.x >> 1;
+  const float* __restrict__ w = dir ? wr : wf;
+  const float* __restrict__ b1 = dir ? bir : bif;
+  const float* __restrict__ b2 = dir ? bhr : bhf;
+  const int Hp = (H + 15) & ~15, nub = Hp >> 4;
+  constexpr int ld = KG * 16 + 4;
+  for (int idx = threadIdx.x; idx < 3 * Hp * ld; idx += 512) {
+    const int g3 = idx / (Hp * ld), rem = idx - g3 * Hp * ld, n = rem / ld, k = rem - n * ld;
+    smem[idx] = (n < H && k < K) ? w[(int64_t)((g3 == 0 ? 0 : g3 + 1) * H + n) * K + k] : 0.f;      // PyTorch gate order i, f, g, o
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (rows + 15) >> 4;
+  const bool vec = (K & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  // A tile: rows past the end repeat the last one (their results are not stored)
+  auto load_a = [&](float4 (&a)[KG], int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile << 4;
+    const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+    const float* xr = x + row * K;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const int k0 = 16 * g + 4 * q;
+      if (vec && k0 + 3 < K) a[g] = *reinterpret_cast<const float4*>(xr + k0);
+      else a[g] = make_float4(k0 < K ? xr[k0] : 0.f, k0 + 1 < K ? xr[k0 + 1] : 0.f, k0 + 2 < K ? xr[k0 + 2] : 0.f, k0 + 3 < K ? xr[k0 + 3] : 0.f);
+    }
+  };
+  const int64_t tstep = (int64_t)nslices * 8;
+  float4 a[KG], an[KG];
+  int64_t tile = (int64_t)slice * 8 + wave;
+  if (tile < ntiles) load_a(a, tile);
+  for (; tile < ntiles; tile += tstep) {
+    const int64_t r0 = tile << 4;
+    // the next tile's rows are requested before this tile's results are stored: memory operations of a wave return in order, so
+    // loads issued behind the epilogue's ~80 stores would wait for all of them
+    if (tile + tstep < ntiles) load_a(an, tile + tstep);
+    // two 16-unit blocks at a time: their stores land next to each other in time, so the two 64-byte halves of a 128-byte line of the
+    // saved gates meet in L2 instead of leaving it one by one (the output is 2 KB per row: the launch is bound by its writes)
+    for (int ub = 0; ub < nub; ub += 2) {
+      const bool two = ub + 1 < nub;
+      f32x4 ai = {0.f, 0.f, 0.f, 0.f}, ag = ai, ao = ai, ci = ai, cg = ai, co = ai;
+      const float* wb = smem + (ub * 16 + j) * ld + 4 * q;
+      const float* wc = wb + (two ? 16 * ld : 0);
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const float4 bi = *reinterpret_cast<const float4*>(wb + 16 * g);
+        const float4 bg = *reinterpret_cast<const float4*>(wb + Hp * ld + 16 * g);
+        const float4 bo = *reinterpret_cast<const float4*>(wb + 2 * Hp * ld + 16 * g);
+        const float4 di = *reinterpret_cast<const float4*>(wc + 16 * g);
+        const float4 dg = *reinterpret_cast<const float4*>(wc + Hp * ld + 16 * g);
+        const float4 dO = *reinterpret_cast<const float4*>(wc + 2 * Hp * ld + 16 * g);
+#define HYPAD_LSTM_STEP(c)                                                   \
+        ai = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, bi.c, ai, 0, 0, 0); \
+        ag = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, bg.c, ag, 0, 0, 0); \
+        ao = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, bo.c, ao, 0, 0, 0); \
+        if (two) {                                                           \
+          ci = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, di.c, ci, 0, 0, 0); \
+          cg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, dg.c, cg, 0, 0, 0); \
+          co = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].c, dO.c, co, 0, 0, 0); \
+        }
+        HYPAD_LSTM_STEP(x) HYPAD_LSTM_STEP(y) HYPAD_LSTM_STEP(z) HYPAD_LSTM_STEP(w)
+#undef HYPAD_LSTM_STEP
+      }
+      // stores through buffer addressing: the tile's base in the descriptor, the lane's (row 4 q, unit) once as a 32-bit offset,
+      // row and gate as scalar offsets -- per-element 64-bit address arithmetic was a third of this epilogue's instructions
+      const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + (HYPAD_LSTM_EXP == 1 ? (r0 & 1023) : r0) * 8 * H : out);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int unit = (ub + half) * 16 + j;
+        if (half == 1 && !two) break;
+        if (unit >= H) continue;
+        const f32x4 pi = half ? ci : ai, pg = half ? cg : ag, po = half ? co : ao;
+        const float bsi = b1[unit] + b2[unit], bsg = b1[2 * H + unit] + b2[2 * H + unit], bso = b1[3 * H + unit] + b2[3 * H + unit];
+        const int vo_h = (4 * q * 2 * H + dir * H + unit) * 4, vo_g = (4 * q * 8 * H + dir * 4 * H + unit) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r0 + 4 * q + r >= rows) continue;
+          const float gi = sigmoidf_(pi[r] + bsi), gg = tanhf_(pg[r] + bsg), go = sigmoidf_(po[r] + bso);
+          const float tc = tanhf_(gi * gg);
+          ob.st(go * tc, vo_h, r * 2 * H * 4);
+          if (gates_save) {
+            gb.st(gi, vo_g, r * 8 * H * 4); gb.st(gg, vo_g, (r * 8 * H + H) * 4);
+            gb.st(go, vo_g, (r * 8 * H + 2 * H) * 4); gb.st(tc, vo_g, (r * 8 * H + 3 * H) * 4);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) a[g] = an[g];
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void lstm_bwd_kernel(const float* wf, const float* wr, const float* __restrict__ gates_saved,
                                                             const float* __restrict__ gout, float* __restrict__ ggates,
                                                             float* __restrict__ gx, int64_t rows, int K, int H) {
@@ -367,6 +475,31 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
                          hypad_stream_t s) {
   if (!x || !wf || !bif || !bhf || !wr || !bir || !bhr || !out || rows < 0 || K <= 0 || H <= 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
+  // many rows: the weights-stationary form (one direction's W_ih in LDS per workgroup); HYPAD_LSTM_LDS=0 keeps the streamed form
+  static const int lds_form = getenv("HYPAD_LSTM_LDS") ? atoi(getenv("HYPAD_LSTM_LDS")) : 1;
+  if (lds_form && rows >= 2048 && H <= 64 && K <= 128) {
+    const int KG = (K + 15) >> 4, Hp = (H + 15) & ~15;
+    const size_t lw = (size_t)3 * Hp * (KG * 16 + 4) * sizeof(float);
+    const int64_t ntiles = (rows + 15) >> 4;
+    int nslices = (int)((ntiles + 7) / 8);
+    if (nslices > 128) nslices = 128;
+    const dim3 grid(2 * nslices);
+#define HYPAD_LSTM_LDS_LAUNCH(KGC)                                                                                               \
+    do {                                                                                                                         \
+      hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC>, lw);                                                      \
+      if (e2 != hipSuccess) return (int)e2;                                                                                      \
+      hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC>), grid, dim3(512), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out,     \
+                         gates_save, rows, K, H);                                                                                \
+    } while (0)
+    switch (KG) {
+      case 1: HYPAD_LSTM_LDS_LAUNCH(1); break; case 2: HYPAD_LSTM_LDS_LAUNCH(2); break; case 3: HYPAD_LSTM_LDS_LAUNCH(3); break;
+      case 4: HYPAD_LSTM_LDS_LAUNCH(4); break; case 5: HYPAD_LSTM_LDS_LAUNCH(5); break; case 6: HYPAD_LSTM_LDS_LAUNCH(6); break;
+      case 7: HYPAD_LSTM_LDS_LAUNCH(7); break; default: HYPAD_LSTM_LDS_LAUNCH(8); break;
+    }
+#undef HYPAD_LSTM_LDS_LAUNCH
+    HYPAD_CHECK_LAUNCH();
+    return HYPAD_OK;
+  }
   size_t lds = (size_t)(16 * (ld_of(K) + ld_of(6 * H) + ld_of(2 * H)) + WST) * sizeof(float);
   if (lds > 150 * 1024) return HYPAD_EUNSUPPORTED;
   hipError_t e = allow_lds((const void*)lstm_fwd_kernel, lds);

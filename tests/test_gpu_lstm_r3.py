@@ -53,3 +53,38 @@ def test_lstm_sequence_entry_point_validates_arguments():
     assert f(None, p, p, p, p, p, p, p, p, None, None, p, None, None, 1, 1, 1, 1, None, 0, _C.stream()) == -1
     assert f(p, p, p, p, p, p, p, p, p, None, None, p, None, None, 1, 1, 1, 65, p, 1 << 20, _C.stream()) == -3        # hidden > 64
     assert f(p, p, p, p, p, p, p, p, p, None, None, p, None, None, 1, 1, 1, 4, None, 0, _C.stream()) == -2            # no workspace
+
+
+@pytest.mark.parametrize("rows,K,H", [(2048 + 37, 100, 50), (4096, 128, 64), (3000, 51, 7), (2500, 20, 64), (2049, 17, 33)])
+def test_weights_stationary_layer_matches_torch_and_feeds_the_backward(rows, K, H):
+    """hypad_lstm_bidir_fwd takes its weights-stationary form from 2 048 rows on (one direction's W_ih in LDS per workgroup, x rows
+    straight into the MFMA A layout, the cell on the accumulators): output against torch.nn.LSTM (T = 1, zero state;
+    models/tadgan.py:15-25,35-38,59-60) and the saved gates through hypad_lstm_bidir_bwd against autograd."""
+    from hypad_amd import _C
+    torch.manual_seed(rows + K)
+    lstm = torch.nn.LSTM(K, H, 1, bidirectional=True)
+    x = torch.randn(1, rows, K, requires_grad=True)
+    out, _ = lstm(x)
+    go = torch.randn(1, rows, 2 * H)
+    names = ["weight_ih_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    ps = [getattr(lstm, n) for n in names]
+    grads = torch.autograd.grad(out, [x] + ps, go)
+    d = [p.detach().cuda().contiguous() for p in ps]
+    dx = x.detach().view(rows, K).cuda().contiguous()
+    o = torch.empty(rows, 2 * H, device="cuda")
+    gs = torch.full((rows, 8 * H), float("nan"), device="cuda")
+    _C.check(_C.lib.hypad_lstm_bidir_fwd(_C.ptr(dx), *[_C.ptr(t) for t in d], _C.ptr(o), _C.ptr(gs), rows, K, H, _C.stream()))
+    assert float((o.cpu() - out.detach().view(rows, 2 * H)).abs().max()) < 1e-5
+    gsv = gs.view(rows, 2, 4, H)
+    assert bool(torch.isfinite(gsv).all())                                 # every (row, direction, gate, unit) was written
+    o2 = torch.empty_like(o)                                               # without the saved gates
+    _C.check(_C.lib.hypad_lstm_bidir_fwd(_C.ptr(dx), *[_C.ptr(t) for t in d], _C.ptr(o2), None, rows, K, H, _C.stream()))
+    assert torch.equal(o, o2)
+    gg = torch.empty(rows, 8 * H, device="cuda")
+    gx = torch.empty(rows, K, device="cuda")
+    _C.check(_C.lib.hypad_lstm_bidir_bwd(_C.ptr(d[0]), _C.ptr(d[3]), _C.ptr(gs), _C.ptr(go.view(rows, 2 * H).cuda().contiguous()), _C.ptr(gg),
+                                         _C.ptr(gx), rows, K, H, _C.stream()))
+    assert float((gx.cpu() - grads[0].view(rows, K)).abs().max()) < 1e-5
+    ggc = gg.cpu().view(rows, 2, 4 * H)
+    scale = max(1.0, float(grads[1].abs().max()))
+    assert float((ggc[:, 0].t() @ x.detach().view(rows, K) - grads[1]).abs().max()) < 2e-4 * scale      # weight_ih_l0 (a sum over `rows` terms)
