@@ -12,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 KERNELS = {"score_forward_packed_kernel": 340312.0 / 2 * 125_000,                  # MACs per launch (algorithmic)
-           "lstm_fwd_kernel": None,
+           "lstm_fwd(_lds)?_kernel": None,
            "gen_kernel": 561824.0 * 64, "dw_adam_kernel": 281872.0 * 64,
            "critic_persistent_kernel": (40400.0 + 156936.0) * 64 * 145}
 d = sys.argv[1]
@@ -21,7 +21,7 @@ acc = {}
 lstm_ids = set()
 rows_all = list(csv.DictReader(open(f)))
 for r in rows_all:
-    if re.search("lstm_fwd_kernel", r["Kernel_Name"]):
+    if re.search("lstm_fwd(_lds)?_kernel", r["Kernel_Name"]):
         lstm_ids.add(int(r["Dispatch_Id"]))
 lstm_sorted = sorted(lstm_ids)
 lstm_first = set(lstm_sorted[: len(lstm_sorted) // 2])           # the target runs the 100 -> 2x50 shape first, then 128 -> 2x64
@@ -30,7 +30,7 @@ for r in rows_all:
     for k in KERNELS:
         if re.search(k, r["Kernel_Name"]):
             key = k
-            if k == "lstm_fwd_kernel":
+            if k == "lstm_fwd(_lds)?_kernel":
                 key = list(LSTM_MACS)[0 if int(r["Dispatch_Id"]) in lstm_first else 1]
             acc.setdefault(key, {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             acc[key][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
