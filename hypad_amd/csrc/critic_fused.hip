@@ -145,6 +145,8 @@ struct PhaseArgs {
                                                // groups incl. the ones column and zero padding, the record fills in0 / dm, d loss / d out is set per
                                                // iteration), so the sweep -- 62 KB of LDS stores, ~1 k cycles -- is only needed once, before the loop
   int xcd_stretch;                             // 1: the critics' workgroup ids are stretched by 8 (one critic's chunks on one XCD); 0: dealt in id order
+  int only;                                    // -1: both critics; 0 / 1: critic_x / critic_z alone (the per-iteration entry points run one critic's
+                                               // iteration as a one-iteration phase: launch grids carry that critic only)
   int fault_it;                                // tests (HYPAD_EPOCH_TEST_GIVE_UP_SHIFT): > 0 = critic_x chunk 0 of signal 0 behaves as if its
                                                // wait for the siblings' shares had timed out at that iteration
 };
@@ -331,7 +333,8 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
 template <int SC, int LC>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WPE, HYPAD_PRE_WPE))) void critic_phase_precompute_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  precompute_body<false, SC, LC>(ax, az, ph, smem, blockIdx.x, blockIdx.y, blockIdx.z >> 1, blockIdx.z & 1, gridDim.y);
+  precompute_body<false, SC, LC>(ax, az, ph, smem, blockIdx.x, blockIdx.y, ph.only < 0 ? blockIdx.z >> 1 : blockIdx.z, ph.only < 0 ? blockIdx.z & 1 : ph.only,
+                                 gridDim.y);
 }
 typedef void (*PreKernel)(IterArgs, IterArgs, PhaseArgs);
 inline PreKernel precompute_kernel(int S, int L) {
@@ -891,7 +894,7 @@ template <int SC, int LC, int BC>
 __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterArgs az, PhaseArgs ph) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (XS && (blockIdx.x & 7) != (blockIdx.y & 7)) return;
-  if (blockIdx.z == 0) critic_iteration_body<true, SC, LC, BC>(ax, ph, smem); else critic_iteration_body<false, SC, LC, BC>(az, ph, smem);
+  if ((ph.only < 0 ? (int)blockIdx.z : ph.only) == 0) critic_iteration_body<true, SC, LC, BC>(ax, ph, smem); else critic_iteration_body<false, SC, LC, BC>(az, ph, smem);
 }
 
 
@@ -1637,8 +1640,12 @@ __global__ __launch_bounds__(FT) void critic_persistent_kernel(IterArgs ax, Iter
   else critic_persistent_body<false, SC, LC, BC>(az, ph, smem, c >> 1, chunk, ns);
 }
 
-__global__ void advance_counters_kernel(int32_t* counters, int n) {
-  if (threadIdx.x == 0) { counters[0] += n; counters[1] += n; counters[3] += n; }
+__global__ void advance_counters_kernel(int32_t* counters, int n, int only) {
+  if (threadIdx.x == 0) {
+    if (only != 1) counters[0] += n;
+    if (only != 0) counters[1] += n;
+    counters[3] += n;
+  }
 }
 
 }  // namespace
@@ -1765,7 +1772,7 @@ void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_flo
 
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
-                     const unsigned* zeroed, int flags) {
+                     const unsigned* zeroed, int flags, int only) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
   const PhasePlan plan = plan_phase(d, extra_floats, n_iters, flags);
@@ -1799,6 +1806,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   PhaseArgs ph{};
   ph.fault_it = (flags >> HYPAD_EPOCH_TEST_GIVE_UP_SHIFT) & 0xff;
   ph.n_signals = n_signals;
+  ph.only = only;
   { const char* xenv = getenv("HYPAD_CRITIC_XCD"); ph.xcd_stretch = (xenv && xenv[0] == '0') ? 0 : 1; }
   { const char* cenv = getenv("HYPAD_CRITIC_CLEAR"); ph.clear_each = (cenv && cenv[0] == '1') ? 1 : 0; }
   // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
@@ -1861,7 +1869,7 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     const bool fold = persistent && !fused && sync_bytes / 4 <= (size_t)nchunks * n_signals * 2 * n * TB;
     ph.zero_ptr = fold ? ph.flags : nullptr; ph.zero_words = fold ? (int)(sync_bytes / 4) : 0; ph.advance = persistent ? 1 : 0;
     if (!fused) {
-      hipLaunchKernelGGL(precompute_kernel(ax.S, ax.L), dim3(nchunks, n_signals, 2 * n), dim3(TB), lds_pre, s, ax, az, ph);
+      hipLaunchKernelGGL(precompute_kernel(ax.S, ax.L), dim3(nchunks, n_signals, (only < 0 ? 2 : 1) * n), dim3(TB), lds_pre, s, ax, az, ph);
       HYPAD_CHECK_LAUNCH();
     }
     if (ev) (void)hipEventRecord(ev[1], s);
@@ -1879,14 +1887,14 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     } else {
       for (int it = 0; it <= n; ++it) {                  // launch n: finalise (last Adam step -> arenas)
         ph.it = it;
-        const dim3 grid((1 << XS) * (it == n ? 1 : nchunks), n_signals, 2);
+        const dim3 grid((1 << XS) * (it == n ? 1 : nchunks), n_signals, only < 0 ? 2 : 1);
         hipLaunchKernelGGL(kern, grid, dim3(FT), lds, s, ax, az, ph);
         HYPAD_CHECK_LAUNCH();
         if (ev && (it == 0 || it == n - 1)) (void)hipEventRecord(ev[it == 0 ? 2 : 3], s);
       }
     }
     if (!persistent) {
-      hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n);
+      hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, s, ax.counters, n, only);
       HYPAD_CHECK_LAUNCH();
     }
   }

@@ -1238,13 +1238,15 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
 }
 // where the scoring kernel's padded critic_x image sits in its workspace: behind the packed generator weights, 16-byte aligned
 HD int score_critic_offset(int S, int L, int hyperbolic) { return (gen_pack(S, L, hyperbolic).total + 3) & ~3; }
-PackTable pack_table(const hypad_dims& dm, bool with_critic = false, bool with_snapshot = false) {
+// nets: bit 0 the encoder's copies, bit 1 the decoder's; forward_only: without the transposed copies of the backward products
+PackTable pack_table(const hypad_dims& dm, bool with_critic = false, bool with_snapshot = false, int nets = 3, bool forward_only = false) {
   const int S = dm.signal_shape, L = dm.latent_dim;
   const EncLayout el = enc_layout(S, L);
   const DecLayout dl = dec_layout(S, L, dm.hyperbolic);
   const GenPack gp = gen_pack(S, L, dm.hyperbolic);
   PackTable t; t.n = 0; t.max_units = 0;
   auto push = [&](int kind, int net, int dst, int nout, int kred, int src0, int src1, int ld, int H) {
+    if (!(nets & (net == HYPAD_NET_ENCODER ? 1 : 2)) || (forward_only && (kind == 2 || kind == 3))) return;
     PackDesc d{kind, net, dst, nout, kred, src0, src1, ld, H};
     t.d[t.n++] = d;
     const int units = kind == 4 ? ((nout + 15) & ~15) : ((nout + 15) >> 4) * ((kred + 15) >> 4) * 64;
@@ -1293,8 +1295,8 @@ PackTable pack_table(const hypad_dims& dm, bool with_critic = false, bool with_s
 // zero_ptr / zero_words: a block the next launches need zeroed (the critic phase's epoch words and flags), one word per thread
 // snap: where to snapshot the critics' state for hypad_epoch_restore, or null
 int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned* zero_ptr = nullptr, int zero_words = 0, bool* zeroed = nullptr,
-                bool with_critic = false, float* snap = nullptr) {
-  const PackTable t = pack_table(dm, with_critic, snap != nullptr);
+                bool with_critic = false, float* snap = nullptr, int nets = 3, bool forward_only = false) {
+  const PackTable t = pack_table(dm, with_critic, snap != nullptr, nets, forward_only);
   const dim3 grid((t.max_units + 255) / 256, t.n, dm.n_signals);
   const bool z = zero_ptr && zero_words > 0 && (int64_t)zero_words <= (int64_t)grid.x * grid.y * grid.z * 256;
   if (zeroed) *zeroed = z;
@@ -1702,12 +1704,49 @@ int hypad_packed_region(const hypad_dims* d, int64_t* offset_floats, int64_t* si
   if (count_floats) *count_floats = gen_pack(d->signal_shape, d->latent_dim, d->hyperbolic).total;
   return HYPAD_OK;
 }
+// One critic's iteration as a ONE-ITERATION PHASE of the hoisted form (critic_fused.hip): pack the frozen generator half the critic
+// looks at (forward copies only), record precompute (decoder(z) or encoder(x), noise / interpolation / dropout -> record), the
+// iteration launch (register-resident MFMA chains -> gradient slabs) and its finalising launch (slab reduction, whole-batch norm,
+// Adam, weights and moments back to the arenas, loss row) -- ~40 us of GPU time against 76 (critic_x) / 47 (critic_z) for the
+// stand-alone pass / gradient-penalty / dW launches below, whose critic passes run on the vector ALU.  Taken when the caller's
+// workspace has room for it (hypad_epoch_workspace_bytes(dims, 1, 1)) and the shape fits the iteration kernel; HYPAD_ITER_PHASE=0
+// keeps the stand-alone launches.  Same arithmetic per row as the epoch's critic phase; against the stand-alone launches only the
+// floating-point summation order (and the device dropout streams) differ.
+static int run_critic_single(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, int critic, hipStream_t s, bool* taken) {
+  *taken = false;
+  static const int enabled = getenv("HYPAD_ITER_PHASE") ? atoi(getenv("HYPAD_ITER_PHASE")) : 1;
+  if (!enabled || check_dims(d) || !critic_phase_supported(*d)) return HYPAD_OK;
+  const size_t base = epoch_base_floats(*d);
+  const size_t have = io->workspace_bytes / sizeof(float);
+  if (!io->workspace || have < base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d)) return HYPAD_OK;
+  IterCall c = from_io(io);
+  IterArgs ax, az;
+  int rc = fill_args(ax, d, st, c, 0);
+  if (!rc) rc = fill_args(az, d, st, c, 1);
+  if (rc) return rc;
+  *taken = true;
+  rc = launch_pack(critic == 0 ? ax : az, *d, s, nullptr, 0, nullptr, false, nullptr, critic == 0 ? 2 : 1, true);
+  if (rc) return rc;
+  hypad_epoch_noise nz{};
+  const bool inj = io->drop.train_mode && io->drop.masks;
+  if (critic == 0) { nz.z_cx = io->z; nz.alpha_cx = io->alpha; nz.masks_cx = inj ? io->drop.masks : nullptr; }
+  else { nz.z_cz = io->z; nz.alpha_cz = io->alpha; nz.masks_cz = inj ? io->drop.masks : nullptr; }
+  // (the phase files critic_x's loss row at row 0 and critic_z's at row 1 of an iteration: the caller's row is row `critic`)
+  return run_critic_phase(ax, az, io->row_index, 1, io->losses - 4 * critic, (float*)io->workspace + base, have - base, d->n_signals, s, nullptr,
+                          &nz, nullptr, nullptr, HYPAD_EPOCH_PER_ITERATION, critic);
+}
 int hypad_critic_x_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
   if (!io) return HYPAD_EINVAL;
+  bool taken = false;
+  const int rc = run_critic_single(d, st, io, 0, (hipStream_t)s, &taken);
+  if (taken || rc) return rc;
   return run_cx(d, st, from_io(io), (hipStream_t)s);
 }
 int hypad_critic_z_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {
   if (!io) return HYPAD_EINVAL;
+  bool taken = false;
+  const int rc = run_critic_single(d, st, io, 1, (hipStream_t)s, &taken);
+  if (taken || rc) return rc;
   return run_cz(d, st, from_io(io), (hipStream_t)s);
 }
 int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, hypad_stream_t s) {

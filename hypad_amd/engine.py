@@ -160,10 +160,23 @@ class Engine:
         _C.check(fn(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), fn.__name__)
         return losses
 
+    # Critic iterations as one-iteration phases of the hoisted form (include/hypad.h, hypad_critic_x_iteration: taken when the workspace
+    # has room).  GPU time per call 45 / 29 us instead of 66 / 39 (critic_x / critic_z), but five launches instead of three: the
+    # reference-style Python loop (bench.py `drop_in`) is bound by the host and comes out SLOWER with it (70.5 against 62.5 us per
+    # iteration), so it is off by default; worth turning on where the calls are captured into a graph or enqueued from a faster host.
+    iteration_phase = os.environ.get("HYPAD_ENGINE_ITER_PHASE", "0") == "1"
+
+    def _room_for_iteration_phase(self):
+        if self.iteration_phase and not self.__dict__.get("_iter_phase_room"):
+            self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 1, 1))
+            self._iter_phase_room = True
+
     def critic_x_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None, x_row_stride=0):
+        self._room_for_iteration_phase()
         return self._iter(_C.lib.hypad_critic_x_iteration, x, row_index, z, alpha, train_mode, masks, x_row_stride)
 
     def critic_z_iteration(self, x, row_index=None, z=None, alpha=None, train_mode=True, masks=None, x_row_stride=0):
+        self._room_for_iteration_phase()
         return self._iter(_C.lib.hypad_critic_z_iteration, x, row_index, z, alpha, train_mode, masks, x_row_stride)
 
     def decoder_iteration(self, x, row_index=None, z=None, train_mode=True, masks=None, x_row_stride=0):

@@ -28,36 +28,42 @@ _NET_OF = {tadgan.Encoder: "enc", tadgan.Decoder: "dec", tadgan.CriticX: "cx", t
 
 
 class _NoiseStage:
-    """Host-drawn noise of one iteration -> device in ONE copy: a ring of pinned host rows [z | alpha] and device rows of the
-    same shape.  NumPy / torch CPU write their draws straight into the pinned row; one non-blocking H2D follows.  A pinned row
-    must not be refilled while its copy is still in flight: the ring is walked in groups of GROUP slots, ONE event is recorded
-    behind a group's last copy and awaited before the group's first slot is refilled a lap later (an event per copy cost ~15 us
-    of host time per iteration: torch's record() looks the current stream up every time).  The device row is protected by
-    stream order: the kernels that read it precede the next copy into it."""
+    """Host-drawn noise of one iteration -> the kernels, without a copy launch: a ring of PINNED host rows [z | alpha].  NumPy /
+    torch CPU write their draws straight into the pinned row and the iteration's first kernel reads it over PCIe through the
+    row's own address (pinned host memory is mapped into the device's address space: 27 KB, read once, ~3 us) -- the
+    non-blocking H2D copy this replaces cost ~10 us of host time per iteration (a torch copy_ launch plus views), in a loop that
+    is bound by the host.  A pinned row must not be refilled while a kernel may still read it: the ring is walked in groups of
+    GROUP slots; on entering a group, ONE event is recorded for the group just left (it covers every kernel enqueued so far) and
+    the event recorded for this group a lap ago is awaited.  HYPAD_DROPIN_ZEROCOPY=0: one H2D copy per iteration into a device
+    row instead (the device row is protected by stream order)."""
     SLOTS, GROUP = 32, 8
+    ZEROCOPY = os.environ.get("HYPAD_DROPIN_ZEROCOPY", "1") != "0"
 
     def __init__(self, device, floats):
         self.floats = floats
         self.host = torch.empty(self.SLOTS, floats, dtype=torch.float32).pin_memory()
         self.host_np = self.host.numpy()
-        self.dev = torch.empty(self.SLOTS, floats, dtype=torch.float32, device=device)
+        self.dev = None if self.ZEROCOPY else torch.empty(self.SLOTS, floats, dtype=torch.float32, device=device)
         self.events = [None] * (self.SLOTS // self.GROUP)
         self.k = self.SLOTS - 1
 
     def slot(self):
         k = self.k = (self.k + 1) % self.SLOTS
-        if k % self.GROUP == 0 and self.events[k // self.GROUP] is not None:
-            self.events[k // self.GROUP].synchronize()
+        if k % self.GROUP == 0:
+            ng = self.SLOTS // self.GROUP
+            g, left = k // self.GROUP, (k // self.GROUP - 1) % ng
+            ev = self.events[left]
+            if ev is None:
+                ev = self.events[left] = torch.cuda.Event()
+            ev.record()                                   # everything enqueued so far: the readers of the group just left among it
+            if self.events[g] is not None:
+                self.events[g].synchronize()              # the readers of this group's rows, a lap ago
         return k
 
     def upload(self, k):
+        if self.ZEROCOPY:
+            return self.host[k]
         self.dev[k].copy_(self.host[k], non_blocking=True)
-        if k % self.GROUP == self.GROUP - 1:
-            g = k // self.GROUP
-            ev = self.events[g]
-            if ev is None:
-                ev = self.events[g] = torch.cuda.Event()
-            ev.record()
         return self.dev[k]
 
 
