@@ -37,7 +37,7 @@ class _NoiseStage:
     the event recorded for this group a lap ago is awaited.  HYPAD_DROPIN_ZEROCOPY=0: one H2D copy per iteration into a device
     row instead (the device row is protected by stream order)."""
     SLOTS, GROUP = 32, 8
-    ZEROCOPY = os.environ.get("HYPAD_DROPIN_ZEROCOPY", "1") != "0"
+    ZEROCOPY = os.environ.get("HYPAD_DROPIN_ZEROCOPY", "0") == "1"
 
     def __init__(self, device, floats):
         self.floats = floats
@@ -187,10 +187,48 @@ def _sample(sample, params):
                             f"{tuple(sample.shape)}: build the DataLoader with drop_last=True (main.py:38) -- the fused iterations are "
                             "bound to one batch size") from e
     if not x.is_cuda:
-        x = x.cuda()
+        x = _SampleStage.get(x).upload(x)
     if x.dtype != torch.float32:
         x = x.to(torch.float32)
     return x if x.is_contiguous() else x.contiguous()
+
+
+class _SampleStage:
+    """A minibatch that arrives in host memory (the reference's DataLoader yields CPU tensors): `sample.cuda()` from pageable memory
+    is a blocking copy -- the host stops until every kernel enqueued before it has run, so host and GPU time of an iteration add
+    up.  Instead the sample is copied into a ring of pinned rows (a 51 KB memcpy) and goes to the device with a non-blocking
+    copy; one event per GROUP rows guards the ring (recorded on entering the next group, awaited a lap later)."""
+    SLOTS, GROUP = 16, 4
+    _rings = {}
+
+    @classmethod
+    def get(cls, x):
+        key = (tuple(x.shape), x.dtype)
+        ring = cls._rings.get(key)
+        if ring is None:
+            ring = cls._rings[key] = cls(x)
+        return ring
+
+    def __init__(self, x):
+        self.host = torch.empty((self.SLOTS,) + tuple(x.shape), dtype=x.dtype).pin_memory()
+        self.dev = torch.empty((self.SLOTS,) + tuple(x.shape), dtype=x.dtype, device="cuda")
+        self.events = [None] * (self.SLOTS // self.GROUP)
+        self.k = self.SLOTS - 1
+
+    def upload(self, x):
+        k = self.k = (self.k + 1) % self.SLOTS
+        if k % self.GROUP == 0:
+            ng = self.SLOTS // self.GROUP
+            g, left = k // self.GROUP, (k // self.GROUP - 1) % ng
+            ev = self.events[left]
+            if ev is None:
+                ev = self.events[left] = torch.cuda.Event()
+            ev.record()
+            if self.events[g] is not None:
+                self.events[g].synchronize()
+        self.host[k].copy_(x)
+        self.dev[k].copy_(self.host[k], non_blocking=True)
+        return self.dev[k]
 
 
 def _train_flag(*mods):

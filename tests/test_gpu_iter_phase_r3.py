@@ -58,14 +58,17 @@ def test_the_phase_form_is_faster_on_the_gpu_and_counts_steps_alike(phase):
         z = torch.randn(1, 64, 20, device=dev); ax = torch.rand(1, 64, 100, device=dev); az = torch.rand(1, 64, 20, device=dev)
         for _ in range(3):
             eng.critic_x_iteration(xb, None, z, ax, train_mode=False); eng.critic_z_iteration(xb, None, z, az, train_mode=False)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(20_000_000)
-        a.record()
-        for _ in range(50):
-            eng.critic_x_iteration(xb, None, z, ax, train_mode=False)
-        b.record(); torch.cuda.synchronize()
-        out[on] = (a.elapsed_time(b) / 50 * 1e3, eng.counters.cpu().tolist()[:4], eng.params["cx"].clone())
+        best = float("inf")
+        for _ in range(5):                              # (GPU time behind a sleeping stream; the best of five: a host hiccup must not count)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(20_000_000)
+            a.record()
+            for _ in range(10):
+                eng.critic_x_iteration(xb, None, z, ax, train_mode=False)
+            b.record(); torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / 10 * 1e3)
+        out[on] = (best, eng.counters.cpu().tolist()[:4], eng.params["cx"].clone())
     print("critic_x GPU us per call: phase form %.1f, stand-alone launches %.1f" % (out[True][0], out[False][0]))
     assert out[True][1] == out[False][1] == [53, 3, 0, 56]
     assert out[True][0] < 0.85 * out[False][0]
