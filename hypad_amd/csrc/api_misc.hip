@@ -105,16 +105,25 @@ __global__ __launch_bounds__(SHUF_THREADS) void epoch_shuffle_kernel(int32_t* __
     keys[i] = k;
   }
   __syncthreads();
+  // 66 compare-exchange stages at 2 048 keys.  Pair t sits in elements [128 (t / 64), 128 (t / 64) + 128) whenever stride < 64, and
+  // a stage with stride 64 reads what the stride-128 stage (other waves) wrote: so only the stages with stride >= 64 -- and the one
+  // right behind such a stage -- need the workgroup barrier (14 + 4 of the 66); in between, the 64 pairs of a wave touch 128 elements
+  // no other wave touches and a wave barrier is enough.  (Measured: 21.5 -> 20.6 us per launch -- the sort is bound by the 66 dependent
+  // LDS round trips themselves, not by the barriers; what would shorten it is keeping the strides below 64 in registers.)
+  bool wide = true;                                                       // the previous stage exchanged across waves (or the fill did)
   for (int size = 2; size <= npow2; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (wide || stride >= 64) __syncthreads();
+      else { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xc07f); }
+      wide = stride >= 64;
       for (int t = threadIdx.x; t < npow2 / 2; t += SHUF_THREADS) {
         const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;     // the pair (lo, lo + stride) of this compare-exchange
         const bool up = (lo & size) == 0;
         const unsigned long long a = keys[lo], b = keys[hi];
         if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
       }
-      __syncthreads();
     }
+  __syncthreads();
   for (int i = threadIdx.x; i < take; i += SHUF_THREADS) out[(int64_t)blockIdx.x * take + i] = (int32_t)(unsigned)keys[i];
 }
 
