@@ -580,7 +580,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get("HYPAD_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
+        # (HYPAD_BENCH_FORCE_DIST=1 under the launcher at ONE rank: the RCCL barrier / max-over-ranks path of the multi-GPU line, exercised
+        # on the one GPU a box has -- scripts/check_launcher.sh)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
