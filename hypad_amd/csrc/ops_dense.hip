@@ -148,8 +148,9 @@ __global__ __launch_bounds__(THREADS) void lstm_fwd_kernel(const float* __restri
 #ifndef HYPAD_LSTM_EXP
 #define HYPAD_LSTM_EXP 0        // development what-if: 1 folds the saved gates of all tiles onto 1 024 rows (same instructions, no HBM writes)
 #endif
-template <int KG>                      // k-groups of 16: in_dim <= 16 KG
-__global__ __launch_bounds__(512) void lstm_fwd_lds_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
+template <int KG, int NW>              // k-groups of 16: in_dim <= 16 KG; NW waves per workgroup (16 where the registers allow: more waves to put
+                                       // under the layer's stores)
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
                                                             const float* wr, const float* bir, const float* bhr, float* __restrict__ out,
                                                             float* __restrict__ gates_save, int64_t rows, int K, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_lds_kernel(const float* __restri
   const float* __restrict__ b2 = dir ? bhr : bhf;
   const int Hp = (H + 15) & ~15, nub = Hp >> 4;
   constexpr int ld = KG * 16 + 4;
-  for (int idx = threadIdx.x; idx < 3 * Hp * ld; idx += 512) {
+  for (int idx = threadIdx.x; idx < 3 * Hp * ld; idx += 64 * NW) {
     const int g3 = idx / (Hp * ld), rem = idx - g3 * Hp * ld, n = rem / ld, k = rem - n * ld;
     smem[idx] = (n < H && k < K) ? w[(int64_t)((g3 == 0 ? 0 : g3 + 1) * H + n) * K + k] : 0.f;      // PyTorch gate order i, f, g, o
   }
@@ -179,9 +180,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_lds_kernel(const float* __restri
       else a[g] = make_float4(k0 < K ? xr[k0] : 0.f, k0 + 1 < K ? xr[k0 + 1] : 0.f, k0 + 2 < K ? xr[k0 + 2] : 0.f, k0 + 3 < K ? xr[k0 + 3] : 0.f);
     }
   };
-  const int64_t tstep = (int64_t)nslices * 8;
+  const int64_t tstep = (int64_t)nslices * NW;
   float4 a[KG], an[KG];
-  int64_t tile = (int64_t)slice * 8 + wave;
+  int64_t tile = (int64_t)slice * NW + wave;
   if (tile < ntiles) load_a(a, tile);
   for (; tile < ntiles; tile += tstep) {
     const int64_t r0 = tile << 4;
@@ -481,15 +482,24 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
     const int KG = (K + 15) >> 4, Hp = (H + 15) & ~15;
     const size_t lw = (size_t)3 * Hp * (KG * 16 + 4) * sizeof(float);
     const int64_t ntiles = (rows + 15) >> 4;
-    int nslices = (int)((ntiles + 7) / 8);
+    static const int nw_env = getenv("HYPAD_LSTM_WAVES") ? atoi(getenv("HYPAD_LSTM_WAVES")) : 0;
+    const int nw = nw_env == 8 ? 8 : 16;            // (16 waves: 357 -> 349 us at 100 -> 2 x 50, 356 -> 321 at 128 -> 2 x 64, gates saved, 200 000 rows)
+    int nslices = (int)((ntiles + nw - 1) / nw);
     if (nslices > 128) nslices = 128;
     const dim3 grid(2 * nslices);
 #define HYPAD_LSTM_LDS_LAUNCH(KGC)                                                                                               \
     do {                                                                                                                         \
-      hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC>, lw);                                                      \
-      if (e2 != hipSuccess) return (int)e2;                                                                                      \
-      hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC>), grid, dim3(512), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out,     \
-                         gates_save, rows, K, H);                                                                                \
+      if (nw == 16) {                                                                                                            \
+        hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC, 16>, lw);                                                \
+        if (e2 != hipSuccess) return (int)e2;                                                                                    \
+        hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC, 16>), grid, dim3(1024), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
+                           gates_save, rows, K, H);                                                                              \
+      } else {                                                                                                                   \
+        hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC, 8>, lw);                                                 \
+        if (e2 != hipSuccess) return (int)e2;                                                                                    \
+        hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC, 8>), grid, dim3(512), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
+                           gates_save, rows, K, H);                                                                              \
+      }                                                                                                                          \
     } while (0)
     switch (KG) {
       case 1: HYPAD_LSTM_LDS_LAUNCH(1); break; case 2: HYPAD_LSTM_LDS_LAUNCH(2); break; case 3: HYPAD_LSTM_LDS_LAUNCH(3); break;
