@@ -168,6 +168,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (rows + 15) >> 4;
   const bool vec = (K & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  const bool nt_ok = (H & 15) == 0 && gates_save && ((uintptr_t)gates_save & 63) == 0;
   // A tile: rows past the end repeat the last one (their results are not stored)
   auto load_a = [&](float4 (&a)[KG], int64_t tile) __attribute__((always_inline)) {
     const int64_t r0 = tile << 4;
@@ -234,8 +235,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
           const float tc = tanhf_(gi * gg);
           ob.st(go * tc, vo_h, r * 2 * H * 4);
           if (gates_save) {
-            gb.st(gi, vo_g, r * 8 * H * 4); gb.st(gg, vo_g, (r * 8 * H + H) * 4);
-            gb.st(go, vo_g, (r * 8 * H + 2 * H) * 4); gb.st(tc, vo_g, (r * 8 * H + 3 * H) * 4);
+            // whole, aligned 64-byte segments (hidden a multiple of 16): past the caches (non-temporal) -- 323 -> 288 us at 128 -> 2 x 64;
+            // with 200-byte gate rows (hidden 50) the same hint makes partial lines and costs 100 us, so it is not given there
+            if (nt_ok) {
+              auto nt = [&](float v, int so) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), gb.rs, vo_g, so, 2); };
+              nt(gi, r * 8 * H * 4); nt(gg, (r * 8 * H + H) * 4); nt(go, (r * 8 * H + 2 * H) * 4); nt(tc, (r * 8 * H + 3 * H) * 4);
+            } else {
+              gb.st(gi, vo_g, r * 8 * H * 4); gb.st(gg, vo_g, (r * 8 * H + H) * 4);
+              gb.st(go, vo_g, (r * 8 * H + 2 * H) * 4); gb.st(tc, vo_g, (r * 8 * H + 3 * H) * 4);
+            }
           }
         }
       }
