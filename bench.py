@@ -402,6 +402,19 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
                "what": "value = test-loop forward + reconstruction numerics (un-roll median, point + DTW(11) errors, rolling mean(200), z-score) "
                        "+ the KDE critic smoothing score_anomalies runs (utils/anomaly_detection_utils.py:470-506); host wall clock around "
                        "the wrappers; without_kde_value = the first two only (the figure of rounds 1-2)"}
+    # the same pass when the window matrix arrives in (pinned) host memory: one 50 MB H2D copy per pass in front of the forward --
+    # reported next to `value`, never as it (inputs resident in HBM is the contract's figure); the series view of the scorers
+    # (x_row_stride = 1: windows n = series[n : n + S]) moves 0.5 MB instead
+    x_host = x.cpu().pin_memory()
+    series_host = torch.empty(n + S - 1, dtype=torch.float32).pin_memory()
+    x_dev, series_dev = torch.empty_like(x), torch.empty(n + S - 1, dtype=torch.float32, device=device)
+    t_h2d = timed(lambda: x_dev.copy_(x_host, non_blocking=True))
+    t_h2d_series = timed(lambda: series_dev.copy_(series_host, non_blocking=True))
+    scoring["pcie_inclusive"] = {"window_matrix_value": n / (t_fwd + t_num + t_kde + t_h2d), "h2d_ms": 1e3 * t_h2d,
+                                 "h2d_GB_per_s": x.numel() * 4 / t_h2d / 1e9,
+                                 "series_view_value": n / (t_fwd + t_num + t_kde + t_h2d_series), "series_h2d_ms": 1e3 * t_h2d_series,
+                                 "what": "value with the input crossing PCIe from pinned host memory in front of every pass: the (N, S) fp32 window "
+                                         "matrix, or the scaled series the windows are views of"}
     if cpu_sample:
         scoring["cpu_baseline"] = cpu_scoring_baseline(cpu_sample)
 

@@ -1,0 +1,5 @@
+import sys, json
+sys.path.insert(0, ".")
+import torch, bench
+sc = bench.bench_scoring(torch.device("cuda", 0), cpu_sample=0)[0]
+print(json.dumps({"value": sc["value"], **sc["pcie_inclusive"]}))
