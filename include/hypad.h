@@ -278,7 +278,8 @@ typedef struct hypad_epoch_io {
    * by an event after the critic phase, joined into it before the call returns its last launches -- so one group's optimizer
    * launch overlaps another group's generator launch.  Results are the same bits with any number of streams (the step number and
    * rng tick of every launch are its own arguments; the counters advance once, after the join).  Capturable like everything else:
-   * the groups become parallel branches of the captured graph.  NULL / 0: everything on `stream`. */
+   * the groups become parallel branches of the captured graph.  NULL / 0: everything on `stream`.  Calls that pass auxiliary streams
+   * share one process-wide set of fork / join events: issue them from one host thread at a time. */
   hypad_stream_t const* aux_streams; int n_aux_streams;
 } hypad_epoch_io;
 enum {
