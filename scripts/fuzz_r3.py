@@ -1,0 +1,52 @@
+"""One-off randomized checks of the round-3 kernels against their references (not part of the test suite; prints mismatches):
+device quantiles vs np.quantile (exact), KDE modes vs scipy (up to fp64 ties), the weights-stationary LSTM layer vs torch."""
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np, torch
+from hypad_amd import _C
+from hypad_amd.utils import anomaly_detection_utils as adu
+from oracle import scoring as osc
+import test_gpu_parity as tp
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+# ---- quantiles
+for trial in range(400):
+    n = int(rng.integers(1, 6000))
+    kind = trial % 5
+    x = [rng.standard_normal(n), rng.integers(-3, 4, n).astype(float), rng.standard_normal(n).astype(np.float32).astype(float),
+         np.exp(rng.standard_normal(n) * 20), -np.abs(rng.standard_t(1.5, n))][kind]
+    q = tuple(float(v) for v in rng.uniform(0, 1, int(rng.integers(1, 3))))
+    got = adu.quantiles(torch.from_numpy(x).cuda(), q).cpu().numpy()
+    ref = np.quantile(x, q)
+    if not np.array_equal(got, ref, equal_nan=True):
+        bad += 1; print("quantile mismatch", n, kind, q, got, ref)
+print("quantiles done")
+# ---- KDE modes
+for trial in range(40):
+    w = int(rng.integers(2, 257)); n = int(rng.integers(1, 120))
+    cr = [rng.standard_normal(n), rng.standard_t(2, n), np.round(rng.standard_normal(n) * 3) / 3, 1e4 + rng.standard_normal(n) * 1e-2][trial % 4].astype(np.float32)
+    got = adu.kde_modes(cr, w).cpu().numpy()
+    ext = np.repeat(cr.astype(np.float64).reshape(-1, 1), w, axis=1)
+    ref = np.array([osc.kde_mode(osc.antidiagonal(ext, i)) for i in range(n + w - 1)])
+    try:
+        tp._assert_same_modes_up_to_fp64_ties(cr, w, got, ref)
+    except AssertionError as e:
+        bad += 1; print("kde mismatch", w, n, trial % 4, str(e)[:200])
+print("kde done")
+# ---- LSTM layer, weights-stationary form
+for trial in range(24):
+    rows = int(rng.integers(2048, 5000)); K = int(rng.integers(1, 129)); H = int(rng.integers(1, 65))
+    torch.manual_seed(trial)
+    lstm = torch.nn.LSTM(K, H, 1, bidirectional=True)
+    x = torch.randn(1, rows, K)
+    with torch.no_grad():
+        out, _ = lstm(x)
+    names = ["weight_ih_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    d = [getattr(lstm, nme).detach().cuda().contiguous() for nme in names]
+    dx = x.view(rows, K).cuda().contiguous()
+    o = torch.empty(rows, 2 * H, device="cuda"); gs = torch.full((rows, 8 * H), float("nan"), device="cuda")
+    _C.check(_C.lib.hypad_lstm_bidir_fwd(_C.ptr(dx), *[_C.ptr(t) for t in d], _C.ptr(o), _C.ptr(gs), rows, K, H, _C.stream()))
+    err = float((o.cpu() - out.view(rows, 2 * H)).abs().max())
+    if err > 1e-5 or not bool(torch.isfinite(gs).all()):
+        bad += 1; print("lstm mismatch", rows, K, H, err)
+print("lstm done; mismatches:", bad)
