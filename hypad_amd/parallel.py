@@ -157,6 +157,27 @@ def sharded_hyperbolic_scores(n_windows, window, evaluate, kde_modes, finish, ne
 
 
 _WS_CACHE = {}
+_GRAPHS = {}
+
+
+def replay_scorer(fn, *tensors, key=()):
+    """A scorer call as ONE hipGraph: ``fn()`` -- a call of ``score_windows_sharded`` / ``score_anomalies_sharded`` with
+    ``as_tensor=True`` on device-resident inputs -- is a fixed launch sequence (two large kernels and ~25 small ones, the
+    collectives included; nothing passes through the host), so repeated scoring of same-shaped inputs can replay it instead of
+    enqueueing it: captured on first use (after one eager call: scratch buffers, RCCL set-up), keyed by ``key`` and the addresses /
+    shapes of ``tensors`` (the inputs and weights the capture froze; refill them in place between calls).  Returns the scores as
+    the graph's own output tensor: it is overwritten by the next replay -- copy it to keep it."""
+    k = (key,) + tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors)
+    ent = _GRAPHS.get(k)
+    if ent is None:
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        ent = _GRAPHS[k] = (g, out)
+    ent[0].replay()
+    return ent[1]
 
 
 def _score_workspace(device, S, L, hyperbolic):

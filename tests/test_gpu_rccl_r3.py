@@ -80,6 +80,17 @@ def _worker(rank, port, ret):
             # reconstructions with the stand-alone kernel: same formula, possibly another summation order)
             assert np.array_equal(got_m, got_s), comb
             np.testing.assert_allclose(got_m, want, rtol=1e-6, atol=1e-9)
+        # ---- the scorer call replayed as ONE hipGraph (collectives captured with it): same scores as the eager call, also after the
+        # input was refilled in place
+        series_d = torch.from_numpy(series).cuda().float().contiguous()
+        eager = par.score_windows_sharded(series_d, enc, dec, cx, S, "mult", x_row_stride=1, as_tensor=True).clone()
+        call = lambda: par.score_windows_sharded(series_d, enc, dec, cx, S, "mult", x_row_stride=1, as_tensor=True)
+        rep = lambda: par.replay_scorer(call, series_d, enc.arena(), dec.arena(), cx.arena(), key="test")
+        assert torch.equal(rep(), eager) and torch.equal(rep(), eager)
+        series_d.copy_(torch.from_numpy(_windows(n, S)[::-1].copy()).cuda().float())
+        eager2 = call().clone()
+        assert not torch.equal(eager2, eager) and torch.equal(rep(), eager2)
+        out["graph_replays"] = 3
         out["calls"] = dict(calls)
         ret[0] = out
     finally:
@@ -92,5 +103,5 @@ def test_sharded_scorers_through_a_one_rank_rccl_group_equal_the_unsharded_pipel
     mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
     out = ret[0]
     print("RCCL:", out)
-    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["backend"] == "nccl" and out["world"] == 1 and out["graph_replays"] == 3
     assert out["calls"]["broadcast"] >= 6 and out["calls"]["all_gather_into_tensor"] >= 10 and out["calls"]["all_reduce"] >= 2
