@@ -402,6 +402,20 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
                "what": "value = test-loop forward + reconstruction numerics (un-roll median, point + DTW(11) errors, rolling mean(200), z-score) "
                        "+ the KDE critic smoothing score_anomalies runs (utils/anomaly_detection_utils.py:470-506); host wall clock around "
                        "the wrappers; without_kde_value = the first two only (the figure of rounds 1-2)"}
+    # the whole pass as ONE replayed hipGraph (parallel.replay_scorer: the pass is a fixed launch sequence -- nothing goes through the host):
+    # reported next to `value`
+    try:
+        from hypad_amd import parallel as par
+
+        def whole():
+            forward()
+            return numerics() + (critic_smoothing(),)
+        rep = lambda: par.replay_scorer(whole, x, enc.arena(), dec.arena(), cx.arena(), key="bench_scoring")
+        rep()
+        scoring["graph_replay_value"] = n / timed(rep)
+    except Exception as e:
+        scoring["graph_replay_value"] = f"{type(e).__name__}: {e}"[:200]
+
     # the same pass when the window matrix arrives in (pinned) host memory: one 50 MB H2D copy per pass in front of the forward --
     # reported next to `value`, never as it (inputs resident in HBM is the contract's figure); the series view of the scorers
     # (x_row_stride = 1: windows n = series[n : n + S]) moves 0.5 MB instead
