@@ -681,10 +681,48 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
       double inv = 0.0;
       if (__builtin_amdgcn_readfirstlane(besti) == 0x7fffffff) inv = 0.5 / cov;          // (only the fp64 pass needs it)
       for (int round = 0; round < (HYPAD_KDE_EXP == 2 ? 0 : 2) && besti == 0x7fffffff; ++round) {
+        // First the candidates' fp64 densities as TREE sums (a lane's own terms, then the wave's butterfly: no LDS, no sequential add):
+        // either order of adding <= 256 positive terms is within 3e-14 of the exact sum, so a candidate more than 1e-12 below the
+        // largest tree sum cannot be the arg-max of the ordered sums either.  One survivor (the usual case): it is the arg-max, and
+        // the ordered sums -- a lane adding 100 terms one after the other: half of this pass's time -- are not taken at all; several
+        // (equal samples, true near-ties): only those go through the ordered sums below, which decide as before.
+        bool keep[KPL];
+        {
+          double dq[KPL];
+#pragma unroll
+          for (int u = 0; u < KPL; ++u) dq[u] = -1.0;
+#pragma unroll
+          for (int u = 0; u < KPL; ++u) {
+            unsigned long long mask = __ballot(lane + 64 * u < cnt && (round == 1 || d32[u] >= thr));
+            while (mask) {                                                        // wave-uniform
+              const int k = __builtin_ctzll(mask) + 64 * u;
+              mask &= mask - 1;
+              const double xk = v[k];
+              double loc = 0.0;
+              for (int m = lane; m < cnt; m += 64) { const double d = xk - v[m]; loc += exp(-d * d * inv); }
+              const double dp = wave_sum(loc);
+              if (lane == (k & 63)) dq[u] = dp;
+            }
+          }
+          double mx2 = -1.0;
+#pragma unroll
+          for (int u = 0; u < KPL; ++u) mx2 = fmax(mx2, dq[u]);
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mx2 = fmax(mx2, __shfl_xor(mx2, off, WAVE));
+          const double thr2 = mx2 * (1.0 - 1e-12);
+          int nkeep = 0, first = 0x7fffffff;
+#pragma unroll
+          for (int u = 0; u < KPL; ++u) {
+            keep[u] = dq[u] >= thr2 && dq[u] > 0.0;
+            const unsigned long long mk = __ballot(keep[u]);
+            nkeep += __builtin_popcountll(mk);
+            if (mk && first == 0x7fffffff) first = __builtin_ctzll(mk) + 64 * u;
+          }
+          if (nkeep == 1) { besti = first; break; }
+        }
 #pragma unroll
         for (int u = 0; u < KPL; ++u) {
-          const int ku = lane + 64 * u;
-          unsigned long long mask = __ballot(ku < cnt && (round == 1 || d32[u] >= thr));
+          unsigned long long mask = __ballot(keep[u]);
           while (mask) {                                                          // wave-uniform
             int kc[KDE_CB];
             int nb = 0;
@@ -724,7 +762,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
           }
         }
       }
-      out = v[besti];
+      out = v[besti < cnt ? besti : 0];                    // (all densities NaN -- a covariance whose reciprocal overflows: scipy's arg-max of NaNs is 0)
     } else {
       // median by rank counting (cnt <= 256)
       double lo = 0.0, hi = 0.0;
