@@ -370,12 +370,15 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
 
     def timed(fn):
         fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        best = float("inf")
+        for _ in range(3):                  # (the fastest of three rounds of `reps` calls: an allocator hiccup must not count)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / reps)
+        return best
 
     ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 1)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=device)
