@@ -191,48 +191,100 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20):
     return out
 
 
-def bench_drop_in(hyperbolic, device, passes=2):
-    """The reference's call surface at speed: `hypad_amd.train.{critic_x,critic_z,decoder}_iteration` driven by the reference's
-    own epoch loop (train.py:315-356) -- nn.Module views of the arenas, one (B, S, 1) float64 sample per call as the
-    DataLoader hands it over, z / alpha drawn on the host by NumPy / torch exactly where the reference draws them.  Times
-    `passes` epochs of 29 x (5 + 5 + 1) iterations after one warm-up epoch."""
+def _synthetic_signal_dataset(test=False):
+    """configs[1]'s data shape through the product's own dataset class: 2 016 samples at 600 s (art_daily_jumpsup aggregated at
+    interval 600) -> 1 916 windows of 100, float64, scaled to [-1, 1] (utils/dataloader.py:61-232)."""
+    import pandas as pd
+    from hypad_amd.utils.dataloader import SignalDataset
+    n = N_WINDOWS + S
+    rng = np.random.default_rng(0)
+    t = np.arange(n)
+    v = np.sin(2 * np.pi * t / 288.0) + 0.05 * rng.standard_normal(n)
+    v[n // 2: n // 2 + 40] += 0.8
+    df = pd.DataFrame({"timestamp": 1_400_000_000 + 600 * t, "value": v})
+    return SignalDataset(df, interval=600, windows_size=S, test=test)
+
+
+def bench_drop_in(hyperbolic, device, epochs=(2, 12)):
+    """The reference's call surface at speed: ``hypad_amd.train.train_tadgan(train_loader, encoder, decoder, critic_x, critic_z,
+    n_epochs, params, path)`` -- the reference's signature (train.py:252), its epoch schedule, its host random numbers (z from
+    NumPy's global generator, alpha and the loader's seeds from torch's CPU generator, in the reference's order) -- where every
+    epoch runs as one captured hypad_train_epoch fed from host-staged planes (hypad_amd/epoch_feed.py).  Each form is timed as the
+    DIFFERENCE of two whole calls (`epochs[0]` and `epochs[1]` epochs: engine construction, graph capture and the first epoch's
+    staging cancel), i.e. steady-state windows/s of the call itself, prints and loss read-back included.
+      host_samples   -- train_loader = a list of 29 host (64, 100, 1) float64 minibatches (what round 3 timed call by call)
+      dataloader     -- torch DataLoader(SignalDataset, batch 64, shuffle, drop_last), as main.py:33-39 builds it: the index path
+      dataloader_staged -- the same loader with every batch really fetched, collated and staged (params.stage_samples)
+      call_by_call   -- the loop over critic_x_iteration / critic_z_iteration / decoder_iteration (params.per_iteration)"""
+    import contextlib
+    import io
     from types import SimpleNamespace
+    from torch.utils.data import DataLoader
+    from hypad_amd import anomaly_detection as had
     from hypad_amd import train as ht
     from hypad_amd.models import tadgan
-    P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=hyperbolic)
-    torch.manual_seed(0)
-    enc, dec, cx, cz = [m.to(device) for m in (tadgan.Encoder(S, L), tadgan.Decoder(S, L, hyperbolic), tadgan.CriticX(S, L), tadgan.CriticZ(L))]
-    opt = ht.make_optimizers(enc, dec, cx, cz, P)
-    data = torch.from_numpy(synth_windows(N_WINDOWS, S, 0)[: N_BATCHES * B, :, None])      # float64, like SignalDataset (dataloader.py:227-232)
-    np.random.seed(0)
 
-    def epoch(resident_samples):
-        n = 0
-        for _ in range(N_CRITICS):
-            for b in range(N_BATCHES):
-                sample = resident_samples[b]
-                ht.critic_x_iteration(sample, dec, cx, opt[0], P)
-                ht.critic_z_iteration(sample, enc, cz, opt[1], P)
-                n += 2
-        for b in range(N_BATCHES):
-            ht.decoder_iteration(resident_samples[b], enc, dec, cx, cz, opt[2], P)
-            n += 1
-        return n
-    out = {"what": "reference epoch loop (train.py:315-356) over hypad_amd.train's iteration functions: host NumPy/torch RNG, "
-                   "one call per iteration", "unit": "windows/s"}
-    for name, samples in (("host_samples", [data[b * B:(b + 1) * B] for b in range(N_BATCHES)]),
-                          ("device_samples", [data[b * B:(b + 1) * B].to(device) for b in range(N_BATCHES)])):
-        epoch(samples)
+    def run(loader, n_epochs, **kw):
+        P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=hyperbolic, resume=False, resume_epoch=0, **kw)
+        torch.manual_seed(0); np.random.seed(0)
+        mods = [m.to(device).train() for m in (tadgan.Encoder(S, L), tadgan.Decoder(S, L, hyperbolic), tadgan.CriticX(S, L), tadgan.CriticZ(L))]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 0
-        for _ in range(passes):
-            n += epoch(samples)
+        with contextlib.redirect_stdout(io.StringIO()):
+            hist = ht.train_tadgan(loader, *mods, n_epochs=n_epochs, params=P, path="/tmp")
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": passes * N_BATCHES * B / dt, "us_per_iteration": 1e6 * dt / n, "ms_per_epoch": 1e3 * dt / passes}
-    out["value"] = out["device_samples"]["value"]
-    out["us_per_iteration"] = out["device_samples"]["us_per_iteration"]
+        assert np.isfinite(hist.dec).all() and len(hist.dec) == n_epochs
+        return time.perf_counter() - t0, mods
+
+    def rate(loader, **kw):
+        run(loader, 1, **kw)                                  # warm-up: code paths, pinned allocations
+        best = float("inf")
+        for _ in range(2):
+            t1, _ = run(loader, epochs[0], **kw)
+            t2, mods = run(loader, epochs[1], **kw)
+            best = min(best, (t2 - t1) / (epochs[1] - epochs[0]))
+        return {"value": N_BATCHES * B / best, "ms_per_epoch": 1e3 * best, "us_per_iteration": 1e6 * best / ((2 * N_CRITICS + 1) * N_BATCHES)}, mods
+
+    data = torch.from_numpy(synth_windows(N_WINDOWS, S, 0)[: N_BATCHES * B, :, None])      # float64, like SignalDataset (dataloader.py:227-232)
+    host_list = [data[b * B:(b + 1) * B] for b in range(N_BATCHES)]
+    ds = _synthetic_signal_dataset()
+    loader = DataLoader(ds, batch_size=B, drop_last=True, shuffle=True, num_workers=0)
+    out = {"what": "hypad_amd.train.train_tadgan(train_loader, ...) -- reference signature, schedule and host RNG order; one captured "
+                   "hypad_train_epoch per epoch (epoch_feed.py); steady-state windows/s of the call (difference of a %d- and a %d-epoch call)" % epochs,
+           "unit": "windows/s", "host_cores": os.cpu_count()}
+    out["host_samples"], mods = rate(host_list)
+    out["dataloader"], _ = rate(loader)
+    out["dataloader_staged"], _ = rate(loader, stage_samples=True)
+    out["call_by_call"], _ = rate(host_list, per_iteration=True)
+    out["value"] = out["host_samples"]["value"]
+    out["ms_per_epoch"] = out["host_samples"]["ms_per_epoch"]
+    # ---- the test loop (anomaly_detection.py:67-113) through a batch-64 DataLoader, as main.py:40-46 builds it
+    enc, dec, cx = mods[0], mods[1], mods[2]
+    tds = _synthetic_signal_dataset(test=True)
+    tloader = DataLoader(tds, batch_size=B, drop_last=False, shuffle=False, num_workers=0)
+    P = SimpleNamespace(batch_size=B, signal_shape=S, hyperbolic=hyperbolic)
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    n = len(tds)
+    t_call = timed(lambda: had.test_tadgan(tloader, enc, dec, cx, path="", signal_shape=S, params=P))
+    t_per = timed(lambda: had.score_batches_per_batch(tloader, enc, dec, cx, S), reps=2)
+    big = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (125_000, S, 1)))
+    bloader = DataLoader(big, batch_size=B, drop_last=False, shuffle=False, num_workers=0)
+    t_big = timed(lambda: had.test_tadgan(bloader, enc, dec, cx, path="", signal_shape=S, params=P), reps=3)
+    out["scoring"] = {"what": "anomaly_detection.test_tadgan(test_loader, ...) through a batch-64 DataLoader (anomaly_detection.py:67-113): "
+                              "loader -> ONE fused forward -> results back as NumPy (D2H included); per_batch = one pack + forward launch per "
+                              "loader batch with every batch fetched and collated (the round-3 form)",
+                      "windows": n, "value": n / t_call, "unit": "windows/s", "ms_per_call": 1e3 * t_call,
+                      "per_batch_value": n / t_per, "per_batch_ms": 1e3 * t_per,
+                      "windows_125000": {"value": 125_000 / t_big, "ms_per_call": 1e3 * t_big,
+                                         "what": "the same call over a DataLoader of 125 000 float64 windows in host memory (one GPU's share of configs[4]): "
+                                                 "float64 -> float32 + H2D of the window matrix and the NumPy results' D2H included"}}
     return out
 
 

@@ -20,7 +20,7 @@ class HypadError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
+ABI_VERSION = 5            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
 
 
 def _load():
@@ -144,6 +144,7 @@ _SIGS = {
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
     "hypad_epoch_shuffles": (c_int, [P, c_int, c_int, c_int, c_uint64, P, P]),
+    "hypad_host_mt19937_normal": (c_int, [P, POINTER(c_int), POINTER(c_int), POINTER(c_double), POINTER(c_void_p), c_int, c_int64, c_int64]),
     "hypad_epoch_status": (c_int, [POINTER(TrainState), POINTER(c_int), P]),
     "hypad_epoch_restore": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, P]),
     "hypad_critic_phase_persistent": (c_int, [POINTER(Dims)]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libhypad_hip.so")
 DEV_LIB = os.path.join(LIB_DIR, "libhypad_hip_dev.so")
-SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "lstm_seq.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip"]
+SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "lstm_seq.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip", "host_rng.cpp"]
 DEV_SOURCES = SOURCES + ["diag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 
@@ -70,9 +70,12 @@ def _build_locked(verbose, dev):
     objs = []
     procs = []
     for src in (DEV_SOURCES if dev else SOURCES):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):               # host-only helpers (no device code): the system compiler
+            cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
+        else:
+            cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -235,13 +235,16 @@ class Engine:
                                              self.counters.data_ptr(), _C.stream()), "epoch_shuffles")
         return row_index
 
-    def train_epoch_graph(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, x_row_stride=0, shuffle_windows=0):
+    def train_epoch_graph(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, x_row_stride=0, shuffle_windows=0,
+                          noise=None):
         """train_epoch captured once into a hipGraph and replayed: the epoch is a fixed launch sequence (device counters, device
         Philox, no host round trip; include/hypad.h: "every call may be captured"), ~62 launches at the reference
         configuration.  `x`, `row_index` and `losses` must be the SAME buffers on every call (their addresses are frozen
         in the graph; refill `row_index` in place with the epoch's shuffles -- or pass ``shuffle_windows`` = number of windows
         (<= 4096): the shuffles are then drawn INSIDE the captured sequence by hypad_epoch_shuffles, fresh at every replay, and
-        `row_index` is only the buffer they land in).  Returns `losses`."""
+        `row_index` is only the buffer they land in).  ``noise``: injected planes as in train_epoch -- static device buffers too,
+        refilled in place before every replay (the drop-in train_tadgan uploads an epoch's host-drawn z / alpha planes there).
+        Returns `losses`."""
         x, _ = self._check_x(x, x_row_stride)
         iters = (2 * n_critics + 1) * n_batches
         if losses is None:
@@ -250,19 +253,20 @@ class Engine:
                 losses = self._graph_losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
         self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
         key = (x.data_ptr(), row_index.data_ptr(), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride), self.seed,
-               int(shuffle_windows), self._graph_state_key())
+               int(shuffle_windows), self._graph_state_key(),
+               tuple(sorted((k, t.data_ptr()) for k, t in (noise or {}).items() if t is not None)))
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                    # (side stream: _C.stream() is torch's current stream inside the block)
                 if shuffle_windows:
                     self.draw_shuffles(row_index, shuffle_windows)
-                self.train_epoch(x, row_index, n_batches, n_critics, train_mode, losses=losses, x_row_stride=x_row_stride)
-            graphs[key] = (g, x, row_index, losses)      # (the buffers whose addresses the graph holds stay alive with it)
+                self.train_epoch(x, row_index, n_batches, n_critics, train_mode, losses=losses, x_row_stride=x_row_stride, noise=noise)
+            graphs[key] = (g, x, row_index, losses, noise)      # (the buffers whose addresses the graph holds stay alive with it)
             # the capture itself did not execute anything
         graphs[key][0].replay()
         self._last_epoch = dict(x=x, row_index=row_index, n_batches=n_batches, n_critics=n_critics, train_mode=train_mode, losses=losses,
-                                x_row_stride=x_row_stride)
+                                x_row_stride=x_row_stride, noise=noise)
         return losses
 
     # ---- status channel of the resident critic launch (include/hypad.h: hypad_epoch_status / hypad_epoch_restore) -------------

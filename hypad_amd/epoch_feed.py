@@ -1,0 +1,217 @@
+"""Host side of ``train.train_tadgan`` (train.py:252-385) when an epoch runs as ONE captured ``hypad_train_epoch``.
+
+The reference's epoch is 5 passes of (critic_x_iteration, critic_z_iteration) and one pass of decoder_iteration over a
+shuffling DataLoader; every iteration draws its latent vectors from NumPy's global generator and its interpolation
+weights from torch's CPU generator, and every pass draws the loader's seeds from torch's generator when its
+iterator is created.  None of these draws depends on a result of the training: an epoch's worth of them can be made
+before the epoch is launched, *from the same generators in the same order*, written into pinned planes and uploaded
+with one copy (``hypad_epoch_noise``).  ``EpochFeed.prepare`` does exactly that for epoch e while the GPU runs e - 1:
+
+* NumPy stream (train.py:24,118,205): z_cx(it), z_cz(it) per critic iteration, then z_gen per generator batch --
+  ``host_rng.global_normal_into`` on a helper thread (no interpreter lock), up to one epoch ahead.
+* torch stream: per pass the loader's iterator is created / advanced to its first batch (``_BaseDataLoaderIter`` draws its
+  base seed, ``RandomSampler`` its own), THEN the pass's alphas are drawn in one call -- alpha_cx(it), alpha_cz(it)
+  interleaved as train.py:64,149 draws them (a single ``torch.rand`` of the concatenated length yields the same values as
+  the successive calls: tests/test_epoch_feed.py).
+* samples: either the loader's batches staged through pinned memory (any iterable with ``len``), or -- a plain
+  ``torch.utils.data.DataLoader`` over one of ``hypad_amd.utils``' datasets or a tensor, default collate -- only the
+  batch *indices*: the loader's own ``batch_sampler`` is iterated after drawing the base seed the way the iterator would,
+  the window matrix stays resident in HBM and no sample is fetched, collated or copied (and no worker process started).
+
+Assumption, stated: fetching a batch does not itself draw from the process-wide NumPy / torch generators (true for
+torch's samplers, which seed a private generator, and for the reference's datasets).  A loader whose dataset does -- random
+augmentation inside ``__getitem__`` -- needs ``params.per_iteration = True`` (the call-by-call loop).
+"""
+import threading
+
+import numpy as np
+import torch
+
+from . import _C, host_rng
+
+def _staging(*shape, dtype=torch.float32):
+    """Host staging buffer: pinned where a GPU exists (non-blocking uploads); plain memory in the CPU-only tests of the draw order."""
+    t = torch.empty(*shape, dtype=dtype)
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+DEPTH = 3          # staging slots: epoch e fills slot e % 3 while e - 1 may still be uploading and e + 1's latent draws run ahead
+
+
+def _index_matrix(loader, test=False):
+    """The (N, S) window matrix behind `loader` if its batches can be described by indices alone, else None.  ``test``: accept the
+    test-mode datasets too (their items are (window, index, y, y_index, X_index) tuples, utils/dataloader.py:229-231; the caller
+    only uses the window)."""
+    from torch.utils.data import DataLoader, IterableDataset
+    from torch.utils.data.dataloader import default_collate
+    if type(loader) is not DataLoader or loader.batch_sampler is None or loader.collate_fn is not default_collate:
+        return None
+    ds = loader.dataset
+    if isinstance(ds, IterableDataset):
+        return None
+    if isinstance(ds, torch.Tensor):
+        m = ds
+    elif isinstance(ds, np.ndarray):
+        m = torch.from_numpy(ds)
+    elif type(ds).__module__.startswith("hypad_amd.") and hasattr(ds, "X") and (test or not getattr(ds, "test", False)):
+        m = torch.as_tensor(np.asarray(ds.X))       # SignalDataset / MultivariateDataset: __getitem__(i) is X[i]
+    else:
+        return None
+    if m.dim() < 2 or len(m) != len(ds):
+        return None
+    return m.reshape(len(m), -1)
+
+
+def loader_batches(loader):
+    """The index batches one pass over `loader` would fetch, with the draws its iterator would make from torch's generators and
+    nothing else: _BaseDataLoaderIter.__init__ (torch/utils/data/dataloader.py) takes one int64 from loader.generator (None = the
+    default generator) as the workers' base seed -- with shuffle=False too --, then the batch sampler runs (RandomSampler draws its
+    own seed at the first next()).  A generator: the caller may interleave its own draws after the first batch, as the reference's
+    loop body does.  Pinned against the real iterator by tests/test_epoch_feed.py."""
+    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
+    yield from loader.batch_sampler
+
+
+class EpochFeed:
+    def __init__(self, train_loader, batch, signal_shape, latent_dim, n_critics, device, index_path=True):
+        self.loader, self.B, self.S, self.L, self.nc, self.device = train_loader, int(batch), int(signal_shape), int(latent_dim), int(n_critics), device
+        try:
+            self.nb = len(train_loader)
+        except TypeError as e:
+            raise _C.HypadError("train_tadgan's epoch form needs len(train_loader); pass params.per_iteration = True for other iterables") from e
+        if self.nb < 1:
+            raise _C.HypadError("the loader yields no minibatch")
+        B, S, L, nb, nc = self.B, self.S, self.L, self.nb, self.nc
+        nit = nb * nc
+        self.nit = nit
+        # one contiguous block per slot: [z_cx | z_cz | z_gen | alpha_cx | alpha_cz]
+        sizes = [("z_cx", nit * B * L), ("z_cz", nit * B * L), ("z_gen", nb * B * L), ("alpha_cx", nit * B * S), ("alpha_cz", nit * B * L)]
+        self.offsets, off = {}, 0
+        for k, n in sizes:
+            self.offsets[k] = (off, n)
+            off += n
+        self.plane_floats = off
+        self.host = [_staging(off) for _ in range(DEPTH)]
+        self.host_np = [h.numpy() for h in self.host]
+        self.dev = torch.empty(off, dtype=torch.float32, device=device)
+        self.noise = {k: self.dev[o:o + n] for k, (o, n) in self.offsets.items()}          # Engine.train_epoch(noise=...)
+        self.alpha_tmp = torch.empty(nb * (B * S + B * L), dtype=torch.float32)
+        rows = (nc + 1) * nb * B
+        matrix = _index_matrix(train_loader) if index_path else None
+        self.index_path = matrix is not None
+        if self.index_path:
+            if matrix.shape[1] != S:
+                raise _C.HypadError(f"the dataset's windows hold {matrix.shape[1]} values, params.signal_shape is {S}")
+            self.x = matrix.to(torch.float32).contiguous().to(device)
+            self.idx_host = [_staging(nc + 1, nb * B, dtype=torch.int32) for _ in range(DEPTH)]
+            self.row_index = torch.empty(nc + 1, nb * B, dtype=torch.int32, device=device)
+        else:
+            self.x = torch.empty(rows, S, dtype=torch.float32, device=device)
+            self.x_host = [_staging(rows, S) for _ in range(DEPTH)]
+            self.row_index = torch.arange(rows, dtype=torch.int32, device=device).view(nc + 1, nb * B)
+            self._on_device = None
+        self._z_thread = {}            # epoch -> helper thread drawing its latent planes
+        self._z_error = None
+        self.last_epoch = None         # epochs beyond this one are never drawn (the generators end where the reference's would)
+
+    # ---- NumPy stream ------------------------------------------------------------------------------------
+    def _draw_z(self, slot):
+        try:
+            h = self.host_np[slot]
+            view = lambda k: h[self.offsets[k][0]: self.offsets[k][0] + self.offsets[k][1]]
+            host_rng.global_normal_into([view("z_cx"), view("z_cz")], self.B * self.L, self.nit)      # train.py:24 then :118, per iteration
+            host_rng.global_normal_into([view("z_gen")], self.B * self.L, self.nb)                    # train.py:205
+        except BaseException as e:             # surfaced by the main thread's join
+            self._z_error = e
+
+    def _start_z(self, epoch):
+        if epoch in self._z_thread or (self.last_epoch is not None and epoch > self.last_epoch):
+            return
+        prev = self._z_thread.get(epoch - 1)
+        if prev is not None:
+            prev.join()                        # one stream: epoch e's draws follow epoch e - 1's
+        t = threading.Thread(target=self._draw_z, args=(epoch % DEPTH,), name="hypad-z-draws", daemon=True)
+        self._z_thread[epoch] = t
+        t.start()
+
+    # ---- torch stream + samples --------------------------------------------------------------------------
+    def _alphas(self, slot, p):
+        """The pass's interpolation weights, drawn where the reference draws them relative to the loader's own draws: after
+        the pass's iterator exists and has produced its first batch."""
+        B, S, L, nb = self.B, self.S, self.L, self.nb
+        torch.rand(self.alpha_tmp.shape, out=self.alpha_tmp)
+        t = self.alpha_tmp.view(nb, B * S + B * L)
+        h = self.host[slot]
+        ox, oz = self.offsets["alpha_cx"][0], self.offsets["alpha_cz"][0]
+        h[ox + p * nb * B * S: ox + (p + 1) * nb * B * S].view(nb, B * S).copy_(t[:, :B * S])
+        h[oz + p * nb * B * L: oz + (p + 1) * nb * B * L].view(nb, B * L).copy_(t[:, B * S:])
+
+    def _pass_indices(self, slot, p):
+        it = loader_batches(self.loader)
+        out = self.idx_host[slot][p]
+        n = 0
+        first = True
+        for idx in it:
+            if len(idx) != self.B:
+                raise _C.HypadError(f"a minibatch of {len(idx)} windows: build the DataLoader with drop_last=True (main.py:38) -- the fused "
+                                    "iterations are bound to one batch size")
+            if n >= self.nb:
+                raise _C.HypadError("the loader yielded more batches than len(train_loader)")
+            out[n * self.B:(n + 1) * self.B] = torch.as_tensor(idx, dtype=torch.int32)
+            n += 1
+            if first and p < self.nc:
+                self._alphas(slot, p)
+                first = False
+        if n != self.nb:
+            raise _C.HypadError(f"the loader yielded {n} batches, len(train_loader) is {self.nb}")
+
+    def _pass_samples(self, slot, p):
+        B, S, nb = self.B, self.S, self.nb
+        base = p * nb * B
+        n = 0
+        for sample in self.loader:
+            if n >= nb:
+                raise _C.HypadError("the loader yielded more batches than len(train_loader)")
+            if n == 0 and p < self.nc:
+                self._alphas(slot, p)
+            try:
+                rows = sample.reshape(B, S)
+            except (RuntimeError, AttributeError) as e:
+                raise _C.HypadError(f"a minibatch must hold batch_size x signal_shape = {B} x {S} values, got {tuple(getattr(sample, 'shape', ()))}: "
+                                    "build the DataLoader with drop_last=True (main.py:38)") from e
+            on_dev = rows.is_cuda
+            if self._on_device is None:
+                self._on_device = on_dev
+            elif self._on_device != on_dev:
+                raise _C.HypadError("the loader mixes host and device minibatches")
+            (self.x if on_dev else self.x_host[slot])[base + n * B: base + (n + 1) * B].copy_(rows)     # (float64 -> float32 here: .float() of the reference)
+            n += 1
+        if n != nb:
+            raise _C.HypadError(f"the loader yielded {n} batches, len(train_loader) is {nb}")
+
+    def prepare(self, epoch):
+        """Everything epoch `epoch` needs from the host, staged in slot epoch % DEPTH.  The slot's previous user was epoch - DEPTH,
+        whose upload has completed (the caller waits for epoch - 2's losses before it calls this for `epoch`... see train_tadgan)."""
+        slot = epoch % DEPTH
+        self._start_z(epoch)
+        for p in range(self.nc + 1):
+            (self._pass_indices if self.index_path else self._pass_samples)(slot, p)
+        self._z_thread.pop(epoch).join()
+        if self._z_error is not None:
+            raise self._z_error
+        self._start_z(epoch + 1)               # runs under this epoch's upload / launch and the next prepare's loader passes
+        return slot
+
+    def upload(self, slot):
+        """Enqueue the slot's planes (one copy) and samples / indices on the current stream: stream order puts them behind the
+        previous epoch's launches, which read the same device buffers."""
+        self.dev.copy_(self.host[slot], non_blocking=True)
+        if self.index_path:
+            self.row_index.copy_(self.idx_host[slot], non_blocking=True)
+        elif not self._on_device:
+            self.x.copy_(self.x_host[slot], non_blocking=True)
+
+    def close(self):
+        for t in list(self._z_thread.values()):
+            t.join()
+        self._z_thread.clear()

@@ -1,19 +1,21 @@
 """Command-line driver (reference: main.py:15-70): YAML config -> datasets -> training -> anomaly detection.
 
-    python -m hypad_amd.main --config configs/univariate.yaml [--data-dir ./data] [--drop-in]
+    python -m hypad_amd.main --config configs/univariate.yaml [--data-dir ./data] [--resident | --per-iteration]
 
-Default: the resident fast path (``train.train_resident``: one ``hypad_train_epoch`` per epoch, the signal trained
-from its scaled series in HBM).  ``--drop-in`` runs the reference-shaped loop instead (``train.train`` over a
-``DataLoader`` with host-side randomness, iteration by iteration).  Scoring is the same either way: fused test-loop
-forward, device scoring kernels, host interval extraction and overlap-segment metrics.  Prints the metrics and returns
-them from ``run``."""
+Default (and ``--drop-in``, kept as an alias): the reference's own call chain -- ``train.train(train_loader, params, config_path)``
+over a shuffling ``DataLoader`` (main.py:33-55) with the reference's host random numbers -- where every epoch runs as one
+captured ``hypad_train_epoch`` (``train.train_tadgan``, hypad_amd/epoch_feed.py).  ``--per-iteration`` runs that loop call by
+call instead (three iteration functions per minibatch); ``--resident`` draws all randomness and the shuffles on the device
+(``train.train_resident``: no host work per epoch at all, a different random stream).  Scoring is the same either way: fused
+test-loop forward, device scoring kernels, host interval extraction and overlap-segment metrics.  Prints the metrics and
+returns them from ``run``."""
 import argparse
 from types import SimpleNamespace
 
 import numpy as np
 
 
-def run(params, config_path=None, data_dir="./data", drop_in=False, log=print):
+def run(params, config_path=None, data_dir="./data", drop_in=True, log=print, resident=False, per_iteration=False):
     import pandas as pd
     from torch.utils.data import DataLoader
 
@@ -25,7 +27,9 @@ def run(params, config_path=None, data_dir="./data", drop_in=False, log=print):
     log("dataset: {}, signal: {}".format(params.dataset, params.signal))
     train_dataset, test_dataset, read_path = od.dataset_selection(params, data_dir)
     multivariate = hasattr(train_dataset, "device_windows")            # utils/dataloader_multivariate.py datasets
-    if drop_in:
+    if not resident:
+        if per_iteration:
+            params.per_iteration = True
         train_loader = DataLoader(train_dataset, batch_size=params.batch_size, drop_last=True, shuffle=True, num_workers=0)
         encoder, decoder, critic_x, _, path = ht.train(train_loader, params, config_path)
     else:
@@ -69,10 +73,12 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="HypAD on MI355X")
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--data-dir", type=str, default="./data")
-    ap.add_argument("--drop-in", action="store_true", help="reference-shaped DataLoader loop with host-side randomness")
+    ap.add_argument("--drop-in", action="store_true", help="(the default) train.train over a DataLoader with the reference's host-side randomness")
+    ap.add_argument("--per-iteration", action="store_true", help="that loop call by call: one critic_x / critic_z / decoder_iteration per minibatch")
+    ap.add_argument("--resident", action="store_true", help="device-side randomness and shuffles (train.train_resident)")
     args = ap.parse_args(argv)
     params = SimpleNamespace(**yaml.load(open(args.config), Loader=yaml.FullLoader))
-    return run(params, args.config, args.data_dir, args.drop_in)
+    return run(params, args.config, args.data_dir, resident=args.resident, per_iteration=args.per_iteration)
 
 
 if __name__ == "__main__":

@@ -305,8 +305,108 @@ def make_optimizers(encoder, decoder, critic_x, critic_z, params):
     return optim_cx, optim_cz, optim_dec
 
 
+def _per_iteration_wanted(train_loader, params):
+    if getattr(params, "per_iteration", False) or os.environ.get("HYPAD_TRAIN_PER_ITERATION") == "1":
+        return True
+    return not hasattr(train_loader, "__len__")
+
+
 def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=2000, params=[], path=""):
-    """train.py:252-385: per epoch 5 passes of (critic_x, critic_z) over the loader, then one generator pass."""
+    """train.py:252-385 at epoch speed: per epoch 5 passes of (critic_x_iteration, critic_z_iteration) over the loader, then one pass
+    of decoder_iteration -- the reference's schedule, its host random numbers (latent vectors from NumPy's global generator, the
+    interpolation weights and the loader's seeds from torch's CPU generator, each stream in the reference's order: epoch_feed.py),
+    its prints and its checkpoint cadence -- but the 319 iterations of an epoch run as ONE captured ``hypad_train_epoch``: the
+    epoch's random planes and minibatches (or just their window indices) are staged on the host while the previous epoch runs,
+    uploaded with one copy and consumed through ``hypad_epoch_noise``; the per-iteration losses come back in one buffer.
+    Dropout masks (the reference draws them on the GPU, not reproducibly) come from the device Philox generator.
+    ``params.per_iteration = True`` selects the call-by-call loop instead."""
+    if _per_iteration_wanted(train_loader, params):
+        return train_tadgan_per_iteration(train_loader, encoder, decoder, critic_x, critic_z, n_epochs, params, path)
+    from .epoch_feed import EpochFeed
+    logging.debug("Starting training")
+    B, S, L = params.batch_size, params.signal_shape, params.latent_space_dim
+    hyp = bool(decoder.hyperbolic)
+    train_mode = _train_flag(encoder, decoder, critic_x, critic_z)
+    mods = {"enc": encoder, "dec": decoder, "cx": critic_x, "cz": critic_z}
+    dev = encoder.arena().device
+    resume = getattr(params, "resume", False)
+    eng = Engine(S, L, B, hyp, 1, dev, lr=params.lr, betas=(0.9, 0.999), gen_weight_decay=1e-5 if hyp else 0.0,          # train.py:274-288
+                 gen_stabilize=10 if hyp else 0, seed=torch.initial_seed() + _resume_salt(params.resume_epoch if resume else None))
+    eng.adopt({k: m.arena() for k, m in mods.items()})
+    n_critics = 5
+    feed = EpochFeed(train_loader, B, S, L, n_critics, dev, index_path=not getattr(params, "stage_samples", False))
+    nb = feed.nb
+    iters = (2 * n_critics + 1) * nb
+    losses_dev = torch.empty(1, iters, 4, dtype=torch.float32, device=dev)
+    back = [torch.empty(iters * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)]        # losses | counters (as bits)
+    done = [torch.cuda.Event() for _ in range(2)]
+    hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[])
+    actual_epoch = 0
+    if resume:
+        n_epochs = n_epochs - params.resume_epoch
+        actual_epoch = params.resume_epoch + 1
+    feed.last_epoch = n_epochs - 1
+    state = {"actual_epoch": actual_epoch}
+
+    def enqueue(e, slot):
+        feed.upload(slot)
+        eng.train_epoch_graph(feed.x, feed.row_index, nb, n_critics, train_mode, losses=losses_dev, noise=feed.noise)
+        b = back[e % 2]
+        b[: iters * 4].copy_(losses_dev.view(-1), non_blocking=True)
+        b[iters * 4:].view(torch.int32).copy_(eng.counters, non_blocking=True)
+        done[e % 2].record()
+
+    def finish(e):
+        """Epoch e's losses on the host: the reference's end-of-epoch bookkeeping (train.py:329-385).  Runs before epoch e + 1 is
+        enqueued, so a checkpoint holds exactly epoch e's weights and a failed resident launch can be repeated in place."""
+        done[e % 2].synchronize()
+        b = back[e % 2]
+        if int(b[iters * 4:].view(torch.int32)[4]) != 0:         # status word of the resident critic launch (hypad_epoch_status)
+            eng.check_status()                                   # restores, repeats the epoch with per-iteration launches
+            b[: iters * 4].copy_(losses_dev.view(-1))
+        rows = b[: iters * 4].view(iters, 4)
+        crit = rows[: 2 * n_critics * nb, 0].view(n_critics, nb, 2).mean(1)          # per pass (train.py:329-330), then over the passes
+        gen = rows[2 * n_critics * nb:].mean(0)
+        hist.cx.append(float(crit[:, 0].mean())); hist.cz.append(float(crit[:, 1].mean())); hist.dec.append(float(gen[0]))
+        if hyp:
+            hist.hyper.append(float(gen[1])); hist.mse.append(0.0)
+        else:
+            hist.mse.append(float(gen[1]))
+        print("Encoder decoder training done in epoch {}".format(e))
+        if hyp:
+            print("Hyperbolic loss {}".format(hist.hyper[-1]))
+        else:
+            print("Eucl mse loss {}".format(hist.mse[-1]))
+        print("critic x loss {:.3f} critic z loss {:.3f} \ndecoder loss {:.3f}\n".format(hist.cx[-1], hist.cz[-1], hist.dec[-1]))
+        state["actual_epoch"] += 1
+        ae = state["actual_epoch"]
+        if (ae % 10 == 0) or (ae == (n_epochs - 1)):             # train.py:381 (cadence kept as is)
+            torch.save(encoder, path + "/encoder_{}.pt".format(ae))
+            torch.save(decoder, path + "/decoder_{}.pt".format(ae))
+            torch.save(critic_x, path + "/critic_x_{}.pt".format(ae))
+            torch.save(critic_z, path + "/critic_z_{}.pt".format(ae))
+
+    try:
+        for epoch in range(n_epochs):
+            logging.debug("Epoch {}".format(epoch))
+            slot = feed.prepare(epoch)              # host work of epoch e, under the GPU's epoch e - 1
+            if epoch:
+                finish(epoch - 1)
+            enqueue(epoch, slot)
+        if n_epochs > 0:
+            finish(n_epochs - 1)
+    finally:
+        feed.close()
+    _set_requires_grad((decoder, encoder), True)     # the flags the reference's loop leaves behind (train.py:331-332)
+    _set_requires_grad((critic_x, critic_z), False)
+    return hist
+
+
+def train_tadgan_per_iteration(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=2000, params=[], path=""):
+    """train.py:252-385, call by call: per epoch 5 passes of (critic_x_iteration, critic_z_iteration) over the loader, then one pass of
+    decoder_iteration -- three (critics) / two (generator) launches and one H2D copy per call, the host in between.  Kept for loaders
+    the epoch form cannot stage (no ``len``; datasets that draw from the global generators while a batch is fetched) and as the
+    reference point of its parity test; ``train_tadgan`` lands here with ``params.per_iteration = True``."""
     logging.debug("Starting training")
     optim_cx, optim_cz, optim_dec = make_optimizers(encoder, decoder, critic_x, critic_z, params)
     cx_epoch_loss, cz_epoch_loss, decoder_epoch_loss, hyp_dec_loss, eucl_dec_loss = [], [], [], [], []

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HYPAD_ABI_VERSION 4
+#define HYPAD_ABI_VERSION 5
 
 enum {
   HYPAD_OK = 0,
@@ -296,6 +296,17 @@ enum {
  * HYPAD_EUNSUPPORTED beyond: draw the permutations with any other generator and pass them to hypad_train_epoch as before. */
 int hypad_epoch_shuffles(int32_t* row_index, int n_passes, int take, int n_windows, uint64_t seed, const int32_t* counters,
                          hypad_stream_t stream);
+
+/* HOST helper (the one entry point whose pointers are host pointers; no device work, no stream): the latent draws of a whole epoch
+ * of the reference's loop -- np.random.normal(size=(1, batch, L)) on NumPy's GLOBAL generator, once per iteration, train.py:24,118,205
+ * -- continued from that generator's state (np.random.get_state(): MT19937 key[624], pos, has_gauss, cached_gaussian; all updated in
+ * place: hand them back with np.random.set_state()) and written as float32 (torch.Tensor(float64 array), train.py:24) into the pinned
+ * planes hypad_epoch_noise is uploaded from.  Draw order: for r in [0, rounds): for k in [0, n_outs): `chunk` values -> outs[k] + r*chunk
+ * (critic phase: outs = {z_cx, z_cz}, chunk = batch * L, rounds = n_critics * n_batches: critic_x_iteration draws before
+ * critic_z_iteration, train.py:320-327; generator pass: outs = {z_gen}).  NumPy's legacy polar Box-Muller bit for bit
+ * (tests/test_host_rng.py); unlike np.random.normal the call does not hold the interpreter lock. */
+int hypad_host_mt19937_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, float* const* outs, int n_outs,
+                              int64_t chunk, int64_t rounds);
 
 /* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
  * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up

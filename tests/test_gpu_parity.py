@@ -952,9 +952,10 @@ def test_multivariate_anomaly_detection(dev):
         assert list(out["known_anomalies"].columns) == ["start", "end"] and len(out["known_anomalies"]) == 1
 
 
-@pytest.mark.parametrize("hyper", [True, False])
-def test_cli_pipeline_end_to_end(dev, tmp_path, monkeypatch, hyper):
-    """main.py:15-70 on the resident fast path: CSV -> SignalDataset -> epochs on the device (series view) -> test loop ->
+@pytest.mark.parametrize("hyper,resident", [(True, False), (False, False), (True, True), (False, True)])
+def test_cli_pipeline_end_to_end(dev, tmp_path, monkeypatch, capsys, hyper, resident):
+    """main.py:15-70, on the default path (train.train over a DataLoader, the reference's host random numbers, one captured epoch
+    per epoch) and on the resident one (device randomness): CSV -> SignalDataset -> epochs on the device -> test loop ->
     scoring kernels -> intervals and overlap-segment counts.  An integration check (the reference's end-to-end numbers
     depend on its host RNG streams): everything finite, shapes right, checkpoints written, training moved the weights."""
     import os
@@ -973,7 +974,9 @@ def test_cli_pipeline_end_to_end(dev, tmp_path, monkeypatch, hyper):
                         save_result=False, filename="", rec_error="dtw", combination="mult", interval=600, unique_dataset=True,
                         resume=False, resume_epoch=0, load=False)
     logs = []
-    out = hmain.run(P, None, d, log=logs.append)
+    out = hmain.run(P, None, d, log=logs.append, resident=resident)
+    if not resident:                                # (train.train_tadgan prints like the reference does)
+        logs += capsys.readouterr().out.splitlines()
     n = int(fxd["dl_nab600_Xshape"][0])
     assert out["final_scores"].shape[0] in (n, n + 99) and np.isfinite(out["final_scores"]).all()
     assert out["intervals"].ndim == 2 and out["intervals"].shape[1] == 3 and len(out["confusion"]) == 4
@@ -1191,7 +1194,7 @@ def test_cli_pipeline_multivariate(dev, tmp_path, monkeypatch):
     for kind in ("sequences", "groundtruth"):
         os.replace(os.path.join(base, "POINTS", "fall", f"fall_{kind}_id1.pt"), os.path.join(base, "POINTS", "multivariate", f"multivariate_{kind}_id1.pt"))
     logs = []
-    out = hmain.run(P, None, d, log=logs.append)
+    out = hmain.run(P, None, d, log=logs.append, resident=True)
     assert out["final_scores"].shape == (600,) and np.isfinite(out["final_scores"]).all()
     assert out["intervals"].ndim == 2 and out["intervals"].shape[1] == 3
     assert len(out["known_anomalies"]) == 1
