@@ -96,6 +96,7 @@ class EpochFeed:
         self.dev = torch.empty(off, dtype=torch.float32, device=device)
         self.noise = {k: self.dev[o:o + n] for k, (o, n) in self.offsets.items()}          # Engine.train_epoch(noise=...)
         self.alpha_tmp = torch.empty(nb * (B * S + B * L), dtype=torch.float32)
+        self.alpha_np = self.alpha_tmp.numpy()
         rows = (nc + 1) * nb * B
         matrix = _index_matrix(train_loader) if index_path else None
         self.index_path = matrix is not None
@@ -140,11 +141,12 @@ class EpochFeed:
         the pass's iterator exists and has produced its first batch."""
         B, S, L, nb = self.B, self.S, self.L, self.nb
         torch.rand(self.alpha_tmp.shape, out=self.alpha_tmp)
-        t = self.alpha_tmp.view(nb, B * S + B * L)
-        h = self.host[slot]
+        # (NumPy copies: a strided torch copy of this size wakes the whole intra-op thread pool -- milliseconds on a 256-core host)
+        t = self.alpha_np.reshape(nb, B * S + B * L)
+        h = self.host_np[slot]
         ox, oz = self.offsets["alpha_cx"][0], self.offsets["alpha_cz"][0]
-        h[ox + p * nb * B * S: ox + (p + 1) * nb * B * S].view(nb, B * S).copy_(t[:, :B * S])
-        h[oz + p * nb * B * L: oz + (p + 1) * nb * B * L].view(nb, B * L).copy_(t[:, B * S:])
+        h[ox + p * nb * B * S: ox + (p + 1) * nb * B * S].reshape(nb, B * S)[:] = t[:, :B * S]
+        h[oz + p * nb * B * L: oz + (p + 1) * nb * B * L].reshape(nb, B * L)[:] = t[:, B * S:]
 
     def _pass_indices(self, slot, p):
         it = loader_batches(self.loader)

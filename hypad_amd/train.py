@@ -13,6 +13,7 @@ arenas attached to it on first use and are mirrored into ``optimizer.state`` as 
 """
 import logging
 import os
+import time
 from types import SimpleNamespace
 
 import numpy as np
@@ -340,7 +341,7 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     losses_dev = torch.empty(1, iters, 4, dtype=torch.float32, device=dev)
     back = [torch.empty(iters * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)]        # losses | counters (as bits)
     done = [torch.cuda.Event() for _ in range(2)]
-    hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[])
+    hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], wall=[])       # wall: time.perf_counter() when each epoch's losses were on the host
     actual_epoch = 0
     if resume:
         n_epochs = n_epochs - params.resume_epoch
@@ -378,6 +379,7 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
         else:
             print("Eucl mse loss {}".format(hist.mse[-1]))
         print("critic x loss {:.3f} critic z loss {:.3f} \ndecoder loss {:.3f}\n".format(hist.cx[-1], hist.cz[-1], hist.dec[-1]))
+        hist.wall.append(time.perf_counter())
         state["actual_epoch"] += 1
         ae = state["actual_epoch"]
         if (ae % 10 == 0) or (ae == (n_epochs - 1)):             # train.py:381 (cadence kept as is)

@@ -102,7 +102,7 @@ def test_epoch_form_against_the_oracle_loop():
     w0 = weights(mods)
     P = P_(B, S, hyper)
     np.random.seed(4); torch.manual_seed(4)
-    hist = ht.train_tadgan(loader, *mods, n_epochs=1, params=P, path="")
+    hist = ht.train_tadgan(loader, *mods, n_epochs=1, params=P, path="/nonexistent")      # (one epoch: no checkpoint is due)
     torch.cuda.synchronize()
     om = [ot.Encoder(S, 20).eval(), ot.Decoder(S, 20, hyper).eval(), ot.CriticX(S, 20).eval(), ot.CriticZ(20).eval()]
     for m, w in zip(om, w0):
@@ -147,7 +147,7 @@ def test_checkpoints_hold_the_epoch_they_are_named_after(tmp_path):
             assert torch.equal(v.cpu(), ref[k]), (name, k)
 
 
-def test_host_batches_on_either_side_and_the_escape_hatch():
+def test_host_batches_on_either_side_and_the_escape_hatch(tmp_path):
     """A list of host minibatches (what bench.py's drop_in hands over) and the same list on the device train identically; an
     iterable without len() falls back to the call-by-call loop."""
     from hypad_amd import train as ht
@@ -157,7 +157,7 @@ def test_host_batches_on_either_side_and_the_escape_hatch():
     for batches in ([data[i * B:(i + 1) * B] for i in range(3)], [data[i * B:(i + 1) * B].cuda() for i in range(3)]):
         mods = build(S, True, 3)
         np.random.seed(8); torch.manual_seed(8)
-        h = ht.train_tadgan(batches, *mods, n_epochs=2, params=P_(B, S, True), path="")
+        h = ht.train_tadgan(batches, *mods, n_epochs=2, params=P_(B, S, True), path=str(tmp_path))
         res.append((h, weights(mods)))
     assert res[0][0].cx == res[1][0].cx and res[0][0].dec == res[1][0].dec
     for wa, wb in zip(res[0][1], res[1][1]):
@@ -167,7 +167,7 @@ def test_host_batches_on_either_side_and_the_escape_hatch():
     class NoLen:
         def __iter__(self):
             return iter([data[:B], data[B:2 * B]])
-    h = ht.train_tadgan(NoLen(), *mods, n_epochs=1, params=P_(B, S, True), path="")
+    h = ht.train_tadgan(NoLen(), *mods, n_epochs=1, params=P_(B, S, True), path=str(tmp_path))
     assert len(h.cx) == 1 and np.isfinite(h.cx[0])
 
 
