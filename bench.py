@@ -109,13 +109,14 @@ def profile_kernels(eng, x, spg, device, reps=24):
     (critic_persistent_kernel; reported per iteration and per launch; with its own record producers, or behind a precompute
     launch) or, where that form cannot run, 145 per-iteration launches (the mean of the steady-state ones); kind 2 =
     decoder_iteration (generator kernel, dW + Adam).  Returns per-launch ms, launches per epoch, epoch share and the
-    algorithmic FLOPs of one launch of each kernel (SURVEY.md §8d accounting)."""
+    algorithmic FLOPs of one launch of each kernel (SURVEY.md §8d accounting).  kind 5 = the generator step's two kernels as the
+    epoch launches them, the mean over 64 back-to-back launches each."""
     persistent = eng.critic_phase_persistent()
-    names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 2: ["gen", "dw_gen"]}
+    names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 5: ["gen", "dw_gen"]}
     acc = {n: [] for v in names.values() for n in v}
     idx = torch.arange(B, device=device, dtype=torch.int32)
     for rep in range(reps):
-        for kind in (4, 2):
+        for kind in (4, 5):            # (5: 64 back-to-back launches per kernel -- an event pair around one 9 us launch also times the event path)
             ms = eng.profile_iteration(kind, x, idx, train_mode=True)
             if rep >= 4:
                 for n, v in zip(names[kind], ms):
@@ -392,6 +393,23 @@ def cpu_scoring_baseline(n):
             "without_kde_value": n / (t_fwd + t_num)}
 
 
+def _event_ms_median(fn, rounds=21, per_round=3):
+    """Median over `rounds` of the mean duration of `per_round` back-to-back calls (HIP events on the launch stream): one slow round
+    (another process on the box, a clock ramp) does not move it."""
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(per_round):
+            fn()
+        b.record()
+        b.synchronize()
+        out.append(a.elapsed_time(b) / per_round)
+    return float(np.median(out))
+
+
 def _event_ms(fn, reps):
     """Mean duration of fn's kernels, HIP events on the stream they are launched on (torch's current stream = _C.stream())."""
     fn()
@@ -544,8 +562,9 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
            "mobius_add (mobius_add_rows)": (lambda: C.hypad_mobius_add_fwd(_C.ptr(ball), _C.ptr(other), _C.ptr(out), m, S, m, st()), 12 * S),
            "poincare_rowdist (rowdist_rows)": (lambda: C.hypad_poincare_rowdist_fwd(_C.ptr(ball), _C.ptr(other), _C.ptr(dv), m, S, st()), 8 * S + 4)}
     roofline_hbm = {"rows": m, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernels": {}}
+    roofline_hbm["timing"] = "median of 21 rounds of 3 back-to-back launches, HIP events"
     for name, (fn, bpr) in ops.items():
-        ms = _event_ms(fn, reps)
+        ms = _event_ms_median(fn)
         gb = m * bpr / (ms * 1e-3) / 1e9
         roofline_hbm["kernels"][name] = {"bytes_per_row": bpr, "ms": ms, "achieved": gb, "frac": gb / HBM_PEAK_GBPS}
     return scoring, roofline_hbm, roofline_scoring
@@ -673,6 +692,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every epoch eagerly instead of replaying its captured hipGraph")
     ap.add_argument("--host-shuffle", action="store_true", help="draw the epoch's shuffles with torch (rand + argsort) instead of inside the captured epoch")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
+    ap.add_argument("--strict", action="store_true", help="fail (instead of reporting) when the per-kernel times add up to more than the step")
     ap.add_argument("--no-drop-in", action="store_true", help="skip timing the reference-style loop over hypad_amd.train's iteration functions")
     ap.add_argument("--no-sharded-scoring", action="store_true", help="skip configs[4]-style scoring sharded over all ranks (RCCL collectives; "
                                                                       "a one-rank nccl group at --gpus 1)")
@@ -731,6 +751,13 @@ def main():
     persistent, producers, n_it = prof["persistent"], prof["producers"], N_CRITICS * N_BATCHES
     flop = prof["flop_per_launch"][dom]                  # algorithmic FLOPs of ONE launch of the dominant kernel
     achieved = flop / (per_launch[dom] * 1e-3) / 1e12
+    # the per-kernel times must add up to no more than the step they were taken from (+ the three small launches not listed:
+    # shuffle, pack, decay): they are kernel times, not event-path times
+    share_sum = float(sum(epoch_share.values()))
+    ms_step = 1e3 * elapsed / args.steps
+    share_ok = share_sum <= 1.01 * ms_step
+    if args.strict:
+        assert share_ok, (share_sum, ms_step)
 
     # memory-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run, so this is the figure
     # of the committed rocprofv3 --pmc passes of this same command (profiles/r0N_pmc_traffic.json, gfx950 FETCH_SIZE correction
@@ -833,7 +860,8 @@ def main():
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
                          "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
                          "us_per_critic_iteration": 1e3 * prof["kern_ms"]["critic_iteration"],
-                         "kernel_ms": per_launch, "epoch_share_ms": epoch_share, "flop_per_launch": flop,
+                         "kernel_ms": per_launch, "epoch_share_ms": epoch_share, "epoch_share_sum_ms": share_sum,
+                         "epoch_share_le_step": bool(share_ok), "flop_per_launch": flop,
                          "flop_per_launch_parts": ({"critic_iterations": 2.0 * MAC_PER_WINDOW["critic_iteration"] * n_it * B * spg,
                                                     "record_producers": 2.0 * (MAC_PER_WINDOW["critic_precompute"] if producers else 0) * n_it * B * spg}
                                                    if dom == "critic_persistent_kernel" else None)},

@@ -1535,8 +1535,10 @@ int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const Iter
 // with_decay = false: the decay-only parameters are left alone (the caller advances them with run_decay_steps)
 // sig0 / nsig / step_add: the models [sig0, sig0 + nsig) only, as generator iteration `step_add` of an epoch (IterArgs.step_add);
 // defaults: all models, counters read and advanced by the launches themselves.
+// reps > 1 (hypad_profile_iteration kind 5): each of the two kernels launched `reps` times back to back between its events -- an
+// event pair around ONE short launch measures the event path too (10 - 20 % on a 9 us kernel)
 int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, hipStream_t s, hipEvent_t* ev = nullptr, bool pack = true,
-            bool with_decay = true, int sig0 = 0, int nsig = -1, int step_add = -1) {
+            bool with_decay = true, int sig0 = 0, int nsig = -1, int step_add = -1, int reps = 1) {
   IterArgs a;
   int rc = fill_args(a, d, st, io, 2);
   if (rc) return rc;
@@ -1557,7 +1559,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   do {                                                                           \
     hipError_t e = allow_lds((const void*)gen_kernel<__VA_ARGS__>, lds);         \
     if (e != hipSuccess) return (int)e;                                          \
-    hipLaunchKernelGGL((gen_kernel<__VA_ARGS__>), grid, dim3(TB), lds, s, a);    \
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gen_kernel<__VA_ARGS__>), grid, dim3(TB), lds, s, a);    \
   } while (0)
   if (a.hyperbolic) { if (ref_cfg) HYPAD_LAUNCH_GEN(true, 100, 20, 64); else if (mv_cfg) HYPAD_LAUNCH_GEN(true, 150, 20, 256); else HYPAD_LAUNCH_GEN(true, 0, 0, 0); }
   else { if (ref_cfg) HYPAD_LAUNCH_GEN(false, 100, 20, 64); else HYPAD_LAUNCH_GEN(false, 0, 0, 0); }
@@ -1568,13 +1570,15 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const char* cenv = getenv("HYPAD_DW_COLOC");
   const bool coloc = cenv ? cenv[0] == '1' : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), nsig);
-  if (coloc) {
-    if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-  } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
-  else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
-  else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+  for (int r = 0; r < reps; ++r) {
+    if (coloc) {
+      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
+    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+  }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
   return HYPAD_OK;
@@ -1759,8 +1763,9 @@ int hypad_decoder_iteration(const hypad_dims* d, const hypad_train_state* st, co
 // dw_adam).  Not capturable (creates events, synchronises).
 int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, float* ms_out,
                             int n_out, hypad_stream_t s) {
-  if (!io || !ms_out || kind < 0 || kind > 4) return HYPAD_EINVAL;
-  const int nk = kind == 2 ? 2 : 3;
+  if (!io || !ms_out || kind < 0 || kind > 5) return HYPAD_EINVAL;
+  const int nk = (kind == 2 || kind == 5) ? 2 : 3;
+  constexpr int GEN_REPS = 64;
   if (n_out < nk) return HYPAD_EINVAL;
   if (kind >= 3 && !io->losses) return HYPAD_EINVAL;
   hipEvent_t ev[4];
@@ -1773,6 +1778,7 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
   if (kind == 0) rc = run_cx(d, st, from_io(io), (hipStream_t)s, ev);
   else if (kind == 1) rc = run_cz(d, st, from_io(io), (hipStream_t)s, ev);
   else if (kind == 2) rc = run_gen(d, st, from_io(io), (hipStream_t)s, ev);
+  else if (kind == 5) rc = run_gen(d, st, from_io(io), (hipStream_t)s, ev, true, false, 0, -1, -1, GEN_REPS);      // (no decay-only tensors: the launch an epoch issues)
   else if (kind == 3) rc = run_critic_pair(d, st, from_io(io), io->losses, io->losses + 4 * (int64_t)d->n_signals, (hipStream_t)s, ev);
   else {
     IterArgs ax, az;
@@ -1802,6 +1808,7 @@ int hypad_profile_iteration(int kind, const hypad_dims* d, const hypad_train_sta
     if (e != hipSuccess) rc = (int)e;
   }
   if (rc == HYPAD_OK && kind4_div > 0) ms_out[2] /= (float)kind4_div;      // mean of the steady-state launches
+  if (rc == HYPAD_OK && kind == 5) { ms_out[0] /= (float)GEN_REPS; ms_out[1] /= (float)GEN_REPS; }
   for (int i = 0; i <= nk; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
 }

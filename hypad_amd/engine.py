@@ -36,7 +36,9 @@ class Engine:
         self.exp_avg_sq = {k: z(k) for k in NETS}
         self.counters = torch.zeros(8, dtype=torch.int32, device=self.device)    # [0..2] optimizer steps, [3] rng tick, [4] status word
         self.epoch_flags = 0                     # hypad_epoch_io.flags of every epoch (EPOCH_PER_ITERATION after a recovery)
-        self._last_epoch = None                  # arguments of the last train_epoch / train_epoch_graph call (check_status re-runs it)
+        self._last_epoch = None                  # arguments of the last train_epoch / train_epoch_graph call
+        self._pending = []                       # ... of every epoch queued since the last check_status that found nothing (it re-runs the lost ones)
+        self._steps_checked = (0, 0)             # counters[0], [2] (critic_x / generator optimizer steps) at that check
         self.dims = _C.Dims(self.S, self.L, self.B, int(self.hyperbolic), self.n)
         nbytes = _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims))
         if nbytes == 0:
@@ -209,7 +211,8 @@ class Engine:
     def profile_iteration(self, kind, x, row_index=None, train_mode=True):
         """Per-kernel milliseconds of one iteration (0 critic_x, 1 critic_z, 2 decoder, 3 critic_x || critic_z pair,
         4 = 145 iterations of train_epoch's hoisted critic phase: precompute, first launch / re-initialisation, mean time per
-        iteration), HIP events on the current stream."""
+        iteration; 5 = the generator step's two kernels as an epoch launches them, 64 back-to-back launches each: mean per launch),
+        HIP events on the current stream."""
         x, stride = self._check_x(x)
         if kind == 4:
             self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), 145, 1))
@@ -221,7 +224,7 @@ class Engine:
         out = (ctypes.c_float * 3)()
         _C.check(_C.lib.hypad_profile_iteration(int(kind), ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), out, 3,
                                                 _C.stream()), "profile_iteration")
-        return list(out)[: 2 if kind == 2 else 3]
+        return list(out)[: 2 if kind in (2, 5) else 3]
 
     NOISE_PLANES = ("z_cx", "alpha_cx", "z_cz", "alpha_cz", "z_gen", "masks_cx", "masks_cz", "masks_gen")
 
@@ -267,7 +270,17 @@ class Engine:
         graphs[key][0].replay()
         self._last_epoch = dict(x=x, row_index=row_index, n_batches=n_batches, n_critics=n_critics, train_mode=train_mode, losses=losses,
                                 x_row_stride=x_row_stride, noise=noise)
+        self._queued(dict(self._last_epoch), shuffle_windows)
         return losses
+
+    MAX_PENDING = 4096
+
+    def _queued(self, call, shuffle_windows=0):
+        """Book-keeping for check_status: the epochs queued since the last check that found status 0."""
+        if len(self._pending) >= self.MAX_PENDING:       # never checked: nothing more is recorded, and a failure cannot be repaired any more
+            self._pending_overflow = True
+            return
+        self._pending.append((call, int(shuffle_windows)))
 
     # ---- status channel of the resident critic launch (include/hypad.h: hypad_epoch_status / hypad_epoch_restore) -------------
     def status(self):
@@ -278,27 +291,56 @@ class Engine:
         return out.value
 
     def check_status(self, recover=True):
-        """Call where the host reads an epoch's losses.  If the epoch's resident critic launch gave up (a withheld CU: CU mask,
-        partitioned or shared device), the launches behind it were no-ops; with ``recover`` the critics and counters are put
-        back to the state that epoch began from, the epoch is repeated with one launch per critic iteration (same random
-        streams: bit for bit a healthy epoch in that form) and every later epoch of this engine uses that form.
+        """Call where the host reads an epoch's losses.  If a resident critic launch gave up (a withheld CU: CU mask, partitioned or
+        shared device), every launch behind it -- the rest of that epoch and ALL epochs queued after it -- was a no-op
+        (fail-stop).  With ``recover`` the critics and counters are put back to the state the failed epoch began from and every
+        epoch queued since (the failed one and those behind it, found from the optimizer-step counter) is repeated in order with
+        one launch per critic iteration (same random streams: bit for bit healthy epochs in that form); every later epoch of this
+        engine uses that form.  The repeats read the callers' buffers as they are NOW: epochs whose inputs the caller refills
+        between launches (host-drawn shuffles or noise planes) must be checked one by one, as train.train_tadgan does; epochs that
+        draw their shuffles inside the captured sequence, or read static buffers, may be queued in any number.
         Returns the status code that was found (0 = nothing happened); raises without ``recover``."""
-        code = self.status()
+        c = self.counters.cpu()                  # (synchronises the stream: everything queued so far has run or was skipped)
+        code = int(c[4])
         if code == 0:
+            self._pending.clear()
+            self._pending_overflow = False
+            self._steps_checked = (int(c[0]), int(c[2]))
             return 0
-        if not recover or self._last_epoch is None:
+        if not recover or not self._pending or self.__dict__.get("_pending_overflow"):
             raise _C.HypadError(f"the resident critic launch gave up (status 0x{code:x}: a bounded wait for a sibling workgroup timed out)")
-        logging.getLogger("hypad_amd").warning(
-            "resident critic launch gave up (status 0x%x): restoring the critics and repeating the epoch with per-iteration launches", code)
         st = self._state()
         _C.check(_C.lib.hypad_epoch_restore(ctypes.byref(self.dims), ctypes.byref(st), self.workspace.data_ptr(), self._ws_bytes, _C.stream()),
                  "epoch_restore")
+        # the epochs that completed before the failed one, from the optimizer-step counters (restored to the failed epoch's start):
+        # critic_x steps and generator steps done since the last clean check
+        c = self.counters.cpu()
+        done_c, done_g = int(c[0]) - self._steps_checked[0], int(c[2]) - self._steps_checked[1]
+        lost = list(self._pending)
+        while lost:
+            nc_, ng_ = lost[0][0]["n_batches"] * lost[0][0]["n_critics"], lost[0][0]["n_batches"]
+            if done_c < nc_ or done_g < ng_:
+                break
+            done_c, done_g = done_c - nc_, done_g - ng_
+            lost.pop(0)
+        logging.getLogger("hypad_amd").warning(
+            "resident critic launch gave up (status 0x%x): restoring the critics and repeating %d epoch(s) with per-iteration launches", code, len(lost))
         self.epoch_flags = (self.epoch_flags & 0xff) | _C.EPOCH_PER_ITERATION      # (any test-hook bits above bit 7 go)
         self._drop_graphs()
-        self.train_epoch(**self._last_epoch)
+        self._pending.clear()
+        self._rerunning = True
+        try:
+            for call, shuffle_windows in lost:
+                if shuffle_windows:
+                    self.draw_shuffles(call["row_index"], shuffle_windows)
+                self.train_epoch(**call)
+        finally:
+            self._rerunning = False
         again = self.status()
         if again:
             raise _C.HypadError(f"status 0x{again:x} after the per-iteration re-run")
+        c = self.counters.cpu()
+        self._steps_checked = (int(c[0]), int(c[2]))
         return code
 
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None,
@@ -335,4 +377,6 @@ class Engine:
             self._last_epoch = dict(x=x, row_index=row_index, n_batches=n_batches, n_critics=n_critics,
                                     train_mode=train_mode, losses=losses, hoist=hoist, x_row_stride=x_row_stride, noise=noise,
                                     workspace_iters=workspace_iters)
+            if not self.__dict__.get("_rerunning"):
+                self._queued(dict(self._last_epoch))
         return losses

@@ -376,7 +376,11 @@ uint64_t hypad_critic_z_seed(uint64_t seed);
  * re-initialisation of its epoch words and the mean is that launch's duration / 145; otherwise X is the first iteration launch
  * (no Adam in its prologue) and the mean is over the 144 steady-state launches that follow back to back.  losses: room for
  * 2 * n_signals * 4 floats (kind 3) / 290 * n_signals * 4 floats (kind 4); workspace for kind 4:
- * hypad_epoch_workspace_bytes(dims, 145, 1).
+ * hypad_epoch_workspace_bytes(dims, 145, 1).  kind 5 = the decoder iteration's two kernels as hypad_train_epoch launches them (the decay-only tensors left to the epoch's
+ * decay launch), each launched 64 times back to back
+ * between its events -> {mean generator kernel, mean dW+Adam}: an event pair around ONE launch of a 9 - 40 us kernel also measures
+ * the event path (the sum of such figures exceeded the epoch they were taken from); the 64 dW+Adam launches are 64 optimizer steps
+ * on the same gradient (the weights move: measure after, not inside, a run whose results matter).
  * Not capturable into a graph. */
 int hypad_profile_iteration(int kind, const hypad_dims* dims, const hypad_train_state* st, const hypad_iter_io* io,
                             float* ms_out, int n_out, hypad_stream_t stream);

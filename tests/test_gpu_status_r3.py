@@ -58,11 +58,13 @@ def test_resident_launch_that_gives_up_is_reported_stops_the_epoch_and_is_recove
     perm_buf = perms[0].clone()                    # (graph replays read the shuffles from one static buffer)
     resident = run(good, perm_buf).clone()         # a healthy epoch, resident form
     assert good.status() == 0
-    good = engine()                                # ... and two healthy epochs with one launch per critic iteration: the reference run
+    good = engine()                                # ... and three healthy epochs with one launch per critic iteration: the reference run
     good.epoch_flags = _C.EPOCH_PER_ITERATION
     l_good = [run(good, perm_buf).clone()]
     assert good.status() == 0 and float((l_good[0] - resident).abs().max()) < 1e-3
     s_good = [_snapshot(good)]
+    l_good.append(run(good, perm_buf).clone())     # (the same shuffles again: the epoch queued behind the failing one, below)
+    s_good.append(_snapshot(good))
     perm_buf.copy_(perms[1])
     l_good.append(run(good, perm_buf).clone())
     s_good.append(_snapshot(good))
@@ -86,16 +88,55 @@ def test_resident_launch_that_gives_up_is_reported_stops_the_epoch_and_is_recove
     # without recovery the host gets an exception
     with pytest.raises(_C.HypadError):
         bad.check_status(recover=False)
-    # recovery: restore + the same epoch with one launch per critic iteration == the healthy per-iteration epoch, bit for bit
+    # recovery: restore + EVERY epoch queued since -- the failed one and the one behind it -- repeated with one launch per critic
+    # iteration == the healthy per-iteration epochs, bit for bit
     assert bad.check_status() == code
     assert bad.status() == 0 and bad.epoch_flags == _C.EPOCH_PER_ITERATION
-    assert torch.equal(bad._last_epoch["losses"], l_good[0])
-    assert _same(_snapshot(bad), s_good[0])
+    assert torch.equal(bad._last_epoch["losses"], l_good[1])
+    assert _same(_snapshot(bad), s_good[1])
     # ... and the engine goes on in that form
     perm_buf.copy_(perms[1])
     l2 = run(bad, perm_buf)
     assert bad.check_status() == 0
-    assert torch.equal(l2, l_good[1]) and _same(_snapshot(bad), s_good[1])
+    assert torch.equal(l2, l_good[2]) and _same(_snapshot(bad), s_good[2])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_epochs_queued_around_a_failure_are_all_repaired(graph):
+    """Four epochs queued without a check in between (bench.py queues 20): the first completes in the resident form, the second's
+    resident launch gives up, the third and fourth are no-ops behind it.  ONE check_status finds the failure, keeps the first epoch,
+    and repeats the other three in order == a run whose epochs 2..4 used the per-iteration form, bit for bit.  With the shuffles
+    drawn inside the captured sequence (graph) the repeats draw the same permutations again (the rng tick is restored)."""
+    from hypad_amd import _C
+    engine, x, perms, nb, nc = _setup(1)
+    n_windows = x.shape[1]
+
+    def run(e, flags=None):
+        buf = e.__dict__.setdefault("_test_perm", perms[0].clone())
+        if graph:
+            if flags is not None:
+                e.epoch_flags = flags
+            return e.train_epoch_graph(x, buf, nb, nc, True, shuffle_windows=n_windows).clone()
+        return e.train_epoch(x, buf, nb, nc, True, flags=flags).clone()
+
+    ref = engine()
+    l_ref = [run(ref)]
+    assert ref.check_status() == 0
+    ref.epoch_flags = _C.EPOCH_PER_ITERATION
+    l_ref += [run(ref, _C.EPOCH_PER_ITERATION if not graph else None) for _ in range(3)]
+    assert ref.check_status() == 0
+    bad = engine()
+    l_bad = [run(bad)]
+    give_up = 3 << _C.EPOCH_TEST_GIVE_UP_SHIFT
+    l_bad.append(run(bad, give_up))
+    if graph:
+        bad.epoch_flags = give_up            # (same captured graph for the epochs behind it: they are no-ops anyway)
+    l_bad += [run(bad, 0 if not graph else None) for _ in range(2)]
+    code = bad.check_status()
+    assert code == 0x100 + 3 and bad.status() == 0
+    assert torch.equal(l_bad[0], l_ref[0])
+    assert torch.equal(bad._last_epoch["losses"], l_ref[3])
+    assert _same(_snapshot(bad), _snapshot(ref))
 
 
 def test_epoch_status_entry_points_validate_their_arguments():
