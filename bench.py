@@ -38,19 +38,39 @@ S, L, B, N_WINDOWS = 100, 20, 64, 1916
 N_BATCHES = N_WINDOWS // B          # 29 (drop_last, main.py:38)
 N_CRITICS = 5                       # train.py:301
 
-# Algorithmic MACs per window, SURVEY.md §8(d) accounting (1 MAC = 2 FLOP), split by the kernel that does the work.
-F_ENC = 2 * (4 * 50) * S + 100 * L                                  # 42 000
-F_DEC = L * 50 + 2 * 256 * 50 + 2 * 256 * 128 + 128 * S             # 104 936
-F_CX = L * S + 3 * L * L + L                                        # 3 220
-F_CZ = 2 * L * L + L                                                # 820
-MAC_PER_WINDOW = {                                                  # hyperbolic=True
-    # critic phase as hypad_train_epoch runs it (critic_fused.hip): the frozen generator's forwards of ALL iterations in
-    # one precompute launch, then one launch per (critic_x || critic_z) iteration
-    "critic_precompute": (F_DEC + S * S) + F_ENC,                           # decoder(z) + head, encoder(x)
-    "critic_iteration": 10 * (F_CX + F_CZ),                                 # 3 fwd + 3 backward-data + second-order chain + 3 weight-gradient passes
-    "gen": 2 * F_ENC + 4 * (F_DEC + S * S) + S * S + 2 * F_CX + 2 * F_CZ,   # fwd + backward-data of decoder_iteration
-    "dw_gen": F_ENC + 2 * (F_DEC + S * S) + S * S,                          # its weight-gradient third
-}
+
+class Cfg:
+    """One training workload: window length, batch, windows per signal, geometry (BASELINE.json configs[0..3])."""
+
+    def __init__(self, name, S=S, B=B, n_windows=N_WINDOWS, hyperbolic=True, data="sine"):
+        self.name, self.S, self.L, self.B, self.n_windows, self.hyperbolic, self.data = name, S, L, B, n_windows, hyperbolic, data
+        self.nb = n_windows // B
+        self.n_it = self.nb * N_CRITICS
+
+    # Algorithmic MACs per window, SURVEY.md §8(d) accounting (1 MAC = 2 FLOP), split by the kernel that does the work.
+    def mac(self):
+        S_, L_ = self.S, self.L
+        f_enc = 2 * (4 * 50) * S_ + 100 * L_                                  # 42 000 at S = 100
+        f_dec = L_ * 50 + 2 * 256 * 50 + 2 * 256 * 128 + 128 * S_             # 104 936
+        f_cx = L_ * S_ + 3 * L_ * L_ + L_                                     # 3 220
+        f_cz = 2 * L_ * L_ + L_                                               # 820
+        head = S_ * S_ if self.hyperbolic else 0                              # the Moebius head's F.linear
+        return {
+            # critic phase as hypad_train_epoch runs it (critic_fused.hip): the frozen generator's forwards of ALL iterations by the
+            # record producers (or one precompute launch), then the (critic_x || critic_z) iterations
+            "critic_precompute": (f_dec + head) + f_enc,                           # decoder(z) + head, encoder(x)
+            "critic_iteration": 10 * (f_cx + f_cz),                                # 3 fwd + 3 backward-data + second-order chain + 3 weight-gradient passes
+            "gen": 2 * f_enc + 4 * (f_dec + head) + head + 2 * f_cx + 2 * f_cz,    # fwd + backward-data of decoder_iteration
+            "dw_gen": f_enc + 2 * (f_dec + head) + head,                           # its weight-gradient third
+        }
+
+    def epoch_flop_per_signal(self):
+        m = self.mac()
+        return 2.0 * self.B * self.nb * (N_CRITICS * (m["critic_precompute"] + m["critic_iteration"]) + m["gen"] + m["dw_gen"])
+
+
+CFG1 = Cfg("configs[1]")
+MAC_PER_WINDOW = CFG1.mac()
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense
 
 
@@ -65,102 +85,110 @@ def synth_windows(n, s, seed):
     return series[np.arange(n)[:, None] + np.arange(s)[None, :]]
 
 
-def build_engine(spg, rank, hyperbolic, device):
+def build_engine(spg, rank, hyperbolic, device, cfg=None):
     from hypad_amd.engine import Engine
     from hypad_amd.models import tadgan
-    eng = Engine(S, L, B, hyperbolic, n_signals=spg, device=device, lr=5e-4, seed=1234 + rank)
+    cfg = cfg or Cfg("configs[1]" if hyperbolic else "configs[0]", hyperbolic=hyperbolic)
+    eng = Engine(cfg.S, L, cfg.B, cfg.hyperbolic, n_signals=spg, device=device, lr=5e-4, seed=1234 + rank)
     xs = []
     for s in range(spg):
         sid = rank * spg + s
         torch.manual_seed(sid)      # random-init weights of the reference architecture (train.py:415-426 order)
-        mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyperbolic), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
+        mods = dict(enc=tadgan.Encoder(cfg.S, L), dec=tadgan.Decoder(cfg.S, L, cfg.hyperbolic), cx=tadgan.CriticX(cfg.S, L), cz=tadgan.CriticZ(L))
         for k, m in mods.items():
             eng.load_state_dict(k, m.state_dict(), s)
-        xs.append(synth_windows(N_WINDOWS, S, sid))
+        if cfg.data == "uniform":   # rows U(-1, 1)
+            xs.append(np.random.default_rng(sid).uniform(-1, 1, (cfg.n_windows, cfg.S)))
+        else:
+            xs.append(synth_windows(cfg.n_windows, cfg.S, sid))
     x = torch.from_numpy(np.stack(xs)).to(device, torch.float32).contiguous()
     return eng, x
 
 
-def make_step(eng, x, spg, gen, device, graph=True, host_shuffle=False):
+def make_step(eng, x, spg, gen, device, graph=True, host_shuffle=False, cfg=CFG1):
     """One timed step = one epoch.  Returns (step, losses).  The DataLoader's shuffles -- a fresh uniform permutation for each of
     the 5 critic passes and the generator pass -- are drawn on the device by the library (hypad_epoch_shuffles: argsort of Philox
     keys in LDS, keyed by the rng tick) as the first node of the captured epoch, so a step is ONE graph replay with no host work
-    and no torch kernel; `host_shuffle` draws them with torch instead (rand + argsort into the static buffer the epoch reads:
-    what rounds 1-2 timed).  Eager launches: same bits as the replay."""
-    losses = torch.empty(spg, (2 * N_CRITICS + 1) * N_BATCHES, 4, device=device)
-    perm_buf = torch.empty(N_CRITICS + 1, N_BATCHES * B, dtype=torch.int32, device=device)
+    and no torch kernel; `host_shuffle` (and signals longer than the in-kernel sort's 4 096 windows) draws them with torch instead
+    (rand + argsort into the static buffer the epoch reads).  Eager launches: same bits as the replay."""
+    nb, Bc, nw = cfg.nb, cfg.B, cfg.n_windows
+    host_shuffle = host_shuffle or nw > eng.SHUFFLE_MAX_WINDOWS
+    losses = torch.empty(spg, (2 * N_CRITICS + 1) * nb, 4, device=device)
+    perm_buf = torch.empty(N_CRITICS + 1, nb * Bc, dtype=torch.int32, device=device)
 
     def step():
         if host_shuffle:
-            perm = torch.rand(N_CRITICS + 1, N_WINDOWS, device=device, generator=gen).argsort(dim=1)[:, : N_BATCHES * B]
+            perm = torch.rand(N_CRITICS + 1, nw, device=device, generator=gen).argsort(dim=1)[:, : nb * Bc]
             perm_buf.copy_(perm)
         if graph:
-            eng.train_epoch_graph(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses, shuffle_windows=0 if host_shuffle else N_WINDOWS)
+            eng.train_epoch_graph(x, perm_buf, nb, N_CRITICS, train_mode=True, losses=losses, shuffle_windows=0 if host_shuffle else nw)
         else:
             if not host_shuffle:
-                eng.draw_shuffles(perm_buf, N_WINDOWS)
-            eng.train_epoch(x, perm_buf, N_BATCHES, N_CRITICS, train_mode=True, losses=losses)
+                eng.draw_shuffles(perm_buf, nw)
+            eng.train_epoch(x, perm_buf, nb, N_CRITICS, train_mode=True, losses=losses)
     return step, losses
 
 
-def profile_kernels(eng, x, spg, device, reps=24):
+def profile_kernels(eng, x, spg, device, reps=24, cfg=CFG1):
     """Per-kernel launch durations of one epoch at `spg` signals, HIP events on the launch stream (hypad_profile_iteration):
-    kind 4 = the critic phase of one epoch (145 iterations) exactly as train_epoch launches it: ONE resident launch
+    kind 4 = the critic phase of one configs[1] epoch (145 iterations) exactly as train_epoch launches it: ONE resident launch
     (critic_persistent_kernel; reported per iteration and per launch; with its own record producers, or behind a precompute
-    launch) or, where that form cannot run, 145 per-iteration launches (the mean of the steady-state ones); kind 2 =
-    decoder_iteration (generator kernel, dW + Adam).  Returns per-launch ms, launches per epoch, epoch share and the
-    algorithmic FLOPs of one launch of each kernel (SURVEY.md §8d accounting).  kind 5 = the generator step's two kernels as the
-    epoch launches them, the mean over 64 back-to-back launches each."""
+    launch) or, where that form cannot run, 145 per-iteration launches (the mean of the steady-state ones); kind 5 = the generator
+    step's two kernels as the epoch launches them, the mean over 64 back-to-back launches each (an event pair around ONE 9 us launch
+    also times the event path).  Returns per-launch ms, launches per epoch, epoch share and the algorithmic FLOPs of one launch of
+    each kernel (SURVEY.md §8d accounting)."""
     persistent = eng.critic_phase_persistent()
     names = {4: ["critic_precompute", "critic_first_or_reinit", "critic_iteration"], 5: ["gen", "dw_gen"]}
     acc = {n: [] for v in names.values() for n in v}
-    idx = torch.arange(B, device=device, dtype=torch.int32)
+    idx = torch.arange(cfg.B, device=device, dtype=torch.int32)
     for rep in range(reps):
-        for kind in (4, 5):            # (5: 64 back-to-back launches per kernel -- an event pair around one 9 us launch also times the event path)
+        for kind in (4, 5):
             ms = eng.profile_iteration(kind, x, idx, train_mode=True)
             if rep >= 4:
                 for n, v in zip(names[kind], ms):
                     acc[n].append(v)
     kern_ms = {n: float(np.mean(v)) for n, v in acc.items() if n != "critic_first_or_reinit"}
-    n_it = N_CRITICS * N_BATCHES
+    n_it, nb, m = cfg.n_it, cfg.nb, cfg.mac()
     producers = persistent and eng.critic_phase_producers(n_it)      # the resident launch writes its own records: no precompute launch
+    pre_scale = n_it / 145.0                                         # (kind 4 precomputes 145 iterations' records)
     if persistent:
         per_launch = {"critic_persistent_kernel": kern_ms["critic_iteration"] * n_it, "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
-        launches = {"critic_persistent_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+        launches = {"critic_persistent_kernel": 1, "gen_kernel": nb, "dw_adam_kernel": nb}
         if not producers:
-            per_launch["critic_phase_precompute_kernel"] = kern_ms["critic_precompute"]
+            per_launch["critic_phase_precompute_kernel"] = kern_ms["critic_precompute"] * pre_scale
             launches["critic_phase_precompute_kernel"] = 1
     else:
-        per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"],
+        per_launch = {"critic_iteration_kernel": kern_ms["critic_iteration"], "critic_phase_precompute_kernel": kern_ms["critic_precompute"] * pre_scale,
                       "gen_kernel": kern_ms["gen"], "dw_adam_kernel": kern_ms["dw_gen"]}
-        launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": N_BATCHES, "dw_adam_kernel": N_BATCHES}
+        launches = {"critic_iteration_kernel": n_it + 1, "critic_phase_precompute_kernel": 1, "gen_kernel": nb, "dw_adam_kernel": nb}
     epoch_share = {k: per_launch[k] * launches[k] for k in per_launch}
     # (with producers the resident launch also does the precompute's work: both parts are its algorithmic FLOPs)
-    mac = {"critic_persistent_kernel": (MAC_PER_WINDOW["critic_iteration"] + (MAC_PER_WINDOW["critic_precompute"] if producers else 0)) * n_it,
-           "critic_iteration_kernel": MAC_PER_WINDOW["critic_iteration"],
-           "critic_phase_precompute_kernel": MAC_PER_WINDOW["critic_precompute"] * n_it, "gen_kernel": MAC_PER_WINDOW["gen"],
-           "dw_adam_kernel": MAC_PER_WINDOW["dw_gen"]}
+    mac = {"critic_persistent_kernel": (m["critic_iteration"] + (m["critic_precompute"] if producers else 0)) * n_it,
+           "critic_iteration_kernel": m["critic_iteration"],
+           "critic_phase_precompute_kernel": m["critic_precompute"] * n_it, "gen_kernel": m["gen"],
+           "dw_adam_kernel": m["dw_gen"]}
     return {"persistent": persistent, "producers": producers, "kern_ms": kern_ms, "per_launch": per_launch, "launches": launches,
             "epoch_share_ms": epoch_share, "dominant": max(epoch_share, key=epoch_share.get),
-            "flop_per_launch": {k: 2.0 * mac[k] * B * spg for k in per_launch}}
+            "flop_per_launch": {k: 2.0 * mac[k] * cfg.B * spg for k in per_launch}}
 
 
-EPOCH_FLOP_PER_SIGNAL = 2.0 * B * N_BATCHES * (N_CRITICS * (MAC_PER_WINDOW["critic_precompute"] + MAC_PER_WINDOW["critic_iteration"])
-                                                + MAC_PER_WINDOW["gen"] + MAC_PER_WINDOW["dw_gen"])
+EPOCH_FLOP_PER_SIGNAL = CFG1.epoch_flop_per_signal()
 
 
-def bench_signals(spg, rank, device, gen, warmup=5, steps=20):
-    """`spg` signals (models) per GPU, otherwise configs[1]: the epoch replayed as a captured hipGraph (static shuffle buffer),
+def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True):
+    """`spg` signals (models) per GPU of workload `cfg`: the epoch replayed as a captured hipGraph (static shuffle buffer),
     `warmup` untimed + `steps` timed epochs; the same epochs launched eagerly (host-bound wherever ~61 launches of CPU enqueue
     exceed the GPU time); per-kernel launch times at this signal count and the chip-level rate: all algorithmic FLOPs of an
     epoch over the epoch's time, against the fp32-MFMA peak."""
-    eng, x = build_engine(spg, spg * rank, True, device)
-    out = {"workload": "configs[2] per-GPU share: %d signals (%d models) per GPU, otherwise as configs[1]" % (spg, spg),
-           "signals_per_gpu": spg, "steps": steps, "warmup": warmup, "unit": "windows/s (this GPU)",
+    eng, x = build_engine(spg, spg * rank, cfg.hyperbolic, device, cfg)
+    out = {"workload": what or ("configs[2] per-GPU share: %d signals (%d models) per GPU, otherwise as configs[1]" % (spg, spg)),
+           "signals_per_gpu": spg, "window": cfg.S, "batch": cfg.B, "windows_per_signal": cfg.n_windows, "hyperbolic": cfg.hyperbolic,
+           "iterations_per_step": (2 * N_CRITICS + 1) * cfg.nb, "steps": steps, "warmup": warmup, "unit": "windows/s (this GPU)",
            "critic_phase_persistent": eng.critic_phase_persistent()}
-    runs = {"graph": [], "eager": []}
-    fns = {mode: make_step(eng, x, spg, gen, device, graph=mode == "graph") for mode in runs}
-    for _ in range(2):                                # the two launch modes alternately, twice: every run is reported, the faster one counts
+    modes = ("graph", "eager") if eager else ("graph",)
+    runs = {m: [] for m in modes}
+    fns = {mode: make_step(eng, x, spg, gen, device, graph=mode == "graph", cfg=cfg) for mode in runs}
+    for _ in range(2):                                # the launch modes alternately, twice: every run is reported, the faster one counts
         for mode, (step, losses) in fns.items():      # (a replay measured right after other GPU processes once came out 15 % slower than the
             for _ in range(warmup):                   # eager launches of the same epoch next to it; it does not reproduce in isolation)
                 step()
@@ -175,17 +203,20 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20):
     for mode, v in runs.items():
         out[mode + "_ms_per_step"] = min(v)
         out[mode + "_ms_per_step_runs"] = v
-    out["launch"] = "hipGraph replay of the captured epoch"
+    out["launch"] = "hipGraph replay of the captured epoch" + (" (shuffles: torch rand + argsort per epoch -- more than 4 096 windows)"
+                                                               if cfg.n_windows > eng.SHUFFLE_MAX_WINDOWS else "")
     out["ms_per_step"] = out["graph_ms_per_step"]
-    out["value"] = spg * N_BATCHES * B / (1e-3 * out["ms_per_step"])
-    prof = profile_kernels(eng, x, spg, device, reps=12)
-    tflops = spg * EPOCH_FLOP_PER_SIGNAL / (1e-3 * out["ms_per_step"]) / 1e12
+    out["value"] = spg * cfg.nb * cfg.B / (1e-3 * out["ms_per_step"])
+    prof = profile_kernels(eng, x, spg, device, reps=12, cfg=cfg)
+    flop_step = spg * cfg.epoch_flop_per_signal()
+    tflops = flop_step / (1e-3 * out["ms_per_step"]) / 1e12
     dom = prof["dominant"]
     out["roofline"] = {"bound": "mfma", "what": "chip level: every kernel's algorithmic FLOPs of one epoch / the epoch's time",
                        "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_F32_MFMA_TFLOPS,
-                       "flop_per_step": spg * EPOCH_FLOP_PER_SIGNAL, "kernel_ms": prof["per_launch"], "launches_per_step": prof["launches"],
+                       "flop_per_step": flop_step, "kernel_ms": prof["per_launch"], "launches_per_step": prof["launches"],
                        "epoch_share_ms": prof["epoch_share_ms"], "dominant": dom,
                        "dominant_achieved": prof["flop_per_launch"][dom] / (prof["per_launch"][dom] * 1e-3) / 1e12,
+                       "dominant_frac": prof["flop_per_launch"][dom] / (prof["per_launch"][dom] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                        "critic_phase": ("resident launch" + (" with its own record producers" if prof["producers"] else " behind a precompute launch"))
                                        if prof["persistent"] else "one launch per iteration"}
     del eng, x
@@ -238,18 +269,13 @@ def bench_drop_in(hyperbolic, device, epochs=(3, 30)):
         return time.perf_counter() - t0, hist, mods
 
     def rate(loader, **kw):
-        """Steady state of ONE call: the epoch form stamps the moment each epoch's losses reach the host (hist.wall) -- the mean
-        spacing of those stamps from the third epoch on; the call-by-call loop has no set-up worth excluding beyond its first epoch
-        (difference of two calls).  Best of two."""
+        """Steady state of ONE call: train_tadgan stamps the moment each epoch's losses reach the host (hist.wall) -- the mean spacing
+        of those stamps from the third epoch on.  Best of two calls."""
         best = float("inf")
+        n_ep = epochs[0] if kw.get("per_iteration") else epochs[1]
         for _ in range(2):
-            if kw.get("per_iteration"):
-                t1, _, mods = run(loader, 1, **kw)
-                t2, _, mods = run(loader, 1 + epochs[0], **kw)
-                best = min(best, (t2 - t1) / epochs[0])
-            else:
-                _, hist, mods = run(loader, epochs[1] + 2, **kw)
-                best = min(best, (hist.wall[-1] - hist.wall[1]) / epochs[1])
+            _, hist, mods = run(loader, n_ep + 2, **kw)
+            best = min(best, (hist.wall[-1] - hist.wall[1]) / n_ep)
         return {"value": N_BATCHES * B / best, "ms_per_epoch": 1e3 * best, "us_per_iteration": 1e6 * best / ((2 * N_CRITICS + 1) * N_BATCHES)}, mods
 
     data = torch.from_numpy(synth_windows(N_WINDOWS, S, 0)[: N_BATCHES * B, :, None])      # float64, like SignalDataset (dataloader.py:227-232)
@@ -426,12 +452,14 @@ def _event_ms(fn, reps):
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec; 6 290 measured for a float4 copy
 
 
-def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
+def bench_scoring(device, n=125_000, reps=5, cpu_sample=0, smooth=200, kernels=True):
     """BASELINE.json's second metric, anomaly-score windows/s, on this GPU's share of configs[4] (10^6 windows over 8 GPUs): the
     test-loop forward with the hyperbolic row distance (anomaly_detection.py:67-113), then un-roll median + point and DTW errors +
     rolling mean + z-score (utils/anomaly_detection_utils.py:866-962, 516-524).  Returns (scoring, roofline_hbm, roofline_scoring):
     kernel-only rates -- every output pre-allocated, HIP events around back-to-back launches through the C ABI -- of the row-wise
-    Poincare-ball kernels (algorithmic bytes per row) and of each scoring kernel."""
+    Poincare-ball kernels (algorithmic bytes per row) and of each scoring kernel.  ``smooth``: window of the
+    reconstruction errors' rolling mean (the reference smooths with 1 % of the windows: anomaly_detection_utils.py:459-460);
+    ``kernels=False``: only the `scoring` section (the 10^6-window run)."""
     from hypad_amd import _C
     from hypad_amd.hyperspace import gmath
     from hypad_amd.models import tadgan
@@ -467,8 +495,8 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
     def numerics():
         true = adu.unroll_true(x)
         pred, _ = adu.unroll_predictions(eucl, False)
-        e1 = adu.rolling_mean(adu._point_wise_error(true, pred), 200)
-        e2 = adu.rolling_mean(adu._dtw_error(true, pred, 10), 200)
+        e1 = adu.rolling_mean(adu._point_wise_error(true, pred), smooth)
+        e2 = adu.rolling_mean(adu._dtw_error(true, pred, 10), smooth)
         return adu.zscore_clip(e1), adu.zscore_clip(e2)
 
     def critic_smoothing():         # final_critic_scores (utils/anomaly_detection_utils.py:365-404): KDE mode per timestep, trimmed z-score, rolling mean
@@ -478,7 +506,8 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
     scoring = {"windows": n, "value": n / (t_fwd + t_num + t_kde), "unit": "windows/s", "forward_windows_per_s": n / t_fwd,
                "numerics_windows_per_s": n / t_num, "critic_smoothing_windows_per_s": n / t_kde,
                "without_kde_value": n / (t_fwd + t_num),
-               "what": "value = test-loop forward + reconstruction numerics (un-roll median, point + DTW(11) errors, rolling mean(200), z-score) "
+               "forward_ms": 1e3 * t_fwd, "numerics_ms": 1e3 * t_num, "critic_smoothing_ms": 1e3 * t_kde, "smoothing_window": smooth,
+               "what": "value = test-loop forward + reconstruction numerics (un-roll median, point + DTW(11) errors, rolling mean(smoothing_window), z-score) "
                        "+ the KDE critic smoothing score_anomalies runs (utils/anomaly_detection_utils.py:470-506); host wall clock around "
                        "the wrappers; without_kde_value = the first two only (the figure of rounds 1-2)"}
     # the whole pass as ONE replayed hipGraph (parallel.replay_scorer: the pass is a fixed launch sequence -- nothing goes through the host):
@@ -489,7 +518,7 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
         def whole():
             forward()
             return numerics() + (critic_smoothing(),)
-        rep = lambda: par.replay_scorer(whole, x, enc.arena(), dec.arena(), cx.arena(), key="bench_scoring")
+        rep = lambda: par.replay_scorer(whole, x, enc.arena(), dec.arena(), cx.arena(), key=("bench_scoring", n, smooth))
         rep()
         scoring["graph_replay_value"] = n / timed(rep)
     except Exception as e:
@@ -510,6 +539,8 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0):
                                          "matrix, or the scaled series the windows are views of"}
     if cpu_sample:
         scoring["cpu_baseline"] = cpu_scoring_baseline(cpu_sample)
+    if not kernels:
+        return scoring, None, None
 
     # ---- each scoring kernel on its own: pre-allocated outputs, HIP events
     T = n + S - 1
@@ -691,6 +722,7 @@ def main():
     ap.add_argument("--no-scoring", action="store_true", help="skip the anomaly-score windows/s section")
     ap.add_argument("--no-graph", action="store_true", help="launch every epoch eagerly instead of replaying its captured hipGraph")
     ap.add_argument("--host-shuffle", action="store_true", help="draw the epoch's shuffles with torch (rand + argsort) instead of inside the captured epoch")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the euclidean / multivariate / signals32 sections")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] (8 signals per GPU) secondary line")
     ap.add_argument("--strict", action="store_true", help="fail (instead of reporting) when the per-kernel times add up to more than the step")
     ap.add_argument("--no-drop-in", action="store_true", help="skip timing the reference-style loop over hypad_amd.train's iteration functions")
@@ -720,7 +752,8 @@ def main():
     hb.build()                      # (rank-safe: file lock; prints nothing -- stdout carries the ONE JSON line)
     hyperbolic = not args.euclidean
     spg = args.signals_per_gpu
-    eng, x = build_engine(spg, rank, hyperbolic, device)
+    cfg_main = Cfg("configs[1]" if hyperbolic else "configs[0] on the GPU", hyperbolic=hyperbolic)
+    eng, x = build_engine(spg, rank, hyperbolic, device, cfg_main)
     gen = torch.Generator(device=device).manual_seed(100 + rank)
 
     def barrier():
@@ -728,7 +761,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step, losses = make_step(eng, x, spg, gen, device, graph=not args.no_graph, host_shuffle=args.host_shuffle)
+    step, losses = make_step(eng, x, spg, gen, device, graph=not args.no_graph, host_shuffle=args.host_shuffle, cfg=cfg_main)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -746,7 +779,8 @@ def main():
     assert all(np.isfinite(last)), "training diverged"
 
     # ---- per-kernel durations, HIP events on the launch stream (same workload, after the timed region)
-    prof = profile_kernels(eng, x, spg, device)
+    prof = profile_kernels(eng, x, spg, device, cfg=cfg_main)
+    mac_main = cfg_main.mac()
     per_launch, launches, epoch_share, dom = prof["per_launch"], prof["launches"], prof["epoch_share_ms"], prof["dominant"]
     persistent, producers, n_it = prof["persistent"], prof["producers"], N_CRITICS * N_BATCHES
     flop = prof["flop_per_launch"][dom]                  # algorithmic FLOPs of ONE launch of the dominant kernel
@@ -812,6 +846,19 @@ def main():
     if spg == 1 and hyperbolic and not args.no_secondary:
         secondary = bench_signals(8, rank, device, gen)
 
+    # ---- the other BASELINE.json configs as sections of the same line, each the graph-replayed epoch of its shape with its own roofline:
+    # configs[0] on the GPU (hyperbolic=False), configs[3] (5 channels x 30 = window 150, batch 256, 20 480 windows: the compile-time
+    # <150, 20, 256> kernels), and 32 signals (models) per GPU -- every CU holds a critic workgroup
+    extra = {}
+    if spg == 1 and hyperbolic and not args.no_extra_configs:
+        extra["euclidean"] = bench_signals(1, rank, device, gen, warmup=3, steps=20, cfg=Cfg("configs[0]", hyperbolic=False), eager=False,
+                                           what="configs[0] on the GPU: univariate, hyperbolic=False, batch 64, window 100, 1 916 windows, 1 signal")
+        extra["multivariate"] = bench_signals(1, rank, device, gen, warmup=2, steps=8, cfg=Cfg("configs[3]", S=150, B=256, n_windows=20480, data="uniform"),
+                                              eager=False, what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
+                                                                "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations")
+        extra["signals32"] = bench_signals(32, rank, device, gen, warmup=2, steps=8, eager=False,
+                                           what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
+
     # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
     # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
     drop_in = None
@@ -862,8 +909,8 @@ def main():
                          "us_per_critic_iteration": 1e3 * prof["kern_ms"]["critic_iteration"],
                          "kernel_ms": per_launch, "epoch_share_ms": epoch_share, "epoch_share_sum_ms": share_sum,
                          "epoch_share_le_step": bool(share_ok), "flop_per_launch": flop,
-                         "flop_per_launch_parts": ({"critic_iterations": 2.0 * MAC_PER_WINDOW["critic_iteration"] * n_it * B * spg,
-                                                    "record_producers": 2.0 * (MAC_PER_WINDOW["critic_precompute"] if producers else 0) * n_it * B * spg}
+                         "flop_per_launch_parts": ({"critic_iterations": 2.0 * mac_main["critic_iteration"] * n_it * B * spg,
+                                                    "record_producers": 2.0 * (mac_main["critic_precompute"] if producers else 0) * n_it * B * spg}
                                                    if dom == "critic_persistent_kernel" else None)},
             "final_losses": {"loss": last[0], "aux": last[1]},
         }
@@ -872,10 +919,14 @@ def main():
         out["config"]["critics_on_one_xcd"] = int(eng.counters[5])          # placement census of the last resident critic launch (of 2 per signal)
         if secondary is not None:
             out["secondary"] = secondary
+        out.update(extra)
         if drop_in is not None:
             out["drop_in"] = drop_in
         if not args.no_scoring:
             out["scoring"], out["roofline_hbm"], out["roofline_scoring"] = bench_scoring(device, cpu_sample=0 if args.no_cpu_baseline else 40000)
+            # configs[4] whole on ONE GPU: 10^6 windows (400 MB of windows; the four (N, S) outputs 1.6 GB), errors smoothed over 10^4
+            torch.cuda.empty_cache()
+            out["scoring_1e6"] = bench_scoring(device, n=1_000_000, reps=3, smooth=10_000, kernels=False)[0]
         if sharded is not None:
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:

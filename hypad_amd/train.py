@@ -411,7 +411,7 @@ def train_tadgan_per_iteration(train_loader, encoder, decoder, critic_x, critic_
     reference point of its parity test; ``train_tadgan`` lands here with ``params.per_iteration = True``."""
     logging.debug("Starting training")
     optim_cx, optim_cz, optim_dec = make_optimizers(encoder, decoder, critic_x, critic_z, params)
-    cx_epoch_loss, cz_epoch_loss, decoder_epoch_loss, hyp_dec_loss, eucl_dec_loss = [], [], [], [], []
+    cx_epoch_loss, cz_epoch_loss, decoder_epoch_loss, hyp_dec_loss, eucl_dec_loss, wall = [], [], [], [], [], []
     actual_epoch = 0
     if params.resume:
         n_epochs = n_epochs - params.resume_epoch
@@ -453,13 +453,14 @@ def train_tadgan_per_iteration(train_loader, encoder, decoder, critic_x, critic_
             print("Eucl mse loss {}".format(eucl_dec_loss[-1]))
         print("critic x loss {:.3f} critic z loss {:.3f} \ndecoder loss {:.3f}\n".format(
             cx_epoch_loss[-1], cz_epoch_loss[-1], decoder_epoch_loss[-1]))
+        wall.append(time.perf_counter())
         actual_epoch += 1
         if (actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1)):       # train.py:381 (cadence kept as is)
             torch.save(encoder, path + "/encoder_{}.pt".format(actual_epoch))
             torch.save(decoder, path + "/decoder_{}.pt".format(actual_epoch))
             torch.save(critic_x, path + "/critic_x_{}.pt".format(actual_epoch))
             torch.save(critic_z, path + "/critic_z_{}.pt".format(actual_epoch))
-    return SimpleNamespace(cx=cx_epoch_loss, cz=cz_epoch_loss, dec=decoder_epoch_loss, hyper=hyp_dec_loss, mse=eucl_dec_loss)
+    return SimpleNamespace(cx=cx_epoch_loss, cz=cz_epoch_loss, dec=decoder_epoch_loss, hyper=hyp_dec_loss, mse=eucl_dec_loss, wall=wall)
 
 
 def model_path(params):
