@@ -54,7 +54,8 @@ class Dropout(Structure):
 
 
 class Dims(Structure):
-    _fields_ = [("signal_shape", c_int), ("latent_dim", c_int), ("batch", c_int), ("hyperbolic", c_int), ("n_signals", c_int)]
+    _fields_ = [("signal_shape", c_int), ("latent_dim", c_int), ("batch", c_int), ("hyperbolic", c_int), ("n_signals", c_int),
+                ("first_signal", c_int)]                       # ABI 5: stream number of model 0 (defaults to 0)
 
 
 class Nets(Structure):
@@ -81,7 +82,8 @@ class EpochIO(Structure):
     _fields_ = [("x", c_void_p), ("x_signal_stride", c_int64), ("x_row_stride", c_int64), ("row_index", c_void_p), ("n_batches", c_int),
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int),
-                ("aux_streams", POINTER(c_void_p)), ("n_aux_streams", c_int)]      # ABI 4: streams for the generator phase's model groups
+                ("aux_streams", POINTER(c_void_p)), ("n_aux_streams", c_int),      # ABI 4: streams for the generator phase's model groups
+                ("row_index_signal_stride", c_int64)]                              # ABI 5: a row_index plane per signal (0: one shared plane)
 
 
 STATS_WORKSPACE_BYTES = 256 * 5 * 8  # HYPAD_STATS_WORKSPACE_BYTES
@@ -144,6 +146,7 @@ _SIGS = {
     "hypad_decoder_iteration": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(IterIO), P]),
     "hypad_train_epoch": (c_int, [POINTER(Dims), POINTER(TrainState), POINTER(EpochIO), P]),
     "hypad_epoch_shuffles": (c_int, [P, c_int, c_int, c_int, c_uint64, P, P]),
+    "hypad_epoch_shuffles_signals": (c_int, [P, c_int64, c_int, c_int, P, c_int, c_int, c_uint64, P, P]),
     "hypad_host_mt19937_normal": (c_int, [P, POINTER(c_int), POINTER(c_int), POINTER(c_double), POINTER(c_void_p), c_int, c_int64, c_int64]),
     "hypad_epoch_status": (c_int, [POINTER(TrainState), POINTER(c_int), P]),
     "hypad_epoch_restore": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, P]),

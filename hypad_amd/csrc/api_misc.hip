@@ -91,11 +91,21 @@ __global__ void rng_fill_kernel(int kind, uint64_t seed, uint32_t tick, uint32_t
 // Philox keys (64-bit key << 32 | index: no ties), one workgroup per pass, bitonic sort in LDS.  Keyed by (seed, tick, pass) with
 // the tick read from the device counters, so a replayed graph draws fresh permutations every epoch.
 constexpr int SHUF_MAX = 4096, SHUF_THREADS = 1024, RS_SHUFFLE = 5;
+// blockIdx.y = model: its own plane (out + y * signal_stride), window count (n_per_signal[y], or `n` for all) and key -- the seed
+// with the model's stream number first_signal + y folded in (stream 0: the seed itself)
 __global__ __launch_bounds__(SHUF_THREADS) void epoch_shuffle_kernel(int32_t* __restrict__ out, int take, int n, int npow2, uint64_t seed,
-                                                                     const int32_t* __restrict__ counters) {
+                                                                     const int32_t* __restrict__ counters, int64_t signal_stride = 0,
+                                                                     const int32_t* __restrict__ n_per_signal = nullptr, int first_signal = 0) {
   __shared__ unsigned long long keys[SHUF_MAX];
   const uint32_t tick = counters ? (uint32_t)counters[3] : 0u;
-  const Philox ph(seed);
+  out += (int64_t)blockIdx.y * signal_stride;
+  if (n_per_signal) {
+    n = n_per_signal[blockIdx.y];
+    n = n < take ? take : n > SHUF_MAX ? SHUF_MAX : n;                    // (validated on the host side where the counts are known; never out of LDS)
+    npow2 = 2;
+    while (npow2 < n) npow2 <<= 1;
+  }
+  const Philox ph(seed ^ ((uint64_t)(uint32_t)(first_signal + (int)blockIdx.y) * 0x9E3779B97F4A7C15ULL));
   for (int i = threadIdx.x; i < npow2; i += SHUF_THREADS) {
     unsigned long long k = ~0ull;                                        // padding sorts last
     if (i < n) {
@@ -139,6 +149,16 @@ int hypad_epoch_shuffles(int32_t* row_index, int n_passes, int take, int n_windo
   while (npow2 < n_windows) npow2 <<= 1;
   hipLaunchKernelGGL(epoch_shuffle_kernel, dim3(n_passes), dim3(SHUF_THREADS), 0, (hipStream_t)stream, row_index, take, n_windows, npow2, seed,
                      counters);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
+int hypad_epoch_shuffles_signals(int32_t* row_index, int64_t signal_stride, int n_signals, int first_signal, const int32_t* n_windows,
+                                 int n_passes, int take, uint64_t seed, const int32_t* counters, hypad_stream_t stream) {
+  if (!row_index || !n_windows || n_signals <= 0 || first_signal < 0 || n_passes <= 0 || take <= 0 || take > SHUF_MAX) return HYPAD_EINVAL;
+  if (n_signals > 1 && signal_stride < (int64_t)n_passes * take) return HYPAD_EINVAL;
+  hipLaunchKernelGGL(epoch_shuffle_kernel, dim3(n_passes, n_signals), dim3(SHUF_THREADS), 0, (hipStream_t)stream, row_index, take, take, 2, seed,
+                     counters, signal_stride, n_windows, first_signal);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

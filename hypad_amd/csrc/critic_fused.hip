@@ -198,7 +198,7 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
   });
   for (int gi = threadIdx.x; gi < 4 * in_dim; gi += blockDim.x) {      // interpolation (train.py:64-69 / 149-154)
     float4 al = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!inj_alpha) al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)(g0 * in_dim) / 4 + gi);
+    if (!inj_alpha) al = rng_uniform4(a.seed, tick, RS_ALPHA, (uint32_t)(sig + a.rng_sig0), (uint32_t)(g0 * in_dim) / 4 + gi);
     const float alv[4] = {al.x, al.y, al.z, al.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -221,7 +221,7 @@ __device__ __forceinline__ void emit_record(const IterArgs& a, const CritGeom& g
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = mb[4 * gi + e];               // (row r, column c) of the tile = flat element r * L + c
     } else if (a.drop_mode == 2) {
-      const float4 uu = rng_uniform4(a.seed, tick, RS_DROP_CRITIC + 8 * pass + li, (uint32_t)sig, (uint32_t)(g0 * L) / 4 + gi);
+      const float4 uu = rng_uniform4(a.seed, tick, RS_DROP_CRITIC + 8 * pass + li, (uint32_t)(sig + a.rng_sig0), (uint32_t)(g0 * L) / 4 + gi);
       v[0] = uu.x >= p_drop ? keep : 0.f; v[1] = uu.y >= p_drop ? keep : 0.f;
       v[2] = uu.z >= p_drop ? keep : 0.f; v[3] = uu.w >= p_drop ? keep : 0.f;
     }
@@ -274,13 +274,13 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
     tail[0] = bc1; tail[1] = bc2s;
   }
   if (threadIdx.x >= 2 && threadIdx.x < 32) rec_w[4 * (grec.rec_rows4 + grec.rec_mask4) + threadIdx.x] = 0.f;
-  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ph.row_index ? ph.row_index + (int64_t)it * B : nullptr, g0, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ph.row_index ? ph.row_index + (int64_t)sig * ax.ri_sig_stride + (int64_t)it * B : nullptr, g0, 16, S, 16);
   if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
     const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
     const float* PD = ax.P.dec + (int64_t)sig * ax.pd;
     const int64_t isl = (int64_t)it * n_signals + sig;                 // (iteration, signal) slice of an injected plane
     const float* zin = ph.inj_z_x ? ph.inj_z_x + (isl * B + g0) * L : nullptr;
-    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(ax.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(ax.seed, tick, RS_Z, (uint32_t)(sig + ax.rng_sig0), (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
     const float* mk = ph.inj_mk_x ? ph.inj_mk_x + isl * ax.mask_sig_stride : nullptr;
     DropSrc ddrop = drop_src(ax, sig, mk ? mk + (int64_t)12 * B * L : nullptr, RS_DROP_DEC0, tick, 0.2f);
@@ -303,7 +303,7 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
     const float* PE = az.P.enc + (int64_t)sig * az.pe;
     const int64_t isl = (int64_t)it * n_signals + sig;
     const float* zin = ph.inj_z_z ? ph.inj_z_z + (isl * B + g0) * L : nullptr;
-    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(az.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((g0 + r) * L + c)); });
+    tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(az.seed, tick, RS_Z, (uint32_t)(sig + az.rng_sig0), (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
     float* zenc = zs + 16 * LP;
     const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
@@ -1773,7 +1773,7 @@ void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_flo
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
                      const unsigned* zeroed, int flags, int only) {
-  hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals;
+  hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals; d.first_signal = ax.rng_sig0;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
   const PhasePlan plan = plan_phase(d, extra_floats, n_iters, flags);
   if (!plan.ok) return HYPAD_EWORKSPACE;

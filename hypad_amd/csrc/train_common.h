@@ -96,6 +96,8 @@ struct IterArgs {
   int step_add;                    // < 0: the launch reads the step / rng tick counters and advances them (one launch group at a time on one
                                    // stream); >= 0: it belongs to generator iteration `step_add` of an epoch -- step = counters[opt] + step_add + 1,
                                    // tick = counters[3] + step_add, nothing is advanced (one closing launch adds the epoch's iterations)
+  int rng_sig0;                    // hypad_dims.first_signal: model `sig` draws its device random streams as stream rng_sig0 + sig
+  int64_t ri_sig_stride;           // int32 elements between the models' row_index planes (0: one plane for all)
   int guard;                       // 1 (hypad_train_epoch): a launch is a no-op while counters[4] -- the resident critic launch's
                                    // status word -- is non-zero (fail-stop, see hypad_epoch_status in hypad.h)
   long long* stamps;               // development aid: shader-clock stamps [role][48 marks][8 waves] of workgroup (0, 0) of the generator kernel, or null
@@ -134,7 +136,7 @@ HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head, int critic_floats, int 
 
 __device__ __forceinline__ DropSrc drop_src(const IterArgs& a, int sig, const float* ptr, uint32_t stream, uint32_t tick, float p) {
   DropSrc s;
-  s.mode = a.drop_mode; s.ptr = ptr; s.batch = a.B; s.seed = a.seed; s.tick = tick; s.stream = stream; s.sig = (uint32_t)sig; s.p = p;
+  s.mode = a.drop_mode; s.ptr = ptr; s.batch = a.B; s.seed = a.seed; s.tick = tick; s.stream = stream; s.sig = (uint32_t)(sig + a.rng_sig0); s.p = p;
   return s;
 }
 

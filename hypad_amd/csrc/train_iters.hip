@@ -58,7 +58,7 @@ __device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, 
   // interpolation (train.py:64-69 / 149-154)
   const float* ainj = a.alpha ? a.alpha + ((int64_t)sig * B + g0) * in_dim : nullptr;
   tile_for(16, in_dim, [&](int r, int c) {
-    float al = ainj ? ainj[r * in_dim + c] : rng_uniform(a.seed, tick, RS_ALPHA, (uint32_t)sig, (uint32_t)((g0 + r) * in_dim + c));
+    float al = ainj ? ainj[r * in_dim + c] : rng_uniform(a.seed, tick, RS_ALPHA, (uint32_t)(sig + a.rng_sig0), (uint32_t)((g0 + r) * in_dim + c));
     inter[r * ldi + c] = al * real[r * ldr + c] + (1.f - al) * fake[r * ldf + c];
   });
   __syncthreads();
@@ -107,14 +107,14 @@ __device__ __forceinline__ void load_z(const IterArgs& a, int sig, int tile, uin
   const int L = a.L;
   if (zinj || (L & 1)) {
     tile_for(16, L, [&](int r, int c) {
-      zs[r * LP + c] = zinj ? zinj[r * L + c] : rng_normal(a.seed, tick, RS_Z, (uint32_t)sig, (uint32_t)((tile * 16 + r) * L + c));
+      zs[r * LP + c] = zinj ? zinj[r * L + c] : rng_normal(a.seed, tick, RS_Z, (uint32_t)(sig + a.rng_sig0), (uint32_t)((tile * 16 + r) * L + c));
     });
   } else {                                  // two normals per Philox evaluation: the same numbers as rng_normal per element
     for (int i = threadIdx.x; i < 16 * (L >> 1); i += blockDim.x) {
       const int r = i / (L >> 1), c = 2 * (i - r * (L >> 1));
       const uint32_t idx = (uint32_t)((tile * 16 + r) * L + c);
       Philox ph(a.seed);
-      const uint4 rr = ph(idx >> 1, RS_Z, tick, (uint32_t)sig);
+      const uint4 rr = ph(idx >> 1, RS_Z, tick, (uint32_t)(sig + a.rng_sig0));
       zs[r * LP + c] = sqrtf(-2.0f * __logf(u32_to_unit_open(rr.x))) * __cosf(6.28318530717958647692f * u32_to_unit(rr.y));
       zs[r * LP + c + 1] = sqrtf(-2.0f * __logf(u32_to_unit_open(rr.z))) * __cosf(6.28318530717958647692f * u32_to_unit(rr.w));
     }
@@ -138,7 +138,7 @@ __device__ __forceinline__ void cx_pass_body(const IterArgs& a, float* smem) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
   if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
-  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, tile * 16, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index ? a.row_index + (int64_t)sig * a.ri_sig_stride : nullptr, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);
   __syncthreads();
   // decoder (frozen, train-mode dropout): x_ = decoder(z)
@@ -178,7 +178,7 @@ __device__ __forceinline__ void cz_pass_body(const IterArgs& a, float* smem) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.counters[a.opt] += 1;
   if (lp.stage) { stage_params(smem + lp.cparams, PC, cl.total); PC = smem + lp.cparams; }
 
-  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, tile * 16, 16, S, 16);
+  tile_load_rows(xs, lp.ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index ? a.row_index + (int64_t)sig * a.ri_sig_stride : nullptr, tile * 16, 16, S, 16);
   load_z(a, sig, tile, tick, zs);                       // real = z ~ N(0,1)
   __syncthreads();
   float* zenc = zs + 16 * LP;                           // fake = encoder(x)
@@ -306,7 +306,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   const CriticPad cpz = critic_pad(L, L, 2);
   // (the gather first: loads return in order, and the weight prefetch -- cold lines, rewritten by the previous launch -- would
   // hold its two dependent round trips back)
-  tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+  tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index ? a.row_index + (int64_t)sig * a.ri_sig_stride : nullptr, g0, 16, S, 16);
   const LstmPre pre_enc = lstm_layer_prefetch<WSC1>(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
   stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
   __syncthreads();
@@ -403,7 +403,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     // ---- encoder(x)  (critic_z(encoder(x)) and its way back through the encoder: chain Z)
     // the window gather is two dependent memory round trips (row index, then the row)
     GEN_STAMP(14);
-    tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index, g0, 16, S, 16);
+    tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index ? a.row_index + (int64_t)sig * a.ri_sig_stride : nullptr, g0, 16, S, 16);
     const LstmPre pre_enc = lstm_layer_prefetch<WSC1>(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);      // behind the gather (loads return in order)
     GEN_STAMP(15);
     GEN_STAMP(12);
@@ -1126,7 +1126,7 @@ DwTable gen_table(const hypad_dims& dm, bool with_decay = true) {
 
 // ------------------------------------------------------------------------------------------------ host: launches
 int check_dims(const hypad_dims* d) {
-  if (!d || d->signal_shape <= 0 || d->latent_dim <= 0 || d->batch <= 0 || d->n_signals <= 0) return HYPAD_EINVAL;
+  if (!d || d->signal_shape <= 0 || d->latent_dim <= 0 || d->batch <= 0 || d->n_signals <= 0 || d->first_signal < 0) return HYPAD_EINVAL;
   if (d->batch % 16 != 0) return HYPAD_EINVAL;
   if (d->signal_shape > MAX_S || d->latent_dim > MAX_L) return HYPAD_EUNSUPPORTED;
   if (gen_table(*d).n < 0) return HYPAD_EUNSUPPORTED;      // cannot happen within MAX_S / MAX_L; the critic tables are far smaller
@@ -1387,7 +1387,7 @@ long long* g_gen_stamps = nullptr;     // development builds only (libhypad_hip_
 #endif
 
 struct IterCall {
-  const float* x; int64_t x_sig_stride; int64_t x_row_stride; const int32_t* row_index;
+  const float* x; int64_t x_sig_stride; int64_t x_row_stride; const int32_t* row_index; int64_t ri_sig_stride = 0;
   const float* z; const float* alpha;
   int train_mode; const float* masks; uint64_t seed;
   float* losses; int64_t loss_sig_stride;
@@ -1418,6 +1418,7 @@ int fill_args(IterArgs& a, const hypad_dims* d, const hypad_train_state* st, con
   a.pk_off = ws_pack_offset(*d) - (opt == 1 ? ws_cz_offset(*d) : 0);       // a.ws is shifted for critic_z
   a.lr = st->lr; a.b1 = st->beta1; a.b2 = st->beta2; a.eps = st->eps; a.wd = 0.f; a.stabilize = 0; a.riemannian = 0;
   a.opt = opt; a.tick_owner = 1; a.stamps = nullptr; a.guard = io.guard; a.sig0 = 0; a.step_add = -1;
+  a.rng_sig0 = d->first_signal; a.ri_sig_stride = io.ri_sig_stride;
 #if HYPAD_DIAG
   a.stamps = g_gen_stamps;
 #endif
@@ -1669,7 +1670,7 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   if (!enc || !dec || !x || rows < 0 || (critic && !cx)) return HYPAD_EINVAL;
   if (!workspace || workspace_bytes < hypad_score_workspace_bytes(S, L, hyperbolic)) return HYPAD_EWORKSPACE;
   if (rows == 0) return HYPAD_OK;
-  hypad_dims d; d.signal_shape = S; d.latent_dim = L; d.batch = 16; d.hyperbolic = hyperbolic; d.n_signals = 1;
+  hypad_dims d; d.signal_shape = S; d.latent_dim = L; d.batch = 16; d.hyperbolic = hyperbolic; d.n_signals = 1; d.first_signal = 0;
   IterArgs pa{};
   pa.S = S; pa.L = L; pa.B = 16; pa.hyperbolic = hyperbolic;
   pa.P.enc = const_cast<float*>(enc); pa.P.dec = const_cast<float*>(dec);
@@ -1852,6 +1853,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   if (inj_masks && !(nz->masks_cx && nz->masks_cz && nz->masks_gen)) return HYPAD_EINVAL;      // all three planes or none
   IterCall c;
   c.x = io->x; c.x_sig_stride = io->x_signal_stride; c.x_row_stride = io->x_row_stride; c.z = nullptr; c.alpha = nullptr;
+  c.ri_sig_stride = io->row_index_signal_stride;
   c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
   c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
   c.guard = 1;                                          // every launch of the epoch stops behind a resident critic launch that gave up

@@ -21,7 +21,9 @@ _NET_ID = dict(enc=_C.NET_ENCODER, dec=_C.NET_DECODER, cx=_C.NET_CRITIC_X, cz=_C
 
 class Engine:
     def __init__(self, signal_shape, latent_dim, batch, hyperbolic, n_signals=1, device="cuda", lr=5e-4, betas=(0.9, 0.999),
-                 eps=1e-8, gen_weight_decay=1e-5, gen_stabilize=10, seed=0):
+                 eps=1e-8, gen_weight_decay=1e-5, gen_stabilize=10, seed=0, first_signal=0):
+        """first_signal: model s draws its device random streams (and, through draw_shuffles, its shuffles) as stream
+        first_signal + s (hypad_dims.first_signal): model k of a group == a single model with first_signal + k, bit for bit."""
         if batch % 16:
             raise _C.HypadError("batch size must be a multiple of 16 (row tiles of the fused kernels)")
         self.S, self.L, self.B, self.hyperbolic, self.n = int(signal_shape), int(latent_dim), int(batch), bool(hyperbolic), int(n_signals)
@@ -39,7 +41,8 @@ class Engine:
         self._last_epoch = None                  # arguments of the last train_epoch / train_epoch_graph call
         self._pending = []                       # ... of every epoch queued since the last check_status that found nothing (it re-runs the lost ones)
         self._steps_checked = (0, 0)             # counters[0], [2] (critic_x / generator optimizer steps) at that check
-        self.dims = _C.Dims(self.S, self.L, self.B, int(self.hyperbolic), self.n)
+        self.first_signal = int(first_signal)
+        self.dims = _C.Dims(self.S, self.L, self.B, int(self.hyperbolic), self.n, self.first_signal)
         nbytes = _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims))
         if nbytes == 0:
             raise _C.HypadError("unsupported dimensions for the fused training kernels")
@@ -231,12 +234,31 @@ class Engine:
     SHUFFLE_MAX_WINDOWS = 4096
 
     def draw_shuffles(self, row_index, n_windows):
-        """The DataLoader's shuffles of one epoch into ``row_index`` ((n_passes, n_batches * batch) int32 on the device), drawn by
-        the library (hypad_epoch_shuffles: capturable, keyed by the engine's seed and the device rng tick)."""
-        n_passes, take = row_index.shape
-        _C.check(_C.lib.hypad_epoch_shuffles(row_index.data_ptr(), int(n_passes), int(take), int(n_windows), self.seed ^ 0x5DEECE66D,
-                                             self.counters.data_ptr(), _C.stream()), "epoch_shuffles")
+        """The DataLoader's shuffles of one epoch, drawn by the library (capturable, keyed by the engine's seed, the model's stream
+        number and the device rng tick) into ``row_index``: (n_passes, n_batches * batch) int32 on the device -- ONE plane, every
+        model of the engine sees the same shuffles (hypad_epoch_shuffles) -- or (n_signals, n_passes, n_batches * batch): a plane
+        per model, each of permutations of its OWN window count (``n_windows``: an int, or one count per model) --
+        hypad_epoch_shuffles_signals; plane s of a group == the plane of a single model with first_signal + s."""
+        planes = row_index.shape[0] if row_index.dim() == 3 else 1
+        n_passes, take = row_index.shape[-2:]
+        if not row_index.is_contiguous():
+            raise _C.HypadError("row_index must be contiguous")
+        nw = self._window_counts(n_windows, planes)
+        _C.check(_C.lib.hypad_epoch_shuffles_signals(row_index.data_ptr(), int(n_passes * take), planes, self.first_signal, nw.data_ptr(),
+                                                     int(n_passes), int(take), self.seed ^ 0x5DEECE66D, self.counters.data_ptr(), _C.stream()),
+                 "epoch_shuffles_signals")
         return row_index
+
+    def _window_counts(self, n_windows, planes):
+        """Device int32[planes] of window counts (cached: a captured epoch holds its address)."""
+        counts = tuple(int(v) for v in (n_windows.tolist() if hasattr(n_windows, "tolist") else
+                                        (n_windows if isinstance(n_windows, (list, tuple)) else [n_windows] * planes)))
+        if len(counts) != planes or min(counts) < 1 or max(counts) > self.SHUFFLE_MAX_WINDOWS:
+            raise _C.HypadError(f"draw_shuffles: {planes} window count(s) in [1, {self.SHUFFLE_MAX_WINDOWS}] expected")
+        cache = self.__dict__.setdefault("_nw_cache", {})
+        if counts not in cache:
+            cache[counts] = torch.tensor(counts, dtype=torch.int32, device=self.device)
+        return cache[counts]
 
     def train_epoch_graph(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, x_row_stride=0, shuffle_windows=0,
                           noise=None):
@@ -255,8 +277,9 @@ class Engine:
             if losses is None or losses.shape != (self.n, iters, 4):
                 losses = self._graph_losses = torch.empty(self.n, iters, 4, dtype=torch.float32, device=self.device)
         self._grow_workspace(_C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), n_batches, n_critics))
-        key = (x.data_ptr(), row_index.data_ptr(), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride), self.seed,
-               int(shuffle_windows), self._graph_state_key(),
+        shuffle_key = tuple(shuffle_windows) if isinstance(shuffle_windows, (list, tuple)) else int(shuffle_windows)
+        key = (x.data_ptr(), row_index.data_ptr(), tuple(row_index.shape), losses.data_ptr(), n_batches, n_critics, bool(train_mode), int(x_row_stride),
+               self.seed, shuffle_key, self._graph_state_key(),
                tuple(sorted((k, t.data_ptr()) for k, t in (noise or {}).items() if t is not None)))
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
@@ -280,7 +303,7 @@ class Engine:
         if len(self._pending) >= self.MAX_PENDING:       # never checked: nothing more is recorded, and a failure cannot be repaired any more
             self._pending_overflow = True
             return
-        self._pending.append((call, int(shuffle_windows)))
+        self._pending.append((call, shuffle_windows))
 
     # ---- status channel of the resident critic launch (include/hypad.h: hypad_epoch_status / hypad_epoch_restore) -------------
     def status(self):
@@ -343,6 +366,15 @@ class Engine:
         self._steps_checked = (int(c[0]), int(c[2]))
         return code
 
+    def _row_index_stride(self, row_index, n_batches, n_critics):
+        """0 for one shared (n_passes, n_batches * batch) plane, the plane stride for a (n_signals, n_passes, n_batches * batch) tensor."""
+        want = (n_critics + 1, n_batches * self.B)
+        if row_index.dim() == 3:
+            if tuple(row_index.shape) != (self.n,) + want or not row_index.is_contiguous():
+                raise _C.HypadError(f"per-signal row_index must be a contiguous {(self.n,) + want} int32 tensor")
+            return want[0] * want[1]
+        return 0
+
     def train_epoch(self, x, row_index, n_batches, n_critics=5, train_mode=True, losses=None, hoist=True, x_row_stride=0, noise=None,
                     workspace_iters=None, flags=None):
         """One epoch of train.py:299-356.  row_index: int32 (n_critics+1, n_batches*batch) on device.
@@ -370,7 +402,7 @@ class Engine:
                         (self._ws_bytes if workspace_iters is None else _C.lib.hypad_epoch_workspace_bytes(ctypes.byref(self.dims), int(workspace_iters), 1))
                         if hoist else _C.lib.hypad_train_workspace_bytes(ctypes.byref(self.dims)),
                         ctypes.pointer(nz) if nz is not None else None, int(self.epoch_flags if flags is None else flags),
-                        *self._aux_stream_args())
+                        *self._aux_stream_args(), self._row_index_stride(row_index, n_batches, n_critics))
         st = self._state()
         _C.check(_C.lib.hypad_train_epoch(ctypes.byref(self.dims), ctypes.byref(st), ctypes.byref(io), _C.stream()), "train_epoch")
         if not torch.cuda.is_current_stream_capturing():

@@ -35,6 +35,17 @@ def run(params, config_path=None, data_dir="./data", drop_in=True, log=print, re
     else:
         resident = train_dataset.device_windows("cpu") if multivariate else train_dataset
         encoder, decoder, critic_x, _, path, _ = ht.train_resident(resident, params, config_path, log=log)
+    return _detect(params, test_dataset, read_path, encoder, decoder, critic_x, path, data_dir, multivariate, log)
+
+
+def _detect(params, test_dataset, read_path, encoder, decoder, critic_x, path, data_dir, multivariate, log):
+    """main.py:57-70 / anomaly_detection.py:20-155: the test loop and the detector for one trained model."""
+    import pandas as pd
+    from torch.utils.data import DataLoader
+
+    from . import anomaly_detection
+    from .utils import anomaly_detection_utils as adu
+    from .utils import data as od
     test_loader = DataLoader(test_dataset, batch_size=params.batch_size, drop_last=False, shuffle=False, num_workers=0)
     recons_signal, true_signal, critic_score = anomaly_detection.test_tadgan(
         test_loader, encoder, decoder, critic_x, read_path=read_path, signal=params.signal, path=path, signal_shape=params.signal_shape,
@@ -61,6 +72,34 @@ def run(params, config_path=None, data_dir="./data", drop_in=True, log=print, re
     return out
 
 
+def run_signals(params, names, config_path=None, data_dir="./data", log=print):
+    """One model per signal for a list of signals (``--signals a,b,c``): datasets -> ``train.train_signals_resident`` (groups of up
+    to 32 models per launch sequence; under ``torchrun`` the signals are sharded over the ranks, one process per GPU) -> per
+    signal the test loop and the detector on the rank that trained it -> the metrics of all signals gathered on every rank."""
+    import copy
+
+    from . import parallel as par
+    from . import train as ht
+    from .utils import data as od
+    sets = []
+    for name in names:
+        p = copy.copy(params)
+        p.signal = name
+        sets.append((p,) + tuple(od.dataset_selection(p, data_dir)))
+    trained = ht.train_signals_resident([t[1] for t in sets], params, names=names, log=log)
+    local = {}
+    for (p, train_ds, test_ds, read_path), name in zip(sets, names):
+        mods = trained[name].get("modules")
+        if mods is None:
+            continue                                   # another rank's signal
+        p.latent_space_dim = 20
+        out = _detect(p, test_ds, read_path, mods[0], mods[1], mods[2], trained[name]["path"], data_dir, hasattr(train_ds, "device_windows"), log)
+        local[name] = {"confusion": [int(v) for v in out.get("confusion", [])] or None, "metrics": out.get("metrics"),
+                       "n_intervals": int(len(out["intervals"])), "final": trained[name]["final"], "path": trained[name]["path"],
+                       "rank": trained[name]["rank"]}
+    return par.gather_signal_metrics(local)
+
+
 def _true_index(test_dataset, params):
     """The reference hands the dataset's FULL index to the detector (anomaly_detection.py:127-129: `index[0]`, length N + S): the
     Euclidean branch scores N + S - 1 un-rolled timesteps, so find_anomalies indexes beyond the N window starts.  (The first N
@@ -76,8 +115,22 @@ def main(argv=None):
     ap.add_argument("--drop-in", action="store_true", help="(the default) train.train over a DataLoader with the reference's host-side randomness")
     ap.add_argument("--per-iteration", action="store_true", help="that loop call by call: one critic_x / critic_z / decoder_iteration per minibatch")
     ap.add_argument("--resident", action="store_true", help="device-side randomness and shuffles (train.train_resident)")
+    ap.add_argument("--signals", type=str, default=None, help="comma-separated signal names of params.dataset: one model per signal, trained side by "
+                                                               "side in groups of up to 32 per GPU (train.train_signals_resident); under torchrun the "
+                                                               "signals are sharded over the ranks")
     args = ap.parse_args(argv)
     params = SimpleNamespace(**yaml.load(open(args.config), Loader=yaml.FullLoader))
+    if args.signals:
+        import os
+        import torch
+        import torch.distributed as dist
+        if "RANK" in os.environ and not dist.is_initialized():           # one process per GPU (torchrun): RCCL for the end-of-run gather
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        res = run_signals(params, [n.strip() for n in args.signals.split(",") if n.strip()], args.config, args.data_dir)
+        for name, r in sorted(res.items()):
+            print(name, r["confusion"], r["metrics"])
+        return res
     return run(params, args.config, args.data_dir, resident=args.resident, per_iteration=args.per_iteration)
 
 

@@ -501,7 +501,7 @@ def train(train_loader, params, config_path):
 
 
 # ------------------------------------------------------------------------------------------------ resident fast path
-def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epochs, params, path="", seed=None, log=print):
+def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epochs, params, path="", seed=None, log=print, first_signal=0):
     """train_tadgan (train.py:252-385) with everything on the device: the same epoch schedule -- 5 passes of
     (critic_x_iteration, critic_z_iteration) over the shuffled minibatches, then one pass of decoder_iteration -- as one
     ``hypad_train_epoch`` call per epoch (205 kernel launches, no host round trip inside).  ``dataset``: a
@@ -509,13 +509,15 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     (N, signal_shape) array / tensor of windows.  Differences from the drop-in loop: latent noise, interpolation weights
     and dropout masks come from the device Philox generator (seeded by ``seed`` / torch.initial_seed()) instead of
     NumPy / torch CPU, and the DataLoader's shuffles are ``torch.randperm`` draws on the device (drop_last semantics:
-    n_batches = N // batch_size, a fresh permutation per pass).  Checkpoint cadence and file names as the reference."""
+    n_batches = N // batch_size, a fresh permutation per pass).  Checkpoint cadence and file names as the reference.
+    ``first_signal``: the device random stream number of this model (Engine): the run then equals that signal's training inside a
+    ``train_signals_resident`` group bit for bit."""
     B, S = params.batch_size, params.signal_shape
     dev = encoder.arena().device
     eng = Engine(S, params.latent_space_dim, B, bool(params.hyperbolic), 1, dev, lr=params.lr,
                  gen_weight_decay=1e-5 if params.hyperbolic else 0.0, gen_stabilize=10 if params.hyperbolic else 0,
                  seed=(torch.initial_seed() if seed is None else seed)
-                 + _resume_salt(params.resume_epoch if getattr(params, "resume", False) else None))
+                 + _resume_salt(params.resume_epoch if getattr(params, "resume", False) else None), first_signal=first_signal)
     mods = {"enc": encoder, "dec": decoder, "cx": critic_x, "cz": critic_z}
     eng.adopt({k: m.arena() for k, m in mods.items()})
     if hasattr(dataset, "window_view"):
@@ -563,7 +565,7 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     return history
 
 
-def train_resident(dataset, params, config_path=None, seed=None, log=print):
+def train_resident(dataset, params, config_path=None, seed=None, log=print, first_signal=0):
     """train.train (train.py:409-466) on the resident fast path; returns (encoder, decoder, critic_x, critic_z, PATH)."""
     params.latent_space_dim = 20
     encoder = tadgan.Encoder(params.signal_shape, params.latent_space_dim).cuda().train()
@@ -577,7 +579,165 @@ def train_resident(dataset, params, config_path=None, seed=None, log=print):
         shutil.copyfile(config_path, os.path.join(PATH, "config.yaml"))
     if getattr(params, "resume", False):
         encoder, decoder, critic_x, critic_z = resume_ckpt(params)
-    history = train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, params.epochs, params, PATH, seed, log)
+    history = train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, params.epochs, params, PATH, seed, log, first_signal)
     for name, m in (("encoder", encoder), ("decoder", decoder), ("critic_x", critic_x), ("critic_z", critic_z)):
         torch.save(m, PATH + "/{}.pt".format(name))
     return encoder, decoder, critic_x, critic_z, PATH, history
+
+
+# ------------------------------------------------------------------------------------------------ many signals (one model per signal)
+GROUP_MODELS = 32          # models advanced by one launch sequence (Engine): 2 * 32 * batch/16 critic workgroups = every CU at batch 64
+
+
+def plan_signal_groups(n_windows, batch, world=1, rank=0, group=GROUP_MODELS):
+    """Which signals this rank trains, and in which launch groups.  The reference trains one model per signal, nothing couples two
+    signals (train.py:428-437): models whose epochs have the same number of minibatches can share every launch (grid.y = model;
+    their window counts may differ: each model shuffles its own windows).  All signals of the call are ordered by (minibatches per
+    epoch, position in the list); a signal's rank in that order is its *stream number* (Engine.first_signal + slot): its latent
+    vectors, interpolation weights, dropout masks and shuffles are keyed by it, so its training does not depend on the world size
+    or on what it is grouped with.  Each run of equal batch counts is cut into contiguous, balanced pieces, one per rank (ranks
+    take turns getting the longer pieces), and a rank's piece into groups of at most ``group`` models.
+    Returns [(first_stream, [signal indices])] for this rank and the {signal index: stream number} map of the whole call."""
+    nb = [int(n) // int(batch) for n in n_windows]
+    for i, b in enumerate(nb):
+        if b < 1:
+            raise _C.HypadError(f"signal {i}: {n_windows[i]} windows do not fill one batch of {batch}")
+    order = sorted(range(len(nb)), key=lambda i: (nb[i], i))
+    stream = {sig: p for p, sig in enumerate(order)}
+    groups, start, turn = [], 0, 0
+    while start < len(order):
+        end = start
+        while end < len(order) and nb[order[end]] == nb[order[start]]:
+            end += 1
+        n = end - start
+        base, extra = divmod(n, world)
+        pos = start
+        for k in range(world):                      # piece k of this run goes to rank (k + turn) % world
+            size = base + (1 if k < extra else 0)
+            if (k + turn) % world == rank:
+                for g0 in range(pos, pos + size, group):
+                    groups.append((g0, order[g0: min(g0 + group, pos + size)]))
+            pos += size
+        turn = (turn + extra) % world
+        start = end
+    return groups, stream
+
+
+def train_signals_resident(datasets, params, names=None, seed=None, init_seed=None, group=None, log=print, save=True, process_group=None):
+    """One TadGAN per signal (train.py:409-466 once per signal, as the reference's users run it in a loop over main.py) for a LIST of
+    signals, sharded over the ranks of ``torch.distributed`` (no collective on the data path; the per-signal
+    metrics are gathered at the end) and advanced in groups of up to 32 models per launch sequence on each GPU.
+
+    datasets: per signal a ``SignalDataset`` / an (N, signal_shape) array of windows -- lengths may differ.  names: per-signal
+    ``params.signal`` (checkpoint directories follow train.py:428-437: .../{dataset}/{signal}/encoder.pt, encoder_{epoch}.pt ...).
+    Model i is initialised under ``torch.manual_seed(init_seed + i)`` (reference construction order, train.py:415-426) and trained
+    with the device random streams of its stream number (plan_signal_groups): the same bits as
+    ``train_resident(datasets[i], ..., seed=seed, first_signal=stream[i])`` after that manual_seed, whatever the world size.
+    Returns {name: {"path", "history", "final", "stream", "rank"}} for ALL signals on every rank (histories of remote signals come
+    through ``gather_signal_metrics``), and the local models as ``result[name]["modules"]`` for the signals this rank trained."""
+    import copy
+    from . import parallel as par
+    import torch.distributed as dist
+    B, S = params.batch_size, params.signal_shape
+    params.latent_space_dim = 20
+    L, hyp = params.latent_space_dim, bool(params.hyperbolic)
+    names = list(names) if names is not None else [f"signal{i}" for i in range(len(datasets))]
+    if len(names) != len(datasets) or len(set(names)) != len(names):
+        raise _C.HypadError("one distinct name per signal")
+    world = dist.get_world_size(process_group) if par._group_active(process_group) else 1
+    rank = dist.get_rank(process_group) if world > 1 or par._group_active(process_group) else 0
+    mats = [None] * len(datasets)
+
+    def windows(i):
+        if mats[i] is None:
+            d = datasets[i]
+            m = np.asarray(d.X if hasattr(d, "X") else d, dtype=np.float64).reshape(len(d), -1)
+            if m.shape[1] != S:
+                raise _C.HypadError(f"signal {names[i]}: windows of {m.shape[1]} values, params.signal_shape is {S}")
+            mats[i] = m
+        return mats[i]
+    counts = [len(d) for d in datasets]
+    plan, stream = plan_signal_groups(counts, B, world, rank, group or GROUP_MODELS)
+    seed = torch.initial_seed() if seed is None else int(seed)
+    init_seed = seed if init_seed is None else int(init_seed)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n_critics, n_epochs = 5, params.epochs
+    engines = []
+    for first, members in plan:
+        k = len(members)
+        nb = counts[members[0]] // B
+        eng = Engine(S, L, B, hyp, k, dev, lr=params.lr, gen_weight_decay=1e-5 if hyp else 0.0, gen_stabilize=10 if hyp else 0, seed=seed,
+                     first_signal=first)
+        nmax = max(counts[i] for i in members)
+        x = torch.zeros(k, nmax, S, dtype=torch.float32, device=dev)
+        for slot, i in enumerate(members):
+            torch.manual_seed(init_seed + i)                     # train.py:415-426 construction order
+            mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
+            for net, m in mods.items():
+                eng.load_state_dict(net, m.state_dict(), slot)
+            x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
+        in_graph = nmax <= eng.SHUFFLE_MAX_WINDOWS
+        ri = torch.empty(k, n_critics + 1, nb * B, dtype=torch.int32, device=dev)
+        gens = None if in_graph else [torch.Generator(device=dev).manual_seed((seed ^ (0x9E3779B97F4A7C15 * (first + s))) & 0x7FFFFFFFFFFFFFFF) for s in range(k)]
+        engines.append(dict(eng=eng, members=members, nb=nb, x=x, ri=ri, in_graph=in_graph, gens=gens, counts=[counts[i] for i in members]))
+    torch.manual_seed(seed)
+    hist = {names[i]: SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[]) for _, ms in plan for i in ms}
+    paths = {}
+    for _, ms in plan:
+        for i in ms:
+            p = copy.copy(params)
+            p.signal = names[i]
+            paths[names[i]] = model_path(p)
+            if save:
+                os.makedirs(paths[names[i]], exist_ok=True)
+
+    def modules_of(g, slot):
+        mods = [tadgan.Encoder(S, L), tadgan.Decoder(S, L, hyp), tadgan.CriticX(S, L), tadgan.CriticZ(L)]
+        for m, net in zip(mods, ("enc", "dec", "cx", "cz")):
+            m.load_state_dict(g["eng"].state_dict(net, slot))
+        return [m.to(dev).train() for m in mods]
+
+    actual_epoch = 0
+    for epoch in range(n_epochs):
+        for g in engines:                                        # every group's epoch is queued before any loss is read
+            eng = g["eng"]
+            if not g["in_graph"]:
+                for s, c in enumerate(g["counts"]):
+                    g["ri"][s].copy_(torch.rand(n_critics + 1, c, device=dev, generator=g["gens"][s]).argsort(dim=1)[:, : g["nb"] * B])
+            g["losses"] = eng.train_epoch_graph(g["x"], g["ri"], g["nb"], n_critics, True, shuffle_windows=g["counts"] if g["in_graph"] else 0)
+        actual_epoch += 1
+        ckpt = save and ((actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1)))        # train.py:381 (cadence kept as is)
+        for g in engines:
+            eng, nb = g["eng"], g["nb"]
+            if eng.check_status():
+                g["losses"] = eng._last_epoch["losses"]
+            lo = g["losses"].cpu()
+            for slot, i in enumerate(g["members"]):
+                h = hist[names[i]]
+                crit = lo[slot, : 2 * n_critics * nb, 0].reshape(n_critics * nb, 2).mean(0)
+                gl = lo[slot, 2 * n_critics * nb:].mean(0)
+                h.cx.append(float(crit[0])); h.cz.append(float(crit[1])); h.dec.append(float(gl[0]))
+                (h.hyper if hyp else h.mse).append(float(gl[1]))
+                if ckpt:
+                    for nm, m in zip(("encoder", "decoder", "critic_x", "critic_z"), modules_of(g, slot)):
+                        torch.save(m, paths[names[i]] + "/{}_{}.pt".format(nm, actual_epoch))
+        if log:
+            mine = [names[i] for g in engines for i in g["members"]]
+            log("epoch {}: {} signal(s) on rank {}: mean critic x loss {:.3f} critic z loss {:.3f} decoder loss {:.3f}".format(
+                epoch, len(mine), rank, *(float(np.mean([getattr(hist[n], k)[-1] for n in mine])) if mine else float("nan") for k in ("cx", "cz", "dec"))))
+    local = {}
+    for g in engines:
+        for slot, i in enumerate(g["members"]):
+            mods = modules_of(g, slot)
+            if save:
+                for nm, m in zip(("encoder", "decoder", "critic_x", "critic_z"), mods):
+                    torch.save(m, paths[names[i]] + "/{}.pt".format(nm))
+            h = hist[names[i]]
+            local[names[i]] = {"path": paths[names[i]], "history": vars(h), "stream": stream[i], "rank": rank,
+                               "final": {k: (getattr(h, k)[-1] if getattr(h, k) else None) for k in ("cx", "cz", "dec", "hyper", "mse")}}
+            g.setdefault("mods", {})[names[i]] = mods
+    merged = par.gather_signal_metrics(local, process_group)
+    for g in engines:
+        for n, mods in g.get("mods", {}).items():
+            merged[n] = dict(merged[n], modules=mods)
+    return merged

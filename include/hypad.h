@@ -186,6 +186,10 @@ typedef struct hypad_dims {
   int batch;         /* params.batch_size; multiple of 16 */
   int hyperbolic;    /* params.hyperbolic */
   int n_signals;     /* independent models trained side by side (one per signal); >= 1 */
+  int first_signal;  /* ABI 5: model s of this call draws its device random streams (latent vectors, interpolation weights, dropout)
+                        as stream first_signal + s.  A signal's training then does not depend on which models share its launches:
+                        model k of a group whose first_signal is f == a single model trained with first_signal = f + k, bit for bit
+                        (hypad_amd.train.train_signals_resident: one model per signal, train.py:428-437).  0 = streams 0 .. n_signals-1 */
 } hypad_dims;
 
 typedef struct hypad_nets { float *enc, *dec, *cx, *cz; } hypad_nets;
@@ -264,7 +268,7 @@ typedef struct hypad_epoch_noise {
 typedef struct hypad_epoch_io {
   const float* x; int64_t x_signal_stride;
   int64_t x_row_stride;      /* as in hypad_iter_io */
-  const int32_t* row_index;
+  const int32_t* row_index;  /* (n_critics + 1, n_batches * batch): the passes' shuffles */
   int n_batches, n_critics;
   int train_mode; uint64_t seed;
   float* losses;
@@ -281,6 +285,10 @@ typedef struct hypad_epoch_io {
    * the groups become parallel branches of the captured graph.  NULL / 0: everything on `stream`.  Calls that pass auxiliary streams
    * share one process-wide set of fork / join events: issue them from one host thread at a time. */
   hypad_stream_t const* aux_streams; int n_aux_streams;
+  /* ABI 5.  int32 elements between the row_index planes of consecutive signals: 0 = ONE plane shared by all signals (every model sees
+   * the same shuffles); (n_critics + 1) * n_batches * batch or more = a plane per signal -- signals of different lengths (each with
+   * permutations of its OWN window count, hypad_epoch_shuffles_signals) trained by the same launches. */
+  int64_t row_index_signal_stride;
 } hypad_epoch_io;
 enum {
   HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits
@@ -296,6 +304,12 @@ enum {
  * HYPAD_EUNSUPPORTED beyond: draw the permutations with any other generator and pass them to hypad_train_epoch as before. */
 int hypad_epoch_shuffles(int32_t* row_index, int n_passes, int take, int n_windows, uint64_t seed, const int32_t* counters,
                          hypad_stream_t stream);
+/* The same for n_signals models of different lengths in one launch: signal s gets its own plane row_index + s * signal_stride
+ * (n_passes, take) of permutations of [0, n_windows[s]) (n_windows: DEVICE int32[n_signals], each in [take, 4096]), keyed by
+ * (seed, first_signal + s, pass, tick): the plane of signal s == hypad_epoch_shuffles' for one model with that seed and
+ * first_signal + s (the key folds the stream number in; stream 0 is the key of hypad_epoch_shuffles itself). */
+int hypad_epoch_shuffles_signals(int32_t* row_index, int64_t signal_stride, int n_signals, int first_signal, const int32_t* n_windows,
+                                 int n_passes, int take, uint64_t seed, const int32_t* counters, hypad_stream_t stream);
 
 /* HOST helper (the one entry point whose pointers are host pointers; no device work, no stream): the latent draws of a whole epoch
  * of the reference's loop -- np.random.normal(size=(1, batch, L)) on NumPy's GLOBAL generator, once per iteration, train.py:24,118,205

@@ -1,0 +1,137 @@
+"""One model per signal for a LIST of signals of different lengths (train.train_signals_resident; BASELINE configs[2]):
+== the same signals trained one at a time with train_resident, bit for bit; two processes sharing the GPU (gloo) own disjoint
+signals and the merged result equals the one-process run; per-signal checkpoint directories; first_signal at the engine level."""
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+S, B = 100, 64
+COUNTS = [3 * B + 5, 2 * B, 3 * B + 40, 2 * B + 63, 5 * B + 1]          # 3, 2, 3, 2, 5 minibatches per epoch
+
+
+def windows(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n + S - 1)
+    series = np.clip(np.sin(2 * np.pi * t / (40.0 + 7 * seed)) + 0.05 * rng.standard_normal(len(t)), -1, 1)
+    return series[np.arange(n)[:, None] + np.arange(S)[None, :]]
+
+
+def P_(epochs=3, hyper=True):
+    return SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=20, lr=5e-4, hyperbolic=hyper, resume=False, resume_epoch=0,
+                           epochs=epochs, dataset="T", signal="x")
+
+
+def flat(mods):
+    return [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in mods]
+
+
+@pytest.mark.parametrize("hyper,group", [(True, None), (False, None), (True, 2)])
+def test_signals_of_different_lengths_equal_single_signal_runs(tmp_path, monkeypatch, hyper, group):
+    from hypad_amd import train as ht
+    monkeypatch.chdir(tmp_path)
+    data = [windows(n, i) for i, n in enumerate(COUNTS)]
+    names = [f"sig{i}" for i in range(len(COUNTS))]
+    res = ht.train_signals_resident(data, P_(hyper=hyper), names=names, seed=77, init_seed=500, group=group, log=None)
+    assert sorted(res) == sorted(names)
+    streams = {n: res[n]["stream"] for n in names}
+    assert sorted(streams.values()) == list(range(5)) and streams["sig1"] == 0 and streams["sig3"] == 1 and streams["sig4"] == 4
+    for i, name in enumerate(names):
+        kind = "hyper" if hyper else "eucl"
+        d = f"./trained_models/models_{kind}_T_3_0.0005/T/{name}"
+        assert res[name]["path"] == d and sorted(os.listdir(d)) == sorted(f"{m}{sfx}.pt" for m in ("encoder", "decoder", "critic_x", "critic_z") for sfx in ("", "_2"))
+        P = P_(hyper=hyper)
+        P.signal = name + "_single"
+        torch.manual_seed(500 + i)
+        enc, dec, cx, cz, path, hist = ht.train_resident(data[i], P, seed=77, log=None, first_signal=streams[name])
+        h = res[name]["history"]
+        for k in ("cx", "cz", "dec", "hyper" if hyper else "mse"):
+            assert h[k] == getattr(hist, k), (name, k)
+        for a, b in zip(flat(res[name]["modules"]), flat([enc, dec, cx, cz])):
+            for key in a:
+                assert torch.equal(a[key], b[key]), (name, key)
+        saved = torch.load(os.path.join(d, "encoder.pt"), weights_only=False)
+        assert all(torch.equal(v.cpu(), flat([enc])[0][k]) for k, v in saved.state_dict().items())
+    # different signals really trained differently
+    assert res["sig0"]["history"]["dec"] != res["sig2"]["history"]["dec"]
+
+
+def test_first_signal_makes_a_model_independent_of_its_group():
+    """Engine level: slot k of a group whose first_signal is f == a single model with first_signal = f + k (device Philox noise and
+    dropout, shuffles drawn in the captured epoch from the model's own window count), bit for bit."""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    nb, nc, k, f = 2, 2, 3, 4
+    counts = [2 * B + 3, 2 * B + 50, 2 * B]
+    x = torch.zeros(k, max(counts), S, device="cuda")
+    for s in range(k):
+        x[s, : counts[s]] = torch.from_numpy(windows(counts[s], 10 + s)).float()
+    def load(eng, s, slot):
+        torch.manual_seed(40 + s)
+        for net, m in dict(enc=ot.Encoder(S, 20), dec=ot.Decoder(S, 20, True), cx=ot.CriticX(S, 20), cz=ot.CriticZ(20)).items():
+            eng.load_state_dict(net, m.state_dict(), slot)
+    grp = Engine(S, 20, B, True, n_signals=k, seed=9, first_signal=f)
+    for s in range(k):
+        load(grp, s, s)
+    ri = torch.empty(k, nc + 1, nb * B, dtype=torch.int32, device="cuda")
+    lg = [grp.train_epoch_graph(x, ri, nb, nc, True, shuffle_windows=counts).clone() for _ in range(2)]
+    assert grp.check_status() == 0
+    for s in range(k):
+        assert int(ri[s].max()) < counts[s]
+        one = Engine(S, 20, B, True, n_signals=1, seed=9, first_signal=f + s)
+        load(one, s, 0)
+        r1 = torch.empty(nc + 1, nb * B, dtype=torch.int32, device="cuda")
+        l1 = [one.train_epoch_graph(x[s: s + 1, : counts[s]].contiguous(), r1, nb, nc, True, shuffle_windows=counts[s]).clone() for _ in range(2)]
+        assert torch.equal(r1, ri[s])
+        for e in range(2):
+            assert torch.equal(l1[e][0], lg[e][s]), (s, e)
+        for net in ("enc", "dec", "cx", "cz"):
+            assert torch.equal(one.params[net][0], grp.params[net][s]), (s, net)
+    assert not torch.equal(ri[0], ri[2])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_worker(rank, world, port, cwd, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.chdir(cwd)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hypad_amd import train as ht
+        data = [windows(n, i) for i, n in enumerate(COUNTS)]
+        res = ht.train_signals_resident(data, P_(), names=[f"sig{i}" for i in range(len(COUNTS))], seed=77, init_seed=500, log=None)
+        ret[rank] = {n: {"history": r["history"], "rank": r["rank"], "local": "modules" in r,
+                         "enc": ({k: v.cpu() for k, v in r["modules"][0].state_dict().items()} if "modules" in r else None)} for n, r in res.items()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_own_disjoint_signals_and_agree_with_one(tmp_path, monkeypatch):
+    import torch.multiprocessing as mp
+    from hypad_amd import train as ht
+    (tmp_path / "two").mkdir(); (tmp_path / "one").mkdir()
+    ret = mp.Manager().dict()
+    mp.spawn(_rank_worker, args=(2, _free_port(), str(tmp_path / "two"), ret), nprocs=2, join=True)
+    monkeypatch.chdir(tmp_path / "one")
+    data = [windows(n, i) for i, n in enumerate(COUNTS)]
+    names = [f"sig{i}" for i in range(len(COUNTS))]
+    one = ht.train_signals_resident(data, P_(), names=names, seed=77, init_seed=500, log=None)
+    owners = {n: ret[0][n]["rank"] for n in names}
+    assert set(owners.values()) == {0, 1} and owners == {n: ret[1][n]["rank"] for n in names}
+    for n in names:
+        assert ret[0][n]["history"] == ret[1][n]["history"] == one[n]["history"], n           # gathered: every rank holds every signal's metrics
+        assert ret[owners[n]][n]["local"] and not ret[1 - owners[n]][n]["local"]
+        enc = ret[owners[n]][n]["enc"]
+        for k, v in one[n]["modules"][0].state_dict().items():
+            assert torch.equal(v.cpu(), enc[k]), (n, k)
+        for sfx in ("", "_2"):                                                                  # the owner wrote the signal's checkpoints
+            assert os.path.exists(tmp_path / "two" / "trained_models" / "models_hyper_T_3_0.0005" / "T" / n / f"encoder{sfx}.pt")
