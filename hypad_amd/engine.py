@@ -283,6 +283,8 @@ class Engine:
                tuple(sorted((k, t.data_ptr()) for k, t in (noise or {}).items() if t is not None)))
         graphs = self.__dict__.setdefault("_graphs", {})
         if key not in graphs:
+            if shuffle_windows:                          # (the device copy of the window counts: made before, not inside, the capture)
+                self._window_counts(shuffle_windows, row_index.shape[0] if row_index.dim() == 3 else 1)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):                    # (side stream: _C.stream() is torch's current stream inside the block)
                 if shuffle_windows:

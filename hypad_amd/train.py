@@ -711,7 +711,7 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
             eng, nb = g["eng"], g["nb"]
             if eng.check_status():
                 g["losses"] = eng._last_epoch["losses"]
-            lo = g["losses"].cpu()
+            lo = g["losses"]                                     # (reduced on the device, slot by slot, exactly as train_tadgan_resident reduces its one model's)
             for slot, i in enumerate(g["members"]):
                 h = hist[names[i]]
                 crit = lo[slot, : 2 * n_critics * nb, 0].reshape(n_critics * nb, 2).mean(0)
