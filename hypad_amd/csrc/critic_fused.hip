@@ -1714,8 +1714,7 @@ static bool persistent_kernel_fits(int S, int L, int B, size_t lds) {
   return cache[dev][slot] > 0;
 }
 bool critic_phase_persistent(const hypad_dims& d, int flags) {
-  const char* env = getenv("HYPAD_CRITIC_PERSISTENT");
-  if ((env && env[0] == '0') || (flags & HYPAD_EPOCH_PER_ITERATION)) return false;
+  if (flags & HYPAD_EPOCH_PER_ITERATION) return false;
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
   const int nchunks = d.batch / 16;
   if (!persist_geom_supported(gx, nchunks) || !persist_geom_supported(gz, nchunks)) return false;
@@ -1738,13 +1737,12 @@ static PhasePlan plan_phase(const hypad_dims& d, size_t extra_floats, int n_iter
   if (p.cap > n_iters) p.cap = n_iters;
   const CritGeom gx = cx_geom(d.signal_shape, d.latent_dim), gz = cz_geom(d.latent_dim);
   p.persistent = critic_phase_persistent(d, flags);
-  const char* prod = getenv("HYPAD_CRITIC_PRODUCERS");
   // Producers share the chip with the resident critics, one workgroup per CU either way: they must find free CUs (every CU taken
   // by a critic that waits for its record would be a deadlock -- the bounded polls would end it with an error) and enough of
   // them to keep up: the critics may hold half of the CUs at most (measured: 12 signals 4.67 -> 3.94 ms per epoch, 16 signals --
   // half the chip -- 5.02 -> 4.95; beyond that the precompute launch in front is the better form).
   const long long critics = (long long)(d.batch / 16) * d.n_signals * 2;
-  p.fused = p.persistent && !(prod && prod[0] == '0') && 2 * critics <= device_cus() &&
+  p.fused = p.persistent && !(flags & HYPAD_EPOCH_NO_PRODUCERS) && 2 * critics <= device_cus() &&
             (size_t)d.n_signals * n_iters * (d.batch / 16) * (size_t)(gx.rec_floats > gz.rec_floats ? gx.rec_floats : gz.rec_floats) * 4 < ((size_t)1 << 30);
   return p;
 }
@@ -1807,8 +1805,8 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
   ph.fault_it = (flags >> HYPAD_EPOCH_TEST_GIVE_UP_SHIFT) & 0xff;
   ph.n_signals = n_signals;
   ph.only = only;
-  { const char* xenv = getenv("HYPAD_CRITIC_XCD"); ph.xcd_stretch = (xenv && xenv[0] == '0') ? 0 : 1; }
-  { const char* cenv = getenv("HYPAD_CRITIC_CLEAR"); ph.clear_each = (cenv && cenv[0] == '1') ? 1 : 0; }
+  ph.xcd_stretch = (flags & HYPAD_EPOCH_ID_ORDER) ? 0 : 1;
+  ph.clear_each = (flags & HYPAD_EPOCH_CLEAR_TILES) ? 1 : 0;
   // the fixed area: optimiser state + gradient slabs of the per-iteration launches, or -- carved out of the same floats -- the
   // persistent form's exchange buffers: [epoch words | error word] (zeroed before every launch), granules, merged shares
   float* p = extra;

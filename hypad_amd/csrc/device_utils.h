@@ -136,6 +136,16 @@ __device__ __forceinline__ float rng_dropout(uint64_t seed, uint32_t tick, uint3
 
 }  // namespace hypad
 
+// Tuning switches of the DEVELOPMENT library only (libhypad_hip_dev.so, -DHYPAD_DIAG=1: scripts/diag_*.py, A/B timing): the product
+// library reads no environment variable -- what a C-ABI call launches depends on its arguments alone (include/hypad.h; the
+// A/B switches of the training epoch are hypad_epoch_io.flags bits).
+#if HYPAD_DIAG
+#include <cstdlib>
+#define HYPAD_TUNE_INT(name, dflt) (std::getenv(name) ? std::atoi(std::getenv(name)) : (dflt))
+#else
+#define HYPAD_TUNE_INT(name, dflt) (dflt)
+#endif
+
 #define HYPAD_CHECK_LAUNCH()                          \
   do {                                                \
     hipError_t e__ = hipGetLastError();               \

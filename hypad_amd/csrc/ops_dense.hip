@@ -485,12 +485,12 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
   if (!x || !wf || !bif || !bhf || !wr || !bir || !bhr || !out || rows < 0 || K <= 0 || H <= 0) return HYPAD_EINVAL;
   if (rows == 0) return HYPAD_OK;
   // many rows: the weights-stationary form (one direction's W_ih in LDS per workgroup); HYPAD_LSTM_LDS=0 keeps the streamed form
-  static const int lds_form = getenv("HYPAD_LSTM_LDS") ? atoi(getenv("HYPAD_LSTM_LDS")) : 1;
+  static const int lds_form = HYPAD_TUNE_INT("HYPAD_LSTM_LDS", 1);
   if (lds_form && rows >= 2048 && H <= 64 && K <= 128) {
     const int KG = (K + 15) >> 4, Hp = (H + 15) & ~15;
     const size_t lw = (size_t)3 * Hp * (KG * 16 + 4) * sizeof(float);
     const int64_t ntiles = (rows + 15) >> 4;
-    static const int nw_env = getenv("HYPAD_LSTM_WAVES") ? atoi(getenv("HYPAD_LSTM_WAVES")) : 0;
+    static const int nw_env = HYPAD_TUNE_INT("HYPAD_LSTM_WAVES", 0);
     const int nw = nw_env == 8 ? 8 : 16;            // (16 waves: 357 -> 349 us at 100 -> 2 x 50, 356 -> 321 at 128 -> 2 x 64, gates saved, 200 000 rows)
     int nslices = (int)((ntiles + nw - 1) / nw);
     if (nslices > 128) nslices = 128;

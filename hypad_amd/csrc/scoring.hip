@@ -992,10 +992,8 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   if (!y_hat || !median || n <= 0 || window <= 0) return HYPAD_EINVAL;
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
   const int64_t T = n + window - 1;
-  const char* fenv = getenv("HYPAD_UNROLL_FILTER");
-  const bool filter = !(fenv && fenv[0] == '0');
-  const char* tenv = getenv("HYPAD_UNROLL_TILE");
-  const int ut = tenv && atoi(tenv) == 64 ? 64 : 128;
+  const bool filter = HYPAD_TUNE_INT("HYPAD_UNROLL_FILTER", 1) != 0;
+  const int ut = HYPAD_TUNE_INT("HYPAD_UNROLL_TILE", 128) == 64 ? 64 : 128;
   const size_t lds = (size_t)(ut * ((window + 3) & ~3) + (ut / 16) * MAX_WINDOW) * sizeof(float);      // 59 KB at window 100, 139 KB at 256
   const dim3 grid(grid_for(T, ut)), block(ut * 4);
   long long* stamps = nullptr;
@@ -1106,7 +1104,7 @@ int hypad_kde_mode(const float* critic, double* modes, int64_t n, int window, hy
   if (window > MAX_WINDOW) return HYPAD_EUNSUPPORTED;
   // (A resident grid -- 256 x HYPAD_KDE_WPE workgroups whose waves stride over ~100 timesteps each -- was measured and dropped: 0.33 ms
   // against 0.30 ms for 8 192 workgroups of ~4 timesteps per wave at 125 000 windows; HYPAD_KDE_GRID caps the grid for such trials.)
-  static const int kde_grid = getenv("HYPAD_KDE_GRID") ? atoi(getenv("HYPAD_KDE_GRID")) : 8192;
+  static const int kde_grid = HYPAD_TUNE_INT("HYPAD_KDE_GRID", 8192);
   int gw = grid_for(n + window - 1, THREADS / 64);
   if (gw > kde_grid) gw = kde_grid;
   const dim3 grid(gw);

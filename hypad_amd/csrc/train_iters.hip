@@ -1393,6 +1393,7 @@ struct IterCall {
   float* losses; int64_t loss_sig_stride;
   void* workspace; size_t workspace_bytes;
   int guard = 0;
+  int flags = 0;                         // hypad_epoch_io.flags (HYPAD_EPOCH_DW_* select the dW + Adam launch's placement)
 };
 
 // opt: 0 critic_x, 1 critic_z, 2 generator
@@ -1568,8 +1569,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
   const DwTable tab = gen_table(*d, with_decay);
-  const char* cenv = getenv("HYPAD_DW_COLOC");
-  const bool coloc = cenv ? cenv[0] == '1' : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
+  const bool coloc = (io.flags & HYPAD_EPOCH_DW_COLOC) ? true : (io.flags & HYPAD_EPOCH_DW_SPREAD) ? false : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
@@ -1691,7 +1691,7 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   if (S == 100 && L == 20) {
     hipError_t e = allow_lds((const void*)score_forward_packed_kernel<100, 20>, lds);
     if (e != hipSuccess) return (int)e;
-    static const int score_threads = getenv("HYPAD_SCORE_THREADS") ? atoi(getenv("HYPAD_SCORE_THREADS")) : TB;      // (development switch)
+    static const int score_threads = HYPAD_TUNE_INT("HYPAD_SCORE_THREADS", TB);      // (development switch)
     hipLaunchKernelGGL((score_forward_packed_kernel<100, 20>), dim3((unsigned)tiles), dim3(score_threads), lds, (hipStream_t)s, a);
   } else {
     hipError_t e = allow_lds((const void*)score_forward_packed_kernel<0, 0>, lds);
@@ -1719,7 +1719,7 @@ int hypad_packed_region(const hypad_dims* d, int64_t* offset_floats, int64_t* si
 // floating-point summation order (and the device dropout streams) differ.
 static int run_critic_single(const hypad_dims* d, const hypad_train_state* st, const hypad_iter_io* io, int critic, hipStream_t s, bool* taken) {
   *taken = false;
-  static const int enabled = getenv("HYPAD_ITER_PHASE") ? atoi(getenv("HYPAD_ITER_PHASE")) : 1;
+  static const int enabled = HYPAD_TUNE_INT("HYPAD_ITER_PHASE", 1);
   if (!enabled || check_dims(d) || !critic_phase_supported(*d)) return HYPAD_OK;
   const size_t base = epoch_base_floats(*d);
   const size_t have = io->workspace_bytes / sizeof(float);
@@ -1857,6 +1857,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   c.train_mode = io->train_mode; c.masks = nullptr; c.seed = io->seed;
   c.workspace = io->workspace; c.workspace_bytes = io->workspace_bytes;
   c.guard = 1;                                          // every launch of the epoch stops behind a resident critic launch that gave up
+  c.flags = io->flags;
   const int iters = (2 * io->n_critics + 1) * io->n_batches;
   c.loss_sig_stride = (int64_t)iters * 4;
   int it = 0;
@@ -1865,9 +1866,8 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   const size_t have = io->workspace_bytes / sizeof(float);
   const int64_t B = d->batch, L = d->latent_dim, S = d->signal_shape, ns = d->n_signals;
   const int64_t mk_cx = 12 * B * L + B * 2 * DEC_H, mk_cz = 6 * B * L, mk_gen = 6 * B * L + 2 * B * 2 * DEC_H;   // hypad_iter_io.drop layouts
-  const char* legacy = getenv("HYPAD_EPOCH_LEGACY");
   const bool hoisted = io->n_critics > 0 && critic_phase_supported(*d) &&
-                       have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(legacy && legacy[0] == '1');
+                       have >= base + critic_phase_fixed_floats(*d) + critic_phase_floats_per_iter(*d) && !(io->flags & HYPAD_EPOCH_PER_MINIBATCH);
   unsigned* zero_ptr = nullptr;                        // the resident critic launch's epoch words / flags: zeroed by the pack launch
   int zero_words = 0;
   bool zeroed = false;

@@ -188,11 +188,16 @@ class Engine:
         return self._iter(_C.lib.hypad_decoder_iteration, x, row_index, z, None, train_mode, masks, x_row_stride)
 
     def critic_phase_persistent(self):
-        """True when train_epoch runs the critic phase as one resident launch (hypad_critic_phase_persistent)."""
+        """True when train_epoch runs the critic phase as one resident launch (hypad_critic_phase_persistent; the engine's
+        ``epoch_flags`` may ask for the per-iteration / per-minibatch forms instead)."""
+        if self.epoch_flags & (_C.EPOCH_PER_ITERATION | _C.EPOCH_PER_MINIBATCH):
+            return False
         return bool(_C.lib.hypad_critic_phase_persistent(ctypes.byref(self.dims)))
 
     def critic_phase_producers(self, n_iters):
         """True when that resident launch also produces the phase's records itself (hypad_critic_phase_producers)."""
+        if not self.critic_phase_persistent() or (self.epoch_flags & _C.EPOCH_NO_PRODUCERS):
+            return False
         return bool(_C.lib.hypad_critic_phase_producers(ctypes.byref(self.dims), int(n_iters)))
 
     def rng_fill(self, kind, n, tick, stream, signal=0, p_drop=0.0, seed=None):

@@ -291,8 +291,16 @@ typedef struct hypad_epoch_io {
   int64_t row_index_signal_stride;
 } hypad_epoch_io;
 enum {
-  HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits
-                                                (what HYPAD_CRITIC_PERSISTENT=0 in the environment selects for every call) */
+  HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits */
+  /* A/B switches (tests, timing).  The library reads NO environment variable: which kernels a call launches depends on its
+   * arguments alone.  Every combination gives the same results bit for bit, except PER_ITERATION / PER_MINIBATCH (another
+   * summation order of the critics' gradient shares). */
+  HYPAD_EPOCH_NO_PRODUCERS = 2,              /* resident critic launch behind a precompute launch instead of with its own record producers */
+  HYPAD_EPOCH_ID_ORDER = 4,                  /* resident critic workgroups in id order (no per-XCD placement: shares go through memory) */
+  HYPAD_EPOCH_CLEAR_TILES = 8,               /* sweep the activation / delta tiles after every resident iteration (round-2 behaviour) */
+  HYPAD_EPOCH_PER_MINIBATCH = 16,            /* no hoisting at all: one launch group per minibatch (critic_x || critic_z pass, penalty, dW) */
+  HYPAD_EPOCH_DW_COLOC = 32,                 /* dW + Adam workgroups co-located per model and XCD (the default from 8 models per call on) */
+  HYPAD_EPOCH_DW_SPREAD = 64,                /* ... spread over the chip (the default below 8 models) */
   HYPAD_EPOCH_TEST_GIVE_UP_SHIFT = 8         /* tests only: bits 8..15 = k > 0 makes the resident launch behave as if its wait for the
                                                 siblings' shares had timed out at critic iteration k (signal 0, critic_x) */
 };
@@ -334,7 +342,7 @@ size_t hypad_epoch_workspace_bytes(const hypad_dims* dims, int n_batches, int n_
 int hypad_critic_phase_persistent(const hypad_dims* dims);
 /* 1 when that resident launch also produces the phase's records itself (extra workgroups behind the resident ones: no separate
  * precompute launch) for a phase of n_iters = n_critics * n_batches iterations: where the resident critics hold at most half of
- * the device's CUs (the producers need the others); HYPAD_CRITIC_PRODUCERS=0 turns it off. */
+ * the device's CUs (the producers need the others); hypad_epoch_io.flags & HYPAD_EPOCH_NO_PRODUCERS turns it off. */
 int hypad_critic_phase_producers(const hypad_dims* dims, int n_iters);
 int hypad_train_epoch(const hypad_dims* dims, const hypad_train_state* st, const hypad_epoch_io* io, hypad_stream_t stream);
 

@@ -171,3 +171,23 @@ def test_results_table_follows_the_reference(tmp_path, monkeypatch):
     adu.save_result(P, "b", [0, 0, 0, 0])
     t = pd.read_csv(f)
     assert list(t.columns) == ["signal", "tn", "fp", "fn", "tp"] and t.values.tolist() == [["a", 5, 1, 2, 7], ["b", 0, 0, 0, 0]]
+
+
+def test_product_library_reads_no_environment_variable():
+    """SURVEY.md 8b "no hidden state": which kernels a C-ABI call launches depends on its arguments alone.  The A/B switches of the
+    training epoch are hypad_epoch_io.flags bits; tuning knobs exist in the development library only (HYPAD_TUNE_INT, -DHYPAD_DIAG=1)."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "hypad_amd", "csrc", "*")):
+        if path.endswith("diag.hip"):
+            continue
+        src = open(path).read()
+        uses = [m.start() for m in re.finditer(r"getenv", src)]
+        if path.endswith("device_utils.h"):
+            block = src[src.index("#if HYPAD_DIAG\n#include <cstdlib>"): src.index("#define HYPAD_TUNE_INT(name, dflt) (dflt)")]
+            assert all(block in src and src.index(block) <= u < src.index(block) + len(block) for u in uses)
+        else:
+            assert not uses, os.path.basename(path)
+    import subprocess
+    from hypad_amd import build
+    und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und

@@ -345,11 +345,12 @@ def test_epoch_as_hip_graph_equals_eager(dev):
 
 
 @pytest.mark.parametrize("persistent", ["1", "0"])
-def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
+def test_critic_phase_in_slices_equals_one_piece(dev, persistent):
     """Phases longer than the workspace's record capacity (512 iterations by default) are processed in slices, the critics'
     state passing through the arenas in between.  Forced here with a workspace of 4 iterations for a phase of 10: same bits
     as the phase in one piece -- for the resident-launch form and for the per-iteration launches."""
-    monkeypatch.setenv("HYPAD_CRITIC_PERSISTENT", persistent)
+    from hypad_amd import _C
+    flags = 0 if persistent == "1" else _C.EPOCH_PER_ITERATION      # (hypad_epoch_io.flags: the library reads no environment variable)
     fx = load("iters_hyper_S100.npz")
     from hypad_amd.engine import Engine
     xs = cu(fx["samples"][:, :, :, 0]).reshape(1, -1, 100)
@@ -358,6 +359,7 @@ def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
     outs = []
     for wi in (None, 4, 3):
         e = Engine(100, 20, 64, True, n_signals=2, lr=5e-4, seed=5)
+        e.epoch_flags = flags
         for net in ("enc", "dec", "cx", "cz"):
             for sgn in range(2):
                 e.load_state_dict(net, sub_state(fx, net, "w0"), sgn)
@@ -372,10 +374,10 @@ def test_critic_phase_in_slices_equals_one_piece(dev, persistent, monkeypatch):
             assert torch.equal(o[1][k], outs[0][1][k]), k
 
 
-def test_records_from_producer_workgroups_equal_the_precompute_launch(dev, monkeypatch):
+def test_records_from_producer_workgroups_equal_the_precompute_launch(dev):
     """The resident critic launch carries its own record producers (blockIdx.z >= 2: no precompute launch in front, records handed
     over through write-through stores and a flag word each).  Same records, same epoch: every loss, every weight and the record
-    area itself are bit-identical to the form with the precompute launch (HYPAD_CRITIC_PRODUCERS=0) -- one and eight signals."""
+    area itself are bit-identical to the form with the precompute launch (HYPAD_EPOCH_NO_PRODUCERS) -- one and eight signals."""
     fx = load("iters_hyper_S100.npz")
     from hypad_amd.engine import Engine
     for ns in (1, 8):
@@ -383,9 +385,11 @@ def test_records_from_producer_workgroups_equal_the_precompute_launch(dev, monke
         nb, nc = 4, 3
         perm = torch.stack([torch.randperm(xs.shape[1], generator=torch.Generator().manual_seed(i))[: nb * 64] for i in range(nc + 1)]).to(torch.int32).cuda()
         outs = []
+        from hypad_amd import _C
         for producers in ("1", "0"):
-            monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", producers)
             e = Engine(100, 20, 64, True, n_signals=ns, lr=5e-4, seed=11)
+            e.epoch_flags = 0 if producers == "1" else _C.EPOCH_NO_PRODUCERS
+            assert e.critic_phase_producers(4 * 3) == (producers == "1")
             for net in ("enc", "dec", "cx", "cz"):
                 for sgn in range(ns):
                     e.load_state_dict(net, sub_state(fx, net, "w0"), sgn)
@@ -403,7 +407,7 @@ def test_records_from_producer_workgroups_equal_the_precompute_launch(dev, monke
             assert torch.equal(outs[0][2][c], outs[1][2][c]), c
 
 
-def test_hand_offs_hold_under_uneven_load(dev, monkeypatch):
+def test_hand_offs_hold_under_uneven_load(dev):
     """The resident critic launch's hand-offs (gradient shares, scalar granules, records from its producer workgroups) with the
     rest of the chip busy and uneven: a side stream streams 256 MB copies and runs matrix products while the epoch runs.  Every
     repetition must reproduce, bit for bit, what the form without in-kernel hand-offs of records (precompute launch in front)
@@ -422,12 +426,12 @@ def test_hand_offs_hold_under_uneven_load(dev, monkeypatch):
             e.params[net][1].mul_(0.99)
         return e
 
-    monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", "0")
+    from hypad_amd import _C
     e = fresh()
+    e.epoch_flags = _C.EPOCH_NO_PRODUCERS
     want_l = e.train_epoch(xs, perm, nb, nc, True).clone()
     want_p = {k: e.params[k].clone() for k in ("cx", "cz", "enc", "dec")}
     torch.cuda.synchronize()
-    monkeypatch.setenv("HYPAD_CRITIC_PRODUCERS", "1")
     side = torch.cuda.Stream()
     a = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
     b = torch.empty_like(a)

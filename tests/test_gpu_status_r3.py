@@ -184,16 +184,17 @@ def test_captured_epoch_is_recaptured_when_what_it_froze_changes():
 def test_chunks_of_a_critic_share_an_xcd_and_the_epoch_keeps_its_bits(ns, S, B, monkeypatch):
     """critic_persistent_kernel deals the chunk workgroups of one critic to one XCD (ids stretched by 8) and, having read from
     the hardware that they really share it, keeps their exchange -- gradient shares, scalar granules, epoch words -- in that
-    XCD's L2 (stores without the write-through bit).  HYPAD_CRITIC_XCD=0 deals them in id order (the round-2 placement: a
+    XCD's L2 (stores without the write-through bit).  HYPAD_EPOCH_ID_ORDER deals them in id order (the round-2 placement: a
     critic's chunks on different XCDs -> the write-through forms).  Placement and store flavour are speed matters only: both
     epochs must agree bit for bit -- losses, all four networks, moments, counters -- also with the chip busy on a side stream;
     and the census word (counters[5]) must say which form ran."""
     nb, nc = 4, 3
     engine, x, perms, _, _ = _setup(ns, seed=7, S=S, B=B, nb=nb, nc=nc)
     outs = {}
+    from hypad_amd import _C
     for mode in ("1", "0"):
-        monkeypatch.setenv("HYPAD_CRITIC_XCD", mode)
         e = engine()
+        e.epoch_flags = 0 if mode == "1" else _C.EPOCH_ID_ORDER
         assert e.critic_phase_persistent()
         l = e.train_epoch(x, perms[0], nb, nc, True).clone()
         l2 = e.train_epoch(x, perms[1], nb, nc, True).clone()
@@ -207,17 +208,14 @@ def test_chunks_of_a_critic_share_an_xcd_and_the_epoch_keeps_its_bits(ns, S, B, 
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert all(torch.equal(a[2][i][k], b[2][i][k]) for i in range(3) for k in a[2][i]) and torch.equal(a[2][3][:5], b[2][3][:5])
     # round 3 also stopped zeroing the activation / delta tiles after every iteration (every element read is written first):
-    # HYPAD_CRITIC_CLEAR=1 brings the sweep back -- same bits
-    monkeypatch.setenv("HYPAD_CRITIC_XCD", "1")
-    monkeypatch.setenv("HYPAD_CRITIC_CLEAR", "1")
+    # HYPAD_EPOCH_CLEAR_TILES brings the sweep back -- same bits
     e = engine()
+    e.epoch_flags = _C.EPOCH_CLEAR_TILES
     l = e.train_epoch(x, perms[0], nb, nc, True).clone()
     l2 = e.train_epoch(x, perms[1], nb, nc, True).clone()
     snap = _snapshot(e)
     assert torch.equal(l, a[0]) and torch.equal(l2, a[1]) and all(torch.equal(snap[i][k], a[2][i][k]) for i in range(3) for k in snap[i])
-    monkeypatch.delenv("HYPAD_CRITIC_CLEAR")
     # the same under an uneven background load, several times
-    monkeypatch.setenv("HYPAD_CRITIC_XCD", "1")
     side = torch.cuda.Stream()
     src = torch.empty(32 << 20, dtype=torch.float32, device="cuda")
     dst = torch.empty_like(src)
