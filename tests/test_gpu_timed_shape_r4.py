@@ -63,7 +63,7 @@ def test_timed_epoch_graph_equals_eager_equals_per_iteration_form():
     runs = {}
     for form in ("graph", "eager", "per_iteration"):
         eng = engine(mods, flags=_C.EPOCH_PER_ITERATION if form == "per_iteration" else 0)
-        assert eng.critic_phase_persistent() and eng.critic_phase_producers(NB * NC)
+        assert eng.critic_phase_persistent() == eng.critic_phase_producers(NB * NC) == (form != "per_iteration")
         perm = torch.empty(NC + 1, NB * B, dtype=torch.int32, device="cuda")
         out = []
         for _ in range(3):
