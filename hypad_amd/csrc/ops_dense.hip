@@ -226,15 +226,29 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
         if (half == 1 && !two) break;
         if (unit >= H) continue;
         const f32x4 pi = half ? ci : ai, pg = half ? cg : ag, po = half ? co : ao;
+#if HYPAD_LSTM_EXP == 4
+        const float bsi = 0.f, bsg = 0.f, bso = 0.f;
+#else
         const float bsi = b1[unit] + b2[unit], bsg = b1[2 * H + unit] + b2[2 * H + unit], bso = b1[3 * H + unit] + b2[3 * H + unit];
+#endif
         const int vo_h = (4 * q * 2 * H + dir * H + unit) * 4, vo_g = (4 * q * 8 * H + dir * 4 * H + unit) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (r0 + 4 * q + r >= rows) continue;
+#if HYPAD_LSTM_EXP == 2
+          const float gi = pi[r] + bsi, gg = pg[r] + bsg, go = po[r] + bso;
+          const float tc = gi * gg;
+#else
           const float gi = sigmoidf_(pi[r] + bsi), gg = tanhf_(pg[r] + bsg), go = sigmoidf_(po[r] + bso);
           const float tc = tanhf_(gi * gg);
+#endif
+#if HYPAD_LSTM_EXP == 3
+          if (gi + gg + go + tc == 123456.f) ob.st(go * tc, vo_h, r * 2 * H * 4);
+          if (false) {
+#else
           ob.st(go * tc, vo_h, r * 2 * H * 4);
           if (gates_save) {
+#endif
             // whole, aligned 64-byte segments (hidden a multiple of 16): past the caches (non-temporal) -- 323 -> 288 us at 128 -> 2 x 64;
             // with 200-byte gate rows (hidden 50) the same hint makes partial lines and costs 100 us, so it is not given there
             if (nt_ok) {
@@ -250,6 +264,173 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
     }
 #pragma unroll
     for (int g = 0; g < KG; ++g) a[g] = an[g];
+  }
+}
+
+// ---- round 4: the same layer with the reference's shapes folded in.  What the kernel above loses (rocprofv3 + what-if builds, round 4:
+// 349 us per 200 000 rows at 100 -> 2 x 50 with the gates saved, 217 us with every store removed, against 109 us of MFMA issue): its
+// run-time "second unit block" branch splits the K loop into basic blocks, the compiler -- at the 128-register budget of four waves
+// per SIMD -- reloads the second block's B operands dword by dword right in front of each MFMA (ds_read_b32, s_waitcnt lgkmcnt(0),
+// v_mfma: the LDS latency exposed three times per k-step), and a quarter of its MFMAs multiply padding (hidden 50 in blocks of 64,
+// K = 100 in groups of 16).  Here H and the k-groups are template arguments:
+//  * column tiles: gate i / g / o of every FULL 16-unit block (H / 16 of them), then ONE remainder tile that holds the last H % 16
+//    units of all three gates side by side (columns [i .. | g .. | o ..], H % 16 <= 5): 10 tiles at H = 50 instead of 12;
+//  * K: full groups of 16 exactly as above (lane (row, q) holds x[row][16 g + 4 q ..+ 3], MFMA c takes component c), the last
+//    partial group in the order k = 16 g + 4 c + q, so it costs ceil(rest / 4) MFMAs instead of four: 25 per tile at K = 100, not 28;
+//  * two passes per row tile (two unit blocks = six accumulators; at H = 50 the second pass has four), every pass a straight-line K
+//    loop; the NEXT tile's x rows are requested inside the last pass, group by group, into the registers the MFMAs have just read
+//    (no second register set: the kernel stays below the budget without spilling);
+//  * the summed biases sit in LDS.
+// Any other shape keeps the kernel above.
+template <int K, int H, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_lds2_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
+                                                             const float* wr, const float* bir, const float* bhr, float* __restrict__ out,
+                                                             float* __restrict__ gates_save, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KG = (K + 15) / 16;
+  constexpr int NFB = H / 16, REM = H % 16, NT = 3 * NFB + (REM ? 1 : 0), ld = KG * 16 + 4;
+  static_assert(REM <= 5, "the remainder tile holds 3 x (H % 16) columns");
+  static_assert(NFB >= 1 && NFB <= 4, "hidden <= 64");
+  const int dir = blockIdx.x & 1, slice = blockIdx.x >> 1, nslices = gridDim.x >> 1;
+  const float* __restrict__ w = dir ? wr : wf;
+  const float* __restrict__ b1 = dir ? bir : bif;
+  const float* __restrict__ b2 = dir ? bhr : bhf;
+  float* bias_s = smem + NT * 16 * ld;                       // [3][H]: b_ih + b_hh of gates i, g, o
+  // column c of tile ct -> (PyTorch gate block, unit)
+  for (int idx = threadIdx.x; idx < NT * 16 * ld; idx += 64 * NW) {
+    const int ct = idx / (16 * ld), rem = idx - ct * 16 * ld, n = rem / ld, k = rem - n * ld;
+    int gate, unit;
+    if (ct < 3 * NFB) { gate = ct % 3; unit = (ct / 3) * 16 + n; }
+    else { gate = REM ? n / (REM ? REM : 1) : 3; unit = NFB * 16 + (REM ? n % (REM ? REM : 1) : 0); }
+    smem[idx] = (gate < 3 && unit < H && k < K) ? w[(int64_t)((gate == 0 ? 0 : gate + 1) * H + unit) * K + k] : 0.f;      // i, f, g, o -> i, g, o
+  }
+  for (int idx = threadIdx.x; idx < 3 * H; idx += 64 * NW) {
+    const int gate = idx / H, unit = idx - gate * H, pg = (gate == 0 ? 0 : gate + 1) * H + unit;
+    bias_s[idx] = b1[pg] + b2[pg];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (rows + 15) >> 4;
+  constexpr int gfull = K >> 4;                               // full k-groups; the rest (K & 15) in `tq` quads
+  constexpr int tq = ((K & 15) + 3) >> 2;
+  const bool vec = (K & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  const bool nt_ok = (H & 15) == 0 && gates_save && ((uintptr_t)gates_save & 63) == 0;
+  float4 a[gfull > 0 ? gfull : 1];                            // full groups: x[row][16 g + 4 q ..+ 3]
+  float at[3] = {0.f, 0.f, 0.f};                              // tail: x[row][16 gfull + 4 c + q]
+  auto load_group = [&](int64_t tile, int g) __attribute__((always_inline)) {
+    const int64_t r0 = tile << 4;
+    const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+    const float* xr = x + row * K;
+    const int k0 = 16 * g + 4 * q;
+    if (vec) a[g] = *reinterpret_cast<const float4*>(xr + k0);
+    else a[g] = make_float4(xr[k0], xr[k0 + 1], xr[k0 + 2], xr[k0 + 3]);
+  };
+  auto load_tail = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile << 4;
+    const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+    const float* xr = x + row * K;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int k = 16 * gfull + 4 * c + q;
+      at[c] = (c < tq && k < K) ? xr[k] : 0.f;
+    }
+  };
+  const int64_t tstep = (int64_t)nslices * NW;
+  int64_t tile = (int64_t)slice * NW + wave;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int g = 0; g < gfull; ++g) load_group(tile, g);
+    load_tail(tile);
+  }
+  // one pass: NTP column tiles starting at ct0 through the whole K; FETCH: the next tile's rows replace a[g] as soon as group g is
+  // done (`next` is always a valid tile: the last one repeats itself -- no branch inside the loop)
+  auto pass = [&](auto ntp_tag, auto fetch_tag, int ct0, f32x4* acc, int64_t next) __attribute__((always_inline)) {
+    constexpr int NTP = decltype(ntp_tag)::value;
+    constexpr bool fetch_next = decltype(fetch_tag)::value;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wb = smem + (ct0 * 16 + j) * ld + 4 * q;
+#pragma unroll
+    for (int g = 0; g < gfull; ++g) {
+      {
+        float4 b[NTP];
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) b[t] = *reinterpret_cast<const float4*>(wb + t * 16 * ld + 16 * g);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b[t].w, acc[t], 0, 0, 0);
+        if constexpr (fetch_next) load_group(next, g);
+      }
+    }
+    // the partial group: lane (n, q) of B holds W[n][16 gfull + 4 c + q]
+    const float* wt = smem + (ct0 * 16 + j) * ld + 16 * gfull + q;
+#pragma unroll
+    for (int c = 0; c < tq; ++c) {
+      float bt[NTP];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) bt[t] = wt[t * 16 * ld + 4 * c];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[c], bt[t], acc[t], 0, 0, 0);
+    }
+    if constexpr (fetch_next) load_tail(next);
+  };
+  for (; tile < ntiles; tile += tstep) {
+    // (the weights in LDS are loop-invariant: without this the compiler hoists their reads out of the tile loop and spills 236 registers)
+    asm volatile("" ::: "memory");
+    const int64_t r0 = tile << 4;
+    const int64_t next = tile + tstep < ntiles ? tile + tstep : tile;
+    const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + r0 * 8 * (HYPAD_LSTM_EXP == 5 ? 64 : H) : out);
+    // the cell on one lane's (i, g, o) of unit `unit`, rows 4 q + r
+    auto cell = [&](const f32x4& pi, const f32x4& pg, const f32x4& po, int unit) __attribute__((always_inline)) {
+      const float bsi = bias_s[unit], bsg = bias_s[H + unit], bso = bias_s[2 * H + unit];
+#if HYPAD_LSTM_EXP == 5      /* what-if: gate rows padded to 64 floats (whole 64-byte sectors), needs a (rows, 8 * 64) buffer */
+      constexpr int HS = 64;
+#else
+      constexpr int HS = H;
+#endif
+      const int vo_h = (4 * q * 2 * H + dir * H + unit) * 4, vo_g = (4 * q * 8 * HS + dir * 4 * HS + unit) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r0 + 4 * q + r >= rows) continue;
+        const float gi = sigmoidf_(pi[r] + bsi), gg = tanhf_(pg[r] + bsg), go = sigmoidf_(po[r] + bso);
+        const float tc = tanhf_(gi * gg);
+        ob.st(go * tc, vo_h, r * 2 * H * 4);
+        if (gates_save) {
+          if (nt_ok) {
+            auto nt = [&](float v, int so) __attribute__((always_inline)) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), gb.rs, vo_g, so, 2); };
+            nt(gi, r * 8 * HS * 4); nt(gg, (r * 8 * HS + HS) * 4); nt(go, (r * 8 * HS + 2 * HS) * 4); nt(tc, (r * 8 * HS + 3 * HS) * 4);
+          } else {
+            gb.st(gi, vo_g, r * 8 * HS * 4); gb.st(gg, vo_g, (r * 8 * HS + HS) * 4);
+            gb.st(go, vo_g, (r * 8 * HS + 2 * HS) * 4); gb.st(tc, vo_g, (r * 8 * HS + 3 * HS) * 4);
+          }
+        }
+      }
+    };
+    // the remainder tile: columns [i x REM | g x REM | o x REM]: g and o of a unit come from the lanes REM and 2 REM further on
+    auto cell_rem = [&](const f32x4& p) __attribute__((always_inline)) {
+      f32x4 pg, po;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pg[r] = __shfl_down(p[r], REM ? REM : 1); po[r] = __shfl_down(p[r], REM ? 2 * REM : 1); }
+      if (j < REM) cell(p, pg, po, NFB * 16 + j);
+    };
+    constexpr int FIRST = NFB >= 2 ? 6 : 3;                  // first pass: two full blocks (or the only one)
+    constexpr int SECOND = NT - FIRST;                       // second pass: what is left (0 .. 6 tiles)
+    f32x4 acc[6];
+    pass(std::integral_constant<int, FIRST>{}, std::integral_constant<bool, SECOND == 0>{}, 0, acc, next);
+    cell(acc[0], acc[1], acc[2], j);
+    if constexpr (FIRST == 6) cell(acc[3], acc[4], acc[5], 16 + j);
+    if constexpr (SECOND > 0) {
+      pass(std::integral_constant<int, SECOND>{}, std::true_type{}, FIRST, acc, next);
+      constexpr int fb2 = NFB - 2;                           // full blocks in the second pass (NFB >= 2 here)
+      if constexpr (fb2 >= 1) cell(acc[0], acc[1], acc[2], 32 + j);
+      if constexpr (fb2 >= 2) cell(acc[3], acc[4], acc[5], 48 + j);
+      if constexpr (REM > 0) cell_rem(acc[3 * fb2]);
+    }
   }
 }
 
@@ -486,6 +667,32 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
   if (rows == 0) return HYPAD_OK;
   // many rows: the weights-stationary form (one direction's W_ih in LDS per workgroup); HYPAD_LSTM_LDS=0 keeps the streamed form
   static const int lds_form = HYPAD_TUNE_INT("HYPAD_LSTM_LDS", 1);
+  if (lds_form && rows >= 2048 && ((H == 50 && K == 100) || (H == 64 && (K == 128 || K == 50)))) {
+    // the reference's three layer shapes (encoder 100 -> 2 x 50; decoder 50 -> 2 x 64 and 128 -> 2 x 64): lstm_fwd_lds2_kernel
+    const int64_t ntiles = (rows + 15) >> 4;
+#ifndef HYPAD_LSTM_NW
+#define HYPAD_LSTM_NW 16
+#endif
+    constexpr int nw = HYPAD_LSTM_NW;
+    int nslices = (int)((ntiles + nw - 1) / nw);
+    if (nslices > 128) nslices = 128;
+    const dim3 grid(2 * nslices);
+#define HYPAD_LSTM_LDS2_LAUNCH(KC, HC)                                                                                           \
+    do {                                                                                                                         \
+      constexpr int NTC = 3 * (HC / 16) + ((HC % 16) ? 1 : 0);                                                                   \
+      const size_t lw2 = (size_t)(NTC * 16 * (((KC + 15) / 16) * 16 + 4) + 3 * HC) * sizeof(float);                              \
+      hipError_t e2 = allow_lds((const void*)lstm_fwd_lds2_kernel<KC, HC, nw>, lw2);                                             \
+      if (e2 != hipSuccess) return (int)e2;                                                                                      \
+      hipLaunchKernelGGL((lstm_fwd_lds2_kernel<KC, HC, nw>), grid, dim3(64 * nw), lw2, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
+                         gates_save, rows);                                                                                      \
+    } while (0)
+    if (H == 50) HYPAD_LSTM_LDS2_LAUNCH(100, 50);
+    else if (K == 128) HYPAD_LSTM_LDS2_LAUNCH(128, 64);
+    else HYPAD_LSTM_LDS2_LAUNCH(50, 64);
+#undef HYPAD_LSTM_LDS2_LAUNCH
+    HYPAD_CHECK_LAUNCH();
+    return HYPAD_OK;
+  }
   if (lds_form && rows >= 2048 && H <= 64 && K <= 128) {
     const int KG = (K + 15) >> 4, Hp = (H + 15) & ~15;
     const size_t lw = (size_t)3 * Hp * (KG * 16 + 4) * sizeof(float);

@@ -9,7 +9,7 @@ torch.manual_seed(0)
 for in_dim, hidden in ((100, 50), (128, 64)):
     lstm = torch.nn.LSTM(input_size=in_dim, hidden_size=hidden, num_layers=1, bidirectional=True).cuda()
     x = torch.randn(rows, in_dim, device="cuda")
-    out, gates = torch.empty(rows, 2 * hidden, device="cuda"), torch.empty(rows, 8 * hidden, device="cuda")
+    out, gates = torch.empty(rows, 2 * hidden, device="cuda"), torch.empty(rows, 8 * 64, device="cuda")
     p = lambda n: _C.ptr(getattr(lstm, n).detach().contiguous())
     ps = [p(n) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
     for gs in (gates, None):
