@@ -434,6 +434,238 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds2_kernel(const float* __r
   }
 }
 
+// ---- the same with the layer's stores staged through LDS (hidden not a multiple of 16: the reference's encoder, 2 x 50): see the
+// comment at "pass A" below.  Column tiles in the order the passes take them.
+template <int K, int H, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_fwd_lds3_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
+                                                             const float* wr, const float* bir, const float* bhr, float* __restrict__ out,
+                                                             float* __restrict__ gates_save, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KG = (K + 15) / 16;
+  constexpr int NFB = H / 16, REM = H % 16, NT = 3 * NFB + (REM ? 1 : 0), ld = KG * 16 + 4;
+  static_assert(REM <= 5, "the remainder tile holds 3 x (H % 16) columns");
+  static_assert(NFB >= 1 && NFB <= 4, "hidden <= 64");
+  const int dir = blockIdx.x & 1, slice = blockIdx.x >> 1, nslices = gridDim.x >> 1;
+  const float* __restrict__ w = dir ? wr : wf;
+  const float* __restrict__ b1 = dir ? bir : bif;
+  const float* __restrict__ b2 = dir ? bhr : bhf;
+  float* bias_s = smem + NT * 16 * ld;                       // [3][H]: b_ih + b_hh of gates i, g, o
+  // column c of tile ct -> (PyTorch gate block, unit)
+  for (int idx = threadIdx.x; idx < NT * 16 * ld; idx += 64 * NW) {
+    const int ct = idx / (16 * ld), rem = idx - ct * 16 * ld, n = rem / ld, k = rem - n * ld;
+    int gate, unit;                                          // tile order: (i, ub), (g, ub) for every full block; the remainder tile; (o, ub)
+    if (ct < 2 * NFB) { gate = ct & 1; unit = (ct >> 1) * 16 + n; }
+    else if (REM && ct == 2 * NFB) { gate = n / (REM ? REM : 1); unit = NFB * 16 + n % (REM ? REM : 1); }
+    else { gate = 2; unit = (ct - 2 * NFB - (REM ? 1 : 0)) * 16 + n; }
+    smem[idx] = (gate < 3 && unit < H && k < K) ? w[(int64_t)((gate == 0 ? 0 : gate + 1) * H + unit) * K + k] : 0.f;      // i, f, g, o -> i, g, o
+  }
+  for (int idx = threadIdx.x; idx < 3 * H; idx += 64 * NW) {
+    const int gate = idx / H, unit = idx - gate * H, pg = (gate == 0 ? 0 : gate + 1) * H + unit;
+    bias_s[idx] = b1[pg] + b2[pg];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (rows + 15) >> 4;
+  constexpr int gfull = K >> 4;                               // full k-groups; the rest (K & 15) in `tq` quads
+  constexpr int tq = ((K & 15) + 3) >> 2;
+  const bool vec = (K & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  const bool nt_ok = (H & 15) == 0 && gates_save && ((uintptr_t)gates_save & 63) == 0;
+  float4 a[gfull > 0 ? gfull : 1];                            // full groups: x[row][16 g + 4 q ..+ 3]
+  float at[3] = {0.f, 0.f, 0.f};                              // tail: x[row][16 gfull + 4 c + q]
+  auto load_group = [&](int64_t tile, int g) __attribute__((always_inline)) {
+    const int64_t r0 = tile << 4;
+    const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+    const float* xr = x + row * K;
+    const int k0 = 16 * g + 4 * q;
+    if (vec) a[g] = *reinterpret_cast<const float4*>(xr + k0);
+    else a[g] = make_float4(xr[k0], xr[k0 + 1], xr[k0 + 2], xr[k0 + 3]);
+  };
+  auto load_tail = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t r0 = tile << 4;
+    const int64_t row = r0 + j < rows ? r0 + j : rows - 1;
+    const float* xr = x + row * K;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int k = 16 * gfull + 4 * c + q;
+      at[c] = (c < tq && k < K) ? xr[k] : 0.f;
+    }
+  };
+  const int64_t tstep = (int64_t)nslices * NW;
+  int64_t tile = (int64_t)slice * NW + wave;
+  if (tile < ntiles) {
+#pragma unroll
+    for (int g = 0; g < gfull; ++g) load_group(tile, g);
+    load_tail(tile);
+  }
+  // one pass: NTP column tiles starting at ct0 through the whole K; FETCH: the next tile's rows replace a[g] as soon as group g is
+  // done (`next` is always a valid tile: the last one repeats itself -- no branch inside the loop)
+  auto pass = [&](auto ntp_tag, auto fetch_tag, int ct0, f32x4* acc, int64_t next) __attribute__((always_inline)) {
+    constexpr int NTP = decltype(ntp_tag)::value;
+    constexpr bool fetch_next = decltype(fetch_tag)::value;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wb = smem + (ct0 * 16 + j) * ld + 4 * q;
+#pragma unroll
+    for (int g = 0; g < gfull; ++g) {
+      {
+        float4 b[NTP];
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) b[t] = *reinterpret_cast<const float4*>(wb + t * 16 * ld + 16 * g);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b[t].w, acc[t], 0, 0, 0);
+        if constexpr (fetch_next) load_group(next, g);
+      }
+    }
+    // the partial group: lane (n, q) of B holds W[n][16 gfull + 4 c + q]
+    const float* wt = smem + (ct0 * 16 + j) * ld + 16 * gfull + q;
+#pragma unroll
+    for (int c = 0; c < tq; ++c) {
+      float bt[NTP];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) bt[t] = wt[t * 16 * ld + 4 * c];
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[c], bt[t], acc[t], 0, 0, 0);
+    }
+    if constexpr (fetch_next) load_tail(next);
+  };
+  // ---- pass A: gates i and g of every unit (+ the remainder tile, which also carries o of the last H % 16 units); pass B: gate o
+  // of the full blocks.  tc = tanh(sigma(i) tanh(g)) needs pass A only and waits in registers for o.  What a pass produces goes
+  // through a wave-private LDS slab, eight rows at a time, and leaves as 16-byte stores of whole row pieces: [i | g] = floats
+  // [0, 2 H) of the row's (direction) block after pass A, [o | tanh c] = floats [2 H, 4 H) and the h row after pass B.  With 4-byte
+  // stores from the accumulator layout (16 units = 64 bytes per row and instruction, at 200-byte gate rows never sector-aligned)
+  // nearly every sector was written in pieces: 305 us with the gates against 163 without, 238 with the gate rows padded to 64
+  // floats (what-if, round 4); whole sectors also take the non-temporal hint.
+  constexpr int NA = 2 * NFB + (REM ? 1 : 0), NB = NFB;       // column tiles of the two passes
+  constexpr int SROW = 3 * H + 2;                             // slab row: [o | tc | h] (pass B) or [i | g] (pass A); even, not a multiple of 32
+  float* slab = smem + NT * 16 * ld + 3 * H + wave * (8 * SROW);
+  const bool g16 = gates_save && (((uintptr_t)gates_save | (uintptr_t)(4 * H * 4)) & 15) == 0;
+  for (; tile < ntiles; tile += tstep) {
+    // (the weights in LDS are loop-invariant: without this the compiler hoists their reads out of the tile loop and spills 236 registers)
+    asm volatile("" ::: "memory");
+    const int64_t r0 = tile << 4;
+    const int64_t next = tile + tstep < ntiles ? tile + tstep : tile;
+    const int nvalid = rows - r0 < 16 ? (int)(rows - r0) : 16;
+    // buffer descriptors sized to the tile's valid rows: stores past the end are dropped by the hardware (no per-row branches)
+    const __amdgpu_buffer_rsrc_t gsr = __builtin_amdgcn_make_buffer_rsrc(gates_save ? gates_save + (r0 * 2 + dir) * 4 * H : out, 0,
+                                                                          gates_save ? (nvalid * 8 * H - dir * 4 * H) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t osr = __builtin_amdgcn_make_buffer_rsrc(out + r0 * 2 * H + dir * H, 0, (nvalid * 2 * H - dir * H) * 4, 0x00020000);
+    f32x4 acc[NA > NB ? NA : NB];
+    float tck[NFB + 1][4], gok[4];                            // tanh(c) of every block's rows 4 q + r; sigma(o) of the remainder units
+    const int lrow = 4 * (q & 1);                             // this lane's first row inside its half of the tile
+    // ---- pass A
+    pass(std::integral_constant<int, NA>{}, std::false_type{}, 0, acc, next);
+    float gi_[NFB + 1][4], gg_[NFB + 1][4];
+#pragma unroll
+    for (int ub = 0; ub < NFB; ++ub) {
+      const int unit = 16 * ub + j;
+      const float bsi = bias_s[unit], bsg = bias_s[H + unit];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi_[ub][r] = sigmoidf_(acc[2 * ub][r] + bsi); gg_[ub][r] = tanhf_(acc[2 * ub + 1][r] + bsg);
+        tck[ub][r] = tanhf_(gi_[ub][r] * gg_[ub][r]);
+      }
+    }
+    if constexpr (REM > 0) {
+      const int unit = 16 * NFB + (j < REM ? j : 0);
+      const float bsi = bias_s[unit], bsg = bias_s[H + unit], bso = bias_s[2 * H + unit];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = acc[2 * NFB][r];
+        const float pg = __shfl_down(p, REM), po = __shfl_down(p, 2 * REM);
+        gi_[NFB][r] = sigmoidf_(p + bsi); gg_[NFB][r] = tanhf_(pg + bsg); gok[r] = sigmoidf_(po + bso);
+        tck[NFB][r] = tanhf_(gi_[NFB][r] * gg_[NFB][r]);
+      }
+    }
+    if (gates_save) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if ((q >> 1) == half) {
+#pragma unroll
+          for (int ub = 0; ub < NFB; ++ub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { slab[(lrow + r) * SROW + 16 * ub + j] = gi_[ub][r]; slab[(lrow + r) * SROW + H + 16 * ub + j] = gg_[ub][r]; }
+          if constexpr (REM > 0) {
+            if (j < REM) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { slab[(lrow + r) * SROW + 16 * NFB + j] = gi_[NFB][r]; slab[(lrow + r) * SROW + H + 16 * NFB + j] = gg_[NFB][r]; }
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // rows 8 half .. + 7, floats [0, 2 H) of the (row, direction) block: 2 H / 4 pieces of 16 bytes per row
+        constexpr int PPR = 2 * H / 4;
+        for (int p = lane; p < 8 * PPR; p += 64) {
+          const int rr = p / PPR, c4 = p - rr * PPR;
+          const float* src = slab + rr * SROW + 4 * c4;
+          const float4 v = make_float4(src[0], src[1], src[2], src[3]);
+          const int off = ((8 * half + rr) * 8 * H + 4 * c4) * 4;
+          if (g16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), gsr, off, 0, 2);
+          else { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), gsr, off, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.y), gsr, off + 4, 0, 0);
+                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.z), gsr, off + 8, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.w), gsr, off + 12, 0, 0); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the slab is rewritten by the other half / by pass B)
+      }
+    }
+    // ---- pass B: o of the full blocks; the next tile's x rows arrive under it
+    pass(std::integral_constant<int, NB>{}, std::true_type{}, NA, acc, next);
+    float go_[NFB + 1][4];
+#pragma unroll
+    for (int ub = 0; ub < NFB; ++ub) {
+      const float bso = bias_s[2 * H + 16 * ub + j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) go_[ub][r] = sigmoidf_(acc[ub][r] + bso);
+    }
+    if constexpr (REM > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) go_[NFB][r] = gok[r];
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((q >> 1) == half) {
+#pragma unroll
+        for (int ub = 0; ub < NFB + (REM ? 1 : 0); ++ub) {
+          if (ub < NFB || j < REM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* row = slab + (lrow + r) * SROW + 16 * ub + j;
+              row[0] = go_[ub][r]; row[H] = tck[ub][r]; row[2 * H] = go_[ub][r] * tck[ub][r];
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (gates_save) {
+        constexpr int PPR = 2 * H / 4;
+        for (int p = lane; p < 8 * PPR; p += 64) {
+          const int rr = p / PPR, c4 = p - rr * PPR;
+          const float* src = slab + rr * SROW + 4 * c4;
+          const float4 v = make_float4(src[0], src[1], src[2], src[3]);
+          const int off = ((8 * half + rr) * 8 * H + 2 * H + 4 * c4) * 4;
+          if (g16 && (H % 2) == 0 && ((2 * H * 4) & 15) == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wl_u32x4, v), gsr, off, 0, 2);
+          else { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), gsr, off, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.y), gsr, off + 4, 0, 0);
+                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.z), gsr, off + 8, 0, 0); __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.w), gsr, off + 12, 0, 0); }
+        }
+      }
+      {                                                         // the h rows: H floats per (row, direction), pieces of 8 bytes
+        constexpr int PPR2 = H / 2;
+        for (int p = lane; p < 8 * PPR2; p += 64) {
+          const int rr = p / PPR2, c2 = p - rr * PPR2;
+          const float* src = slab + rr * SROW + 2 * H + 2 * c2;
+          const int off = ((8 * half + rr) * 2 * H + 2 * c2) * 4;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wl_u32x2, make_float2(src[0], src[1])), osr, off, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void lstm_bwd_kernel(const float* wf, const float* wr, const float* __restrict__ gates_saved,
                                                             const float* __restrict__ gout, float* __restrict__ ggates,
                                                             float* __restrict__ gx, int64_t rows, int K, int H) {
@@ -686,7 +918,14 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
       hipLaunchKernelGGL((lstm_fwd_lds2_kernel<KC, HC, nw>), grid, dim3(64 * nw), lw2, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
                          gates_save, rows);                                                                                      \
     } while (0)
-    if (H == 50) HYPAD_LSTM_LDS2_LAUNCH(100, 50);
+    if (H == 50 && !gates_save) HYPAD_LSTM_LDS2_LAUNCH(100, 50);      // (forward only: 163 us per 200 000 rows, 171 through the slab)
+    else if (H == 50) {
+      constexpr int KC = 100, HC = 50, NTC = 3 * (HC / 16) + 1;
+      const size_t lw3 = (size_t)(NTC * 16 * (((KC + 15) / 16) * 16 + 4) + 3 * HC + nw * 8 * (3 * HC + 2)) * sizeof(float);
+      hipError_t e3 = allow_lds((const void*)lstm_fwd_lds3_kernel<KC, HC, nw>, lw3);
+      if (e3 != hipSuccess) return (int)e3;
+      hipLaunchKernelGGL((lstm_fwd_lds3_kernel<KC, HC, nw>), grid, dim3(64 * nw), lw3, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, gates_save, rows);
+    }
     else if (K == 128) HYPAD_LSTM_LDS2_LAUNCH(128, 64);
     else HYPAD_LSTM_LDS2_LAUNCH(50, 64);
 #undef HYPAD_LSTM_LDS2_LAUNCH

@@ -210,6 +210,7 @@ struct PackedPre { float4 w[8]; };
 // It is also the form a consumer must use for EVERY byte another workgroup of the same launch has just written with `sc1`
 // stores (cdna_hip_programming.md Guideline 16 R1).
 typedef unsigned int wl_u32x4 __attribute__((vector_size(16)));
+typedef unsigned int wl_u32x2 __attribute__((vector_size(8)));
 template <bool SC1>
 struct WeightBlocks {
   const float4* wp; __amdgpu_buffer_rsrc_t rs; int voff;

@@ -9,7 +9,7 @@ torch.manual_seed(0)
 for in_dim, hidden in ((100, 50), (128, 64)):
     lstm = torch.nn.LSTM(input_size=in_dim, hidden_size=hidden, num_layers=1, bidirectional=True).cuda()
     x = torch.randn(rows, in_dim, device="cuda")
-    out, gates = torch.empty(rows, 2 * hidden, device="cuda"), torch.empty(rows, 8 * 64, device="cuda")
+    out, gates = torch.empty(rows, 2 * hidden, device="cuda"), torch.zeros(rows, 8 * hidden, device="cuda")
     p = lambda n: _C.ptr(getattr(lstm, n).detach().contiguous())
     ps = [p(n) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
     for gs in (gates, None):
@@ -22,4 +22,4 @@ for in_dim, hidden in ((100, 50), (128, 64)):
         us = a.elapsed_time(b) / 10 * 1e3
         flop = 2.0 * 2 * 3 * hidden * in_dim * rows
         print("LDS form" if os.environ.get("HYPAD_LSTM_LDS", "1") != "0" else "streamed", "%d -> 2 x %d" % (in_dim, hidden), "gates saved" if gs is not None else "no gates",
-              "%.1f us  %.1f TFLOP/s = %.1f %% of 157.3" % (us, flop / us / 1e6, flop / us / 1e6 / 157.3 * 100), "checksum %.4f" % float(out.double().sum()))
+              "%.1f us  %.1f TFLOP/s = %.1f %% of 157.3" % (us, flop / us / 1e6, flop / us / 1e6 / 157.3 * 100), "checksum %.4f" % float(out.double().sum()), ("gates %.4f" % float(gs[:, : 8 * hidden].double().sum())) if gs is not None else "")
