@@ -601,6 +601,42 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0, smooth=200, kernels=T
     return scoring, roofline_hbm, roofline_scoring
 
 
+def bench_lstm_layers(device, rows=200_000):
+    """The reference's bidirectional LSTM layers as stand-alone kernels (hypad_lstm_bidir_fwd: T = 1, h0 = c0 = 0, models/tadgan.py:15-27,
+    35-38,58-62 -- the weights-stationary LDS forms of ops_dense.hip) at 200 000 rows: microseconds per launch, the rate of the gate
+    products the algorithm needs (2 x 3 x H x K MAC per row and direction) against the fp32-MFMA peak, and the bytes the layer must
+    move (x once, h, the saved gates) against HBM; and the general-T layer (hypad_lstm_bidir_seq_fwd: W_hh in LDS, one barrier per
+    step) in microseconds per time step."""
+    from hypad_amd import _C
+    from hypad_amd import autograd as hag
+    out = {"rows": rows, "unit": "us per launch", "timing": "median of 21 rounds of 3 back-to-back launches, HIP events", "layers": {}, "sequence": {}}
+    torch.manual_seed(0)
+    for in_dim, hidden in ((100, 50), (128, 64), (50, 64)):
+        lstm = torch.nn.LSTM(input_size=in_dim, hidden_size=hidden, num_layers=1, bidirectional=True).to(device)
+        x = torch.randn(rows, in_dim, device=device)
+        o, gates = torch.empty(rows, 2 * hidden, device=device), torch.empty(rows, 8 * hidden, device=device)
+        ps = [_C.ptr(getattr(lstm, n).detach().contiguous()) for n in ("weight_ih_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse",
+                                                                        "bias_ih_l0_reverse", "bias_hh_l0_reverse")]
+        for gs, tag in ((gates, "gates saved"), (None, "forward only")):
+            fn = lambda: _C.check(_C.lib.hypad_lstm_bidir_fwd(_C.ptr(x), *ps, _C.ptr(o), _C.ptr(gs) if gs is not None else None, rows, in_dim, hidden, _C.stream()), "lstm")
+            ms = _event_ms_median(fn)
+            flop = 2.0 * 2 * 3 * hidden * in_dim * rows
+            nbytes = rows * 4 * (in_dim + 2 * hidden + (8 * hidden if gs is not None else 0))
+            out["layers"]["%d -> 2 x %d, %s" % (in_dim, hidden, tag)] = {
+                "us": 1e3 * ms, "tflops": flop / (ms * 1e-3) / 1e12, "frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_bytes": nbytes, "GB_per_s": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    for T, nrows, in_dim, hidden in ((100, 64, 100, 50), (100, 64, 128, 64), (100, 4096, 128, 64)):
+        lstm = torch.nn.LSTM(input_size=in_dim, hidden_size=hidden, num_layers=1, bidirectional=True).to(device)
+        x = torch.randn(T, nrows, in_dim, device=device)
+        with torch.no_grad():
+            fn = lambda: hag.lstm_seq_forward(x, lstm)
+            ms = _event_ms_median(fn, rounds=7, per_round=2)
+        flop = 2.0 * 2 * 4 * hidden * (in_dim + hidden) * nrows * T
+        out["sequence"]["T=%d rows=%d %d -> 2 x %d" % (T, nrows, in_dim, hidden)] = {"us_per_call": 1e3 * ms, "us_per_step": 1e3 * ms / T,
+                                                                                   "tflops": flop / (ms * 1e-3) / 1e12}
+    return out
+
+
 def bench_scoring_sharded(device, world, rank, per_gpu=125_000, reps=5):
     """configs[4] across the ranks: 125 000 windows per GPU of one long series.  Rank 0 holds the trained weights; ONE RCCL
     broadcast of the parameter arenas (~1 MB) gives them to every rank (parallel.broadcast_weights); every rank then scores its
@@ -800,7 +836,7 @@ def main():
     traffic, traffic_note = None, "no committed PMC profile matches these kernel sources"
     try:
         from hypad_amd.build import source_digest
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -816,10 +852,11 @@ def main():
     # committed rocprofv3 --pmc pass, under the same source-digest rule as `traffic`
     roofline_mfma = None
     try:
-        path = os.path.join(ROOT, "profiles", "r03_mfma_util.json")
+        mfname = "r04_mfma_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_mfma_util.json")) else "r03_mfma_util.json"
+        path = os.path.join(ROOT, "profiles", mfname)
         mf = json.load(open(path))
         same = mf.get("source_sha256") == source_digest()
-        roofline_mfma = {"source": "profiles/r03_mfma_util.json" + (" (same kernel sources: sha256 matches)" if same else
+        roofline_mfma = {"source": "profiles/" + mfname + (" (same kernel sources: sha256 matches)" if same else
                                                                      " (kernel sources changed since: indicative only)"),
                          "formula": mf.get("formula"),
                          "kernels": {k: {"mfma_util": v.get("mfma_util"), "algorithmic_util": v.get("algorithmic_util"),
@@ -927,6 +964,8 @@ def main():
             # configs[4] whole on ONE GPU: 10^6 windows (400 MB of windows; the four (N, S) outputs 1.6 GB), errors smoothed over 10^4
             torch.cuda.empty_cache()
             out["scoring_1e6"] = bench_scoring(device, n=1_000_000, reps=3, smooth=10_000, kernels=False)[0]
+            torch.cuda.empty_cache()
+            out["roofline_lstm"] = bench_lstm_layers(device)
         if sharded is not None:
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:

@@ -1,7 +1,7 @@
-"""profiles/r03_mfma_util.json from one rocprofv3 counter pass over scripts/profile_mfma_target.py:
+"""profiles/r0N_mfma_util.json from one rocprofv3 counter pass over scripts/profile_mfma_target.py:
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d out -o pmc -- python3 scripts/profile_mfma_target.py
-    python scripts/mfma_util.py out > profiles/r03_mfma_util.json
+    python scripts/mfma_util.py out > profiles/r0N_mfma_util.json
 
 MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs): the share of the chip's SIMD-cycles
 during the dispatch in which the matrix pipe was busy (the gfx94x MfmaUtil formula; ROCm 7.2 ships no gfx950 derived counters).
@@ -12,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 KERNELS = {"score_forward_packed_kernel": 340312.0 / 2 * 125_000,                  # MACs per launch (algorithmic)
-           "lstm_fwd(_lds)?_kernel": None,
+           "lstm_fwd(_lds[0-9]?)?_kernel": None,
            "gen_kernel": 561824.0 * 64, "dw_adam_kernel": 281872.0 * 64,
            "critic_persistent_kernel": (40400.0 + 156936.0) * 64 * 145}
 d = sys.argv[1]
@@ -21,16 +21,16 @@ acc = {}
 lstm_ids = set()
 rows_all = list(csv.DictReader(open(f)))
 for r in rows_all:
-    if re.search("lstm_fwd(_lds)?_kernel", r["Kernel_Name"]):
+    if re.search("lstm_fwd(_lds[0-9]?)?_kernel", r["Kernel_Name"]):
         lstm_ids.add(int(r["Dispatch_Id"]))
 lstm_sorted = sorted(lstm_ids)
 lstm_first = set(lstm_sorted[: len(lstm_sorted) // 2])           # the target runs the 100 -> 2x50 shape first, then 128 -> 2x64
-LSTM_MACS = {"lstm_bidir_fwd (100 -> 2 x 50, 200 000 rows)": 2 * 4 * 50 * 100 * 200_000.0, "lstm_bidir_fwd (128 -> 2 x 64, 200 000 rows)": 2 * 4 * 64 * 128 * 200_000.0}
+LSTM_MACS = {"lstm_bidir_fwd (100 -> 2 x 50, 200 000 rows)": 2 * 3 * 50 * 100 * 200_000.0, "lstm_bidir_fwd (128 -> 2 x 64, 200 000 rows)": 2 * 3 * 64 * 128 * 200_000.0}      # (i, g, o: the f gate meets c0 = 0 and is never formed)
 for r in rows_all:
     for k in KERNELS:
         if re.search(k, r["Kernel_Name"]):
             key = k
-            if k == "lstm_fwd(_lds)?_kernel":
+            if k == "lstm_fwd(_lds[0-9]?)?_kernel":
                 key = list(LSTM_MACS)[0 if int(r["Dispatch_Id"]) in lstm_first else 1]
             acc.setdefault(key, {}).setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
             acc[key][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
