@@ -877,6 +877,49 @@ def main():
         shares_in_l2 = int(eng.counters[5]) == 2 * spg
         traffic_algorithmic = float(spg * n_it * ((2 if producers else 1) * rec + (0 if shares_in_l2 else share_bytes * (1 + nchunks))))
 
+    # algorithmic memory-side bytes of ONE generator launch and ONE dW + Adam launch (DESIGN.md §3 layout): gen_kernel reads the packed
+    # generator weights once (forward and transposed copies) and the gathered windows, and writes the iteration scratch once (operand
+    # rows of every weight gradient, saved gates / activations, dropout masks); dw_adam_kernel reads that scratch once, moves 28 bytes
+    # of optimiser traffic per updated parameter (p, m, v read; p, m, v written; + the gradient never leaves the accumulators) and
+    # writes every updated matrix element to its two packed positions
+    traffic_alg_all = {dom: traffic_algorithmic} if traffic_algorithmic else {}
+    try:
+        import ctypes
+        from hypad_amd import _C
+        o_, st_, c_ = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _C.check(_C.lib.hypad_packed_region(ctypes.byref(eng.dims), ctypes.byref(o_), ctypes.byref(st_), ctypes.byref(c_)), "packed_region")
+        scratch_bytes, packed_bytes = 4.0 * o_.value, 4.0 * c_.value
+        upd = mat = 0
+        for net in ("enc", "dec"):
+            for name, off, shape in eng.catalogue(net):
+                n = int(np.prod(shape))
+                if "weight_hh" in name:
+                    continue                                        # never read, decayed once per epoch (decay_steps_kernel)
+                if "lstm." in name:
+                    n = n * 3 // 4                                  # the f-gate rows meet c0 = 0: decay only
+                upd += n
+                mat += n if len(shape) == 2 else 0
+        traffic_alg_all["gen_kernel"] = spg * (packed_bytes + scratch_bytes + 2.0 * B * S * 4)
+        traffic_alg_all["dw_adam_kernel"] = spg * (scratch_bytes + 28.0 * upd + 8.0 * mat)
+    except Exception as e:                                          # (reported, never fatal for the line)
+        traffic_alg_all["error"] = f"{type(e).__name__}: {e}"[:200]
+    traffic_all = {}
+    try:
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                pmc = json.load(open(path))
+                same = pmc.get("source_sha256") == source_digest()
+                for k in ("critic_persistent_kernel", "gen_kernel", "dw_adam_kernel"):
+                    if k in pmc["kernels"] and hyperbolic and spg == 1:
+                        b_ = pmc["kernels"][k]["hbm_bytes_per_launch"]
+                        traffic_all[k] = {"pmc_bytes_per_launch": b_, "algorithmic": traffic_alg_all.get(k),
+                                          "ratio": (b_ / traffic_alg_all[k]) if traffic_alg_all.get(k) else None,
+                                          "source": f"profiles/{name}" + ("" if same else " (kernel sources changed since: indicative only)")}
+                break
+    except (OSError, KeyError, ValueError, NameError):
+        pass
+
     # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
     # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
     secondary = None
@@ -939,7 +982,8 @@ def main():
                                    "drawn inside the epoch's launch sequence (hypad_epoch_shuffles)", "rccl_world_size": world},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
-                         "traffic_algorithmic": traffic_algorithmic,
+                         "traffic_algorithmic": traffic_algorithmic, "traffic_algorithmic_by_kernel": traffic_alg_all,
+                         "traffic_by_kernel": traffic_all,
                          "traffic_ratio": (traffic / traffic_algorithmic) if traffic and traffic_algorithmic else None,
                          "launch_ms": per_launch[dom], "launches_per_step": launches[dom],
                          "iterations_per_launch": n_it if dom == "critic_persistent_kernel" else 1,
