@@ -73,7 +73,7 @@ def _build_locked(verbose, dev):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if src.endswith(".cpp"):               # host-only helpers (no device code): the system compiler
-            cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
             cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

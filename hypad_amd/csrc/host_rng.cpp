@@ -6,10 +6,12 @@
 // exactly where a reference-style loop would have left it.  Same numbers bit for bit (tests/test_host_rng.py); the point is
 // that ctypes releases the interpreter lock for the call (np.random.normal keeps it) and that no float64 temporaries are
 // built: the epoch's 408 320 draws overlap the loader iteration and the torch.rand draws of the main thread.
+//
 // No device code in this file: compiled with g++ -O2 -ffp-contract=off (hypad_amd/build.py; clang's -O3 code for this loop is 1.9x slower)
 // and linked into libhypad_hip.so.
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "../../include/hypad.h"
 
@@ -52,36 +54,114 @@ struct Mt {
   }
 };
 
+// The stream of normals as legacy_gauss returns them: per accepted pair first f * x2, then (cached) f * x1.
+// Two phases per call.  (1) ONE thread runs the generator and the rejection test for all pairs the call needs.  Candidate pairs are
+// consecutive pairs of doubles of the generator -- a rejected pair consumes exactly two doubles like an accepted one -- so a block
+// of NC candidates is data-parallel: 4 NC tempered words -> 2 NC doubles -> (x1, x2, r2) -> the accepted ones compacted.  A block is
+// only taken whole while at least NC accepted pairs are still needed (it cannot yield more): the generator then ends exactly where
+// NumPy's would; the last < NC pairs come from the pair-by-pair loop.  (2) f = sqrt(-2 log(r2) / r2), the two products and the
+// float32 stores, independent per pair: a loop whose iterations the core overlaps (NumPy's loop serialises the log / divide /
+// square-root latencies behind its rejection branch).  Each pair sees the same operations in the same order: same bits.
+struct Gen {
+  Mt g;
+  static constexpr int NC = 512;                    // candidate pairs per block
+  uint32_t w[4 * NC];
+  double d[2 * NC];
+
+  void words(uint32_t* out, int n) {                // the next n tempered outputs
+    while (n > 0) {
+      if (g.pos == MT_N) { mt_refill(g.key); g.pos = 0; }
+      int take = MT_N - g.pos;
+      if (take > n) take = n;
+      const uint32_t* src = g.key + g.pos;
+      for (int i = 0; i < take; ++i) {
+        uint32_t y = src[i];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        out[i] = y;
+      }
+      out += take; n -= take; g.pos += take;
+    }
+  }
+  // exactly `pairs` accepted (x1, x2, r2) triples
+  void accepted(int64_t pairs, double* x1, double* x2, double* r2) {
+    int64_t k = 0;
+    while (pairs - k >= NC) {
+      words(w, 4 * NC);
+      for (int i = 0; i < 2 * NC; ++i) {
+        const int32_t a = (int32_t)(w[2 * i] >> 5), b = (int32_t)(w[2 * i + 1] >> 6);
+        d[i] = (a * 67108864.0 + b) / 9007199254740992.0;
+      }
+      for (int i = 0; i < NC; ++i) {
+        const double a = 2.0 * d[2 * i] - 1.0, b = 2.0 * d[2 * i + 1] - 1.0, s2 = a * a + b * b;
+        x1[k] = a; x2[k] = b; r2[k] = s2;
+        k += (s2 < 1.0 && s2 != 0.0) ? 1 : 0;       // (branch-free compaction: a rejected candidate is overwritten by the next one;
+      }                                             //  the arrays have NC entries of slack for the last block's overhang)
+    }
+    for (; k < pairs; ++k) {                        // the tail: pair by pair, never a candidate too many
+      double a, b, s2;
+      do {
+        a = 2.0 * g.next_double() - 1.0;
+        b = 2.0 * g.next_double() - 1.0;
+        s2 = a * a + b * b;
+      } while (s2 >= 1.0 || s2 == 0.0);
+      x1[k] = a; x2[k] = b; r2[k] = s2;
+    }
+  }
+};
+
+struct Dest {                                       // value index -> its float: outs[(i / chunk) % n_outs][(i / (chunk * n_outs)) * chunk + i % chunk]
+  float* const* outs; int n_outs; int64_t chunk;
+  inline float* at(int64_t i) const {
+    const int64_t c = i / chunk, pos = i - c * chunk;
+    return outs[c % n_outs] + (c / n_outs) * chunk + pos;
+  }
+};
+
+// pairs [p0, p1): value `first + 2 p` = f x2, `first + 2 p + 1` = f x1 (when below `total`; else it is the value left cached)
+void transform_range(const double* x1, const double* x2, const double* r2, int64_t p0, int64_t p1, int64_t first, int64_t total, const Dest& dst,
+                     double* cached_out) {
+  for (int64_t p = p0; p < p1; ++p) {
+    const double f = std::sqrt(-2.0 * std::log(r2[p]) / r2[p]);
+    const double a = f * x2[p], b = f * x1[p];
+    const int64_t i = first + 2 * p;
+    *dst.at(i) = (float)(0.0 + 1.0 * a);            // legacy_normal(loc 0, scale 1), then float32 (torch.Tensor(float64 array))
+    if (i + 1 < total) *dst.at(i + 1) = (float)(0.0 + 1.0 * b);
+    else *cached_out = b;
+  }
+}
+
 }  // namespace
 
 extern "C" int hypad_host_mt19937_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, float* const* outs, int n_outs,
                                          int64_t chunk, int64_t rounds) {
   if (!key || !pos || !has_gauss || !cached_gaussian || !outs || n_outs <= 0 || chunk < 0 || rounds < 0 || *pos < 0 || *pos > MT_N)
     return HYPAD_EINVAL;
-  Mt g{key, *pos};
-  int have = *has_gauss;
-  double spare = *cached_gaussian;
-  for (int64_t r = 0; r < rounds; ++r)
-    for (int k = 0; k < n_outs; ++k) {
-      float* out = outs[k] + r * chunk;
-      for (int64_t i = 0; i < chunk; ++i) {
-        double v;
-        if (have) {
-          v = spare; have = 0; spare = 0.0;
-        } else {
-          double x1, x2, r2;
-          do {
-            x1 = 2.0 * g.next_double() - 1.0;
-            x2 = 2.0 * g.next_double() - 1.0;
-            r2 = x1 * x1 + x2 * x2;
-          } while (r2 >= 1.0 || r2 == 0.0);
-          const double f = std::sqrt(-2.0 * std::log(r2) / r2);
-          spare = f * x1; have = 1;
-          v = f * x2;
-        }
-        out[i] = (float)(0.0 + 1.0 * v);      // legacy_normal(loc = 0, scale = 1), then torch.Tensor(float64 array): round to nearest
-      }
-    }
-  *pos = g.pos; *has_gauss = have; *cached_gaussian = spare;
+  const int64_t total = rounds * n_outs * chunk;
+  if (total == 0) return HYPAD_OK;
+  const Dest dst{outs, n_outs, chunk};
+  int64_t first = 0;                                // value index of the first pair's first value
+  if (*has_gauss) {                                 // the value a previous call (or NumPy itself) left cached comes first
+    *dst.at(0) = (float)(0.0 + 1.0 * *cached_gaussian);
+    *has_gauss = 0; *cached_gaussian = 0.0;
+    first = 1;
+  }
+  const int64_t pairs = (total - first + 1) / 2;
+  if (pairs == 0) return HYPAD_OK;
+  static thread_local std::vector<double> buf;
+  buf.resize((size_t)(3 * (pairs + Gen::NC)));
+  double* x1 = buf.data(); double* x2 = x1 + pairs + Gen::NC; double* r2 = x2 + pairs + Gen::NC;
+  static thread_local Gen gen;
+  gen.g.key = key; gen.g.pos = *pos;
+  gen.accepted(pairs, x1, x2, r2);
+  *pos = gen.g.pos;
+  double cached = 0.0;
+  const bool odd = ((total - first) & 1) != 0;      // an odd count leaves the second value of the last pair cached, as legacy_gauss would
+  // (one thread: splitting the transform over four std::threads made the call SLOWER inside a process with torch and the HIP
+  // runtime loaded -- 2.6 ms against 1.7 -- creating a thread there initialises every loaded library's thread-local block)
+  transform_range(x1, x2, r2, 0, pairs, first, total, dst, &cached);
+  if (odd) { *has_gauss = 1; *cached_gaussian = cached; }
   return HYPAD_OK;
 }

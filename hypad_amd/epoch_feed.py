@@ -22,6 +22,7 @@ Assumption, stated: fetching a batch does not itself draw from the process-wide 
 torch's samplers, which seed a private generator, and for the reference's datasets).  A loader whose dataset does -- random
 augmentation inside ``__getitem__`` -- needs ``params.per_iteration = True`` (the call-by-call loop).
 """
+import queue
 import threading
 
 import numpy as np
@@ -35,7 +36,8 @@ def _staging(*shape, dtype=torch.float32):
     return t.pin_memory() if torch.cuda.is_available() else t
 
 
-DEPTH = 3          # staging slots: epoch e fills slot e % 3 while e - 1 may still be uploading and e + 1's latent draws run ahead
+DEPTH = 4          # staging slots: the producer thread fills slot (e + 2) % 4 while the caller handles epoch e; that slot's last user, e - 2,
+                   # finished uploading before the caller took epoch e (see EpochFeed.get)
 
 
 def _index_matrix(loader, test=False):
@@ -70,6 +72,20 @@ def loader_batches(loader):
     loop body does.  Pinned against the real iterator by tests/test_epoch_feed.py."""
     torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
     yield from loader.batch_sampler
+
+
+def _plain_random_batches(loader):
+    """(sampler, n) when `loader`'s batches are the consecutive batch_size-runs of ONE permutation drawn by torch's own RandomSampler
+    (DataLoader(shuffle=True, drop_last=True) builds exactly that), else None: the pass's indices are then one tensor slice instead of
+    1 916 Python-level yields."""
+    from torch.utils.data import BatchSampler, RandomSampler
+    bs = loader.batch_sampler
+    if type(bs) is not BatchSampler or type(bs.sampler) is not RandomSampler or not bs.drop_last:
+        return None
+    sm = bs.sampler
+    if sm.replacement or sm._num_samples is not None:
+        return None
+    return sm, len(sm.data_source)
 
 
 class EpochFeed:
@@ -111,7 +127,11 @@ class EpochFeed:
             self.x_host = [_staging(rows, S) for _ in range(DEPTH)]
             self.row_index = torch.arange(rows, dtype=torch.int32, device=device).view(nc + 1, nb * B)
             self._on_device = None
+        self._fast_sampler = _plain_random_batches(train_loader) if self.index_path else None
         self._z_thread = {}            # epoch -> helper thread drawing its latent planes
+        self._producer = None          # background thread that stages epochs ahead of the caller (get)
+        self._queue = None
+        self._stop = False
         self._z_error = None
         self.last_epoch = None         # epochs beyond this one are never drawn (the generators end where the reference's would)
 
@@ -149,8 +169,28 @@ class EpochFeed:
         h[oz + p * nb * B * L: oz + (p + 1) * nb * B * L].reshape(nb, B * L)[:] = t[:, B * S:]
 
     def _pass_indices(self, slot, p):
-        it = loader_batches(self.loader)
         out = self.idx_host[slot][p]
+        fast = self._fast_sampler
+        if fast is not None and self.loader.batch_sampler.batch_size == self.B:
+            # RandomSampler.__iter__ (torch/utils/data/sampler.py), its draws in its order: the iterator's base seed, the sampler's
+            # seed (default generator, unless the sampler owns one), ONE permutation from the private generator -- and a second one
+            # whose head of zero indices it discards (num_samples % n == 0), which matters when the generator is a shared one
+            sm, n = fast
+            torch.empty((), dtype=torch.int64).random_(generator=self.loader.generator)
+            if sm.generator is None:
+                g = torch.Generator()
+                g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+            else:
+                g = sm.generator
+            perm = torch.randperm(n, generator=g)
+            torch.randperm(n, generator=g)
+            if n < self.nb * self.B or n // self.B != self.nb:
+                raise _C.HypadError(f"the loader yields {n // self.B} batches, len(train_loader) is {self.nb}")
+            out.copy_(perm[: self.nb * self.B])
+            if p < self.nc:
+                self._alphas(slot, p)
+            return
+        it = loader_batches(self.loader)
         n = 0
         first = True
         for idx in it:
@@ -191,9 +231,10 @@ class EpochFeed:
         if n != nb:
             raise _C.HypadError(f"the loader yielded {n} batches, len(train_loader) is {nb}")
 
-    def prepare(self, epoch):
-        """Everything epoch `epoch` needs from the host, staged in slot epoch % DEPTH.  The slot's previous user was epoch - DEPTH,
-        whose upload has completed (the caller waits for epoch - 2's losses before it calls this for `epoch`... see train_tadgan)."""
+    def prepare(self, epoch, z_ahead=True):
+        """Everything epoch `epoch` needs from the host, staged in slot epoch % DEPTH: the NumPy stream on a helper thread next to
+        the torch stream and the loader passes.  ``z_ahead``: start the next epoch's latent draws at the end (callers that prepare
+        epoch by epoch on their own thread; the producer thread is ahead of the caller anyway)."""
         slot = epoch % DEPTH
         self._start_z(epoch)
         for p in range(self.nc + 1):
@@ -201,7 +242,41 @@ class EpochFeed:
         self._z_thread.pop(epoch).join()
         if self._z_error is not None:
             raise self._z_error
-        self._start_z(epoch + 1)               # runs under this epoch's upload / launch and the next prepare's loader passes
+        if z_ahead:
+            self._start_z(epoch + 1)
+        return slot
+
+    # ---- epochs staged ahead of the caller ----------------------------------------------------------------------------------------
+    def _produce(self, first):
+        try:
+            for e in range(first, self.last_epoch + 1):
+                if self._stop:
+                    return
+                slot = self.prepare(e, z_ahead=False)
+                self._queue.put((e, slot, None))                 # (blocks while the caller has not taken the previous epoch)
+        except BaseException as exc:
+            self._queue.put((-1, -1, exc))
+
+    def get(self, epoch):
+        """Slot holding epoch `epoch`, staged.  Epoch 0 is staged by the caller's thread; from then on a producer thread runs ahead:
+        while the caller handles epoch e (waits for e - 1's losses, uploads and launches e) it stages e + 1 and then e + 2, never
+        more (a one-element queue).  Staging e + 2 overwrites slot (e - 2) mod 4, whose upload is known complete: the caller waited for
+        epoch e - 2's losses before it took epoch e.  Minibatches that arrive as DEVICE tensors are copied on the caller's stream in
+        the caller's order, so such loaders are staged epoch by epoch on the caller's thread."""
+        if self.last_epoch is None:
+            raise _C.HypadError("EpochFeed.get needs last_epoch (the generators must end where the reference's loop leaves them)")
+        if self._producer is None:
+            slot = self.prepare(epoch, z_ahead=bool(not self.index_path and self._on_device))
+            if (self.index_path or not self._on_device) and epoch < self.last_epoch:
+                self._queue = queue.Queue(maxsize=1)
+                self._producer = threading.Thread(target=self._produce, args=(epoch + 1,), name="hypad-epoch-feed", daemon=True)
+                self._producer.start()
+            return slot
+        e, slot, exc = self._queue.get()
+        if exc is not None:
+            raise exc
+        if e != epoch:
+            raise _C.HypadError(f"epochs must be taken in order (asked for {epoch}, staged {e})")
         return slot
 
     def upload(self, slot):
@@ -214,6 +289,15 @@ class EpochFeed:
             self.x.copy_(self.x_host[slot], non_blocking=True)
 
     def close(self):
+        self._stop = True
+        if self._producer is not None:
+            while self._producer.is_alive():                   # (unblock a producer waiting to hand over an epoch nobody will take)
+                try:
+                    self._queue.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            self._producer.join()
+            self._producer = None
         for t in list(self._z_thread.values()):
             t.join()
         self._z_thread.clear()

@@ -391,7 +391,7 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     try:
         for epoch in range(n_epochs):
             logging.debug("Epoch {}".format(epoch))
-            slot = feed.prepare(epoch)              # host work of epoch e, under the GPU's epoch e - 1
+            slot = feed.get(epoch)                  # epoch e staged on the host (a producer thread runs up to two epochs ahead)
             if epoch:
                 finish(epoch - 1)
             enqueue(epoch, slot)

@@ -145,3 +145,68 @@ def test_loader_batches_draws_what_the_iterator_draws(shuffle):
     assert [len(b) for b in idx] == [64, 64, 22]
     for b, r in zip(idx, real):
         assert torch.equal(torch.from_numpy(ds.X[b]), r)
+
+
+@pytest.mark.parametrize("index_path", [True, False])
+def test_epochs_staged_ahead_by_the_producer_thread_equal_the_loop(index_path):
+    """EpochFeed.get: epoch 0 on the caller's thread, then a producer thread one to two epochs ahead -- the same planes, batches and
+    final generator states as the call-by-call loop; abandoning the feed mid-way joins cleanly."""
+    B, S, L, n, nc, epochs = 16, 33, 7, 100, 2, 6
+    ds = Windows(n, S)
+    loader = DataLoader(ds, batch_size=B, drop_last=True, shuffle=True)
+    np.random.seed(21); torch.manual_seed(21)
+    want = [reference_epoch(loader, B, S, L, nc) for _ in range(epochs)]
+    end_ref = gen_states()
+    np.random.seed(21); torch.manual_seed(21)
+    feed = EpochFeed(loader, B, S, L, nc, "cpu", index_path=index_path)
+    feed.last_epoch = epochs - 1
+    for e in range(epochs):
+        slot = feed.get(e)
+        assert slot == e % DEPTH
+        feed.upload(slot)
+        planes, xs = want[e]
+        assert all(torch.equal(feed.noise[k], v) for k, v in planes.items()), e
+        assert torch.equal(feed.x[feed.row_index.reshape(-1).long()], xs), e
+    feed.close()
+    assert same_states(gen_states(), end_ref)
+    feed = EpochFeed(loader, B, S, L, nc, "cpu", index_path=index_path)           # abandoned after two epochs
+    feed.last_epoch = 50
+    feed.get(0); feed.get(1)
+    feed.close()
+    assert feed._producer is None
+
+
+def test_other_samplers_take_the_generic_index_path():
+    """Only DataLoader(shuffle=True, drop_last=True)'s own RandomSampler is reduced to one permutation slice; any other sampler is
+    iterated through the loader's batch_sampler -- same contract."""
+    from torch.utils.data import SubsetRandomSampler
+    from hypad_amd.epoch_feed import _plain_random_batches
+    B, S, L, nc = 16, 12, 5, 2
+    ds = Windows(90, S)
+    fast = DataLoader(ds, batch_size=B, drop_last=True, shuffle=True)
+    assert _plain_random_batches(fast) is not None
+    for loader in (DataLoader(ds, batch_size=B, drop_last=True, sampler=SubsetRandomSampler(range(10, 90))),
+                   DataLoader(ds, batch_size=B, drop_last=True, shuffle=False),
+                   DataLoader(ds, batch_size=B, drop_last=True, shuffle=True, generator=torch.Generator().manual_seed(5))):
+        shared = loader.generator is not None
+        assert (_plain_random_batches(loader) is not None) == shared
+        if shared:
+            loader.generator.manual_seed(5)
+        np.random.seed(2); torch.manual_seed(2)
+        want = [reference_epoch(loader, B, S, L, nc) for _ in range(2)]
+        end_ref = gen_states()
+        gstate = loader.generator.get_state().clone() if shared else None
+        if shared:
+            loader.generator.manual_seed(5)
+        np.random.seed(2); torch.manual_seed(2)
+        feed = EpochFeed(loader, B, S, L, nc, "cpu")
+        assert feed.index_path
+        feed.last_epoch = 1
+        for e in range(2):
+            feed.upload(feed.get(e))
+            assert all(torch.equal(feed.noise[k], v) for k, v in want[e][0].items())
+            assert torch.equal(feed.x[feed.row_index.reshape(-1).long()], want[e][1])
+        feed.close()
+        assert same_states(gen_states(), end_ref)
+        if shared:
+            assert torch.equal(loader.generator.get_state(), gstate)           # the loader's own generator too
