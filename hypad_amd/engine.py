@@ -305,6 +305,14 @@ class Engine:
 
     MAX_PENDING = 4096
 
+    def confirm_epochs(self, n=1):
+        """The caller has read status 0 (counters[4], e.g. from its own read-back of the counters) BEHIND the n oldest queued epochs:
+        they completed; check_status need not look at them again.  (What check_status does itself when it finds status 0 -- for callers
+        that keep more than one epoch in flight and read the counters without synchronising the stream.)"""
+        for _ in range(min(int(n), len(self._pending))):
+            call, _ = self._pending.pop(0)
+            self._steps_checked = (self._steps_checked[0] + call["n_batches"] * call["n_critics"], self._steps_checked[1] + call["n_batches"])
+
     def _queued(self, call, shuffle_windows=0):
         """Book-keeping for check_status: the epochs queued since the last check that found status 0."""
         if len(self._pending) >= self.MAX_PENDING:       # never checked: nothing more is recorded, and a failure cannot be repaired any more

@@ -109,8 +109,11 @@ class EpochFeed:
         self.plane_floats = off
         self.host = [_staging(off) for _ in range(DEPTH)]
         self.host_np = [h.numpy() for h in self.host]
-        self.dev = torch.empty(off, dtype=torch.float32, device=device)
-        self.noise = {k: self.dev[o:o + n] for k, (o, n) in self.offsets.items()}          # Engine.train_epoch(noise=...)
+        # TWO device sets (epoch parity): epoch e + 1 is uploaded and launched before the host has looked at epoch e's status word, and a
+        # failed epoch is repeated from ITS planes / batches (Engine.check_status)
+        self.dev_sets = [torch.empty(off, dtype=torch.float32, device=device) for _ in range(2)]
+        self.noise_sets = [{k: d[o:o + n] for k, (o, n) in self.offsets.items()} for d in self.dev_sets]      # Engine.train_epoch(noise=...)
+        self.dev, self.noise = self.dev_sets[0], self.noise_sets[0]                                            # (the set last uploaded)
         self.alpha_tmp = torch.empty(nb * (B * S + B * L), dtype=torch.float32)
         self.alpha_np = self.alpha_tmp.numpy()
         rows = (nc + 1) * nb * B
@@ -119,14 +122,17 @@ class EpochFeed:
         if self.index_path:
             if matrix.shape[1] != S:
                 raise _C.HypadError(f"the dataset's windows hold {matrix.shape[1]} values, params.signal_shape is {S}")
-            self.x = matrix.to(torch.float32).contiguous().to(device)
+            xm = matrix.to(torch.float32).contiguous().to(device)
+            self.x_sets = [xm, xm]
             self.idx_host = [_staging(nc + 1, nb * B, dtype=torch.int32) for _ in range(DEPTH)]
-            self.row_index = torch.empty(nc + 1, nb * B, dtype=torch.int32, device=device)
+            self.row_index_sets = [torch.empty(nc + 1, nb * B, dtype=torch.int32, device=device) for _ in range(2)]
         else:
-            self.x = torch.empty(rows, S, dtype=torch.float32, device=device)
+            self.x_sets = [torch.empty(rows, S, dtype=torch.float32, device=device) for _ in range(2)]
             self.x_host = [_staging(rows, S) for _ in range(DEPTH)]
-            self.row_index = torch.arange(rows, dtype=torch.int32, device=device).view(nc + 1, nb * B)
+            ri = torch.arange(rows, dtype=torch.int32, device=device).view(nc + 1, nb * B)
+            self.row_index_sets = [ri, ri]
             self._on_device = None
+        self.x, self.row_index = self.x_sets[0], self.row_index_sets[0]
         self._fast_sampler = _plain_random_batches(train_loader) if self.index_path else None
         self._z_thread = {}            # epoch -> helper thread drawing its latent planes
         self._producer = None          # background thread that stages epochs ahead of the caller (get)
@@ -226,7 +232,9 @@ class EpochFeed:
                 self._on_device = on_dev
             elif self._on_device != on_dev:
                 raise _C.HypadError("the loader mixes host and device minibatches")
-            (self.x if on_dev else self.x_host[slot])[base + n * B: base + (n + 1) * B].copy_(rows)     # (float64 -> float32 here: .float() of the reference)
+            # (float64 -> float32 here: .float() of the reference.  Device batches go straight into the epoch's device set -- slot and
+            # epoch have the same parity -- on the caller's stream, in the caller's order.)
+            (self.x_sets[slot & 1] if on_dev else self.x_host[slot])[base + n * B: base + (n + 1) * B].copy_(rows)
             n += 1
         if n != nb:
             raise _C.HypadError(f"the loader yielded {n} batches, len(train_loader) is {nb}")
@@ -280,13 +288,17 @@ class EpochFeed:
         return slot
 
     def upload(self, slot):
-        """Enqueue the slot's planes (one copy) and samples / indices on the current stream: stream order puts them behind the
-        previous epoch's launches, which read the same device buffers."""
+        """Enqueue the slot's planes (one copy) and samples / indices on the current stream into the device set of the slot's parity
+        (= the epoch's: DEPTH is even); stream order puts the copies behind the launches of the epoch before last, which read that set.
+        Returns (x, row_index, noise) of the set -- also left in ``self.x / .row_index / .noise``."""
+        k = slot & 1
+        self.dev, self.noise, self.x, self.row_index = self.dev_sets[k], self.noise_sets[k], self.x_sets[k], self.row_index_sets[k]
         self.dev.copy_(self.host[slot], non_blocking=True)
         if self.index_path:
             self.row_index.copy_(self.idx_host[slot], non_blocking=True)
         elif not self._on_device:
             self.x.copy_(self.x_host[slot], non_blocking=True)
+        return self.x, self.row_index, self.noise
 
     def close(self):
         self._stop = True

@@ -334,11 +334,12 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     eng = Engine(S, L, B, hyp, 1, dev, lr=params.lr, betas=(0.9, 0.999), gen_weight_decay=1e-5 if hyp else 0.0,          # train.py:274-288
                  gen_stabilize=10 if hyp else 0, seed=torch.initial_seed() + _resume_salt(params.resume_epoch if resume else None))
     eng.adopt({k: m.arena() for k, m in mods.items()})
+    eng.epoch_flags = int(getattr(params, "epoch_flags", 0))      # hypad_epoch_io.flags (A/B forms of the critic phase; tests)
     n_critics = 5
     feed = EpochFeed(train_loader, B, S, L, n_critics, dev, index_path=not getattr(params, "stage_samples", False))
     nb = feed.nb
     iters = (2 * n_critics + 1) * nb
-    losses_dev = torch.empty(1, iters, 4, dtype=torch.float32, device=dev)
+    losses_dev = [torch.empty(1, iters, 4, dtype=torch.float32, device=dev) for _ in range(2)]       # per epoch parity, like the feed's device sets
     back = [torch.empty(iters * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)]        # losses | counters (as bits)
     done = [torch.cuda.Event() for _ in range(2)]
     hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], wall=[])       # wall: time.perf_counter() when each epoch's losses were on the host
@@ -347,24 +348,32 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
         n_epochs = n_epochs - params.resume_epoch
         actual_epoch = params.resume_epoch + 1
     feed.last_epoch = n_epochs - 1
-    state = {"actual_epoch": actual_epoch}
+    state = {"repaired_until": -1}
+    saves = lambda e: ((actual_epoch + e + 1) % 10 == 0) or ((actual_epoch + e + 1) == (n_epochs - 1))      # train.py:381 (cadence kept as is)
 
     def enqueue(e, slot):
-        feed.upload(slot)
-        eng.train_epoch_graph(feed.x, feed.row_index, nb, n_critics, train_mode, losses=losses_dev, noise=feed.noise)
+        x, row_index, noise = feed.upload(slot)
+        eng.train_epoch_graph(x, row_index, nb, n_critics, train_mode, losses=losses_dev[e % 2], noise=noise)
         b = back[e % 2]
-        b[: iters * 4].copy_(losses_dev.view(-1), non_blocking=True)
+        b[: iters * 4].copy_(losses_dev[e % 2].view(-1), non_blocking=True)
         b[iters * 4:].view(torch.int32).copy_(eng.counters, non_blocking=True)
         done[e % 2].record()
 
     def finish(e):
-        """Epoch e's losses on the host: the reference's end-of-epoch bookkeeping (train.py:329-385).  Runs before epoch e + 1 is
-        enqueued, so a checkpoint holds exactly epoch e's weights and a failed resident launch can be repeated in place."""
+        """Epoch e's losses on the host: the reference's end-of-epoch bookkeeping (train.py:329-385).  Epoch e + 1 is usually already
+        queued behind it (the GPU never waits for this bookkeeping); before a checkpoint epoch it is not, so the files hold exactly
+        epoch e's weights.  A resident critic launch that gave up stops everything behind it: check_status repeats epoch e AND the
+        epoch queued behind it, each from its own planes, batches and loss buffer."""
         done[e % 2].synchronize()
         b = back[e % 2]
-        if int(b[iters * 4:].view(torch.int32)[4]) != 0:         # status word of the resident critic launch (hypad_epoch_status)
-            eng.check_status()                                   # restores, repeats the epoch with per-iteration launches
-            b[: iters * 4].copy_(losses_dev.view(-1))
+        if e > state["repaired_until"]:
+            if int(b[iters * 4:].view(torch.int32)[4]) != 0:     # status word of the resident critic launch (hypad_epoch_status)
+                eng.check_status()                               # restores, repeats every queued epoch with per-iteration launches
+                state["repaired_until"] = e + 1
+            else:
+                eng.confirm_epochs(1)                            # epoch e completed: one epoch less for a later repair to look at
+        if e <= state["repaired_until"]:
+            b[: iters * 4].copy_(losses_dev[e % 2].view(-1))     # (its pinned copy was taken from the stopped run)
         rows = b[: iters * 4].view(iters, 4)
         crit = rows[: 2 * n_critics * nb, 0].view(n_critics, nb, 2).mean(1)          # per pass (train.py:329-330), then over the passes
         gen = rows[2 * n_critics * nb:].mean(0)
@@ -380,9 +389,8 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
             print("Eucl mse loss {}".format(hist.mse[-1]))
         print("critic x loss {:.3f} critic z loss {:.3f} \ndecoder loss {:.3f}\n".format(hist.cx[-1], hist.cz[-1], hist.dec[-1]))
         hist.wall.append(time.perf_counter())
-        state["actual_epoch"] += 1
-        ae = state["actual_epoch"]
-        if (ae % 10 == 0) or (ae == (n_epochs - 1)):             # train.py:381 (cadence kept as is)
+        if saves(e):
+            ae = actual_epoch + e + 1
             torch.save(encoder, path + "/encoder_{}.pt".format(ae))
             torch.save(decoder, path + "/decoder_{}.pt".format(ae))
             torch.save(critic_x, path + "/critic_x_{}.pt".format(ae))
@@ -392,9 +400,12 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
         for epoch in range(n_epochs):
             logging.debug("Epoch {}".format(epoch))
             slot = feed.get(epoch)                  # epoch e staged on the host (a producer thread runs up to two epochs ahead)
-            if epoch:
+            first = epoch > 0 and saves(epoch - 1)  # a checkpoint of epoch e - 1 must see epoch e - 1's weights: finish it first
+            if first:
                 finish(epoch - 1)
             enqueue(epoch, slot)
+            if epoch > 0 and not first:
+                finish(epoch - 1)
         if n_epochs > 0:
             finish(n_epochs - 1)
     finally:

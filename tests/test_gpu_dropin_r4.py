@@ -198,3 +198,25 @@ def test_one_call_test_loop_equals_the_batch_loop(tmp_path, hyper, n, foreign):
             assert one[k].shape == per[k].shape and torch.equal(one[k].cpu(), per[k].cpu()), k
     rec, true, crit = ad.test_tadgan(loader, enc, dec, cx, path=str(tmp_path), signal_shape=S, params=P_(64, S, hyper))
     assert rec.shape == (n, S) and len(crit) == n and os.path.exists(tmp_path / "recons_signal.pt")
+
+
+def test_a_resident_launch_that_gives_up_inside_train_tadgan_is_repaired(tmp_path):
+    """train_tadgan keeps the next epoch queued behind the one whose losses it reads.  A resident critic launch that gives up
+    (injected: hypad_epoch_io.flags test bits) stops its epoch AND the one behind it; the repair repeats both from their own planes,
+    batches and loss buffers with per-iteration launches: the run equals one that used that form from the start, bit for bit."""
+    from hypad_amd import _C
+    from hypad_amd import train as ht
+    S, B = 100, 64
+    loader = DataLoader(Windows(3 * B + 9, S), batch_size=B, drop_last=True, shuffle=True)
+    runs = []
+    for flags in (_C.EPOCH_PER_ITERATION, 4 << _C.EPOCH_TEST_GIVE_UP_SHIFT):
+        mods = build(S, True, 2)
+        np.random.seed(6); torch.manual_seed(6)
+        h = ht.train_tadgan(loader, *mods, n_epochs=5, params=P_(B, S, True, epoch_flags=flags), path=str(tmp_path))
+        torch.cuda.synchronize()
+        runs.append((h, weights(mods)))
+    for k in ("cx", "cz", "dec", "hyper"):
+        assert getattr(runs[0][0], k) == getattr(runs[1][0], k), k
+    assert all(np.isfinite(runs[1][0].cx))
+    for wa, wb in zip(runs[0][1], runs[1][1]):
+        assert all(torch.equal(wa[k], wb[k]) for k in wa)
