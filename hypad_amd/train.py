@@ -351,8 +351,21 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     state = {"repaired_until": -1}
     saves = lambda e: ((actual_epoch + e + 1) % 10 == 0) or ((actual_epoch + e + 1) == (n_epochs - 1))      # train.py:381 (cadence kept as is)
 
+    copy_stream = torch.cuda.Stream(device=dev)
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+
     def enqueue(e, slot):
-        x, row_index, noise = feed.upload(slot)
+        # the epoch's planes and batches go up on a copy stream, under the previous epoch's kernels: its device set was last read by
+        # epoch e - 2, whose completion event the copy waits for; the replay waits for the copy
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(copy_stream):
+            if e >= 2:
+                copy_stream.wait_event(done[e % 2])
+            else:
+                copy_stream.wait_stream(main)
+            x, row_index, noise = feed.upload(slot)
+            uploaded[e % 2].record()
+        main.wait_event(uploaded[e % 2])
         eng.train_epoch_graph(x, row_index, nb, n_critics, train_mode, losses=losses_dev[e % 2], noise=noise)
         b = back[e % 2]
         b[: iters * 4].copy_(losses_dev[e % 2].view(-1), non_blocking=True)

@@ -13,7 +13,7 @@ def wrap(obj, name):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); T.setdefault(name, []).append(time.perf_counter() - t0); return r
     setattr(obj, name, g)
-for n in ("prepare", "upload", "_alphas", "_pass_samples", "_pass_indices", "_draw_z"):
+for n in ("get", "prepare", "upload", "_alphas", "_pass_samples", "_pass_indices", "_draw_z"):
     wrap(epoch_feed.EpochFeed, n)
 from hypad_amd import engine
 wrap(engine.Engine, "train_epoch_graph")
@@ -29,7 +29,7 @@ for nthreads in (None, 1):
         mods = [m.cuda().train() for m in (tadgan.Encoder(S, L), tadgan.Decoder(S, L, True), tadgan.CriticX(S, L), tadgan.CriticZ(L))]
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
-            ht.train_tadgan(loader, *mods, n_epochs=8, params=P, path="/tmp")
+            ht.train_tadgan(loader, *mods, n_epochs=24, params=P, path="/tmp")
         torch.cuda.synchronize()
         print(name, "threads", torch.get_num_threads(), "total ms", 1e3 * (time.perf_counter() - t0))
         for k, v in T.items():
