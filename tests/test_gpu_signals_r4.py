@@ -135,3 +135,34 @@ def test_two_processes_own_disjoint_signals_and_agree_with_one(tmp_path, monkeyp
             assert torch.equal(v.cpu(), enc[k]), (n, k)
         for sfx in ("", "_2"):                                                                  # the owner wrote the signal's checkpoints
             assert os.path.exists(tmp_path / "two" / "trained_models" / "models_hyper_T_3_0.0005" / "T" / n / f"encoder{sfx}.pt")
+
+
+def _nccl_worker(rank, port, cwd, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.chdir(cwd)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from hypad_amd import train as ht
+        data = [windows(n, i) for i, n in enumerate(COUNTS[:3])]
+        res = ht.train_signals_resident(data, P_(epochs=2), names=["a", "b", "c"], seed=5, init_seed=9, log=None)
+        ret["hist"] = {n: r["history"] for n, r in res.items()}
+        ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_signal_metrics_gather_through_a_one_rank_rccl_group(tmp_path, monkeypatch):
+    """The end-of-run gather of train_signals_resident (the only collective of multi-signal training) through RCCL: a world-size-1
+    `nccl` group in a fresh process == no process group at all."""
+    import torch.multiprocessing as mp
+    from hypad_amd import train as ht
+    (tmp_path / "nccl").mkdir(); (tmp_path / "plain").mkdir()
+    ret = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(_free_port(), str(tmp_path / "nccl"), ret), nprocs=1, join=True)
+    assert ret["backend"] == "nccl"
+    monkeypatch.chdir(tmp_path / "plain")
+    data = [windows(n, i) for i, n in enumerate(COUNTS[:3])]
+    plain = ht.train_signals_resident(data, P_(epochs=2), names=["a", "b", "c"], seed=5, init_seed=9, log=None)
+    assert {n: r["history"] for n, r in plain.items()} == dict(ret["hist"])
