@@ -1237,6 +1237,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         for (int u = 0; u < PS; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (CHAIN && u >= NA) continue;                           // (a chain wave owns layer-0 quads only: the other slots' registers are dead in this body)
             const int o = arena_off(u, r);
             if (o >= 0) { arena_p[o] = pv[u][r]; arena_m[o] = mv[u][r]; arena_v[o] = vv[u][r]; }
           }
