@@ -1014,6 +1014,10 @@ def main():
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hyperbolic)
+        if drop_in is not None:                                  # the reference's call surface against the device-RNG path and the CPU
+            drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
+            if out.get("cpu_baseline", {}).get("value"):
+                drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if dist is not None:
