@@ -157,6 +157,7 @@ class SignalDataset:
         self.series = agg * scale + (-1.0 - lo * scale)                 # (T, columns), float64
         self.X, self.y, self.X_index, self.y_index = rolling_window_sequences(
             self.series, self.index, window_size=windows_size, target_size=1, step_size=1, target_column=0)
+        self._X_built = self.X                                          # (series_windows: X is still the matrix built here)
 
     def __len__(self):
         return len(self.X)
@@ -173,6 +174,15 @@ class SignalDataset:
         """(T,) fp32 tensor of the scaled target column on the device (univariate signals)."""
         import torch
         return torch.as_tensor(np.ascontiguousarray(self.series[:, 0]), dtype=torch.float32).to(device)
+
+    def series_windows(self, device="cuda"):
+        """window_view() when the window matrix is, row for row, the overlapping rows of the scaled series -- a univariate signal
+        whose ``X`` is the object the constructor built (not re-assigned, e.g. to a subset); else None."""
+        if self.X is not getattr(self, "_X_built", None) or self.series.shape[1] != 1 or self.X.ndim != 3 or self.X.shape[2] != 1:
+            return None
+        if len(self.X) + self.windows_size > len(self.series):
+            return None
+        return self.window_view(device)
 
     def window_view(self, device="cuda"):
         """(series, n_windows, row_stride = 1): window n is series[n : n + windows_size].  Pass to

@@ -200,6 +200,51 @@ def test_one_call_test_loop_equals_the_batch_loop(tmp_path, hyper, n, foreign):
     assert rec.shape == (n, S) and len(crit) == n and os.path.exists(tmp_path / "recons_signal.pt")
 
 
+@pytest.mark.parametrize("hyper", [True, False])
+def test_test_loop_over_a_signal_reads_the_series_not_the_window_matrix(tmp_path, hyper):
+    """test_tadgan over DataLoader(SignalDataset(test=True)): the ordered windows of a univariate signal are scored from the scaled
+    series on the device (x_row_stride = 1; nothing of the float64 window matrix is uploaded) == the batch-by-batch loop over the
+    fetched and collated batches, bit for bit; a dataset whose X was re-assigned falls back to the matrix."""
+    import pandas as pd
+    from hypad_amd import anomaly_detection as ad
+    from hypad_amd.utils.dataloader import SignalDataset
+    S, n = 100, 64 * 4 + 7
+    rng = np.random.default_rng(3)
+    t = np.arange(n + S)
+    df = pd.DataFrame({"timestamp": 1_400_000_000 + 600 * t, "value": np.sin(2 * np.pi * t / 90.0) + 0.1 * rng.standard_normal(len(t))})
+    ds = SignalDataset(df, interval=600, windows_size=S, test=True)
+    assert len(ds) == n and ds.series_windows("cpu") is not None
+    loader = DataLoader(ds, batch_size=64, drop_last=False, shuffle=False)
+    enc, dec, cx, _ = build(S, hyper, 21)
+    seen = []
+    real = ad.score_windows
+    def spy(true, *a, series=None, **kw):
+        seen.append(series is not None)
+        return real(true, *a, series=series, **kw)
+    ad.score_windows = spy
+    try:
+        one = ad.score_batches(loader, enc, dec, cx, S)
+    finally:
+        ad.score_windows = real
+    assert seen == [True]
+    per = ad.score_batches_per_batch(loader, enc, dec, cx, S)
+    for k in one:
+        assert (one[k] is None) == (per[k] is None), k
+        if one[k] is not None:
+            assert one[k].shape == per[k].shape and torch.equal(one[k].cpu(), per[k].cpu()), k
+    rec, true, crit = ad.test_tadgan(loader, enc, dec, cx, path=str(tmp_path), signal_shape=S, params=P_(64, S, hyper))
+    assert np.array_equal(rec, one["recons"].cpu().numpy()) and np.array_equal(np.asarray(crit), one["critic"].cpu().numpy())
+    assert np.array_equal(true, (one["hyper_real"].cpu().numpy() if hyper else ds.X))
+    assert np.array_equal(torch.load(tmp_path / "gt_signal.pt", weights_only=False), ds.X)
+    dl = DataLoader(ds, batch_size=64, drop_last=True, shuffle=False)       # whole batches only: the first 256 rows, from the matrix
+    a, b = ad.score_batches(dl, enc, dec, cx, S), ad.score_batches_per_batch(dl, enc, dec, cx, S)
+    assert a["recons"].shape == (256, S) and torch.equal(a["recons"].cpu(), b["recons"].cpu()) and torch.equal(a["critic"].cpu(), b["critic"].cpu())
+    ds.X = ds.X[:100].copy()                     # no longer the constructor's matrix: scored from the matrix
+    assert ds.series_windows("cpu") is None
+    sub = ad.score_batches(DataLoader(ds, batch_size=64, shuffle=False), enc, dec, cx, S)
+    assert torch.equal(sub["recons"].cpu(), one["recons"][:100].cpu())
+
+
 def test_a_resident_launch_that_gives_up_inside_train_tadgan_is_repaired(tmp_path):
     """train_tadgan keeps the next epoch queued behind the one whose losses it reads.  A resident critic launch that gives up
     (injected: hypad_epoch_io.flags test bits) stops its epoch AND the one behind it; the repair repeats both from their own planes,
