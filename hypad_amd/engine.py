@@ -328,7 +328,7 @@ class Engine:
         _C.check(_C.lib.hypad_epoch_status(ctypes.byref(st), ctypes.byref(out), _C.stream()), "epoch_status")
         return out.value
 
-    def check_status(self, recover=True):
+    def check_status(self, recover=True, on_epoch=None):
         """Call where the host reads an epoch's losses.  If a resident critic launch gave up (a withheld CU: CU mask, partitioned or
         shared device), every launch behind it -- the rest of that epoch and ALL epochs queued after it -- was a no-op
         (fail-stop).  With ``recover`` the critics and counters are put back to the state the failed epoch began from and every
@@ -337,6 +337,8 @@ class Engine:
         engine uses that form.  The repeats read the callers' buffers as they are NOW: epochs whose inputs the caller refills
         between launches (host-drawn shuffles or noise planes) must be checked one by one, as train.train_tadgan does; epochs that
         draw their shuffles inside the captured sequence, or read static buffers, may be queued in any number.
+        ``on_epoch(i)``: called behind the i-th repeated epoch's launches (i = 0 for the failed one), stream-ordered in front of the
+        next one's -- a caller that wants the weights of one of them (a checkpoint) takes its copy there.
         Returns the status code that was found (0 = nothing happened); raises without ``recover``."""
         c = self.counters.cpu()                  # (synchronises the stream: everything queued so far has run or was skipped)
         code = int(c[4])
@@ -368,10 +370,12 @@ class Engine:
         self._pending.clear()
         self._rerunning = True
         try:
-            for call, shuffle_windows in lost:
+            for i, (call, shuffle_windows) in enumerate(lost):
                 if shuffle_windows:
                     self.draw_shuffles(call["row_index"], shuffle_windows)
                 self.train_epoch(**call)
+                if on_epoch is not None:
+                    on_epoch(i)
         finally:
             self._rerunning = False
         again = self.status()

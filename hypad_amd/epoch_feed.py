@@ -129,6 +129,7 @@ class EpochFeed:
         else:
             self.x_sets = [torch.empty(rows, S, dtype=torch.float32, device=device) for _ in range(2)]
             self.x_host = [_staging(rows, S) for _ in range(DEPTH)]
+            self.x_host_np = [t.numpy().reshape(-1, B, S) for t in self.x_host]      # (batch-sized views: NumPy converts a host batch in ~3 us, a torch copy_ takes ~15)
             ri = torch.arange(rows, dtype=torch.int32, device=device).view(nc + 1, nb * B)
             self.row_index_sets = [ri, ri]
             self._on_device = None
@@ -234,7 +235,12 @@ class EpochFeed:
                 raise _C.HypadError("the loader mixes host and device minibatches")
             # (float64 -> float32 here: .float() of the reference.  Device batches go straight into the epoch's device set -- slot and
             # epoch have the same parity -- on the caller's stream, in the caller's order.)
-            (self.x_sets[slot & 1] if on_dev else self.x_host[slot])[base + n * B: base + (n + 1) * B].copy_(rows)
+            if on_dev:
+                self.x_sets[slot & 1][base + n * B: base + (n + 1) * B].copy_(rows)
+            elif rows.dtype in (torch.float64, torch.float32) and not rows.requires_grad:
+                np.copyto(self.x_host_np[slot][p * nb + n], rows.numpy(), casting="same_kind")
+            else:
+                self.x_host[slot][base + n * B: base + (n + 1) * B].copy_(rows)
             n += 1
         if n != nb:
             raise _C.HypadError(f"the loader yielded {n} batches, len(train_loader) is {nb}")

@@ -13,6 +13,7 @@ arenas attached to it on first use and are mirrored into ``optimizer.state`` as 
 """
 import logging
 import os
+import sys
 import time
 from types import SimpleNamespace
 
@@ -306,6 +307,73 @@ def make_optimizers(encoder, decoder, critic_x, critic_z, params):
     return optim_cx, optim_cz, optim_dec
 
 
+class _CheckpointWriter:
+    """The checkpoint files of train.py:381-385 without stopping the epoch pipeline for them: the main thread copies the four
+    parameter arenas on the device (``snapshot``: stream-ordered behind the epoch just queued, in front of the next one -- 1 MB,
+    microseconds), a worker thread puts a snapshot into its own copies of the modules and pickles those with ``torch.save`` (the
+    device-to-host copies and the file writes: 2-4 ms per checkpoint, which every tenth epoch used to wait for with an empty
+    queue behind it).  Same files: the copies are deep copies of the live modules, taken at the first checkpoint."""
+
+    def __init__(self, modules, device):
+        self.modules, self.device = modules, device
+        self.templates = None
+        self.jobs = None
+        self.thread = None
+        self.error = None
+
+    def snapshot(self):
+        snap = {k: m.arena().detach().clone() for k, m in self.modules.items()}
+        ev = torch.cuda.Event()
+        ev.record()
+        return snap, ev
+
+    def submit(self, snapshot, files):
+        """files: {module key: path}.  Returns at once; ``close`` waits for every file."""
+        import queue, threading
+        if self.thread is None:
+            self.jobs = queue.Queue()
+            self.thread = threading.Thread(target=self._run, name="hypad-checkpoints", daemon=True)
+            self.thread.start()
+        self.jobs.put((snapshot, files))
+
+    def _run(self):
+        torch.cuda.set_device(self.device)
+        # a stream of its own: the device-to-host copies inside torch.save wait for THEIR stream -- on the training stream that wait
+        # would stand behind the epochs queued there and keep the training thread from queueing the next one meanwhile
+        side = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(side):
+            self._serve()
+
+    def _serve(self):
+        import copy
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            if self.error is not None:
+                continue
+            try:
+                (snap, ev), files = job
+                torch.cuda.current_stream().wait_event(ev)
+                if self.templates is None:
+                    self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
+                for k, f in files.items():
+                    t = self.templates[k]
+                    t.arena().data.copy_(snap[k])
+                    torch.save(t, f)
+            except BaseException as e:                       # (re-raised by close on the caller's thread)
+                self.error = e
+
+    def close(self):
+        if self.thread is not None:
+            self.jobs.put(None)
+            self.thread.join()
+            self.thread = None
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+
 def _per_iteration_wanted(train_loader, params):
     if getattr(params, "per_iteration", False) or os.environ.get("HYPAD_TRAIN_PER_ITERATION") == "1":
         return True
@@ -353,6 +421,8 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
 
     copy_stream = torch.cuda.Stream(device=dev)
     uploaded = [torch.cuda.Event() for _ in range(2)]
+    writer = _CheckpointWriter(mods, dev)
+    snaps = {}
 
     def enqueue(e, slot):
         # the epoch's planes and batches go up on a copy stream, under the previous epoch's kernels: its device set was last read by
@@ -371,17 +441,23 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
         b[: iters * 4].copy_(losses_dev[e % 2].view(-1), non_blocking=True)
         b[iters * 4:].view(torch.int32).copy_(eng.counters, non_blocking=True)
         done[e % 2].record()
+        if saves(e):
+            snaps[e] = writer.snapshot()                         # epoch e's weights, before epoch e + 1 is queued
 
     def finish(e):
-        """Epoch e's losses on the host: the reference's end-of-epoch bookkeeping (train.py:329-385).  Epoch e + 1 is usually already
-        queued behind it (the GPU never waits for this bookkeeping); before a checkpoint epoch it is not, so the files hold exactly
-        epoch e's weights.  A resident critic launch that gave up stops everything behind it: check_status repeats epoch e AND the
-        epoch queued behind it, each from its own planes, batches and loss buffer."""
+        """Epoch e's losses on the host: the reference's end-of-epoch bookkeeping (train.py:329-385).  Epoch e + 1 is already queued
+        behind it (the GPU never waits for this bookkeeping); a checkpoint's files hold exactly epoch e's weights all the same: they
+        are written from the device copy enqueue took between the two epochs (_CheckpointWriter).  A resident critic launch that
+        gave up stops everything behind it: check_status repeats epoch e AND the epoch queued behind it, each from its own planes,
+        batches and loss buffer -- a checkpoint epoch among them is copied again, behind its repeat."""
         done[e % 2].synchronize()
         b = back[e % 2]
         if e > state["repaired_until"]:
             if int(b[iters * 4:].view(torch.int32)[4]) != 0:     # status word of the resident critic launch (hypad_epoch_status)
-                eng.check_status()                               # restores, repeats every queued epoch with per-iteration launches
+                def recopy(i):
+                    if e + i in snaps:
+                        snaps[e + i] = writer.snapshot()
+                eng.check_status(on_epoch=recopy)                # restores, repeats every queued epoch with per-iteration launches
                 state["repaired_until"] = e + 1
             else:
                 eng.confirm_epochs(1)                            # epoch e completed: one epoch less for a later repair to look at
@@ -404,25 +480,21 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
         hist.wall.append(time.perf_counter())
         if saves(e):
             ae = actual_epoch + e + 1
-            torch.save(encoder, path + "/encoder_{}.pt".format(ae))
-            torch.save(decoder, path + "/decoder_{}.pt".format(ae))
-            torch.save(critic_x, path + "/critic_x_{}.pt".format(ae))
-            torch.save(critic_z, path + "/critic_z_{}.pt".format(ae))
+            writer.submit(snaps.pop(e), {"enc": path + "/encoder_{}.pt".format(ae), "dec": path + "/decoder_{}.pt".format(ae),
+                                         "cx": path + "/critic_x_{}.pt".format(ae), "cz": path + "/critic_z_{}.pt".format(ae)})
 
     try:
         for epoch in range(n_epochs):
             logging.debug("Epoch {}".format(epoch))
             slot = feed.get(epoch)                  # epoch e staged on the host (a producer thread runs up to two epochs ahead)
-            first = epoch > 0 and saves(epoch - 1)  # a checkpoint of epoch e - 1 must see epoch e - 1's weights: finish it first
-            if first:
-                finish(epoch - 1)
             enqueue(epoch, slot)
-            if epoch > 0 and not first:
+            if epoch > 0:
                 finish(epoch - 1)
         if n_epochs > 0:
             finish(n_epochs - 1)
     finally:
         feed.close()
+        writer.close()                              # every checkpoint file is complete when the call returns
     _set_requires_grad((decoder, encoder), True)     # the flags the reference's loop leaves behind (train.py:331-332)
     _set_requires_grad((critic_x, critic_z), False)
     return hist

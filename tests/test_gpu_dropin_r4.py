@@ -126,8 +126,9 @@ def test_epoch_form_against_the_oracle_loop():
 
 
 def test_checkpoints_hold_the_epoch_they_are_named_after(tmp_path):
-    """train.py:381 cadence; epoch e + 1 is staged while e runs, but a checkpoint is written before e + 1 is enqueued: the file of
-    actual_epoch 10 equals the final weights of a 10-epoch run bit for bit (train mode: device Philox dropout is keyed by seed and tick)."""
+    """train.py:381 cadence; epoch e + 1 is queued while e runs and the checkpoint files are written by a worker thread, from a device
+    copy taken between the two epochs: the file of actual_epoch 10 equals the final weights of a 10-epoch run bit for bit (train mode:
+    device Philox dropout is keyed by seed and tick), and every file is complete when the call returns."""
     from hypad_amd import train as ht
     S, B, n = 100, 64, 2 * 64
     loader = DataLoader(Windows(n, S), batch_size=B, drop_last=True, shuffle=True)
