@@ -181,3 +181,49 @@ def test_unroll_true_from_the_fp32_matrix():
     out = torch.empty(1_099, dtype=torch.float64, device="cuda")
     _C.check(_C.lib.hypad_unroll_true_f32(_C.ptr(series), 1, _C.ptr(out), 1_000, 100, _C.stream()), "unroll_true_f32")
     assert torch.equal(out, series.double())
+
+
+def test_branches_beside_each_other_equal_one_after_the_other():
+    """anomaly_detection_utils.concurrently: the critic smoothing (KDE modes, trimmed z-score, rolling mean) on a side stream beside the
+    reconstruction numerics (un-roll median, errors, rolling mean, z-score) == the two run one after the other, bit for bit -- eagerly,
+    repeated (the per-stream scratch buffers), and as one replayed graph with the fork and the join as edges; score_anomalies, which
+    queues its two halves that way, == its result with the branches forced onto one stream."""
+    from hypad_amd import parallel as par
+    from hypad_amd.utils import anomaly_detection_utils as adu
+    n, S = 6_000, 100
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(n, S, device="cuda", generator=g) * 2 - 1
+    y_hat = (x + 0.05 * torch.randn(n, S, device="cuda", generator=g)).contiguous()
+    critic = torch.randn(n, device="cuda", generator=g)
+
+    def numerics():
+        true = adu.unroll_true(x)
+        pred, _ = adu.unroll_predictions(y_hat, False)
+        return adu.zscore_clip(adu.rolling_mean(true, 60, minus=pred)), adu.zscore_clip(adu.rolling_mean(adu._dtw_error(true, pred, 10), 60))
+
+    def smoothing():
+        return adu._compute_critic_score(adu.kde_modes(critic, S), n // 100)
+
+    a1, a2 = numerics()
+    b = smoothing()
+    for _ in range(3):
+        (c1, c2), d = adu.concurrently(numerics, smoothing)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, c1) and torch.equal(a2, c2) and torch.equal(b, d)
+
+    def whole():
+        (p, q), r = adu.concurrently(numerics, smoothing)
+        return p, q, r
+    for _ in range(2):
+        p, q, r = par.replay_scorer(whole, x, y_hat, critic, key=("beside",))
+        torch.cuda.synchronize()
+        assert torch.equal(a1, p) and torch.equal(a2, q) and torch.equal(b, r)
+    y = x.cpu().numpy()[:, :, None].astype(np.float64)
+    got, _, _, _ = adu.score_anomalies(y, y_hat.cpu().numpy(), critic.cpu().numpy(), None, rec_error_type="dtw", comb="mult")
+    keep = adu.concurrently
+    adu.concurrently = lambda fa, fb: (lambda rb: (fa(), rb))(fb())          # one stream: the side branch first, then the main one
+    try:
+        want, _, _, _ = adu.score_anomalies(y, y_hat.cpu().numpy(), critic.cpu().numpy(), None, rec_error_type="dtw", comb="mult")
+    finally:
+        adu.concurrently = keep
+    assert np.array_equal(np.asarray(got), np.asarray(want))
