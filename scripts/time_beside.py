@@ -1,4 +1,5 @@
-"""score_anomalies_sharded at one rank, 125 000 windows: its two pairs of independent chains beside each other or one after the other."""
+"""The scoring pass of bench.py's `scoring` section (125 000 windows, hyperbolic forward): the critic smoothing beside the reconstruction
+numerics (anomaly_detection_utils.concurrently) or one after the other.  --streams k: after the process has used k other streams."""
 import sys, time
 sys.path.insert(0, ".")
 import torch
@@ -7,17 +8,14 @@ from hypad_amd.models import tadgan
 from hypad_amd.utils import anomaly_detection_utils as adu
 S, L, n = 100, 20, 125_000
 torch.manual_seed(0)
+if "--streams" in sys.argv:          # a process that has used a dozen streams before (the end of a full bench.py run)
+    many = [torch.cuda.Stream() for _ in range(int(sys.argv[sys.argv.index("--streams") + 1]))]
+    for st in many:
+        with torch.cuda.stream(st):
+            torch.zeros(16, device="cuda").add_(1)
+    torch.cuda.synchronize()
 enc, dec, cx = tadgan.Encoder(S, L).cuda().eval(), tadgan.Decoder(S, L, False).cuda().eval(), tadgan.CriticX(S, L).cuda().eval()
 x = (torch.rand(n, S, device="cuda") * 2 - 1).contiguous()
-real = par._beside
-seq = lambda fa, fb, probe: (lambda rb: (fa(), rb))(fb())
-calls = {"n": 0}
-def first_only(fa, fb, probe):
-    calls["n"] += 1
-    return real(fa, fb, probe) if calls["n"] % 2 == 1 else seq(fa, fb, probe)
-def second_only(fa, fb, probe):
-    calls["n"] += 1
-    return real(fa, fb, probe) if calls["n"] % 2 == 0 else seq(fa, fb, probe)
 def timed(fn, reps=5):
     fn(); best = 1e9
     for _ in range(4):
@@ -25,11 +23,6 @@ def timed(fn, reps=5):
         for _ in range(reps): fn()
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / reps)
     return best
-for name, b in (("both beside", real), ("one after the other", seq), ("errors || modes only", first_only), ("z-score || critic score only", second_only), ("both beside", real)):
-    par._beside = b; calls["n"] = 0
-    t = timed(lambda: par.score_anomalies_sharded(x, enc, dec, cx, S, rec_error_type="dtw", comb="mult", as_tensor=True))
-    print("%-32s %.3f ms  %.1f M windows/s" % (name, 1e3 * t, n / t / 1e6))
-
 # ---- the un-sharded pass of bench.py's `scoring` section (hyperbolic forward): whole pass, branches beside / one after the other
 from hypad_amd import _C
 dec_h = tadgan.Decoder(S, L, True).cuda().eval()
