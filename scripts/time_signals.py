@@ -1,16 +1,16 @@
-"""Graph replay vs eager launches of the epoch at --spg signals per GPU, alternating (bench.make_step on both), several rounds."""
 import sys, time
 sys.path.insert(0, ".")
-import argparse, torch, bench
-ap = argparse.ArgumentParser(); ap.add_argument("--spg", type=int, default=8); ap.add_argument("--reps", type=int, default=20); args = ap.parse_args()
+import torch, bench
 dev = torch.device("cuda", 0)
-eng, x = bench.build_engine(args.spg, 0, True, dev)
-gen = torch.Generator(device=dev).manual_seed(1)
-steps = {m: bench.make_step(eng, x, args.spg, gen, dev, graph=m == "graph")[0] for m in ("graph", "eager")}
-for rnd in range(4):
-    for m in ("graph", "eager"):
-        for _ in range(5): steps[m]()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(args.reps): steps[m]()
-        torch.cuda.synchronize()
-        print(rnd, m, "epoch ms %.3f" % ((time.perf_counter() - t0) / args.reps * 1e3))
+for spg in (8, 16, 32):
+    eng, x = bench.build_engine(spg, 0, True, dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    step, losses = bench.make_step(eng, x, spg, gen, dev)
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(10): step()
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 10 * 1e3)
+    print("%d signals: %.3f ms per epoch, status %d" % (spg, best, eng.status()))
