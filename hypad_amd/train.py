@@ -13,7 +13,6 @@ arenas attached to it on first use and are mirrored into ``optimizer.state`` as 
 """
 import logging
 import os
-import sys
 import time
 from types import SimpleNamespace
 
@@ -308,33 +307,38 @@ def make_optimizers(encoder, decoder, critic_x, critic_z, params):
 
 
 class _CheckpointWriter:
-    """The checkpoint files of train.py:381-385 without stopping the epoch pipeline for them: the main thread copies the four
-    parameter arenas on the device (``snapshot``: stream-ordered behind the epoch just queued, in front of the next one -- 1 MB,
-    microseconds), a worker thread puts a snapshot into its own copies of the modules and pickles those with ``torch.save`` (the
-    device-to-host copies and the file writes: 2-4 ms per checkpoint, which every tenth epoch used to wait for with an empty
-    queue behind it).  Same files: the copies are deep copies of the live modules, taken at the first checkpoint."""
+    """The checkpoint files of train.py:381-385 without stopping the epoch pipeline for them: the training thread copies the
+    parameter arenas on the device (``snapshot``: stream-ordered behind the epoch just queued, in front of the next one -- 1 MB per
+    model, microseconds), a worker thread puts a copy into ITS OWN module objects (``templates``: deep copies of the live modules,
+    taken at the first checkpoint -- or the modules the caller hands over) and pickles those with ``torch.save``: the
+    device-to-host copies and the file writes, 2-4 ms per model, which every tenth epoch used to wait for with an empty queue
+    behind it.  Same files; all of them complete when ``close`` returns."""
 
-    def __init__(self, modules, device):
-        self.modules, self.device = modules, device
+    def __init__(self, device, modules=None, max_jobs=0):
+        self.modules, self.device = modules, device            # modules: {key: live module} to deep-copy once, or None
         self.templates = None
+        self.max_jobs = max_jobs
         self.jobs = None
         self.thread = None
         self.error = None
 
-    def snapshot(self):
-        snap = {k: m.arena().detach().clone() for k, m in self.modules.items()}
+    def snapshot(self, tensors=None):
+        """{key: device copy} of the live modules' arenas (or of ``tensors``) + the event that follows the copies."""
+        src = tensors if tensors is not None else {k: m.arena().detach() for k, m in self.modules.items()}
+        snap = {k: t.clone() for k, t in src.items()}
         ev = torch.cuda.Event()
         ev.record()
         return snap, ev
 
-    def submit(self, snapshot, files):
-        """files: {module key: path}.  Returns at once; ``close`` waits for every file."""
+    def submit(self, snapshot, files, pick=None):
+        """files: {key: path} -- or, with ``pick``, a list of (template module, key, index into the snapshot's first dimension, path).
+        Returns at once (unless ``max_jobs`` snapshots are already waiting); ``close`` waits for every file."""
         import queue, threading
         if self.thread is None:
-            self.jobs = queue.Queue()
+            self.jobs = queue.Queue(maxsize=self.max_jobs)
             self.thread = threading.Thread(target=self._run, name="hypad-checkpoints", daemon=True)
             self.thread.start()
-        self.jobs.put((snapshot, files))
+        self.jobs.put((snapshot, files, pick))
 
     def _run(self):
         torch.cuda.set_device(self.device)
@@ -353,13 +357,16 @@ class _CheckpointWriter:
             if self.error is not None:
                 continue
             try:
-                (snap, ev), files = job
+                (snap, ev), files, pick = job
                 torch.cuda.current_stream().wait_event(ev)
-                if self.templates is None:
-                    self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
-                for k, f in files.items():
-                    t = self.templates[k]
-                    t.arena().data.copy_(snap[k])
+                if pick is None:
+                    if self.templates is None:
+                        self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
+                    pick = [(self.templates[k], k, None, f) for k, f in files.items()]
+                for t, k, i, f in pick:
+                    if not next(t.parameters()).is_cuda:
+                        t.to(self.device)
+                    t.arena().data.copy_(snap[k] if i is None else snap[k][i])
                     torch.save(t, f)
             except BaseException as e:                       # (re-raised by close on the caller's thread)
                 self.error = e
@@ -421,7 +428,7 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
 
     copy_stream = torch.cuda.Stream(device=dev)
     uploaded = [torch.cuda.Event() for _ in range(2)]
-    writer = _CheckpointWriter(mods, dev)
+    writer = _CheckpointWriter(dev, mods)
     snaps = {}
 
     def enqueue(e, slot):
@@ -597,6 +604,15 @@ def train(train_loader, params, config_path):
 
 
 # ------------------------------------------------------------------------------------------------ resident fast path
+def _resident_epoch_means(rows, n_critics, n_batches):
+    """(critic_x, critic_z, generator, hyperbolic-or-mse) epoch means of ONE model from its (iterations, 4) loss rows ON THE HOST: the
+    one reduction both resident loops use (train_tadgan_resident for its model, train_signals_resident slot by slot), so that a
+    signal's history does not depend on which of them trained it."""
+    crit = rows[: 2 * n_critics * n_batches, 0].reshape(n_critics * n_batches, 2).mean(0)
+    gl = rows[2 * n_critics * n_batches:].mean(0)
+    return float(crit[0]), float(crit[1]), float(gl[0]), float(gl[1])
+
+
 def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epochs, params, path="", seed=None, log=print, first_signal=0):
     """train_tadgan (train.py:252-385) with everything on the device: the same epoch schedule -- 5 passes of
     (critic_x_iteration, critic_z_iteration) over the shuffled minibatches, then one pass of decoder_iteration -- as one
@@ -646,14 +662,12 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
         # check_status restores the critics and repeats the epoch with one launch per critic iteration, for good
         if eng.check_status():
             losses = eng._last_epoch["losses"]
-        losses = losses[0]
-        crit = losses[: 2 * n_critics * n_batches, 0].reshape(n_critics * n_batches, 2).mean(0)
-        gl = losses[2 * n_critics * n_batches:].mean(0)
-        history.cx.append(float(crit[0])); history.cz.append(float(crit[1])); history.dec.append(float(gl[0]))
-        (history.hyper if params.hyperbolic else history.mse).append(float(gl[1]))
+        cx_, cz_, dec_, aux_ = _resident_epoch_means(losses[0].cpu(), n_critics, n_batches)      # (one copy; the reduction on the host)
+        history.cx.append(cx_); history.cz.append(cz_); history.dec.append(dec_)
+        (history.hyper if params.hyperbolic else history.mse).append(aux_)
         if log:
             log("epoch {}: critic x loss {:.3f} critic z loss {:.3f} decoder loss {:.3f} {} {:.5f}".format(
-                epoch, history.cx[-1], history.cz[-1], history.dec[-1], "hyperbolic loss" if params.hyperbolic else "mse", float(gl[1])))
+                epoch, history.cx[-1], history.cz[-1], history.dec[-1], "hyperbolic loss" if params.hyperbolic else "mse", aux_))
         actual_epoch += 1
         if path and ((actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1))):      # train.py:381 (cadence kept as is)
             for name, m in (("encoder", encoder), ("decoder", decoder), ("critic_x", critic_x), ("critic_z", critic_z)):
@@ -765,17 +779,21 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
         eng = Engine(S, L, B, hyp, k, dev, lr=params.lr, gen_weight_decay=1e-5 if hyp else 0.0, gen_stabilize=10 if hyp else 0, seed=seed,
                      first_signal=first)
         nmax = max(counts[i] for i in members)
+        templates = []
         x = torch.zeros(k, nmax, S, dtype=torch.float32, device=dev)
         for slot, i in enumerate(members):
             torch.manual_seed(init_seed + i)                     # train.py:415-426 construction order
             mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
             for net, m in mods.items():
                 eng.load_state_dict(net, m.state_dict(), slot)
+            templates.append(mods)                               # (the signal's module objects: checkpoints and the result are written through them)
             x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
         in_graph = nmax <= eng.SHUFFLE_MAX_WINDOWS
         ri = torch.empty(k, n_critics + 1, nb * B, dtype=torch.int32, device=dev)
         gens = None if in_graph else [torch.Generator(device=dev).manual_seed((seed ^ (0x9E3779B97F4A7C15 * (first + s))) & 0x7FFFFFFFFFFFFFFF) for s in range(k)]
-        engines.append(dict(eng=eng, members=members, nb=nb, x=x, ri=ri, in_graph=in_graph, gens=gens, counts=[counts[i] for i in members]))
+        engines.append(dict(eng=eng, members=members, nb=nb, x=x, ri=ri, in_graph=in_graph, gens=gens, counts=[counts[i] for i in members], templates=templates,
+                            back=[torch.empty(k * (2 * n_critics + 1) * nb * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)],
+                            done=[torch.cuda.Event() for _ in range(2)], snaps={}))
     torch.manual_seed(seed)
     hist = {names[i]: SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[]) for _, ms in plan for i in ms}
     paths = {}
@@ -787,47 +805,93 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
             if save:
                 os.makedirs(paths[names[i]], exist_ok=True)
 
-    def modules_of(g, slot):
-        mods = [tadgan.Encoder(S, L), tadgan.Decoder(S, L, hyp), tadgan.CriticX(S, L), tadgan.CriticZ(L)]
-        for m, net in zip(mods, ("enc", "dec", "cx", "cz")):
-            m.load_state_dict(g["eng"].state_dict(net, slot))
-        return [m.to(dev).train() for m in mods]
+    NETS = ("enc", "dec", "cx", "cz")
+    FILES = dict(enc="encoder", dec="decoder", cx="critic_x", cz="critic_z")
+    writer = _CheckpointWriter(dev, max_jobs=2)
+    saves = lambda e: save and (((e + 1) % 10 == 0) or ((e + 1) == (n_epochs - 1)))        # train.py:381 (cadence kept as is; e + 1 = actual_epoch)
+    # Every group's epoch is one graph replay; its per-iteration losses and the counters come back in ONE copy per group -- looked at
+    # one epoch later, when the next epoch is already queued -- and each model's epoch means are taken from them on the host
+    # (_resident_epoch_means, slot by slot: the bits train_tadgan_resident gets for its one model).  The round-4 loop read 4 values
+    # per model and epoch with a synchronising float() each: 9.2 ms per epoch of 32 models against 6.0 for the launches alone.
+    # Groups whose shuffles are drawn on the host (signals beyond the in-graph sort's 4 096 windows) are finished epoch by epoch: a
+    # repair repeats epochs from the buffers as they are then.
+    pipelined = all(g["in_graph"] for g in engines)
 
-    actual_epoch = 0
-    for epoch in range(n_epochs):
-        for g in engines:                                        # every group's epoch is queued before any loss is read
+    def enqueue(e):
+        for g in engines:
             eng = g["eng"]
             if not g["in_graph"]:
-                for s, c in enumerate(g["counts"]):
-                    g["ri"][s].copy_(torch.rand(n_critics + 1, c, device=dev, generator=g["gens"][s]).argsort(dim=1)[:, : g["nb"] * B])
+                for s_, c in enumerate(g["counts"]):
+                    g["ri"][s_].copy_(torch.rand(n_critics + 1, c, device=dev, generator=g["gens"][s_]).argsort(dim=1)[:, : g["nb"] * B])
             g["losses"] = eng.train_epoch_graph(g["x"], g["ri"], g["nb"], n_critics, True, shuffle_windows=g["counts"] if g["in_graph"] else 0)
-        actual_epoch += 1
-        ckpt = save and ((actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1)))        # train.py:381 (cadence kept as is)
+            b, n = g["back"][e % 2], g["losses"].numel()
+            b[:n].copy_(g["losses"].view(-1), non_blocking=True)
+            b[n:].view(torch.int32).copy_(eng.counters, non_blocking=True)
+            g["done"][e % 2].record()
+            if saves(e):
+                g["snaps"][e] = writer.snapshot(eng.params)          # epoch e's weights, before epoch e + 1 is queued
+
+    def finish(e):
         for g in engines:
-            eng, nb = g["eng"], g["nb"]
-            if eng.check_status():
-                g["losses"] = eng._last_epoch["losses"]
-            lo = g["losses"]                                     # (reduced on the device, slot by slot, exactly as train_tadgan_resident reduces its one model's)
+            eng, k, nb = g["eng"], len(g["members"]), g["nb"]
+            g["done"][e % 2].synchronize()
+            b, n = g["back"][e % 2], g["losses"].numel()
+            if e > g.get("repaired_until", -1):
+                if int(b[n:].view(torch.int32)[4]) != 0:             # the resident critic launch gave up: this epoch and the one queued behind it were no-ops
+                    kept = {}
+
+                    def redo(i, g=g, e=e, kept=kept):
+                        kept[e + i] = g["losses"].detach().cpu()     # (the repeat's losses: the buffer is the next repeat's too)
+                        if e + i in g["snaps"]:
+                            g["snaps"][e + i] = writer.snapshot(g["eng"].params)
+                    eng.check_status(on_epoch=redo)
+                    g["repaired"] = kept
+                    g["repaired_until"] = max(kept) if kept else e
+                else:
+                    eng.confirm_epochs(1)
+            rows = g["repaired"][e].view(k, -1, 4) if e <= g.get("repaired_until", -1) and e in g.get("repaired", {}) else b[:n].view(k, -1, 4)
             for slot, i in enumerate(g["members"]):
                 h = hist[names[i]]
-                crit = lo[slot, : 2 * n_critics * nb, 0].reshape(n_critics * nb, 2).mean(0)
-                gl = lo[slot, 2 * n_critics * nb:].mean(0)
-                h.cx.append(float(crit[0])); h.cz.append(float(crit[1])); h.dec.append(float(gl[0]))
-                (h.hyper if hyp else h.mse).append(float(gl[1]))
-                if ckpt:
-                    for nm, m in zip(("encoder", "decoder", "critic_x", "critic_z"), modules_of(g, slot)):
-                        torch.save(m, paths[names[i]] + "/{}_{}.pt".format(nm, actual_epoch))
+                cx_, cz_, dec_, aux_ = _resident_epoch_means(rows[slot], n_critics, nb)
+                h.cx.append(cx_); h.cz.append(cz_); h.dec.append(dec_)
+                (h.hyper if hyp else h.mse).append(aux_)
+            if saves(e):
+                pick = [(g["templates"][slot][net], net, slot, paths[names[i]] + "/{}_{}.pt".format(FILES[net], e + 1))
+                        for slot, i in enumerate(g["members"]) for net in NETS]
+                writer.submit(g["snaps"].pop(e), None, pick)
         if log:
             mine = [names[i] for g in engines for i in g["members"]]
             log("epoch {}: {} signal(s) on rank {}: mean critic x loss {:.3f} critic z loss {:.3f} decoder loss {:.3f}".format(
-                epoch, len(mine), rank, *(float(np.mean([getattr(hist[n], k)[-1] for n in mine])) if mine else float("nan") for k in ("cx", "cz", "dec"))))
+                e, len(mine), rank, *(float(np.mean([getattr(hist[n], k)[-1] for n in mine])) if mine else float("nan") for k in ("cx", "cz", "dec"))))
+
+    try:
+        for epoch in range(n_epochs):
+            enqueue(epoch)
+            if not pipelined:
+                finish(epoch)
+            elif epoch > 0:
+                finish(epoch - 1)
+        if pipelined and n_epochs > 0:
+            finish(n_epochs - 1)
+        # the final weights: into the signals' own module objects (the result), and -- train.py:461-464 -- their files
+        last = {id(g): writer.snapshot(g["eng"].params) for g in engines}
+        if save:
+            for g in engines:
+                writer.submit(last[id(g)], None, [(g["templates"][slot][net], net, slot, paths[names[i]] + "/{}.pt".format(FILES[net]))
+                                                  for slot, i in enumerate(g["members"]) for net in NETS])
+    finally:
+        writer.close()
     local = {}
     for g in engines:
+        snap = last[id(g)][0]
         for slot, i in enumerate(g["members"]):
-            mods = modules_of(g, slot)
-            if save:
-                for nm, m in zip(("encoder", "decoder", "critic_x", "critic_z"), mods):
-                    torch.save(m, paths[names[i]] + "/{}.pt".format(nm))
+            mods = []
+            for net in NETS:
+                m = g["templates"][slot][net]
+                if not next(m.parameters()).is_cuda:
+                    m.to(dev)
+                m.arena().data.copy_(snap[net][slot])
+                mods.append(m.train())
             h = hist[names[i]]
             local[names[i]] = {"path": paths[names[i]], "history": vars(h), "stream": stream[i], "rank": rank,
                                "final": {k: (getattr(h, k)[-1] if getattr(h, k) else None) for k in ("cx", "cz", "dec", "hyper", "mse")}}
