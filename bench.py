@@ -175,6 +175,38 @@ def profile_kernels(eng, x, spg, device, reps=24, cfg=CFG1):
 EPOCH_FLOP_PER_SIGNAL = CFG1.epoch_flop_per_signal()
 
 
+def bench_signals_product(n_signals, device, epochs=24):
+    """The product loop over many signals -- ``hypad_amd.train.train_signals_resident``: per-signal models, histories, checkpoint
+    cadence and files (train.py:428-437, 381-385) -- on the workload of the `signals32` section: wall time between the epochs'
+    log lines inside ONE call, without and with checkpoint files."""
+    import tempfile
+    from types import SimpleNamespace
+    from hypad_amd import train as ht
+    datasets = [synth_windows(N_WINDOWS, S, s) for s in range(n_signals)]
+    out = {"what": "train_signals_resident(%d signals of %d windows): ms between the log lines of consecutive epochs inside one %d-epoch call (median; mean from "
+                   "epoch 3 on), save=False and with the reference's checkpoint cadence (every 10th epoch: 4 files per signal, written by a worker thread)"
+                   % (n_signals, N_WINDOWS, epochs), "signals": n_signals, "epochs": epochs, "unit": "windows/s (this GPU)"}
+    cwd = os.getcwd()
+    for save in (False, True):
+        with tempfile.TemporaryDirectory() as d:
+            os.chdir(d)                               # (model_path is relative to the working directory, as in the reference)
+            try:
+                P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=True, epochs=epochs, dataset="bench", signal="s",
+                                    resume=False, resume_epoch=0)
+                stamps = []
+                t0 = time.perf_counter()
+                ht.train_signals_resident(datasets, P, seed=1, log=lambda s_: stamps.append(time.perf_counter()), save=save)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            finally:
+                os.chdir(cwd)
+        w = np.diff(np.asarray(stamps)) * 1e3
+        key = "with_checkpoints" if save else "no_files"
+        out[key] = {"ms_per_epoch_median": float(np.median(w)), "ms_per_epoch_mean": float(w[2:].mean()), "value": n_signals * (N_WINDOWS // B) * B / float(w[2:].mean()) * 1e3,
+                    "call_ms": 1e3 * dt, "setup_and_first_epoch_ms": 1e3 * (stamps[0] - t0), "after_last_epoch_ms": 1e3 * (t0 + dt - stamps[-1])}
+    return out
+
+
 def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True):
     """`spg` signals (models) per GPU of workload `cfg`: the epoch replayed as a captured hipGraph (static shuffle buffer),
     `warmup` untimed + `steps` timed epochs; the same epochs launched eagerly (host-bound wherever ~61 launches of CPU enqueue
@@ -957,6 +989,11 @@ def main():
                                                                 "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations")
         extra["signals32"] = bench_signals(32, rank, device, gen, warmup=2, steps=8, eager=False,
                                            what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
+
+        try:
+            extra["signals32"]["product_loop"] = bench_signals_product(32, device)
+        except Exception as e:      # (reported, not hidden; the section above stands on its own)
+            extra["signals32"]["product_loop"] = f"{type(e).__name__}: {e}"[:300]
 
     # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
     # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
