@@ -648,30 +648,69 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     if getattr(params, "resume", False):
         n_epochs = n_epochs - params.resume_epoch
         actual_epoch = params.resume_epoch + 1
-    for epoch in range(n_epochs):
-        # one uniform permutation per pass: drawn by the library inside the captured epoch where it can (<= 4096 windows:
-        # hypad_epoch_shuffles), else by one batched torch sort (argsort of uniform keys) into the buffer the epoch reads
-        in_graph = n_windows <= eng.SHUFFLE_MAX_WINDOWS
+    # one uniform permutation per pass: drawn by the library inside the captured epoch where it can (<= 4096 windows:
+    # hypad_epoch_shuffles), else by one batched torch sort (argsort of uniform keys) into the buffer the epoch reads
+    in_graph = n_windows <= eng.SHUFFLE_MAX_WINDOWS
+    iters = (2 * n_critics + 1) * n_batches
+    back = [torch.empty(iters * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)]        # losses | counters (as bits), by epoch parity
+    done = [torch.cuda.Event() for _ in range(2)]
+    writer = _CheckpointWriter(dev, mods)
+    snaps, state = {}, {"repaired_until": -1, "repaired": {}}
+    first_epoch = actual_epoch
+    saves = lambda e: bool(path) and (((first_epoch + e + 1) % 10 == 0) or ((first_epoch + e + 1) == (n_epochs - 1)))      # train.py:381 (cadence kept as is)
+
+    def enqueue(e):
         if not in_graph:
             perm = torch.rand(n_critics + 1, n_windows, device=dev, generator=gen).argsort(dim=1)[:, : n_batches * B]
             perm_buf.copy_(perm)
         # the epoch is a fixed launch sequence: captured once as a hipGraph, replayed every epoch (Engine.train_epoch_graph)
         losses = eng.train_epoch_graph(x, perm_buf, n_batches, n_critics, True, x_row_stride=stride, shuffle_windows=n_windows if in_graph else 0)
-        # the host reads the losses next (a synchronisation anyway): did the epoch's resident critic launch complete?  If one of
-        # its bounded waits gave up (a CU withheld by a CU mask / a shared device), the epoch's remaining launches were no-ops;
-        # check_status restores the critics and repeats the epoch with one launch per critic iteration, for good
-        if eng.check_status():
-            losses = eng._last_epoch["losses"]
-        cx_, cz_, dec_, aux_ = _resident_epoch_means(losses[0].cpu(), n_critics, n_batches)      # (one copy; the reduction on the host)
+        b = back[e % 2]
+        b[: iters * 4].copy_(losses.view(-1), non_blocking=True)
+        b[iters * 4:].view(torch.int32).copy_(eng.counters, non_blocking=True)
+        done[e % 2].record()
+        if saves(e):
+            snaps[e] = writer.snapshot()                         # epoch e's weights, before epoch e + 1 is queued (_CheckpointWriter)
+
+    def finish(e):
+        """Epoch e's losses on the host -- with its shuffles drawn inside the captured epoch the next epoch is already queued behind it.
+        Did its resident critic launch complete?  If one of its bounded waits gave up (a CU withheld by a CU mask / a shared device),
+        the launches behind it were no-ops: check_status restores the critics and repeats the queued epochs with one launch per critic
+        iteration, for good."""
+        done[e % 2].synchronize()
+        b = back[e % 2]
+        if e > state["repaired_until"]:
+            if int(b[iters * 4:].view(torch.int32)[4]) != 0:
+                def redo(i):
+                    state["repaired"][e + i] = eng._last_epoch["losses"].detach().cpu().view(-1)
+                    if e + i in snaps:
+                        snaps[e + i] = writer.snapshot()
+                eng.check_status(on_epoch=redo)
+                state["repaired_until"] = max(state["repaired"]) if state["repaired"] else e
+            else:
+                eng.confirm_epochs(1)
+        rows = (state["repaired"].pop(e) if e in state["repaired"] else b[: iters * 4]).view(iters, 4)
+        cx_, cz_, dec_, aux_ = _resident_epoch_means(rows, n_critics, n_batches)      # (the reduction on the host: one copy per epoch)
         history.cx.append(cx_); history.cz.append(cz_); history.dec.append(dec_)
         (history.hyper if params.hyperbolic else history.mse).append(aux_)
         if log:
             log("epoch {}: critic x loss {:.3f} critic z loss {:.3f} decoder loss {:.3f} {} {:.5f}".format(
-                epoch, history.cx[-1], history.cz[-1], history.dec[-1], "hyperbolic loss" if params.hyperbolic else "mse", aux_))
-        actual_epoch += 1
-        if path and ((actual_epoch % 10 == 0) or (actual_epoch == (n_epochs - 1))):      # train.py:381 (cadence kept as is)
-            for name, m in (("encoder", encoder), ("decoder", decoder), ("critic_x", critic_x), ("critic_z", critic_z)):
-                torch.save(m, path + "/{}_{}.pt".format(name, actual_epoch))
+                e, history.cx[-1], history.cz[-1], history.dec[-1], "hyperbolic loss" if params.hyperbolic else "mse", aux_))
+        if saves(e):
+            ae = first_epoch + e + 1
+            writer.submit(snaps.pop(e), {k: path + "/{}_{}.pt".format(nm, ae) for k, nm in (("enc", "encoder"), ("dec", "decoder"), ("cx", "critic_x"), ("cz", "critic_z"))})
+
+    try:
+        for epoch in range(n_epochs):
+            enqueue(epoch)
+            if not in_graph:                        # host-drawn shuffles: a repair repeats epochs from the buffer as it is then -- one epoch at a time
+                finish(epoch)
+            elif epoch > 0:
+                finish(epoch - 1)
+        if in_graph and n_epochs > 0:
+            finish(n_epochs - 1)
+    finally:
+        writer.close()                              # every checkpoint file is complete when the call returns
     return history
 
 
