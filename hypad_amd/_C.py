@@ -20,7 +20,7 @@ class HypadError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
+ABI_VERSION = 6            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
 
 
 def _load():
@@ -83,7 +83,8 @@ class EpochIO(Structure):
                 ("n_critics", c_int), ("train_mode", c_int), ("seed", c_uint64), ("losses", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t), ("noise", POINTER(EpochNoise)), ("flags", c_int),
                 ("aux_streams", POINTER(c_void_p)), ("n_aux_streams", c_int),      # ABI 4: streams for the generator phase's model groups
-                ("row_index_signal_stride", c_int64)]                              # ABI 5: a row_index plane per signal (0: one shared plane)
+                ("row_index_signal_stride", c_int64),                              # ABI 5: a row_index plane per signal (0: one shared plane)
+                ("enc_table", c_void_p), ("enc_table_rows", c_int64)]              # ABI 6: encoder(x) once per window row (NULL: once per pass)
 
 
 STATS_WORKSPACE_BYTES = 256 * 5 * 8  # HYPAD_STATS_WORKSPACE_BYTES

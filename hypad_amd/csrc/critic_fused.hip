@@ -149,6 +149,10 @@ struct PhaseArgs {
                                                // iteration as a one-iteration phase: launch grids carry that critic only)
   int fault_it;                                // tests (HYPAD_EPOCH_TEST_GIVE_UP_SHIFT): > 0 = critic_x chunk 0 of signal 0 behaves as if its
                                                // wait for the siblings' shares had timed out at that iteration
+  // hypad_epoch_io.enc_table (ABI 6): encoder(x) of every window row, (n_signals, enc_rows, L), filled by encoder_table_kernel in
+  // front of the phase -- the encoder is frozen through it (train.py:306-309) and every pass shuffles the same windows: critic_z's
+  // records gather their 16 rows from it instead of running the encoder on them once per pass.  Null: they run it.
+  const float* enc_table; int64_t enc_rows;
 };
 // (HYPAD_DIAG: development builds only -- libhypad_hip_dev.so, `python -m hypad_amd.build --dev`; the product library carries
 // neither the stamps nor their setter)
@@ -274,7 +278,9 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
     tail[0] = bc1; tail[1] = bc2s;
   }
   if (threadIdx.x >= 2 && threadIdx.x < 32) rec_w[4 * (grec.rec_rows4 + grec.rec_mask4) + threadIdx.x] = 0.f;
-  tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ph.row_index ? ph.row_index + (int64_t)sig * ax.ri_sig_stride + (int64_t)it * B : nullptr, g0, 16, S, 16);
+  const int32_t* ridx = ph.row_index ? ph.row_index + (int64_t)sig * ax.ri_sig_stride + (int64_t)it * B : nullptr;
+  const bool from_table = role == 1 && ph.enc_table != nullptr;
+  if (!from_table) tile_load_rows(xs, lp.ldS, ax.x + sig * ax.x_sig_stride, ax.x_ld, ridx, g0, 16, S, 16);
   if (role == 0) {          // critic_x side: x_ = decoder(z), train-mode dropout (train.py:24-33)
     const DecLayout dl = dec_layout(S, L, ax.hyperbolic);
     const float* PD = ax.P.dec + (int64_t)sig * ax.pd;
@@ -306,8 +312,13 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
     tile_for(16, L, [&](int r, int c) { zs[r * LP + c] = zin ? zin[r * L + c] : rng_normal(az.seed, tick, RS_Z, (uint32_t)(sig + az.rng_sig0), (uint32_t)((g0 + r) * L + c)); });
     __syncthreads();
     float* zenc = zs + 16 * LP;
-    const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
-    encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
+    if (from_table) {       // the rows' encoder outputs, computed once per window in front of the phase (same function of the row: same bits)
+      const float* tab = ph.enc_table + (int64_t)sig * ph.enc_rows * L;
+      tile_for(16, L, [&](int r, int c) { zenc[r * LP + c] = tab[(int64_t)(ridx ? ridx[g0 + r] : g0 + r) * L + c]; });
+    } else {
+      const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
+      encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
+    }
     __syncthreads();
     const CritGeom g = cz_geom(L);
     emit_record<false>(az, g, rec_w, zs, LP, zenc, LP, sig, g0, tick, 0.2f, ph.inj_al_z ? ph.inj_al_z + isl * B * L : nullptr,
@@ -335,6 +346,24 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WP
   extern __shared__ __attribute__((aligned(16))) float smem[];
   precompute_body<false, SC, LC>(ax, az, ph, smem, blockIdx.x, blockIdx.y, ph.only < 0 ? blockIdx.z >> 1 : blockIdx.z, ph.only < 0 ? blockIdx.z & 1 : ph.only,
                                  gridDim.y);
+}
+// encoder(x) of every window row of every model -> hypad_epoch_io.enc_table (PhaseArgs.enc_table): one workgroup per 16 rows
+template <int SC, int LC>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WPE, HYPAD_PRE_WPE))) void encoder_table_kernel(IterArgs az, float* table, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = SC ? SC : az.S, L = LC ? LC : az.L;
+  const PreLds lp = pre_lds(S);
+  float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
+  const int sig = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int valid = (int)(rows - r0 < 16 ? rows - r0 : 16);
+  tile_load(xs, lp.ldS, az.x + sig * az.x_sig_stride + r0 * az.x_ld, az.x_ld, 16, S, valid);
+  __syncthreads();
+  const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
+  encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, 16);
+  __syncthreads();
+  float* out = table + ((int64_t)sig * rows + r0) * L;
+  tile_for(16, L, [&](int r, int c) { if (r < valid) out[r * L + c] = zs[r * LP + c]; });
 }
 typedef void (*PreKernel)(IterArgs, IterArgs, PhaseArgs);
 inline PreKernel precompute_kernel(int S, int L) {
@@ -1771,7 +1800,7 @@ void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_flo
 
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
-                     const unsigned* zeroed, int flags, int only) {
+                     const unsigned* zeroed, int flags, int only, float* enc_table, int64_t enc_rows) {
   hypad_dims d; d.signal_shape = ax.S; d.latent_dim = ax.L; d.batch = ax.B; d.hyperbolic = ax.hyperbolic; d.n_signals = n_signals; d.first_signal = ax.rng_sig0;
   if (!critic_phase_supported(d)) return HYPAD_EUNSUPPORTED;
   const PhasePlan plan = plan_phase(d, extra_floats, n_iters, flags);
@@ -1842,6 +1871,19 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
 #else
   ph.stamps = nullptr;
 #endif
+  if (enc_table && enc_rows > 0 && only != 0) {            // encoder(x) once per window row, for every slice of the phase
+    const bool cfg100 = ax.S == 100 && ax.L == 20;
+    const void* tfn = cfg100 ? (const void*)encoder_table_kernel<100, 20> : (const void*)encoder_table_kernel<0, 0>;
+    if (lds_pre > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(tfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pre);
+      if (e != hipSuccess) return (int)e;
+    }
+    const dim3 tgrid((unsigned)((enc_rows + 15) / 16), n_signals);
+    if (cfg100) hipLaunchKernelGGL((encoder_table_kernel<100, 20>), tgrid, dim3(TB), lds_pre, s, az, enc_table, enc_rows);
+    else hipLaunchKernelGGL((encoder_table_kernel<0, 0>), tgrid, dim3(TB), lds_pre, s, az, enc_table, enc_rows);
+    HYPAD_CHECK_LAUNCH();
+    ph.enc_table = enc_table; ph.enc_rows = enc_rows;
+  }
   for (int it0 = 0; it0 < n_iters; it0 += cap) {
     const int n = n_iters - it0 < cap ? n_iters - it0 : cap;
     ph.n_iters = n;

@@ -226,7 +226,8 @@ size_t critic_phase_fixed_floats(const hypad_dims& d);     // double-buffered op
 size_t critic_phase_floats_per_iter(const hypad_dims& d);  // precomputed records of one (critic_x || critic_z) iteration
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise = nullptr, int* persistent_used = nullptr,
-                     const unsigned* zeroed = nullptr, int flags = 0, int only = -1);      // only: 0 / 1 = critic_x / critic_z alone
+                     const unsigned* zeroed = nullptr, int flags = 0, int only = -1,       // only: 0 / 1 = critic_x / critic_z alone
+                     float* enc_table = nullptr, int64_t enc_rows = 0);                    // hypad_epoch_io.enc_table
 // the block the resident form needs zero in front of its first launch (null: none) -- the caller's previous launch may zero it
 void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_floats, int n_iters, unsigned** ptr, int* words, int flags = 0);
 bool critic_phase_producers(const hypad_dims& d, int n_iters);      // ... and that launch produces the records itself

@@ -1891,8 +1891,9 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
     c.masks = nullptr;
     if (rc) return rc;
     const int n = io->n_critics * io->n_batches;
+    if (io->enc_table && io->enc_table_rows <= 0) return HYPAD_EINVAL;
     rc = run_critic_phase(ax, az, io->row_index, n, io->losses, (float*)io->workspace + base, have - base, d->n_signals,
-                          (hipStream_t)s, nullptr, nz, nullptr, zeroed ? zero_ptr : nullptr, io->flags);
+                          (hipStream_t)s, nullptr, nz, nullptr, zeroed ? zero_ptr : nullptr, io->flags, -1, io->enc_table, io->enc_table_rows);
     if (rc) return rc;
     it = 2 * n;
   } else {

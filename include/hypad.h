@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HYPAD_ABI_VERSION 5
+#define HYPAD_ABI_VERSION 6
 
 enum {
   HYPAD_OK = 0,
@@ -289,6 +289,13 @@ typedef struct hypad_epoch_io {
    * the same shuffles); (n_critics + 1) * n_batches * batch or more = a plane per signal -- signals of different lengths (each with
    * permutations of its OWN window count, hypad_epoch_shuffles_signals) trained by the same launches. */
   int64_t row_index_signal_stride;
+  /* ABI 6.  Optional scratch, n_signals x enc_table_rows x latent_dim floats, enc_table_rows = number of window rows of `x` a row
+   * index may name (every model: rows 0 .. enc_table_rows - 1 of its x must be readable).  The encoder is frozen through the critic
+   * phase (train.py:306-309) and every pass shuffles the same windows, so encoder(x) -- critic_z's fake input, train.py:111-116 --
+   * is then evaluated ONCE per window row in front of the phase (one launch) and gathered by the record producers, instead of once
+   * per pass (n_critics times): worth it from 14 models per call on, where the producers bound the phase (16 models: 4.25 -> 3.97 ms
+   * per epoch, 32: 5.99 -> 5.76); the same bits either way (the encoder output of a row does not depend on the other rows of its tile).  NULL: off. */
+  float* enc_table; int64_t enc_table_rows;
 } hypad_epoch_io;
 enum {
   HYPAD_EPOCH_PER_ITERATION = 1,             /* run the critic phase as one launch per iteration even where the resident form fits */

@@ -94,6 +94,48 @@ def test_first_signal_makes_a_model_independent_of_its_group():
     assert not torch.equal(ri[0], ri[2])
 
 
+@pytest.mark.parametrize("k,per_signal,series", [(3, True, False), (16, False, False), (2, False, True)])
+def test_encoder_table_equals_the_encoder_run_per_pass(k, per_signal, series):
+    """hypad_epoch_io.enc_table (ABI 6): encoder(x) evaluated once per window row in front of the critic phase and gathered by critic_z's
+    record producers == the producers running the encoder on their rows in every pass, bit for bit (losses, weights): signals of
+    different lengths with their own shuffle planes, 16 models (the resident launch with its own producers), the series view; as a
+    replayed graph and eagerly."""
+    from hypad_amd.engine import Engine
+    from oracle import tadgan as ot
+    nb, nc = 2, 3
+    counts = [2 * B + 3, 2 * B + 50, 2 * B][:k] if per_signal else [2 * B + 7] * k
+    if series:
+        x = torch.stack([torch.from_numpy(windows(counts[0], 20 + s)[:, 0].copy()) for s in range(k)]).float().cuda().contiguous()      # any series will do
+        x = torch.cat([x, x[:, : S - 1]], 1).contiguous()                       # (k, counts[0] + S - 1): window n = x[n : n + S]
+        stride = 1
+    else:
+        x = torch.zeros(k, max(counts), S, device="cuda")
+        for s_ in range(k):
+            x[s_, : counts[s_]] = torch.from_numpy(windows(counts[s_], 10 + s_)).float()
+        stride = 0
+    results = []
+    for table in (False, True):
+        eng = Engine(S, 20, B, True, n_signals=k, seed=11, first_signal=2)
+        eng.enc_table = table
+        for s_ in range(k):
+            torch.manual_seed(60 + s_)
+            for net, m in dict(enc=ot.Encoder(S, 20), dec=ot.Decoder(S, 20, True), cx=ot.CriticX(S, 20), cz=ot.CriticZ(20)).items():
+                eng.load_state_dict(net, m.state_dict(), s_)
+        ri = torch.empty((k, nc + 1, nb * B) if per_signal else (nc + 1, nb * B), dtype=torch.int32, device="cuda")
+        sw = counts if per_signal else counts[0]
+        ls = [eng.train_epoch_graph(x, ri, nb, nc, True, x_row_stride=stride, shuffle_windows=sw).clone() for _ in range(2)]
+        eng.draw_shuffles(ri, sw)
+        ls.append(eng.train_epoch(x, ri, nb, nc, True, x_row_stride=stride).clone())                                                     # eagerly
+        assert eng.check_status() == 0
+        assert (eng.__dict__.get("_enc_table") is not None) == table
+        results.append((ls, {n: eng.params[n].clone() for n in ("enc", "dec", "cx", "cz")}))
+    (la, pa), (lb, pb) = results
+    for e in range(3):
+        assert torch.isfinite(la[e]).all() and torch.equal(la[e], lb[e]), e
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), n
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
