@@ -334,6 +334,9 @@ class _CheckpointWriter:
         """files: {key: path} -- or, with ``pick``, a list of (template module, key, index into the snapshot's first dimension, path).
         Returns at once (unless ``max_jobs`` snapshots are already waiting); ``close`` waits for every file."""
         import queue, threading
+        if self.error is not None:                   # an earlier file could not be written: fail at this checkpoint, not at the end of the run
+            e, self.error = self.error, None
+            raise e
         if self.thread is None:
             self.jobs = queue.Queue(maxsize=self.max_jobs)
             self.thread = threading.Thread(target=self._run, name="hypad-checkpoints", daemon=True)

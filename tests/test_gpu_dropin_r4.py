@@ -266,3 +266,15 @@ def test_a_resident_launch_that_gives_up_inside_train_tadgan_is_repaired(tmp_pat
     assert all(np.isfinite(runs[1][0].cx))
     for wa, wb in zip(runs[0][1], runs[1][1]):
         assert all(torch.equal(wa[k], wb[k]) for k in wa)
+
+
+def test_a_checkpoint_that_cannot_be_written_fails_the_call(tmp_path):
+    """The checkpoint files are written by a worker thread: its error (here: the directory does not exist) is raised on the caller's
+    thread -- at the next checkpoint or at the end of the call, whichever comes first -- never swallowed."""
+    from hypad_amd import train as ht
+    S, B = 100, 64
+    loader = DataLoader(Windows(2 * B, S), batch_size=B, drop_last=True, shuffle=True)
+    mods = build(S, True, 3, train=True)
+    np.random.seed(0); torch.manual_seed(0)
+    with pytest.raises((OSError, RuntimeError)):
+        ht.train_tadgan(loader, *mods, n_epochs=12, params=P_(B, S, True), path=str(tmp_path / "missing" / "dir"))
