@@ -635,6 +635,7 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
                  + _resume_salt(params.resume_epoch if getattr(params, "resume", False) else None), first_signal=first_signal)
     mods = {"enc": encoder, "dec": decoder, "cx": critic_x, "cz": critic_z}
     eng.adopt({k: m.arena() for k, m in mods.items()})
+    eng.epoch_flags = int(getattr(params, "epoch_flags", 0))      # hypad_epoch_io.flags (A/B forms of the critic phase; tests)
     if hasattr(dataset, "window_view"):
         x, n_windows, stride = dataset.window_view(dev)
     else:
@@ -820,6 +821,7 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
         nb = counts[members[0]] // B
         eng = Engine(S, L, B, hyp, k, dev, lr=params.lr, gen_weight_decay=1e-5 if hyp else 0.0, gen_stabilize=10 if hyp else 0, seed=seed,
                      first_signal=first)
+        eng.epoch_flags = int(getattr(params, "epoch_flags", 0))      # hypad_epoch_io.flags (A/B forms of the critic phase; tests)
         nmax = max(counts[i] for i in members)
         templates = []
         x = torch.zeros(k, nmax, S, dtype=torch.float32, device=dev)

@@ -136,6 +136,58 @@ def test_encoder_table_equals_the_encoder_run_per_pass(k, per_signal, series):
         assert torch.equal(pa[n], pb[n]), n
 
 
+def test_the_resident_loops_repair_a_launch_that_gave_up(tmp_path, monkeypatch):
+    """train_tadgan_resident and train_signals_resident read an epoch's losses when the next epoch is already queued and write their
+    checkpoints from device copies taken between epochs.  A resident critic launch that gives up in epoch 0 (injected: the test bits
+    of hypad_epoch_io.flags) makes that epoch AND the one queued behind it no-ops: both are repeated with per-iteration launches, the
+    losses of each repeat are kept and a checkpoint epoch among them is copied again behind its repeat -- histories, final weights
+    and the checkpoint files equal those of a run in the per-iteration form from the start."""
+    from hypad_amd import _C
+    from hypad_amd import train as ht
+    from hypad_amd.models import tadgan
+    monkeypatch.chdir(tmp_path)
+    def files(d):
+        out = {}
+        for f in sorted(os.listdir(d)):
+            if f.endswith(".pt"):
+                out[f] = {k: v.cpu() for k, v in torch.load(os.path.join(d, f), weights_only=False).state_dict().items()}
+        return out
+    def same(a, b):
+        assert sorted(a) == sorted(b) and len(a) >= 4, (sorted(a), sorted(b))
+        for f in a:
+            assert all(torch.equal(a[f][k], b[f][k]) for k in a[f]), f
+    # one model
+    got = []
+    for tag, flags in (("ref", _C.EPOCH_PER_ITERATION), ("hit", 3 << _C.EPOCH_TEST_GIVE_UP_SHIFT)):
+        torch.manual_seed(21)
+        mods = [m.cuda().train() for m in (tadgan.Encoder(S, 20), tadgan.Decoder(S, 20, True), tadgan.CriticX(S, 20), tadgan.CriticZ(20))]
+        d = tmp_path / ("one_" + tag)
+        d.mkdir()
+        P = P_(2)
+        P.epoch_flags = flags
+        h = ht.train_tadgan_resident(windows(2 * B + 5, 3), *mods, n_epochs=2, params=P, path=str(d), seed=5, log=None)
+        got.append((vars(h), [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in mods], files(d)))
+    assert got[0][0] == got[1][0] and all(np.isfinite(got[1][0]["cx"])) and len(got[1][0]["cx"]) == 2
+    for wa, wb in zip(got[0][1], got[1][1]):
+        assert all(torch.equal(wa[k], wb[k]) for k in wa)
+    same(got[0][2], got[1][2])                      # encoder_1.pt ...: the checkpoint of the failed epoch holds ITS weights
+    # three models of different lengths in one group
+    res = []
+    for tag, flags in (("ref", _C.EPOCH_PER_ITERATION), ("hit", 3 << _C.EPOCH_TEST_GIVE_UP_SHIFT)):
+        P = P_(2)
+        P.epoch_flags = flags
+        P.dataset = "grp_" + tag
+        data = [windows(n, 30 + i) for i, n in enumerate((2 * B + 1, 2 * B + 40, 2 * B))]
+        r = ht.train_signals_resident(data, P, names=["a", "b", "c"], seed=9, init_seed=100, log=None)
+        res.append(r)
+    for n in ("a", "b", "c"):
+        assert res[0][n]["history"] == res[1][n]["history"], n
+        for ma, mb in zip(res[0][n]["modules"], res[1][n]["modules"]):
+            sa, sb = ma.state_dict(), mb.state_dict()
+            assert all(torch.equal(sa[k], sb[k]) for k in sa), n
+        same(files(res[0][n]["path"]), files(res[1][n]["path"]))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
