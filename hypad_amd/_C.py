@@ -150,6 +150,8 @@ _SIGS = {
     "hypad_epoch_shuffles": (c_int, [P, c_int, c_int, c_int, c_uint64, P, P]),
     "hypad_epoch_shuffles_signals": (c_int, [P, c_int64, c_int, c_int, P, c_int, c_int, c_uint64, P, P]),
     "hypad_host_mt19937_normal": (c_int, [P, POINTER(c_int), POINTER(c_int), POINTER(c_double), POINTER(c_void_p), c_int, c_int64, c_int64]),
+    "hypad_host_torch_mt19937_uniform": (c_int, [P, c_size_t, P, c_int64]),
+    "hypad_host_mt19937_normal_mt": (c_int, [P, POINTER(c_int), POINTER(c_int), POINTER(c_double), POINTER(c_void_p), c_int, c_int64, c_int64, c_int]),
     "hypad_epoch_status": (c_int, [POINTER(TrainState), POINTER(c_int), P]),
     "hypad_epoch_restore": (c_int, [POINTER(Dims), POINTER(TrainState), c_void_p, c_size_t, P]),
     "hypad_critic_phase_persistent": (c_int, [POINTER(Dims)]),

@@ -147,7 +147,8 @@ class EpochFeed:
         try:
             h = self.host_np[slot]
             view = lambda k: h[self.offsets[k][0]: self.offsets[k][0] + self.offsets[k][1]]
-            host_rng.global_normal_into([view("z_cx"), view("z_cz")], self.B * self.L, self.nit)      # train.py:24 then :118, per iteration
+            # (configs[3]: 4.1 M values per epoch -- the transforms on three helper threads; the reference configuration's 371 200 stay on this one)
+            host_rng.global_normal_into([view("z_cx"), view("z_cz")], self.B * self.L, self.nit, threads=3)      # train.py:24 then :118, per iteration
             host_rng.global_normal_into([view("z_gen")], self.B * self.L, self.nb)                    # train.py:205
         except BaseException as e:             # surfaced by the main thread's join
             self._z_error = e
@@ -155,19 +156,23 @@ class EpochFeed:
     def _start_z(self, epoch):
         if epoch in self._z_thread or (self.last_epoch is not None and epoch > self.last_epoch):
             return
-        prev = self._z_thread.get(epoch - 1)
-        if prev is not None:
-            prev.join()                        # one stream: epoch e's draws follow epoch e - 1's
-        t = threading.Thread(target=self._draw_z, args=(epoch % DEPTH,), name="hypad-z-draws", daemon=True)
-        self._z_thread[epoch] = t
-        t.start()
+        # ONE long-lived helper thread takes the epochs' draws in order (one stream: epoch e's follow epoch e - 1's).  A thread per
+        # epoch was measurably slower on the GPU box's two-socket host: each new thread started on whatever core was free, half the
+        # time across the socket link from the generator's buffers and the pinned planes (configs[3]: 13 ms per epoch against 7).
+        ex = self.__dict__.get("_z_exec")
+        if ex is None:
+            from concurrent.futures import ThreadPoolExecutor
+            ex = self._z_exec = ThreadPoolExecutor(1, thread_name_prefix="hypad-z-draws")
+        fut = ex.submit(self._draw_z, epoch % DEPTH)
+        fut.join = fut.result                  # (the callers' vocabulary)
+        self._z_thread[epoch] = fut
 
     # ---- torch stream + samples --------------------------------------------------------------------------
     def _alphas(self, slot, p):
         """The pass's interpolation weights, drawn where the reference draws them relative to the loader's own draws: after
         the pass's iterator exists and has produced its first batch."""
         B, S, L, nb = self.B, self.S, self.L, self.nb
-        torch.rand(self.alpha_tmp.shape, out=self.alpha_tmp)
+        host_rng.torch_rand_into(self.alpha_tmp)          # == torch.rand(shape, out=alpha_tmp), natively (no interpreter lock, ~3x torch's rate)
         # (NumPy copies: a strided torch copy of this size wakes the whole intra-op thread pool -- milliseconds on a 256-core host)
         t = self.alpha_np.reshape(nb, B * S + B * L)
         h = self.host_np[slot]
@@ -319,3 +324,6 @@ class EpochFeed:
         for t in list(self._z_thread.values()):
             t.join()
         self._z_thread.clear()
+        ex = self.__dict__.pop("_z_exec", None)
+        if ex is not None:
+            ex.shutdown(wait=True)

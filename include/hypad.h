@@ -336,6 +336,16 @@ int hypad_epoch_shuffles_signals(int32_t* row_index, int64_t signal_stride, int 
  * (tests/test_host_rng.py); unlike np.random.normal the call does not hold the interpreter lock. */
 int hypad_host_mt19937_normal(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, float* const* outs, int n_outs,
                               int64_t chunk, int64_t rounds);
+/* hypad_host_mt19937_normal with `threads` helper threads: the calling thread runs the generator and the polar method's rejection test
+ * (sequential), the helpers take the accepted pairs' transforms -- sqrt(-2 log(r2) / r2), two products, the float32 stores; independent
+ * per pair -- block by block as they become ready.  Same values, same final state; threads < 1 = hypad_host_mt19937_normal.  Worth it
+ * from about a million values per call on (configs[3]: 4.1 M per epoch). */
+int hypad_host_mt19937_normal_mt(uint32_t* key, int* pos, int* has_gauss, double* cached_gaussian, float* const* outs, int n_outs,
+                                 int64_t chunk, int64_t rounds, int threads);
+/* The interpolation weights of train.py:64,149 -- torch.rand(...) on torch's default CPU generator -- for a whole pass in one call:
+ * `state` = the bytes of torch.get_rng_state() (5 056: at::CPUGeneratorImplState, an at::mt19937 inside), advanced in place as n draws
+ * leave it; out[i] = the i-th float32 torch.rand would have returned.  HOST pointers, like hypad_host_mt19937_normal. */
+int hypad_host_torch_mt19937_uniform(void* state, size_t state_bytes, float* out, int64_t n);
 
 /* Workspace that lets hypad_train_epoch hoist the frozen generator's forwards (decoder(z_i), encoder(x_i) of every
  * critic iteration, train.py:306-328) out of the sequential critic chain: hypad_train_workspace_bytes plus room for up

@@ -1,35 +1,28 @@
-"""Host-side cost of the reference's per-iteration random draws (train.py:24,64,118,149,205) on this machine."""
-import time, os, threading, numpy as np, torch
-def t(f, n=300):
-    f(); t0 = time.perf_counter()
-    for _ in range(n): f()
-    return (time.perf_counter() - t0) / n * 1e6
-print("cpus", os.cpu_count(), "torch threads", torch.get_num_threads())
-print("np normal (1,64,20) us", t(lambda: np.random.normal(size=(1, 64, 20))))
-print("np normal (319,64,20) us", t(lambda: np.random.normal(size=(319, 64, 20)), 20))
-print("torch rand (1,64,100) us", t(lambda: torch.rand((1, 64, 100))))
-print("torch rand (29*7680,) us", t(lambda: torch.rand((29 * 7680,)), 50))
-buf = torch.empty(145 * 7680).pin_memory() if torch.cuda.is_available() else torch.empty(145 * 7680)
-print("torch rand out= pinned (29*7680) us", t(lambda: torch.rand((29 * 7680,), out=buf[:29 * 7680]), 50))
-def both():
-    th = threading.Thread(target=lambda: np.random.normal(size=(319, 64, 20)))
-    th.start()
-    for _ in range(5): torch.rand((29 * 7680,))
-    th.join()
-print("np (319 iters) || torch (5 passes) us", t(both, 20))
-from torch.utils.data import DataLoader
-X = np.random.rand(1916, 100, 1)
-class DS:
-    def __len__(self): return len(X)
-    def __getitem__(self, i): return torch.from_numpy(X[i])
-dl = DataLoader(DS(), batch_size=64, shuffle=True, drop_last=True, num_workers=0)
-def it():
-    for s in dl: pass
-print("DataLoader pass (29 batches, workers=0) us", t(it, 20))
-import sys; sys.path.insert(0, "."); from hypad_amd import host_rng
-zx = np.zeros((145, 1280), np.float32); zz = np.zeros_like(zx); zg = np.zeros((29, 1280), np.float32)
-def native():
-    host_rng.global_normal_into([zx, zz], 1280, 145); host_rng.global_normal_into([zg], 1280, 29)
-best = min(t(native, 10) for _ in range(5))
-print("native MT19937 normal, one epoch's 408 320 draws us (best of 5 x 10)", best)
-print("np normal (319,64,20) us (best of 5 x 10)", min(t(lambda: np.random.normal(size=(319, 64, 20)), 10) for _ in range(5)))
+"""In-process timing of hypad_amd.host_rng: the epoch's latent draws of configs[1] (371 200 + 37 120 values) and configs[3] (4 096 000 + 409 600)
+into pageable and page-locked arrays, with 0 / 1 / 3 helper threads; torch.rand natively vs torch."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from hypad_amd import host_rng
+def timed(fn, reps=5):
+    fn(); ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return 1e3 * min(ts)
+for name, chunk, rounds in (("configs[1]", 1280, 145), ("configs[3]", 5120, 400)):
+    for kind in ("pageable", "pinned"):
+        outs = [torch.empty(chunk * rounds, pin_memory=(kind == "pinned")).numpy() for _ in range(2)]
+        for th in (0, 1, 3, 6):
+            old = host_rng.PIPELINE_FROM
+            host_rng.PIPELINE_FROM = 1
+            try:
+                ms = timed(lambda: host_rng.global_normal_into(outs, chunk, rounds, threads=th))
+            finally:
+                host_rng.PIPELINE_FROM = old
+            print("%s %-8s %d helper thread(s): %.2f ms for %d values = %.2f ns each" % (name, kind, th, ms, 2 * chunk * rounds, 1e6 * ms / (2 * chunk * rounds)), flush=True)
+buf = torch.empty(29 * (256 * 150 + 256 * 20) * 3)
+print("torch.rand(%d): %.2f ms; natively %.2f ms" % (buf.numel(), timed(lambda: torch.rand(buf.shape, out=buf)), timed(lambda: host_rng.torch_rand_into(buf))))
+host_rng.PIPELINE_FROM = 1
+tiny = [np.empty(64, np.float32)]
+for th in (0, 1, 3, 6):
+    print("64 values, %d helper thread(s): %.3f ms (thread start + join)" % (th, timed(lambda: host_rng.global_normal_into(tiny, 64, 1, threads=th), reps=20)))

@@ -63,3 +63,59 @@ def test_other_bit_generators_fall_back_to_numpy(monkeypatch):
     a = np.zeros((2, 6), np.float32); b = np.zeros((2, 6), np.float32)
     host_rng.global_normal_into([a, b], 6, 2)
     assert np.array_equal(np.stack([a[0], b[0], a[1], b[1]]), want)
+
+
+def test_torch_rand_continued_natively():
+    """hypad_host_torch_mt19937_uniform == torch.rand on the default CPU generator, bit for bit, for every way the engine's block
+    boundary can fall: a freshly seeded generator (no block generated yet), draws that end exactly on a boundary, across several
+    blocks, interleaved with torch's own draws on both sides (uniform, normal -- whose cached sample must survive -- and integer),
+    and an empty draw; the generator is left where torch.rand would have left it."""
+    import torch
+    from hypad_amd import host_rng
+    for seed, sizes in ((0, [5, 619, 624, 1, 3000, 0, 7]), (1234, [624]), (7, [1248, 1]), (99, [100_003, 17])):
+        torch.manual_seed(seed)
+        want, mid = [], []
+        for n in sizes:
+            want.append(torch.rand(n))
+            mid.append((torch.randn(3), torch.randint(0, 1000, (2,)), torch.rand(2, dtype=torch.float64)))
+        end = torch.get_rng_state().clone()
+        torch.manual_seed(seed)
+        for n, w, m in zip(sizes, want, mid):
+            got = host_rng.torch_rand_into(torch.empty(n))
+            assert torch.equal(got, w), (seed, n)
+            assert torch.equal(torch.randn(3), m[0]) and torch.equal(torch.randint(0, 1000, (2,)), m[1]) and torch.equal(torch.rand(2, dtype=torch.float64), m[2])
+        assert torch.equal(torch.get_rng_state(), end), seed
+    # a shaped, strided-free destination inside a larger buffer, as epoch_feed uses it
+    torch.manual_seed(3)
+    w = torch.rand(29 * (64 * 100 + 64 * 20))
+    torch.manual_seed(3)
+    buf = torch.empty(29 * (64 * 100 + 64 * 20))
+    assert torch.equal(host_rng.torch_rand_into(buf), w)
+    with pytest.raises(Exception):
+        host_rng.torch_rand_into(torch.empty(4, dtype=torch.float64))
+
+
+def test_threaded_normal_draw_equals_numpy():
+    """hypad_host_mt19937_normal_mt (the generator on the calling thread, the transforms on helper threads, blocks of 32 768 pairs) == the
+    per-iteration np.random.normal calls, bit for bit: several blocks, even and odd totals, a cached value going in and coming out, the
+    generator's state afterwards."""
+    old = host_rng.PIPELINE_FROM
+    host_rng.PIPELINE_FROM = 1
+    try:
+        for seed, chunk, rounds, n_outs, warm, threads in ((1, 1280, 145, 2, 0, 3), (2, 77, 13, 3, 1, 2), (3, 5120, 29, 1, 3, 1), (4, 1, 200_001, 1, 0, 4), (5, 64, 3, 2, 1, 0)):
+            np.random.seed(seed)
+            np.random.normal(size=warm)                              # (an odd `warm` leaves a cached value)
+            want = [np.empty(rounds * chunk, np.float32) for _ in range(n_outs)]
+            for r in range(rounds):
+                for o in want:
+                    o[r * chunk:(r + 1) * chunk] = np.random.normal(size=(1, chunk))
+            tail = np.random.normal(size=5)
+            np.random.seed(seed)
+            np.random.normal(size=warm)
+            got = [np.full(rounds * chunk, np.nan, np.float32) for _ in range(n_outs)]
+            host_rng.global_normal_into(got, chunk, rounds, threads=threads)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b), (seed, chunk, rounds)
+            assert np.array_equal(np.random.normal(size=5), tail), seed
+    finally:
+        host_rng.PIPELINE_FROM = old
