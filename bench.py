@@ -1009,10 +1009,11 @@ def main():
         extra["signals32"] = bench_signals(32, rank, device, gen, warmup=2, steps=8, eager=False,
                                            what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
 
-        try:
-            extra["signals32"]["product_loop"] = bench_signals_product(32, device)
-        except Exception as e:      # (reported, not hidden; the section above stands on its own)
-            extra["signals32"]["product_loop"] = f"{type(e).__name__}: {e}"[:300]
+        if world == 1:              # (under a process group train_signals_resident shards its list over the ranks: another measurement)
+            try:
+                extra["signals32"]["product_loop"] = bench_signals_product(32, device)
+            except Exception as e:  # (reported, not hidden; the section above stands on its own)
+                extra["signals32"]["product_loop"] = f"{type(e).__name__}: {e}"[:300]
 
     # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
     # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
