@@ -94,16 +94,16 @@ def test_first_signal_makes_a_model_independent_of_its_group():
     assert not torch.equal(ri[0], ri[2])
 
 
-@pytest.mark.parametrize("k,per_signal,series", [(3, True, False), (16, False, False), (2, False, True)])
-def test_encoder_table_equals_the_encoder_run_per_pass(k, per_signal, series):
+@pytest.mark.parametrize("k,per_signal,series,nb,nc", [(3, True, False, 2, 3), (16, False, False, 2, 3), (2, False, True, 2, 3),
+                                                       (32, False, False, 29, 5)])      # (the last: bench.py's `signals32` epoch, precompute launch in front)
+def test_encoder_table_equals_the_encoder_run_per_pass(k, per_signal, series, nb, nc):
     """hypad_epoch_io.enc_table (ABI 6): encoder(x) evaluated once per window row in front of the critic phase and gathered by critic_z's
     record producers == the producers running the encoder on their rows in every pass, bit for bit (losses, weights): signals of
     different lengths with their own shuffle planes, 16 models (the resident launch with its own producers), the series view; as a
     replayed graph and eagerly."""
     from hypad_amd.engine import Engine
     from oracle import tadgan as ot
-    nb, nc = 2, 3
-    counts = [2 * B + 3, 2 * B + 50, 2 * B][:k] if per_signal else [2 * B + 7] * k
+    counts = [2 * B + 3, 2 * B + 50, 2 * B][:k] if per_signal else [nb * B + 7] * k
     if series:
         x = torch.stack([torch.from_numpy(windows(counts[0], 20 + s)[:, 0].copy()) for s in range(k)]).float().cuda().contiguous()      # any series will do
         x = torch.cat([x, x[:, : S - 1]], 1).contiguous()                       # (k, counts[0] + S - 1): window n = x[n : n + S]
