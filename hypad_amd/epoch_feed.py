@@ -57,11 +57,42 @@ def _index_matrix(loader, test=False):
         m = torch.from_numpy(ds)
     elif type(ds).__module__.startswith("hypad_amd.") and hasattr(ds, "X") and (test or not getattr(ds, "test", False)):
         m = torch.as_tensor(np.asarray(ds.X))       # SignalDataset / MultivariateDataset: __getitem__(i) is X[i]
+    elif hasattr(ds, "X") and (test or not getattr(ds, "test", False)) and _items_are_rows_of_X(ds):
+        # somebody else's dataset class built like the reference's (utils/dataloader.py:61-232: the windows in ``X``, ``__getitem__(i)``
+        # = ``torch.from_numpy(X[i])`` [, the index arrays]) -- what a user who swaps only train.py / anomaly_detection.py passes in
+        m = torch.as_tensor(np.asarray(ds.X))
     else:
         return None
     if m.dim() < 2 or len(m) != len(ds):
         return None
     return m.reshape(len(m), -1)
+
+
+def _items_are_rows_of_X(ds, probes=10):
+    """Does ``ds[i]`` (its first element, for the test-mode tuples) equal ``ds.X[i]`` bit for bit?  Asked of ``probes`` items spread over
+    the dataset -- first, last and fixed pseudo-random ones -- with the global generators' states put back afterwards (a dataset that
+    augments its items draws from them and fails the comparison: it keeps the fetch-and-collate path)."""
+    import random
+    try:
+        X = np.asarray(ds.X)
+        n = len(ds)
+        if X.ndim < 2 or len(X) != n or n < 1 or X.dtype.kind != "f":
+            return False
+        states = (np.random.get_state(), torch.get_rng_state(), random.getstate())
+        try:
+            for k in range(probes):
+                i = (0, n - 1)[k] if k < 2 else (k * 2654435761) % n
+                item = ds[i]
+                if isinstance(item, (tuple, list)):
+                    item = item[0]
+                a = item.numpy() if isinstance(item, torch.Tensor) and not item.is_cuda else np.asarray(item)
+                if a.shape != X[i].shape or a.dtype != X.dtype or not np.array_equal(a, X[i]):
+                    return False
+        finally:
+            np.random.set_state(states[0]); torch.set_rng_state(states[1]); random.setstate(states[2])
+        return True
+    except Exception:
+        return False
 
 
 def loader_batches(loader):

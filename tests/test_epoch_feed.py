@@ -113,9 +113,53 @@ def test_loaders_the_index_path_must_not_take():
     assert _index_matrix([torch.zeros(16, 10)]) is None
     ds.test = True                                                                                          # test datasets yield tuples
     assert _index_matrix(DataLoader(ds, batch_size=16)) is None
-    class Foreign(Windows):
+    class Augmenting(Windows):                    # somebody else's class whose items are NOT the rows of X: its batches are fetched and staged
         __module__ = "somewhere.else"
-    assert _index_matrix(DataLoader(Foreign(64, 10), batch_size=16)) is None                               # unknown __getitem__: stage its batches
+        def __getitem__(self, i):
+            return torch.from_numpy(self.X[i] + 0.01 * np.random.standard_normal(self.X[i].shape))
+    class Scaling(Augmenting):
+        def __getitem__(self, i):
+            return torch.from_numpy(self.X[i] * 2.0)
+    st = gen_states()
+    assert _index_matrix(DataLoader(Augmenting(64, 10), batch_size=16)) is None
+    assert _index_matrix(DataLoader(Scaling(64, 10), batch_size=16)) is None
+    assert same_states(st, gen_states())                                                                   # (the probe put the generators back)
+
+
+def test_a_foreign_dataset_built_like_the_references_takes_the_index_path():
+    """What a user who swaps only train.py passes in: the REFERENCE's own SignalDataset (utils/dataloader.py:61-232) -- windows in ``X``,
+    ``__getitem__(i)`` = ``torch.from_numpy(X[i])`` (test mode: a tuple that starts with it).  A class hypad_amd has never seen whose
+    sampled items equal its rows bit for bit is read by index like hypad_amd's own; the staged planes equal the fetched-and-collated
+    ones, and probing the dataset leaves the global generators where they were."""
+    class TheirDataset:
+        __module__ = "utils.dataloader"
+        def __init__(self, n, S, test=False):
+            t = np.arange(n + S - 1)
+            series = np.sin(t / 7.0)
+            self.X = series[np.arange(n)[:, None] + np.arange(S)[None, :]][:, :, None].copy()
+            self.test, self.index = test, np.arange(n)
+        def __len__(self):
+            return len(self.X)
+        def __getitem__(self, i):
+            x = torch.from_numpy(self.X[i])
+            return (x, self.index, 0, 0, 0) if self.test else x
+    B, S, L, nc = 16, 10, 4, 2
+    st = gen_states()
+    m = _index_matrix(DataLoader(TheirDataset(70, S), batch_size=B, shuffle=True, drop_last=True))
+    assert m is not None and m.shape == (70, S) and same_states(st, gen_states())
+    assert _index_matrix(DataLoader(TheirDataset(70, S, test=True), batch_size=B)) is None                 # (a test dataset under the training loop: no)
+    assert _index_matrix(DataLoader(TheirDataset(70, S, test=True), batch_size=B), test=True) is not None
+    planes = []
+    for ip in (True, False):
+        np.random.seed(9); torch.manual_seed(9)
+        feed = EpochFeed(DataLoader(TheirDataset(70, S), batch_size=B, shuffle=True, drop_last=True), B, S, L, nc, "cpu", index_path=ip)
+        assert feed.index_path == ip
+        feed.last_epoch = 0
+        feed.upload(feed.prepare(0))
+        feed.close()
+        x = feed.x[feed.row_index.reshape(-1).long()] if ip else feed.x
+        planes.append((x.reshape(-1, S).clone(), {k: v.clone() for k, v in feed.noise.items()}))
+    assert torch.equal(planes[0][0], planes[1][0]) and all(torch.equal(planes[0][1][k], planes[1][1][k]) for k in planes[0][1])
 
 
 def test_short_last_batch_is_refused():
