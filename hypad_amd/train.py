@@ -306,6 +306,45 @@ def make_optimizers(encoder, decoder, critic_x, critic_z, params):
     return optim_cx, optim_cz, optim_dec
 
 
+class _SavedLayout:
+    """``torch.save(module, f)`` for a module whose parameters are views of ONE flat storage (hypad_amd's arena modules), repeated: the
+    archive ``torch.save`` writes is a plain stored zip -- the pickled object graph (``data.pkl``: identical from save to save as long as
+    the module's structure is), a few constant members, and the storage's raw bytes as ``data/0`` -- so every save after the first
+    re-writes that zip with only the storage record replaced.  Pickling the object graph is ~0.5 ms of interpreter time per module
+    (a Python call-back per pickled object); 128 files per checkpoint of 32 models made the checkpoint worker, not the GPU, the bound of
+    ``train_signals_resident`` (9 ms per epoch against 5.8).  ``parse`` returns None for anything it does not recognise exactly (no or
+    several storage records with the arena's bytes, a compressed member): the caller then keeps calling ``torch.save``."""
+
+    def __init__(self, members, record, nbytes):
+        self.members, self.record, self.nbytes = members, record, nbytes
+
+    @classmethod
+    def parse(cls, raw, storage_bytes):
+        import io, re, zipfile
+        try:
+            with zipfile.ZipFile(io.BytesIO(raw)) as z:
+                infos = z.infolist()
+                if any(i.compress_type != zipfile.ZIP_STORED for i in infos):
+                    return None
+                records = [i for i in infos if re.fullmatch(r".*/data/\d+", i.filename)]
+                # (other storage records -- the ball's curvature and the like, a few bytes each, not trained: nothing outside the arena is -- are kept as they are)
+                mine = [i for i in records if i.file_size == len(storage_bytes) and z.read(i) == storage_bytes]
+                if len(mine) != 1:
+                    return None
+                members = [(i.filename, None if i is mine[0] else z.read(i)) for i in infos]
+            return cls(members, mine[0].filename, len(storage_bytes))
+        except Exception:
+            return None
+
+    def write(self, f, storage_bytes):
+        import zipfile
+        if len(storage_bytes) != self.nbytes:
+            raise _C.HypadError("checkpoint layout: the storage changed size")
+        with zipfile.ZipFile(f, "w", compression=zipfile.ZIP_STORED) as z:
+            for name, data in self.members:
+                z.writestr(zipfile.ZipInfo(name), storage_bytes if data is None else data)
+
+
 class _CheckpointWriter:
     """The checkpoint files of train.py:381-385 without stopping the epoch pipeline for them: the training thread copies the
     parameter arenas on the device (``snapshot``: stream-ordered behind the epoch just queued, in front of the next one -- 1 MB per
@@ -318,6 +357,7 @@ class _CheckpointWriter:
         self.modules, self.device = modules, device            # modules: {key: live module} to deep-copy once, or None
         self.templates = None
         self.max_jobs = max_jobs
+        self.layouts = {}                                      # id(template module) -> _SavedLayout, or False (keep calling torch.save)
         self.jobs = None
         self.thread = None
         self.error = None
@@ -352,7 +392,7 @@ class _CheckpointWriter:
             self._serve()
 
     def _serve(self):
-        import copy
+        import copy, io
         while True:
             job = self.jobs.get()
             if job is None:
@@ -366,11 +406,27 @@ class _CheckpointWriter:
                     if self.templates is None:
                         self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
                     pick = [(self.templates[k], k, None, f) for k, f in files.items()]
-                for t, k, i, f in pick:
+                host = {}                                    # the snapshot on the host: ONE copy per arena tensor, not one per file -- a small
+                for t, k, i, f in pick:                      # copy queues behind the kernels that hold the chip (128 of them: 40-130 ms)
+                    src = snap[k] if i is None else snap[k][i]
+                    layout = self.layouts.get(id(t))
+                    if layout:                               # every save after the module's first: its zip with the storage record replaced
+                        if k not in host:
+                            host[k] = snap[k].cpu().numpy()
+                        layout.write(f, (host[k] if i is None else host[k][i]).reshape(-1).tobytes())
+                        continue
                     if not next(t.parameters()).is_cuda:
                         t.to(self.device)
-                    t.arena().data.copy_(snap[k] if i is None else snap[k][i])
-                    torch.save(t, f)
+                    t.arena().data.copy_(src)
+                    if layout is None and isinstance(f, (str, os.PathLike)):
+                        buf = io.BytesIO()
+                        torch.save(t, buf)
+                        raw = buf.getvalue()
+                        with open(f, "wb") as fh:
+                            fh.write(raw)
+                        self.layouts[id(t)] = _SavedLayout.parse(raw, t.arena().detach().reshape(-1).cpu().numpy().tobytes()) or False
+                    else:
+                        torch.save(t, f)
             except BaseException as e:                       # (re-raised by close on the caller's thread)
                 self.error = e
 

@@ -133,7 +133,7 @@ def test_checkpoints_hold_the_epoch_they_are_named_after(tmp_path):
     S, B, n = 100, 64, 2 * 64
     loader = DataLoader(Windows(n, S), batch_size=B, drop_last=True, shuffle=True)
     finals = {}
-    for ne in (12, 10):
+    for ne in (12, 10, 11):
         mods = build(S, True, 1, train=True)
         np.random.seed(2); torch.manual_seed(2)
         d = tmp_path / str(ne)
@@ -142,10 +142,14 @@ def test_checkpoints_hold_the_epoch_they_are_named_after(tmp_path):
         finals[ne] = weights(mods)
     saved = sorted(os.listdir(tmp_path / "12"))
     assert saved == sorted(f"{m}_{e}.pt" for m in ("encoder", "decoder", "critic_x", "critic_z") for e in (10, 11)), saved
-    for name, ref in zip(("encoder", "decoder", "critic_x", "critic_z"), finals[10]):
-        m = torch.load(tmp_path / "12" / f"{name}_10.pt", weights_only=False)
-        for k, v in m.state_dict().items():
-            assert torch.equal(v.cpu(), ref[k]), (name, k)
+    for e in (10, 11):                                  # (the second file of a module is its first one's archive with the storage record replaced: _SavedLayout)
+        for name, ref in zip(("encoder", "decoder", "critic_x", "critic_z"), finals[e]):
+            m = torch.load(tmp_path / "12" / f"{name}_{e}.pt", weights_only=False)
+            assert type(m).__name__ in ("Encoder", "Decoder", "CriticX", "CriticZ") and next(m.parameters()).is_cuda
+            for k, v in m.state_dict().items():
+                assert torch.equal(v.cpu(), ref[k]), (name, e, k)
+    x = torch.randn(4, 100, 1, device="cuda", dtype=torch.float64)
+    assert torch.isfinite(torch.load(tmp_path / "12" / "encoder_11.pt", weights_only=False)(x)).all()      # a loaded module works as one
 
 
 def test_host_batches_on_either_side_and_the_escape_hatch(tmp_path):
