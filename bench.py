@@ -204,6 +204,25 @@ def bench_signals_product(n_signals, device, epochs=24):
         key = "with_checkpoints" if save else "no_files"
         out[key] = {"ms_per_epoch_median": float(np.median(w)), "ms_per_epoch_mean": float(w[2:].mean()), "value": n_signals * (N_WINDOWS // B) * B / float(w[2:].mean()) * 1e3,
                     "call_ms": 1e3 * dt, "setup_and_first_epoch_ms": 1e3 * (stamps[0] - t0), "after_last_epoch_ms": 1e3 * (t0 + dt - stamps[-1])}
+    # signals of many different lengths: the planner is left with small groups (one launch sequence per batch count); dealt over lanes
+    # (streams that run beside each other) against one after the other
+    counts = [B * nb + 7 * (i % 5) for i, nb in enumerate([6, 6, 6, 9, 9, 9, 9, 12, 12, 12, 15, 15, 15, 15, 18, 18, 18, 21, 21, 21, 21, 24, 24, 24, 27, 27, 27, 27, 29, 29, 29, 29])][:n_signals]
+    ragged = [synth_windows(n, S, s) for s, n in enumerate(counts)]
+    out["ragged"] = {"what": "%d signals of %d different lengths (%d..%d windows): ms per epoch of all, the groups one after the other on one stream / dealt over lanes"
+                             % (len(counts), len(set(n // B for n in counts)), min(counts), max(counts)), "groups": [len(m) for _, m in ht.plan_signal_groups(counts, B)[0]]}
+    for lanes in (1, None):
+        with tempfile.TemporaryDirectory() as d:
+            os.chdir(d)
+            try:
+                P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=True, epochs=epochs, dataset="bench", signal="s",
+                                    resume=False, resume_epoch=0, lanes=lanes)
+                stamps = []
+                ht.train_signals_resident(ragged, P, seed=1, log=lambda s_: stamps.append(time.perf_counter()), save=False)
+            finally:
+                os.chdir(cwd)
+        w = np.diff(np.asarray(stamps)) * 1e3
+        out["ragged"]["one_stream" if lanes == 1 else "lanes"] = {"ms_per_epoch_median": float(np.median(w)),
+                                                                  "value": sum(n // B * B for n in counts) / float(np.median(w)) * 1e3}
     return out
 
 

@@ -916,20 +916,44 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
     # Groups whose shuffles are drawn on the host (signals beyond the in-graph sort's 4 096 windows) are finished epoch by epoch: a
     # repair repeats epochs from the buffers as they are then.
     pipelined = all(g["in_graph"] for g in engines)
+    # Small groups -- signals of many different lengths leave plan_signal_groups with few models per batch count -- are latency-bound
+    # one by one (an epoch of 4 models takes 3.2 ms, of 32 models 5.8): dealt over LANES (streams that really run beside each other,
+    # hypad_amd/streams.py) their epochs overlap.  Measured, epochs of all groups: 8 groups of 4 models 25.5 -> 8.9 ms on four lanes, 8 x 1
+    # model 23.2 -> 6.4, 4 x 8 models 13.3 -> 7.9 on two.  At most 16 models run at any time (their resident critic launches hold 8 CUs
+    # per model and need the other half of the chip for their record producers), so a group of more than 8 models keeps the GPU alone.
+    from contextlib import nullcontext
+    biggest = max((len(g["members"]) for g in engines), default=1)
+    n_lanes = min(4, 16 // biggest, len(engines)) if len(engines) > 1 else 1
+    if getattr(params, "lanes", None) is not None:               # (A/B timing, tests)
+        n_lanes = max(1, min(int(params.lanes), n_lanes))
+    lane_streams = []
+    if n_lanes > 1:
+        from . import streams as _streams
+        lane_streams = _streams.lanes(n_lanes, dev)
+        here = torch.cuda.current_stream()
+        for st in lane_streams:
+            st.wait_stream(here)                                 # (the groups' data went up on this stream)
+    for i, g in enumerate(engines):
+        g["lane"] = lane_streams[i % n_lanes] if lane_streams else None
+    on_lane = lambda g: torch.cuda.stream(g["lane"]) if g["lane"] is not None else nullcontext()
 
     def enqueue(e):
         for g in engines:
-            eng = g["eng"]
-            if not g["in_graph"]:
-                for s_, c in enumerate(g["counts"]):
-                    g["ri"][s_].copy_(torch.rand(n_critics + 1, c, device=dev, generator=g["gens"][s_]).argsort(dim=1)[:, : g["nb"] * B])
-            g["losses"] = eng.train_epoch_graph(g["x"], g["ri"], g["nb"], n_critics, True, shuffle_windows=g["counts"] if g["in_graph"] else 0)
-            b, n = g["back"][e % 2], g["losses"].numel()
-            b[:n].copy_(g["losses"].view(-1), non_blocking=True)
-            b[n:].view(torch.int32).copy_(eng.counters, non_blocking=True)
-            g["done"][e % 2].record()
-            if saves(e):
-                g["snaps"][e] = writer.snapshot(eng.params)          # epoch e's weights, before epoch e + 1 is queued
+            with on_lane(g):
+                enqueue_group(g, e)
+
+    def enqueue_group(g, e):
+        eng = g["eng"]
+        if not g["in_graph"]:
+            for s_, c in enumerate(g["counts"]):
+                g["ri"][s_].copy_(torch.rand(n_critics + 1, c, device=dev, generator=g["gens"][s_]).argsort(dim=1)[:, : g["nb"] * B])
+        g["losses"] = eng.train_epoch_graph(g["x"], g["ri"], g["nb"], n_critics, True, shuffle_windows=g["counts"] if g["in_graph"] else 0)
+        b, n = g["back"][e % 2], g["losses"].numel()
+        b[:n].copy_(g["losses"].view(-1), non_blocking=True)
+        b[n:].view(torch.int32).copy_(eng.counters, non_blocking=True)
+        g["done"][e % 2].record()
+        if saves(e):
+            g["snaps"][e] = writer.snapshot(eng.params)          # epoch e's weights, before epoch e + 1 is queued
 
     def finish(e):
         for g in engines:
@@ -944,7 +968,8 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
                         kept[e + i] = g["losses"].detach().cpu()     # (the repeat's losses: the buffer is the next repeat's too)
                         if e + i in g["snaps"]:
                             g["snaps"][e + i] = writer.snapshot(g["eng"].params)
-                    eng.check_status(on_epoch=redo)
+                    with on_lane(g):                                 # (the repeats on the group's own stream, behind whatever it still holds)
+                        eng.check_status(on_epoch=redo)
                     g["repaired"] = kept
                     g["repaired_until"] = max(kept) if kept else e
                 else:
@@ -974,7 +999,12 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
         if pipelined and n_epochs > 0:
             finish(n_epochs - 1)
         # the final weights: into the signals' own module objects (the result), and -- train.py:461-464 -- their files
-        last = {id(g): writer.snapshot(g["eng"].params) for g in engines}
+        last = {}
+        for g in engines:
+            with on_lane(g):
+                last[id(g)] = writer.snapshot(g["eng"].params)
+        for st in lane_streams:
+            torch.cuda.current_stream().wait_stream(st)         # (what follows on this stream reads the groups' weights)
         if save:
             for g in engines:
                 writer.submit(last[id(g)], None, [(g["templates"][slot][net], net, slot, paths[names[i]] + "/{}.pt".format(FILES[net]))

@@ -101,31 +101,9 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream_for(main, dev):
-    """A stream whose work really runs beside ``main``'s.  The runtime deals streams onto a handful of hardware queues; two streams
-    on one queue run one after the other (measured: the scoring pass at the end of a process that had created a dozen streams,
-    1.05 ms instead of 0.95).  So candidates are tried: a ~0.5 ms spin on ``main``, a trivial fill on the candidate -- the candidate is
-    taken if its fill is done while the spin still runs.  (Not while a capture is open: a graph's branches are parallel by construction.)"""
-    first = torch.cuda.Stream(device=dev)
-    if torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep"):
-        return first
-    probe = torch.empty(64, device=f"cuda:{dev}")
-    cand = first
-    for _ in range(8):
-        main.synchronize()
-        spun, filled = torch.cuda.Event(), torch.cuda.Event()
-        with torch.cuda.stream(main):
-            torch.cuda._sleep(1_000_000)
-            spun.record()
-        with torch.cuda.stream(cand):
-            probe.fill_(1.0)
-            filled.record()
-        filled.synchronize()
-        beside = not spun.query()
-        main.synchronize()
-        if beside:
-            return cand
-        cand = torch.cuda.Stream(device=dev)
-    return first
+    """A stream whose work really runs beside ``main``'s (hypad_amd/streams.py: streams can share a hardware queue)."""
+    from .. import streams
+    return streams.beside([main], dev)
 
 
 def concurrently(fn_main, fn_side):

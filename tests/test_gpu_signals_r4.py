@@ -188,6 +188,37 @@ def test_the_resident_loops_repair_a_launch_that_gave_up(tmp_path, monkeypatch):
         same(files(res[0][n]["path"]), files(res[1][n]["path"]))
 
 
+def test_small_groups_on_lanes_equal_the_groups_one_after_the_other(tmp_path, monkeypatch):
+    """Signals of several different lengths leave the planner with small groups; train_signals_resident deals them over lanes (streams
+    that run beside each other, hypad_amd/streams.py) -- the same histories, final weights and checkpoint files as with every group
+    on one stream (a signal's training depends on its seed, stream number and data only), losses read an epoch late on both."""
+    from hypad_amd import train as ht
+    monkeypatch.chdir(tmp_path)
+    counts = [2 * B + 1, 2 * B + 9, 3 * B + 4, 3 * B, 4 * B + 2, 5 * B + 3, 5 * B]
+    data = [windows(n, 70 + i) for i, n in enumerate(counts)]
+    names = [f"s{i}" for i in range(len(counts))]
+    plan, _ = ht.plan_signal_groups(counts, B)
+    assert len(plan) == 4 and max(len(m) for _, m in plan) == 2
+    runs = []
+    for lanes in (1, None):
+        P = P_(11)
+        P.lanes = lanes
+        P.dataset = "lanes_%s" % lanes
+        runs.append(ht.train_signals_resident(data, P, names=names, seed=3, init_seed=40, log=None))
+    for n in names:
+        assert runs[0][n]["history"] == runs[1][n]["history"], n
+        assert len(runs[1][n]["history"]["dec"]) == 11 and np.isfinite(runs[1][n]["history"]["dec"]).all()
+        for ma, mb in zip(runs[0][n]["modules"], runs[1][n]["modules"]):
+            sa, sb = ma.state_dict(), mb.state_dict()
+            assert all(torch.equal(sa[k], sb[k]) for k in sa), n
+        fa, fb = sorted(os.listdir(runs[0][n]["path"])), sorted(os.listdir(runs[1][n]["path"]))
+        assert fa == fb and "encoder_10.pt" in fa and "encoder.pt" in fa
+        for f in fa:
+            a = torch.load(os.path.join(runs[0][n]["path"], f), weights_only=False).state_dict()
+            b = torch.load(os.path.join(runs[1][n]["path"], f), weights_only=False).state_dict()
+            assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a), (n, f)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
