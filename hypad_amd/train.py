@@ -935,6 +935,11 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
             st.wait_stream(here)                                 # (the groups' data went up on this stream)
     for i, g in enumerate(engines):
         g["lane"] = lane_streams[i % n_lanes] if lane_streams else None
+        if lane_streams:
+            # several resident critic launches at once: their workgroups in id order (dealt evenly over the XCDs, 16 per XCD at the 16-model
+            # limit) instead of a critic's chunks packed onto one XCD -- packed, every launch would want the SAME first XCDs (32 workgroups
+            # on a 32-CU XCD at the limit: no slack for whatever else the dispatcher put there).  Same bits (hypad.h: HYPAD_EPOCH_ID_ORDER).
+            g["eng"].epoch_flags |= _C.EPOCH_ID_ORDER
     on_lane = lambda g: torch.cuda.stream(g["lane"]) if g["lane"] is not None else nullcontext()
 
     def enqueue(e):
