@@ -923,7 +923,8 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
     # per model and need the other half of the chip for their record producers), so a group of more than 8 models keeps the GPU alone.
     from contextlib import nullcontext
     biggest = max((len(g["members"]) for g in engines), default=1)
-    n_lanes = min(4, 16 // biggest, len(engines)) if len(engines) > 1 else 1
+    active_limit = max(1, torch.cuda.get_device_properties(dev).multi_processor_count // 16)      # models whose critics fill half the CUs: 16 on an MI355X
+    n_lanes = max(1, min(4, active_limit // biggest, len(engines))) if len(engines) > 1 else 1
     if getattr(params, "lanes", None) is not None:               # (A/B timing, tests)
         n_lanes = max(1, min(int(params.lanes), n_lanes))
     lane_streams = []
