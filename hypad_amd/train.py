@@ -485,7 +485,8 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     state = {"repaired_until": -1}
     saves = lambda e: ((actual_epoch + e + 1) % 10 == 0) or ((actual_epoch + e + 1) == (n_epochs - 1))      # train.py:381 (cadence kept as is)
 
-    copy_stream = torch.cuda.Stream(device=dev)
+    from . import streams as _streams
+    copy_stream = _streams.beside([torch.cuda.current_stream()], dev)      # (a stream that shares the training stream's hardware queue would copy BEHIND the epoch, not under it)
     uploaded = [torch.cuda.Event() for _ in range(2)]
     writer = _CheckpointWriter(dev, mods)
     snaps = {}
