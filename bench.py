@@ -836,6 +836,71 @@ def _claim_stdout():
     return real
 
 
+HEADLINE_MAX_BYTES = 4096           # the driver keeps a bounded tail of stdout: the LAST line must be small and whole
+
+_HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "traffic_ratio", "launch_ms", "launches_per_step",
+              "iterations_per_launch", "flop_per_launch")
+_CPU_KEYS = ("value", "unit", "cores", "host_cores", "kind", "sample")
+
+
+def _finite(o):
+    """The same structure with every non-finite float replaced by None (strict JSON has no NaN / Infinity)."""
+    if isinstance(o, float):
+        return o if np.isfinite(o) else None
+    if isinstance(o, (np.floating, np.integer)):
+        return _finite(o.item())
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def headline(full):
+    """The compact strict-JSON object the driver parses: the contract's keys, `roofline` of the dominant kernel, `cpu_baseline`, and one
+    figure per detail section (each section whole: bench_detail.json next to this file, and one line per section on stderr)."""
+    full = _finite(full)
+    head = {k: full[k] for k in _HEAD_KEYS if k in full}
+    cfg = full.get("config", {})
+    head["config"] = {k: cfg[k] for k in ("workload", "signals_per_gpu", "iterations_per_step", "launch", "rccl_world_size") if k in cfg}
+    if "roofline" in full:
+        head["roofline"] = {k: full["roofline"][k] for k in _ROOF_KEYS if k in full["roofline"]}
+    if isinstance(full.get("cpu_baseline"), dict):
+        head["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in _CPU_KEYS if k in full["cpu_baseline"]}
+        if head["cpu_baseline"].get("value"):
+            head["vs_cpu_baseline"] = full["value"] / head["cpu_baseline"]["value"]
+    also = {}
+    for name, sec in full.items():                     # one number per section, so the line says what the detail file holds
+        if isinstance(sec, dict) and name not in ("config", "roofline", "cpu_baseline", "final_losses") and isinstance(sec.get("value"), (int, float)):
+            also[name] = round(sec["value"], 1)
+    head["also_windows_per_s"] = also
+    head["detail"] = "bench_detail.json"
+    line = json.dumps(head, allow_nan=False, separators=(",", ":"))
+    if len(line) >= HEADLINE_MAX_BYTES:                # never grow past what the driver keeps: drop the optional parts, keep the contract
+        head.pop("also_windows_per_s", None)
+        line = json.dumps(head, allow_nan=False, separators=(",", ":"))
+    assert len(line) < HEADLINE_MAX_BYTES, len(line)
+    return line
+
+
+def emit(full, json_out, detail_path=None):
+    """Every section whole -> bench_detail.json and stderr (one section per line); the compact headline -> the LAST line of stdout."""
+    full = _finite(full)
+    detail_path = detail_path or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+    except OSError as e:                               # (a read-only checkout must not cost the run its line)
+        print("bench_detail.json not written: %s" % e, file=sys.stderr)
+    for name, sec in full.items():
+        if isinstance(sec, (dict, list)):
+            print(json.dumps({name: sec}, allow_nan=False), file=sys.stderr)
+    sys.stderr.flush()
+    json_out.write(headline(full) + "\n")
+    json_out.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1113,8 +1178,7 @@ def main():
             drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
             if out.get("cpu_baseline", {}).get("value"):
                 drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+        emit(out, json_out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
