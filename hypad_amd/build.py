@@ -17,7 +17,7 @@ LIB = os.path.join(LIB_DIR, "libhypad_hip.so")
 DEV_LIB = os.path.join(LIB_DIR, "libhypad_hip_dev.so")
 SOURCES = ["api_misc.hip", "ops_hyper.hip", "ops_dense.hip", "lstm_seq.hip", "train_iters.hip", "critic_fused.hip", "scoring.hip", "host_rng.cpp"]
 DEV_SOURCES = SOURCES + ["diag.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wno-pass-failed", "-Wno-unused-result"]
 
 
 def source_digest():
@@ -32,7 +32,7 @@ def source_digest():
 
 
 def _newest_source():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hypad.h")]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "hypad.h"), os.path.abspath(__file__)]
     return max(os.path.getmtime(f) for f in files)
 
 
@@ -73,7 +73,7 @@ def _build_locked(verbose, dev):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if src.endswith(".cpp"):               # host-only helpers (no device code): the system compiler
-            cmd = [os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [os.environ.get("CXX", "g++"), "-O3", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-ffp-contract=off", "-c", os.path.join(CSRC, src), "-o", obj]
         else:
             cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -86,7 +86,8 @@ def _build_locked(verbose, dev):
         if verbose and out.strip():
             print(out)
     tmp = lib + ".tmp.%d" % os.getpid()
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+                           "-o", tmp, *objs])
     os.replace(tmp, lib)                       # atomic: a concurrent importer never maps a half-written library
     return lib
 

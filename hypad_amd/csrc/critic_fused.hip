@@ -1962,5 +1962,5 @@ int critic_phase_record_info(const hypad_dims& d, int n_iters, int critic, hypad
 
 #if HYPAD_DIAG
 // development aid (dev library only): device buffer of 128 int64 that the next critic launches stamp, or null
-extern "C" void hypad_diag_set_fused_stamps(long long* p) { g_stamps = p; }
+extern "C" __attribute__((visibility("default"))) void hypad_diag_set_fused_stamps(long long* p) { g_stamps = p; }
 #endif

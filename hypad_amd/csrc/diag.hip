@@ -111,7 +111,7 @@ __global__ void diag_decoder_packed_kernel(const float* __restrict__ pk, PackedO
 
 }  // namespace
 
-extern "C" int hypad_diag_decoder_packed(const float* pk, const int* offs, const float* head_b, const float* z, float* hyper, int64_t rows,
+extern "C" __attribute__((visibility("default"))) int hypad_diag_decoder_packed(const float* pk, const int* offs, const float* head_b, const float* z, float* hyper, int64_t rows,
                                          int S, int L, long long* stamps, void* stream) {
   PackedOffs po;
   for (int i = 0; i < 13; ++i) po.o[i] = offs[i];
@@ -123,7 +123,7 @@ extern "C" int hypad_diag_decoder_packed(const float* pk, const int* offs, const
   return (int)hipGetLastError();
 }
 
-extern "C" int hypad_diag_decoder_timeline(const float* P, const float* z, float* hyper, int64_t rows, int S, int L, int mt,
+extern "C" __attribute__((visibility("default"))) int hypad_diag_decoder_timeline(const float* P, const float* z, float* hyper, int64_t rows, int S, int L, int mt,
                                            int threads, long long* stamps, hypad_stream_t s) {
   const int R = mt * 16;
   const int ldS = pad4(S) + 4;
@@ -229,7 +229,7 @@ __global__ void diag_coissue_kernel(long long* out, float seed, int mode, int w2
   }
 }
 }  // namespace
-extern "C" int hypad_diag_coissue(int mode, int w2, long long* out, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_coissue(int mode, int w2, long long* out, hypad_stream_t s) {
   const int kind = (mode >> 2) & 3;
   if (mode & 32) {
 #define CO(K, N) hipLaunchKernelGGL((diag_coissue_kernel<K, N>), dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, 4)
@@ -244,7 +244,7 @@ extern "C" int hypad_diag_coissue(int mode, int w2, long long* out, hypad_stream
   else hipLaunchKernelGGL(diag_coissue_kernel<3>, dim3(1), dim3(512), 0, (hipStream_t)s, out, 1.0f, mode, w2);
   return (int)hipGetLastError();
 }
-extern "C" int hypad_diag_mfma(int variant, int threads, long long* out, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_mfma(int variant, int threads, long long* out, hypad_stream_t s) {
   if (variant == 1) hipLaunchKernelGGL(diag_mfma_kernel<1>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
   else if (variant == 2) hipLaunchKernelGGL(diag_mfma_kernel<2>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
   else if (variant == 4) hipLaunchKernelGGL(diag_mfma_kernel<4>, dim3(1), dim3(threads), 0, (hipStream_t)s, out, 1.0f);
@@ -283,7 +283,7 @@ __global__ void diag_load_kernel(const float* __restrict__ W, int ldw, int ntile
   if (acc == 123.456f) sink[0] = acc;
 }
 }  // namespace
-extern "C" int hypad_diag_load(const float* W, int ldw, int ntiles, int mode, int threads, long long* out, float* sink, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_load(const float* W, int ldw, int ntiles, int mode, int threads, long long* out, float* sink, hypad_stream_t s) {
   hipLaunchKernelGGL(diag_load_kernel, dim3(1), dim3(threads), 0, (hipStream_t)s, W, ldw, ntiles, mode, out, sink);
   return (int)hipGetLastError();
 }
@@ -311,7 +311,7 @@ __global__ void diag_gemm_kernel(const float* __restrict__ W, int K, int N, long
   if (threadIdx.x == 0) { out[0] = t[1] - t[0]; out[1] = t[4] - t[3]; out[2] = (long long)ys[0]; }
 }
 }  // namespace
-extern "C" int hypad_diag_gemm(const float* W, int K, int N, int mt, int kind, int threads, long long* out, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_gemm(const float* W, int K, int N, int mt, int kind, int threads, long long* out, hypad_stream_t s) {
   const int ldx = pad4(K > N ? K : N) + 4;
   size_t lds = (size_t)(2 * mt * 16 * ldx + 16 * WSTAGE_FLOATS) * sizeof(float);
 #define LAUNCH(MT, KIND)                                                                                              \
@@ -411,7 +411,7 @@ __global__ void diag_tile_kernel(const float* __restrict__ W, long long* out) {
   if (acc[0] + acc2[0] == 123.456f) out[63] = 1;
 }
 }  // namespace
-extern "C" int hypad_diag_tile(const float* W, int mode, int threads, long long* out, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_tile(const float* W, int mode, int threads, long long* out, hypad_stream_t s) {
   size_t lds = (size_t)(16 * 132 + 16 * WSTAGE_FLOATS) * sizeof(float);
   switch (mode) {
     case 0: hipLaunchKernelGGL(diag_tile_kernel<0>, dim3(1), dim3(threads), lds, (hipStream_t)s, W, out); break;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void diag_store16_check_kernel(const unsigned*
 }  // namespace
 
 // buf: blocks * 256 * iters * 16 bytes (<= 2 GB); bad: device counter, zeroed by the caller.  Returns 0 or a HIP error.
-extern "C" int hypad_diag_store16(int form, int nops, int blocks, int iters, unsigned* buf, unsigned long long* bad, hypad_stream_t s) {
+extern "C" __attribute__((visibility("default"))) int hypad_diag_store16(int form, int nops, int blocks, int iters, unsigned* buf, unsigned long long* bad, hypad_stream_t s) {
   if (form < 0 || form > 2 || nops < 0 || nops > 4 || blocks < 1 || iters < 1 || (long long)blocks * 256 * iters * 16 > 0x7fffffffLL) return HYPAD_EINVAL;
 #define ST16_LAUNCH(F, N) hipLaunchKernelGGL((diag_store16_kernel<F, N>), dim3(blocks), dim3(256), 0, (hipStream_t)s, buf, iters)
 #define ST16_N(F) do { switch (nops) { case 0: ST16_LAUNCH(F, 0); break; case 1: ST16_LAUNCH(F, 1); break; case 2: ST16_LAUNCH(F, 2); break; \

@@ -1172,5 +1172,5 @@ int hypad_combine_scores(int mode, const double* c, const double* r, const doubl
 }  // extern "C"
 
 #if HYPAD_DIAG
-extern "C" void hypad_diag_set_unroll_stamps(long long* p) { g_unroll_stamps = p; }
+extern "C" __attribute__((visibility("default"))) void hypad_diag_set_unroll_stamps(long long* p) { g_unroll_stamps = p; }
 #endif

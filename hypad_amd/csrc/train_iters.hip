@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(64) void radam_ball_kernel(float* p, const float* g
 
 // development aid (not declared in hypad.h): device buffer of 64 int64 stamped by the generator kernel, or null
 #if HYPAD_DIAG
-extern "C" void hypad_diag_set_gen_stamps(long long* p) { g_gen_stamps = p; }
+extern "C" __attribute__((visibility("default"))) void hypad_diag_set_gen_stamps(long long* p) { g_gen_stamps = p; }
 #endif
 
 extern "C" {

@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the declarations below are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define HYPAD_ABI_VERSION 6
 
@@ -494,6 +498,9 @@ enum { HYPAD_COMB_SUM = 0, HYPAD_COMB_MULT = 1, HYPAD_COMB_UNCERTAINTY = 2, HYPA
 int hypad_combine_scores(int combination, const double* critic_scores, const double* rec_scores,
                          const double* uncertainty, double* out, int64_t n, hypad_stream_t stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
