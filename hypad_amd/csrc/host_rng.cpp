@@ -261,13 +261,19 @@ extern "C" int hypad_host_mt19937_normal_mt(uint32_t* key, int* pos, int* has_ga
     // helpers were SLOWER than one (15.7 against 11.9 ms for 4.1 M values: every accepted pair crossing the socket link).  Held on the
     // eight cores around the caller's (one core complex on that host: consecutive core numbers) 5.2 ms; on the caller's socket 8.3.
     // A mask the kernel refuses is simply not applied.
+    // Only the CPUs the caller may run on count (a cpuset / taskset that overlaps the eight partly would otherwise squeeze the helpers
+    // onto one or two cores while the generator keeps producing): with fewer than threads + 1 of them left, no pinning at all.
     const int cpu = sched_getcpu();
-    if (cpu >= 0) {
+    cpu_set_t allowed;
+    if (cpu >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
       cpu_set_t set;
       CPU_ZERO(&set);
       const int base = cpu & ~7;
-      for (int c = base; c < base + 8; ++c) CPU_SET(c, &set);
-      for (auto& t : pool) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
+      int n_set = 0;
+      for (int c = base; c < base + 8 && c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &allowed)) { CPU_SET(c, &set); ++n_set; }
+      if (n_set >= threads + 1)
+        for (auto& t : pool) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
     }
   }
 #endif

@@ -63,69 +63,3 @@ def torch_rand_into(out):
         return out
     torch.set_rng_state(state)
     return out
-
-
-TORCH_STATE_BYTES = 5056      # at::CPUGeneratorImplState (an at::mt19937 + the normal sampler's caches)
-
-
-def torch_rand_into(out):
-    """``out[...] = torch.rand(out.shape)`` on torch's DEFAULT CPU generator -- the same float32 values, the generator left where that
-    call would have left it (include/hypad.h: hypad_host_torch_mt19937_uniform) -- at ~3x the rate of torch's serial kernel and
-    without the interpreter lock.  ``out``: a contiguous float32 CPU tensor.  Falls back to ``torch.rand(out=)`` if the generator's
-    state is not the layout this was written for."""
-    import torch
-    if out.dtype != torch.float32 or not out.is_contiguous() or out.is_cuda:
-        raise _C.HypadError("torch_rand_into: a contiguous float32 CPU tensor")
-    state = torch.get_rng_state()
-    if state.numel() != TORCH_STATE_BYTES or state.dtype != torch.uint8 or not state.is_contiguous():
-        torch.rand(out.shape, out=out)
-        return out
-    rc = _C.lib.hypad_host_torch_mt19937_uniform(state.data_ptr(), TORCH_STATE_BYTES, out.data_ptr(), out.numel())
-    if rc != 0:                                   # (an unseeded / foreign engine state: let torch do it)
-        torch.rand(out.shape, out=out)
-        return out
-    torch.set_rng_state(state)
-    return out
-
-
-def _global_normal_pipelined(outs, chunk, rounds, pool):
-    """global_normal_into with phase 1 (hypad_host_mt19937_pairs: the sequential part) on this thread and phase 2
-    (hypad_host_normal_pairs_to_f32) of every block of ``BLOCK_PAIRS`` accepted pairs on ``pool``."""
-    st = np.random.get_state()
-    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
-    pos = ctypes.c_int(int(st[2]))
-    n_outs, total = len(outs), int(chunk) * int(rounds) * len(outs)
-    ptrs = (ctypes.c_void_p * n_outs)(*(o.ctypes.data for o in outs))
-    first = 0
-    if int(st[3]):                                   # the value NumPy left cached comes first
-        outs[0].reshape(-1)[0] = np.float32(0.0 + 1.0 * float(st[4]))
-        first = 1
-    pairs = (total - first + 1) // 2
-    cached = ctypes.c_double(0.0)
-    lib = _C.lib
-    ring = [[np.empty(BLOCK_PAIRS + 512, dtype=np.float64) for _ in range(3)] + [None] for _ in range(getattr(pool, "_max_workers", 2) + 2)]
-    errors = []
-
-    def transform(buf, n, p0):
-        rc = lib.hypad_host_normal_pairs_to_f32(buf[0].ctypes.data, buf[1].ctypes.data, buf[2].ctypes.data, n, p0, first, total, ptrs, n_outs, int(chunk),
-                                                ctypes.byref(cached))
-        if rc:
-            errors.append(rc)
-    p0, k = 0, 0
-    while p0 < pairs:
-        buf = ring[k % len(ring)]
-        if buf[3] is not None:
-            buf[3].result()                          # (the block that used these arrays last has been transformed)
-        n = min(BLOCK_PAIRS, pairs - p0)
-        _C.check(lib.hypad_host_mt19937_pairs(key.ctypes.data, ctypes.byref(pos), n, buf[0].ctypes.data, buf[1].ctypes.data, buf[2].ctypes.data),
-                 "host_mt19937_pairs")
-        buf[3] = pool.submit(transform, buf, n, p0)
-        p0 += n
-        k += 1
-    for buf in ring:
-        if buf[3] is not None:
-            buf[3].result()
-    if errors:
-        raise _C.HypadError(f"hypad_host_normal_pairs_to_f32: status {errors[0]}")
-    odd = (total - first) & 1
-    np.random.set_state(("MT19937", key, pos.value, 1 if odd else 0, cached.value if odd else 0.0))

@@ -16,6 +16,8 @@ import numpy as np
 
 
 def run(params, config_path=None, data_dir="./data", drop_in=True, log=print, resident=False, per_iteration=False):
+    """``drop_in`` (default True) = the reference's call chain over a DataLoader; ``drop_in=False`` or ``resident=True`` = the resident path."""
+    resident = resident or not drop_in
     import pandas as pd
     from torch.utils.data import DataLoader
 
@@ -124,10 +126,16 @@ def main(argv=None):
         import os
         import torch
         import torch.distributed as dist
+        own_group = False
         if "RANK" in os.environ and not dist.is_initialized():           # one process per GPU (torchrun): RCCL for the end-of-run gather
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        res = run_signals(params, [n.strip() for n in args.signals.split(",") if n.strip()], args.config, args.data_dir)
+            own_group = True
+        try:
+            res = run_signals(params, [n.strip() for n in args.signals.split(",") if n.strip()], args.config, args.data_dir)
+        finally:
+            if own_group:
+                dist.destroy_process_group()
         for name, r in sorted(res.items()):
             print(name, r["confusion"], r["metrics"])
         return res

@@ -340,9 +340,16 @@ class _SavedLayout:
         import zipfile
         if len(storage_bytes) != self.nbytes:
             raise _C.HypadError("checkpoint layout: the storage changed size")
+        import struct
         with zipfile.ZipFile(f, "w", compression=zipfile.ZIP_STORED) as z:
             for name, data in self.members:
-                z.writestr(zipfile.ZipInfo(name), storage_bytes if data is None else data)
+                info = zipfile.ZipInfo(name)
+                # every record's bytes start on a 64-byte boundary, as in torch.save's own archives (PyTorchStreamWriter pads the local
+                # header with an "FB" extra field): what lets torch.load(mmap=True) and other readers map the storage in place
+                start = z.fp.tell() + 30 + len(name.encode()) + 4
+                pad = -start % 64
+                info.extra = b"FB" + struct.pack("<H", pad) + b"Z" * pad
+                z.writestr(info, storage_bytes if data is None else data)
 
 
 class _CheckpointWriter:
@@ -406,6 +413,9 @@ class _CheckpointWriter:
                     if self.templates is None:
                         self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
                     pick = [(self.templates[k], k, None, f) for k, f in files.items()]
+                for t, k, _, _ in pick:                      # the flags the reference's loop has set when it saves (train.py:333-340, 381-385):
+                    if id(t) not in self.layouts:            # generator trainable, critics frozen -- pickled with the module, so set before its first save
+                        _set_requires_grad((t,), k in ("enc", "dec"))
                 host = {}                                    # the snapshot on the host: ONE copy per arena tensor, not one per file -- a small
                 for t, k, i, f in pick:                      # copy queues behind the kernels that hold the chip (128 of them: 40-130 ms)
                     src = snap[k] if i is None else snap[k][i]
@@ -476,7 +486,8 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
     losses_dev = [torch.empty(1, iters, 4, dtype=torch.float32, device=dev) for _ in range(2)]       # per epoch parity, like the feed's device sets
     back = [torch.empty(iters * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)]        # losses | counters (as bits)
     done = [torch.cuda.Event() for _ in range(2)]
-    hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], wall=[])       # wall: time.perf_counter() when each epoch's losses were on the host
+    hist = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], wall=[], repairs=0)      # wall: time.perf_counter() when each epoch's losses were on the
+    # host; repairs: resident critic launches that gave up (bounded wait) and were repeated launch by launch -- a ~10x slower epoch each
     actual_epoch = 0
     if resume:
         n_epochs = n_epochs - params.resume_epoch
@@ -526,6 +537,7 @@ def train_tadgan(train_loader, encoder, decoder, critic_x, critic_z, n_epochs=20
                         snaps[e + i] = writer.snapshot()
                 eng.check_status(on_epoch=recopy)                # restores, repeats every queued epoch with per-iteration launches
                 state["repaired_until"] = e + 1
+                hist.repairs += 1
             else:
                 eng.confirm_epochs(1)                            # epoch e completed: one epoch less for a later repair to look at
         if e <= state["repaired_until"]:
@@ -623,7 +635,7 @@ def train_tadgan_per_iteration(train_loader, encoder, decoder, critic_x, critic_
             torch.save(decoder, path + "/decoder_{}.pt".format(actual_epoch))
             torch.save(critic_x, path + "/critic_x_{}.pt".format(actual_epoch))
             torch.save(critic_z, path + "/critic_z_{}.pt".format(actual_epoch))
-    return SimpleNamespace(cx=cx_epoch_loss, cz=cz_epoch_loss, dec=decoder_epoch_loss, hyper=hyp_dec_loss, mse=eucl_dec_loss, wall=wall)
+    return SimpleNamespace(cx=cx_epoch_loss, cz=cz_epoch_loss, dec=decoder_epoch_loss, hyper=hyp_dec_loss, mse=eucl_dec_loss, wall=wall, repairs=0)
 
 
 def model_path(params):
@@ -664,6 +676,14 @@ def train(train_loader, params, config_path):
 
 
 # ------------------------------------------------------------------------------------------------ resident fast path
+def _host_shuffle_generator(dev, seed, stream):
+    """The device generator that draws a signal's shuffles when they cannot be drawn inside the captured epoch (more than
+    Engine.SHUFFLE_MAX_WINDOWS windows): keyed by (run seed, the signal's stream number = first_signal + slot) -- ONE rule for
+    train_tadgan_resident and train_signals_resident, so that a long signal trains the same way alone and inside a group, and two
+    signals of a run never share their permutations."""
+    return torch.Generator(device=dev).manual_seed((int(seed) ^ (0x9E3779B97F4A7C15 * int(stream))) & 0x7FFFFFFFFFFFFFFF)
+
+
 def _resident_epoch_means(rows, n_critics, n_batches):
     """(critic_x, critic_z, generator, hyperbolic-or-mse) epoch means of ONE model from its (iterations, 4) loss rows ON THE HOST: the
     one reduction both resident loops use (train_tadgan_resident for its model, train_signals_resident slot by slot), so that a
@@ -702,9 +722,9 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
     if n_batches < 1:
         raise _C.HypadError(f"{n_windows} windows do not fill one batch of {B}")
     n_critics = 5
-    gen = torch.Generator(device=dev).manual_seed(int(eng.seed) & 0x7FFFFFFF)
+    gen = _host_shuffle_generator(dev, eng.seed, first_signal)
     perm_buf = torch.empty(n_critics + 1, n_batches * B, dtype=torch.int32, device=dev)
-    history = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[])
+    history = SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], repairs=0)      # repairs: resident critic launches that gave up and were repeated
     actual_epoch = 0
     if getattr(params, "resume", False):
         n_epochs = n_epochs - params.resume_epoch
@@ -748,6 +768,7 @@ def train_tadgan_resident(dataset, encoder, decoder, critic_x, critic_z, n_epoch
                         snaps[e + i] = writer.snapshot()
                 eng.check_status(on_epoch=redo)
                 state["repaired_until"] = max(state["repaired"]) if state["repaired"] else e
+                history.repairs += 1
             else:
                 eng.confirm_epochs(1)
         rows = (state["repaired"].pop(e) if e in state["repaired"] else b[: iters * 4]).view(iters, 4)
@@ -891,12 +912,12 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
             x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
         in_graph = nmax <= eng.SHUFFLE_MAX_WINDOWS
         ri = torch.empty(k, n_critics + 1, nb * B, dtype=torch.int32, device=dev)
-        gens = None if in_graph else [torch.Generator(device=dev).manual_seed((seed ^ (0x9E3779B97F4A7C15 * (first + s))) & 0x7FFFFFFFFFFFFFFF) for s in range(k)]
+        gens = None if in_graph else [_host_shuffle_generator(dev, eng.seed, first + s) for s in range(k)]
         engines.append(dict(eng=eng, members=members, nb=nb, x=x, ri=ri, in_graph=in_graph, gens=gens, counts=[counts[i] for i in members], templates=templates,
                             back=[torch.empty(k * (2 * n_critics + 1) * nb * 4 + 8, dtype=torch.float32).pin_memory() for _ in range(2)],
                             done=[torch.cuda.Event() for _ in range(2)], snaps={}))
     torch.manual_seed(seed)
-    hist = {names[i]: SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[]) for _, ms in plan for i in ms}
+    hist = {names[i]: SimpleNamespace(cx=[], cz=[], dec=[], hyper=[], mse=[], repairs=0) for _, ms in plan for i in ms}
     paths = {}
     for _, ms in plan:
         for i in ms:
@@ -979,6 +1000,8 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
                         eng.check_status(on_epoch=redo)
                     g["repaired"] = kept
                     g["repaired_until"] = max(kept) if kept else e
+                    for i in g["members"]:                           # (every model of the group went through the repeat)
+                        hist[names[i]].repairs += 1
                 else:
                     eng.confirm_epochs(1)
             rows = g["repaired"][e].view(k, -1, 4) if e <= g.get("repaired_until", -1) and e in g.get("repaired", {}) else b[:n].view(k, -1, 4)

@@ -66,3 +66,30 @@ def test_layouts_it_does_not_recognise_are_refused():
         assert False
     except Exception as e:
         assert "size" in str(e)
+
+
+def _data_offsets(raw):
+    """{member name: file offset of its first data byte} from the local headers"""
+    import struct
+    out = {}
+    with zipfile.ZipFile(io.BytesIO(raw)) as z:
+        for i in z.infolist():
+            n, e = struct.unpack("<HH", raw[i.header_offset + 26: i.header_offset + 30])
+            out[i.filename] = i.header_offset + 30 + n + e
+    return out
+
+
+def test_rewritten_archive_keeps_torch_saves_64_byte_record_alignment():
+    m = Flat(n=48)
+    m.lin.weight = torch.nn.Parameter(m.flat.data[:12].view(3, 4))
+    raw = _saved(m)
+    ref = _data_offsets(raw)
+    assert all(off % 64 == 0 for name, off in ref.items() if "/data/" in name)                 # what torch.save itself does
+    lay = _SavedLayout.parse(raw, m.flat.detach().numpy().tobytes())
+    out = io.BytesIO()
+    lay.write(out, (m.flat.detach() * 3).numpy().tobytes())
+    mine = _data_offsets(out.getvalue())
+    assert set(mine) == set(ref)
+    assert all(off % 64 == 0 for off in mine.values()), mine
+    out.seek(0)
+    assert torch.equal(torch.load(out, weights_only=False).flat.detach(), m.flat.detach() * 3)

@@ -45,8 +45,10 @@ def test_drop_in_functions_in_the_phase_form(phase):
     tp.test_drop_in_iteration_functions_follow_host_rng(torch.device("cuda"))
 
 
-def test_the_phase_form_is_faster_on_the_gpu_and_counts_steps_alike(phase):
-    """Same step / tick accounting as the stand-alone launches (counters), and less GPU time per call."""
+def test_the_phase_form_counts_steps_like_the_stand_alone_launches(phase):
+    """Same step / tick accounting as the stand-alone launches (counters) and the same trajectory.  The GPU time of the two forms is
+    printed, not asserted: a timing claim does not belong in a parity suite the driver runs with -x (scripts/check_phase_form_speed.py
+    asserts it on request)."""
     import bench
     from hypad_amd.engine import Engine
     dev = torch.device("cuda", 0)
@@ -71,5 +73,4 @@ def test_the_phase_form_is_faster_on_the_gpu_and_counts_steps_alike(phase):
         out[on] = (best, eng.counters.cpu().tolist()[:4], eng.params["cx"].clone())
     print("critic_x GPU us per call: phase form %.1f, stand-alone launches %.1f" % (out[True][0], out[False][0]))
     assert out[True][1] == out[False][1] == [53, 3, 0, 56]
-    assert out[True][0] < 0.95 * out[False][0]          # (measured 44.5-45.0 against 63.3-63.7 us: the margin is for a busy host, this is a parity suite)
     assert float((out[True][2] - out[False][2]).abs().max()) < 5e-3        # 53 Adam steps on the same data: same trajectory to rounding

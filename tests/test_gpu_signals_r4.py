@@ -60,6 +60,33 @@ def test_signals_of_different_lengths_equal_single_signal_runs(tmp_path, monkeyp
     assert res["sig0"]["history"]["dec"] != res["sig2"]["history"]["dec"]
 
 
+def test_long_signals_with_host_drawn_shuffles_equal_single_signal_runs(tmp_path, monkeypatch):
+    """Signals beyond the in-graph sort's 4 096 windows draw their shuffles with a torch device generator: ONE seeding rule
+    (train._host_shuffle_generator: run seed x stream number) for the group loop and the single-signal loop, so the equivalence above
+    holds there too -- and two long signals of a run do not share their permutations."""
+    from hypad_amd import train as ht
+    from hypad_amd.engine import Engine
+    monkeypatch.chdir(tmp_path)
+    counts = [Engine.SHUFFLE_MAX_WINDOWS + 4, Engine.SHUFFLE_MAX_WINDOWS + 70, Engine.SHUFFLE_MAX_WINDOWS + 30]      # 64, 65, 64 minibatches
+    data = [windows(n, 20 + i) for i, n in enumerate(counts)]
+    names = ["long0", "long1", "long2"]
+    res = ht.train_signals_resident(data, P_(epochs=1), names=names, seed=31, init_seed=900, log=None, save=False)
+    for i, name in enumerate(names):
+        P = P_(epochs=1)
+        P.signal = name + "_single"
+        torch.manual_seed(900 + i)
+        enc, dec, cx, cz, path, hist = ht.train_resident(data[i], P, seed=31, log=None, first_signal=res[name]["stream"])
+        h = res[name]["history"]
+        for k in ("cx", "cz", "dec", "hyper"):
+            assert h[k] == getattr(hist, k), (name, k)
+        assert h["repairs"] == 0 and hist.repairs == 0
+        for a, b in zip(flat(res[name]["modules"]), flat([enc, dec, cx, cz])):
+            for key in a:
+                assert torch.equal(a[key], b[key]), (name, key)
+    g0, g1 = (ht._host_shuffle_generator("cuda", 31, s) for s in (0, 1))
+    assert not torch.equal(torch.rand(8, device="cuda", generator=g0), torch.rand(8, device="cuda", generator=g1))
+
+
 def test_first_signal_makes_a_model_independent_of_its_group():
     """Engine level: slot k of a group whose first_signal is f == a single model with first_signal = f + k (device Philox noise and
     dropout, shuffles drawn in the captured epoch from the model's own window count), bit for bit."""
