@@ -226,7 +226,16 @@ def bench_signals_product(n_signals, device, epochs=24):
     return out
 
 
-def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True):
+def _max_over_ranks(ms, dist, device):
+    """A per-rank duration -> the slowest rank's (the job's) under a process group; unchanged without one."""
+    if dist is None:
+        return ms
+    t = torch.tensor([ms], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True, dist=None, world=1):
     """`spg` signals (models) per GPU of workload `cfg`: the epoch replayed as a captured hipGraph (static shuffle buffer),
     `warmup` untimed + `steps` timed epochs; the same epochs launched eagerly (host-bound wherever ~61 launches of CPU enqueue
     exceed the GPU time); per-kernel launch times at this signal count and the chip-level rate: all algorithmic FLOPs of an
@@ -244,11 +253,13 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=Non
             for _ in range(warmup):                   # eager launches of the same epoch next to it; it does not reproduce in isolation)
                 step()
             torch.cuda.synchronize()
+            if dist is not None:                      # every rank's timed region starts together; the job's time is the slowest rank's
+                dist.barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
             torch.cuda.synchronize()
-            runs[mode].append(1e3 * (time.perf_counter() - t0) / steps)
+            runs[mode].append(_max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, dist, device))
             eng.check_status()
             assert bool(torch.isfinite(losses).all())
     for mode, v in runs.items():
@@ -257,7 +268,9 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=Non
     out["launch"] = "hipGraph replay of the captured epoch" + (" (shuffles: torch rand + argsort per epoch -- more than 4 096 windows)"
                                                                if cfg.n_windows > eng.SHUFFLE_MAX_WINDOWS else "")
     out["ms_per_step"] = out["graph_ms_per_step"]
-    out["value"] = spg * cfg.nb * cfg.B / (1e-3 * out["ms_per_step"])
+    out["value"] = world * spg * cfg.nb * cfg.B / (1e-3 * out["ms_per_step"])      # all ranks' windows / the slowest rank's time
+    out["n_gpus"] = world
+    out["unit"] = "windows/s (all %d GPU(s); per-rank times max-reduced)" % world
     prof = profile_kernels(eng, x, spg, device, reps=12, cfg=cfg)
     flop_step = spg * cfg.epoch_flop_per_signal()
     tflops = flop_step / (1e-3 * out["ms_per_step"]) / 1e12
@@ -271,6 +284,113 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=Non
                        "critic_phase": ("resident launch" + (" with its own record producers" if prof["producers"] else " behind a precompute launch"))
                                        if prof["persistent"] else "one launch per iteration"}
     del eng, x
+    return out
+
+
+def bench_signals_sharded(device, world, rank, per_gpu=8, epochs=24, warm=3):
+    """BASELINE.json configs[2] through the PRODUCT path under a process group: ``per_gpu * world`` signals of 1 916 windows through
+    ``hypad_amd.train.train_signals_resident`` -- plan_signal_groups shards the list over the ranks, every rank trains its own signals (one
+    model per signal, no collective on the data path), the per-signal metrics are gathered at the end (all_gather_object through RCCL).
+    All ranks call this.  dist.barrier() in front of and behind the call; `call_ms` = the slowest rank's; the steady-state epoch time =
+    the spacing of a rank's epoch log lines from epoch `warm` on, max over ranks; value = all ranks' windows / that.  At one GPU a
+    world-size-1 nccl group is created for the section, as bench_scoring_sharded does."""
+    import tempfile
+    from types import SimpleNamespace
+    import torch.distributed as dist
+    from hypad_amd import train as ht
+    own_group = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+        own_group = True
+    try:
+        n = per_gpu * world
+        datasets = [synth_windows(N_WINDOWS, S, s) for s in range(n)]                  # (every rank holds the list; it uploads only its own signals)
+        names = ["sig%03d" % i for i in range(n)]
+        plan, _ = ht.plan_signal_groups([N_WINDOWS] * n, B, world, rank)
+        mine = sum(len(m) for _, m in plan)
+        P = SimpleNamespace(batch_size=B, signal_shape=S, latent_space_dim=L, lr=5e-4, hyperbolic=True, epochs=epochs, dataset="bench", signal="s",
+                            resume=False, resume_epoch=0)
+        stamps = []
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as d:
+            os.chdir(d)
+            try:
+                dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = ht.train_signals_resident(datasets, P, names=names, seed=1, log=lambda s_: stamps.append(time.perf_counter()), save=False)
+                torch.cuda.synchronize(); dist.barrier()
+                call_ms = 1e3 * (time.perf_counter() - t0)
+            finally:
+                os.chdir(cwd)
+        assert sorted(res) == names and all(len(res[k]["history"]["dec"]) == epochs for k in names)      # every rank holds every signal's history
+        assert all(np.isfinite(res[k]["history"]["dec"]).all() for k in names)
+        w = np.diff(np.asarray(stamps))[warm - 1:] * 1e3
+        steady = _max_over_ranks(float(w.mean()), dist, device)
+        setup = _max_over_ranks(1e3 * (stamps[0] - t0), dist, device)
+        call_ms = _max_over_ranks(call_ms, dist, device)
+        return {"what": "configs[2] through train_signals_resident under a process group: %d signals of %d windows (%d per GPU), hyperbolic, %d epochs; "
+                        "value = all ranks' windows per epoch / the slowest rank's steady-state epoch time (epochs %d.. of one call)" % (n, N_WINDOWS, per_gpu, epochs, warm),
+                "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "signals": n, "signals_this_rank": mine,
+                "ranks_of_signals": sorted({res[k]["rank"] for k in names}), "epochs": epochs,
+                "ms_per_epoch": steady, "value": n * N_BATCHES * B / steady * 1e3, "unit": "windows/s (all ranks)",
+                "call_ms": call_ms, "setup_and_first_epoch_ms": setup, "call_value": n * N_BATCHES * B * epochs / call_ms * 1e3,
+                "repairs": int(sum(res[k]["history"].get("repairs", 0) for k in names))}
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+
+
+def bench_call_level(device, epochs=40):
+    """What a user's call costs, set-up included (the headline is steady state): ``hypad_amd.train.train(train_loader, params, config_path)``
+    -- main.py:53 -- at configs[1] with the reference's 40 epochs (configs/univariate.yaml:3): models built, engine and graph set up, 40
+    epochs, final checkpoint files; wall time of the whole call and of its parts."""
+    import contextlib
+    import io
+    import tempfile
+    from types import SimpleNamespace
+    from torch.utils.data import DataLoader
+    from hypad_amd import train as ht
+    ds = _synthetic_signal_dataset()
+    out = {"what": "train.train(DataLoader(SignalDataset, batch 64, shuffle, drop_last), params, None): configs[1], %d epochs (configs/univariate.yaml), "
+                   "checkpoints at the reference's cadence; call_ms = the whole call (second of two calls in this process; first_call_ms = the first: "
+                   "library load, stream probe, allocator warm-up)" % epochs, "epochs": epochs}
+    cwd = os.getcwd()
+    calls = []
+    for rep in range(2):
+        loader = DataLoader(ds, batch_size=B, drop_last=True, shuffle=True, num_workers=0)
+        P = SimpleNamespace(batch_size=B, signal_shape=S, lr=5e-4, hyperbolic=True, epochs=epochs, dataset="bench", signal="call%d" % rep, resume=False, resume_epoch=0)
+        torch.manual_seed(rep); np.random.seed(rep)
+        with tempfile.TemporaryDirectory() as d:
+            os.chdir(d)
+            try:
+                stamps = []
+
+                class Stamper(io.StringIO):              # the epochs' print lines (train.py:367), stamped as they are written
+                    def write(self, text):
+                        if "training done in epoch" in text:
+                            stamps.append(time.perf_counter())
+                        return len(text)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(Stamper()):
+                    ht.train(loader, P, None)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                calls.append(1e3 * (t1 - t0))
+                parts = {"setup_and_first_epoch_ms": 1e3 * (stamps[0] - t0), "ms_per_epoch": 1e3 * float(np.diff(stamps)[1:].mean()),
+                         "after_last_epoch_ms": 1e3 * (t1 - stamps[-1])}
+                parts["setup_ms"] = parts["setup_and_first_epoch_ms"] - parts["ms_per_epoch"]
+            finally:
+                os.chdir(cwd)
+    out["first_call_ms"], out["call_ms"] = calls
+    out.update(parts)                                    # (of the second call)
+    out["value"] = epochs * N_BATCHES * B / (calls[1] * 1e-3)
+    out["unit"] = "windows/s over the whole call"
     return out
 
 
@@ -1076,34 +1196,48 @@ def main():
 
     # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
     # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
+    def section(fn, *a, **kw):
+        """A detail section must never cost the run its headline: an exception is reported in its place (under a process group it is
+        re-raised -- the other ranks would wait for this one in the section's collectives)."""
+        try:
+            return fn(*a, **kw)
+        except Exception as e:
+            if world > 1:
+                raise
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
     secondary = None
     if spg == 1 and hyperbolic and not args.no_secondary:
-        secondary = bench_signals(8, rank, device, gen)
+        secondary = section(bench_signals, 8, rank, device, gen, dist=dist, world=world)
 
     # ---- the other BASELINE.json configs as sections of the same line, each the graph-replayed epoch of its shape with its own roofline:
     # configs[0] on the GPU (hyperbolic=False), configs[3] (5 channels x 30 = window 150, batch 256, 20 480 windows: the compile-time
     # <150, 20, 256> kernels), and 32 signals (models) per GPU -- every CU holds a critic workgroup
     extra = {}
     if spg == 1 and hyperbolic and not args.no_extra_configs:
-        extra["euclidean"] = bench_signals(1, rank, device, gen, warmup=3, steps=20, cfg=Cfg("configs[0]", hyperbolic=False), eager=False,
-                                           what="configs[0] on the GPU: univariate, hyperbolic=False, batch 64, window 100, 1 916 windows, 1 signal")
-        extra["multivariate"] = bench_signals(1, rank, device, gen, warmup=2, steps=8, cfg=Cfg("configs[3]", S=150, B=256, n_windows=20480, data="uniform"),
-                                              eager=False, what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
-                                                                "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations")
-        extra["signals32"] = bench_signals(32, rank, device, gen, warmup=2, steps=8, eager=False,
-                                           what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
-
-        if world == 1:              # (under a process group train_signals_resident shards its list over the ranks: another measurement)
-            try:
-                extra["signals32"]["product_loop"] = bench_signals_product(32, device)
-            except Exception as e:  # (reported, not hidden; the section above stands on its own)
-                extra["signals32"]["product_loop"] = f"{type(e).__name__}: {e}"[:300]
+        extra["euclidean"] = section(bench_signals, 1, rank, device, gen, warmup=3, steps=20, cfg=Cfg("configs[0]", hyperbolic=False), eager=False, dist=dist, world=world,
+                                     what="configs[0] on the GPU: univariate, hyperbolic=False, batch 64, window 100, 1 916 windows, 1 signal")
+        extra["multivariate"] = section(bench_signals, 1, rank, device, gen, warmup=2, steps=8, cfg=Cfg("configs[3]", S=150, B=256, n_windows=20480, data="uniform"),
+                                        eager=False, dist=dist, world=world,
+                                        what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
+                                             "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations")
+        extra["signals32"] = section(bench_signals, 32, rank, device, gen, warmup=2, steps=8, eager=False, dist=dist, world=world,
+                                     what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
+        if world == 1 and "error" not in extra["signals32"]:      # (one process: the 32-model product loop with its set-up and checkpoint files)
+            extra["signals32"]["product_loop"] = section(bench_signals_product, 32, device)
+    # ---- configs[2] through the product path under a process group (train_signals_resident + plan_signal_groups): every rank, by default
+    if spg == 1 and hyperbolic and not args.no_secondary:
+        extra["signals_sharded"] = section(bench_signals_sharded, device, world, rank)
+    if spg == 1 and hyperbolic and rank == 0 and not args.no_drop_in:
+        extra["call_level"] = section(bench_call_level, device)
 
     # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
     # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
     drop_in = None
     if spg == 1 and rank == 0 and not args.no_drop_in:
-        drop_in = bench_drop_in(hyperbolic, device)
+        drop_in = section(bench_drop_in, hyperbolic, device)
 
     sharded = None
     # (one GPU: on by default, through a one-rank RCCL group; several GPUs: only on request -- the multi-GPU collectives have never
@@ -1174,7 +1308,7 @@ def main():
             out["scoring_sharded"] = sharded
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hyperbolic)
-        if drop_in is not None:                                  # the reference's call surface against the device-RNG path and the CPU
+        if drop_in is not None and "value" in drop_in:          # the reference's call surface against the device-RNG path and the CPU
             drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
             if out.get("cpu_baseline", {}).get("value"):
                 drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]

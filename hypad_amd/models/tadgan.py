@@ -21,6 +21,7 @@ from .. import _C
 from .. import autograd as hag
 from ..arena import ArenaModule
 from ..hyperspace.hyrnn_nets import MobiusLinear
+from .init import linear_init, lstm_init
 
 _tick = itertools.count(1)
 
@@ -50,10 +51,9 @@ class Encoder(ArenaModule):
         super().__init__()
         self.signal_shape, self.latent_space_dim = signal_shape, latent_space_dim
         # same construction (and RNG consumption) order as models/tadgan.py:15-21
-        lstm = nn.LSTM(input_size=signal_shape, hidden_size=50, num_layers=1, bidirectional=True)
-        dense = nn.Linear(in_features=100, out_features=latent_space_dim)
-        init = {f"lstm.{k}": v for k, v in _named(lstm).items()}
-        init.update({f"dense.{k}": v for k, v in _named(dense).items()})
+        # (init.py: the draws of nn.LSTM(signal_shape, 50, 1, bidirectional=True) and nn.Linear(100, latent), without the modules)
+        init = {f"lstm.{k}": v for k, v in lstm_init(signal_shape, 50, 1, True).items()}
+        init.update({f"dense.{k}": v for k, v in linear_init(100, latent_space_dim).items()})
         self._init_arena(_C.NET_ENCODER, signal_shape, latent_space_dim, False, init)
 
     def forward(self, x):
@@ -70,12 +70,9 @@ class Decoder(ArenaModule):
     def __init__(self, signal_shape=100, latent_space_dim=20, hyperbolic=False):
         super().__init__()
         self.signal_shape, self.latent_space_dim, self.hyperbolic = signal_shape, latent_space_dim, hyperbolic
-        dense1 = nn.Linear(in_features=latent_space_dim, out_features=50)                       # models/tadgan.py:34
-        lstm = nn.LSTM(input_size=50, hidden_size=64, num_layers=2, dropout=0.2, bidirectional=True)
-        dense2 = nn.Linear(in_features=128, out_features=signal_shape)
-        init = {f"dense1.{k}": v for k, v in _named(dense1).items()}
-        init.update({f"lstm.{k}": v for k, v in _named(lstm).items()})
-        init.update({f"dense2.{k}": v for k, v in _named(dense2).items()})
+        init = {f"dense1.{k}": v for k, v in linear_init(latent_space_dim, 50).items()}        # models/tadgan.py:34
+        init.update({f"lstm.{k}": v for k, v in lstm_init(50, 64, 2, True).items()})          # nn.LSTM(50, 64, num_layers=2, dropout=0.2, bidirectional=True)
+        init.update({f"dense2.{k}": v for k, v in linear_init(128, signal_shape).items()})
         from ..arena import _Group
         self.dense1, self.lstm, self.dense2 = _Group(), _Group(), _Group()      # registration order = the reference's
         if hyperbolic:
@@ -111,7 +108,7 @@ class CriticX(ArenaModule):
         dims = [(signal_shape, latent_space_dim)] + [(latent_space_dim, latent_space_dim)] * 3 + [(latent_space_dim, 1)]
         init = {}
         for i, (a, b) in enumerate(dims, 1):                                                    # models/tadgan.py:77-89
-            init.update({f"dense{i}.{k}": v for k, v in _named(nn.Linear(a, b)).items()})
+            init.update({f"dense{i}.{k}": v for k, v in linear_init(a, b).items()})
         self._init_arena(_C.NET_CRITIC_X, signal_shape, latent_space_dim, False, init)
 
     def forward(self, x, dropout_masks=None):
@@ -130,7 +127,7 @@ class CriticZ(ArenaModule):
         self.latent_space_dim = latent_space_dim
         init = {}
         for i, (a, b) in enumerate([(latent_space_dim, latent_space_dim)] * 2 + [(latent_space_dim, 1)], 1):
-            init.update({f"dense{i}.{k}": v for k, v in _named(nn.Linear(a, b)).items()})      # models/tadgan.py:113-119
+            init.update({f"dense{i}.{k}": v for k, v in linear_init(a, b).items()})            # models/tadgan.py:113-119
         self.dropout = nn.Dropout(p=0.2)
         self.leakyrelu = nn.LeakyReLU(0.2)
         self._init_arena(_C.NET_CRITIC_Z, latent_space_dim, latent_space_dim, False, init)

@@ -906,10 +906,13 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
         for slot, i in enumerate(members):
             torch.manual_seed(init_seed + i)                     # train.py:415-426 construction order
             mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
-            for net, m in mods.items():
-                eng.load_state_dict(net, m.state_dict(), slot)
             templates.append(mods)                               # (the signal's module objects: checkpoints and the result are written through them)
             x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
+        for net in ("enc", "dec", "cx", "cz"):                   # the group's initial weights: ONE upload per network (a module's host arena IS the
+            host = torch.stack([t[net]._arena for t in templates])      # engine's row layout: arena.py / hypad_param_info), not 54 tensor copies per model
+            if host.shape != eng.params[net].shape:
+                raise _C.HypadError(f"arena layout mismatch for {net}: {tuple(host.shape)} vs {tuple(eng.params[net].shape)}")
+            eng.params[net].copy_(host)
         in_graph = nmax <= eng.SHUFFLE_MAX_WINDOWS
         ri = torch.empty(k, n_critics + 1, nb * B, dtype=torch.int32, device=dev)
         gens = None if in_graph else [_host_shuffle_generator(dev, eng.seed, first + s) for s in range(k)]

@@ -20,4 +20,6 @@ for (S,B,hyper,n) in [(100,64,True,1916),(100,64,False,256),(150,256,True,2*256+
     for a,b in (("epoch","epoch_pi"),("epoch_pi","call"),("epoch","call")):
         mx = max(float((wa[k]-wb[k]).abs().max()) for wa,wb in zip(runs[a][1],runs[b][1]) for k in wa)
         hd = max(abs(x-y) for nm in ("cx","cz","dec") for x,y in zip(getattr(runs[a][0],nm),getattr(runs[b][0],nm)))
-        print(S,B,hyper,n,a,b,"max weight diff",mx,"max hist diff",hd)
+        rel = max(float((wa[k]-wb[k]).norm() / wb[k].norm().clamp_min(1e-12)) for wa,wb in zip(runs[a][1],runs[b][1]) for k in wa if "weight_hh" not in k)
+        worst = max(((float((wa[k]-wb[k]).norm() / wb[k].norm().clamp_min(1e-12)), k) for wa,wb in zip(runs[a][1],runs[b][1]) for k in wa if "weight_hh" not in k))
+        print(S,B,hyper,n,a,b,"max weight diff",mx,"max hist diff",hd, "max rel L2", rel, worst[1])

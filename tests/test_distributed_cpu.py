@@ -200,3 +200,35 @@ def test_two_rank_sharded_euclidean_scores_equal_unsharded():
         want, _, _ = scoring.score_anomalies(y, y_hat, critic, kind, "mult")
         assert np.allclose(one, want, rtol=0, atol=1e-10, equal_nan=True), kind
         assert np.isnan(one).all() == (w == 0)                                # fewer than 100 windows: pandas' window-0 NaNs
+
+
+def _bench_aggregate_worker(rank, world, port, ret):
+    """bench.py's multi-rank accounting (bench_signals / bench_signals_sharded): per-rank durations are max-reduced over the group, the
+    job's rate = ALL ranks' windows / the slowest rank's time; plan_signal_groups gives every rank its share of the 8 x world signals."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from hypad_amd import train as ht
+        mine_ms = 3.0 + 2.0 * rank                                      # rank 1 is the slow one
+        job_ms = bench._max_over_ranks(mine_ms, dist, torch.device("cpu"))
+        n = 8 * world
+        plan, stream = ht.plan_signal_groups([bench.N_WINDOWS] * n, bench.B, world, rank)
+        members = [i for _, ms in plan for i in ms]
+        every = [None] * world
+        dist.all_gather_object(every, members)
+        ret[rank] = (job_ms, len(members), sorted(i for m in every for i in m), n * bench.N_BATCHES * bench.B / job_ms * 1e3)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_aggregate_is_all_ranks_windows_over_the_slowest_rank():
+    import bench
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_bench_aggregate_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        job_ms, mine, union, value = ret[r]
+        assert job_ms == 5.0 and mine == 8 and union == list(range(16))
+        assert abs(value - 16 * 29 * 64 / 5.0e-3) < 1e-6
+    assert bench._max_over_ranks(1.25, None, torch.device("cpu")) == 1.25      # no group: unchanged

@@ -194,6 +194,7 @@ def test_the_resident_loops_repair_a_launch_that_gave_up(tmp_path, monkeypatch):
         P.epoch_flags = flags
         h = ht.train_tadgan_resident(windows(2 * B + 5, 3), *mods, n_epochs=2, params=P, path=str(d), seed=5, log=None)
         got.append((vars(h), [{k: v.detach().cpu() for k, v in m.state_dict().items()} for m in mods], files(d)))
+    assert got[0][0].pop("repairs") == 0 and got[1][0].pop("repairs") == 1        # the give-up is COUNTED in the history it repaired (not only logged)
     assert got[0][0] == got[1][0] and all(np.isfinite(got[1][0]["cx"])) and len(got[1][0]["cx"]) == 2
     for wa, wb in zip(got[0][1], got[1][1]):
         assert all(torch.equal(wa[k], wb[k]) for k in wa)
@@ -208,6 +209,7 @@ def test_the_resident_loops_repair_a_launch_that_gave_up(tmp_path, monkeypatch):
         r = ht.train_signals_resident(data, P, names=["a", "b", "c"], seed=9, init_seed=100, log=None)
         res.append(r)
     for n in ("a", "b", "c"):
+        assert res[0][n]["history"].pop("repairs") == 0 and res[1][n]["history"].pop("repairs") == 1, n
         assert res[0][n]["history"] == res[1][n]["history"], n
         for ma, mb in zip(res[0][n]["modules"], res[1][n]["modules"]):
             sa, sb = ma.state_dict(), mb.state_dict()
@@ -234,6 +236,7 @@ def test_small_groups_on_lanes_equal_the_groups_one_after_the_other(tmp_path, mo
         runs.append(ht.train_signals_resident(data, P, names=names, seed=3, init_seed=40, log=None))
     for n in names:
         assert runs[0][n]["history"] == runs[1][n]["history"], n
+        assert runs[0][n]["history"]["repairs"] == 0 and runs[1][n]["history"]["repairs"] == 0, n      # co-resident lanes: no resident launch gave up
         assert len(runs[1][n]["history"]["dec"]) == 11 and np.isfinite(runs[1][n]["history"]["dec"]).all()
         for ma, mb in zip(runs[0][n]["modules"], runs[1][n]["modules"]):
             sa, sb = ma.state_dict(), mb.state_dict()
@@ -318,3 +321,66 @@ def test_signal_metrics_gather_through_a_one_rank_rccl_group(tmp_path, monkeypat
     data = [windows(n, i) for i, n in enumerate(COUNTS[:3])]
     plain = ht.train_signals_resident(data, P_(epochs=2), names=["a", "b", "c"], seed=5, init_seed=9, log=None)
     assert {n: r["history"] for n, r in plain.items()} == dict(ret["hist"])
+
+
+def test_run_signals_end_to_end_on_two_csv_signals(tmp_path, monkeypatch, capsys):
+    """``python -m hypad_amd.main --config cfg.yaml --signals siga,sigb`` (main.run_signals; /root/reference/main.py:32-70 once per
+    signal, train.py:428-437 directories): two synthetic CSV signals -> SignalDataset -> train_signals_resident (one group of two
+    models) -> per signal the test loop, the scoring kernels, intervals and the overlap-segment counts -> metrics of both signals.
+    Through the argument parser and through the function; the per-signal models equal train_resident on that signal alone."""
+    import json
+    import yaml
+    from hypad_amd import main as hmain
+    from hypad_amd import train as ht
+    from hypad_amd.utils import data as od
+    d = tmp_path / "data"
+    d.mkdir()
+    n = 700
+    t0 = 1_400_000_000
+    rows = []
+    for k, name in enumerate(("siga", "sigb")):
+        rng = np.random.default_rng(50 + k)
+        tt = np.arange(n)
+        v = np.sin(2 * np.pi * tt / (60.0 + 11 * k)) + 0.05 * rng.standard_normal(n)
+        v[400:430] += 1.5
+        with open(d / f"{name}.csv", "w") as f:
+            f.write("timestamp,value\n" + "\n".join(f"{t0 + 600 * i},{x:.6f}" for i, x in zip(tt, v)) + "\n")
+        rows.append('%s,"[[%d, %d]]"' % (name, t0 + 600 * 395, t0 + 600 * 435))
+    with open(d / "anomalies.csv", "w") as f:
+        f.write("signal,events\n" + "\n".join(rows) + "\n")
+    cfg = dict(dataset="NAB", signal="siga", epochs=2, hyperbolic=True, signal_shape=100, lr=5e-4, batch_size=64, save_result=False, filename="",
+               rec_error="dtw", combination="mult", interval=600, unique_dataset=True, resume=False, resume_epoch=0, load=False)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(9)
+    res = hmain.main(["--config", str(tmp_path / "cfg.yaml"), "--data-dir", str(d), "--signals", "siga, sigb"])
+    out = capsys.readouterr().out
+    assert sorted(res) == ["siga", "sigb"] and "siga" in out and "sigb" in out
+    for name in ("siga", "sigb"):
+        r = res[name]
+        assert r["path"] == f"./trained_models/models_hyper_NAB_2_0.0005/NAB/{name}" and r["rank"] == 0
+        assert len(r["confusion"]) == 4 and r["n_intervals"] >= 0 and np.isfinite(r["final"]["dec"])
+        assert sorted(os.listdir(r["path"]))[:4] == ["critic_x.pt", "critic_z.pt", "decoder.pt", "encoder.pt"]
+        assert os.path.exists(os.path.join(r["path"], "recons_signal.pt"))          # the test loop's artefacts (anomaly_detection.py:116-131)
+        json.dumps(r)                                                                # plain data: what all_gather_object carries
+    # the function form with the same seed trains the same models, and each equals its single-signal run
+    P = SimpleNamespace(**cfg)
+    torch.manual_seed(9)
+    again = hmain.run_signals(P, ["siga", "sigb"], None, str(d), log=lambda s_: None)
+    assert {k: again[k]["final"] for k in again} == {k: res[k]["final"] for k in res}
+    sets = []
+    for name in ("siga", "sigb"):
+        p = SimpleNamespace(**cfg); p.signal = name
+        sets.append(od.dataset_selection(p, str(d))[0])
+    torch.manual_seed(9)
+    both = ht.train_signals_resident(sets, SimpleNamespace(**cfg), names=["siga", "sigb"], log=None, save=False)
+    for i, name in enumerate(("siga", "sigb")):
+        assert both[name]["final"] == res[name]["final"]
+        p = SimpleNamespace(**cfg); p.signal = name + "_alone"
+        torch.manual_seed(9 + i)
+        enc, dec, cx, cz, _, hist = ht.train_resident(sets[i], p, seed=9, log=None, first_signal=both[name]["stream"])
+        assert hist.dec == both[name]["history"]["dec"] and hist.hyper == both[name]["history"]["hyper"]
+        saved = torch.load(os.path.join(res[name]["path"], "decoder.pt"), weights_only=False)
+        for k, v in dec.state_dict().items():
+            assert torch.equal(v.cpu(), saved.state_dict()[k].cpu()), (name, k)
