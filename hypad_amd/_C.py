@@ -235,8 +235,20 @@ def require_cuda(t, name="tensor", dtype=torch.float32):
     return t
 
 
+_catalogues = {}
+
+
 def param_catalogue(net, S, L, hyperbolic):
-    """[(name, offset, shape)] and the padded float count of one network's arena."""
+    """[(name, offset, shape)] and the padded float count of one network's arena (a function of the four arguments only: remembered --
+    every module construction asks, 0.8 ms of ctypes calls each)."""
+    key = (int(net), int(S), int(L), int(bool(hyperbolic)))
+    if key not in _catalogues:
+        _catalogues[key] = _param_catalogue(*key)
+    cat, total = _catalogues[key]
+    return list(cat), total
+
+
+def _param_catalogue(net, S, L, hyperbolic):
     n = lib.hypad_param_tensors(net, int(hyperbolic))
     if n < 0:
         raise HypadError("bad network id")

@@ -676,6 +676,22 @@ def train(train_loader, params, config_path):
 
 
 # ------------------------------------------------------------------------------------------------ resident fast path
+import contextlib
+
+
+@contextlib.contextmanager
+def _one_host_thread():
+    """Module construction is thousands of tiny CPU tensor ops (fills and copies of <= 40 000 floats).  On a many-core host torch's
+    intra-op pool wakes every core for the ones above its grain size -- torch.zeros of a 63 000-float arena took 1.7 ms on the GPU box's
+    256-core host, half of train_signals_resident's set-up -- so they run on the calling thread; the setting is restored on exit."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(n)
+
+
 def _host_shuffle_generator(dev, seed, stream):
     """The device generator that draws a signal's shuffles when they cannot be drawn inside the captured epoch (more than
     Engine.SHUFFLE_MAX_WINDOWS windows): keyed by (run seed, the signal's stream number = first_signal + slot) -- ONE rule for
@@ -903,16 +919,17 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
         nmax = max(counts[i] for i in members)
         templates = []
         x = torch.zeros(k, nmax, S, dtype=torch.float32, device=dev)
-        for slot, i in enumerate(members):
-            torch.manual_seed(init_seed + i)                     # train.py:415-426 construction order
-            mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
-            templates.append(mods)                               # (the signal's module objects: checkpoints and the result are written through them)
-            x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
-        for net in ("enc", "dec", "cx", "cz"):                   # the group's initial weights: ONE upload per network (a module's host arena IS the
-            host = torch.stack([t[net]._arena for t in templates])      # engine's row layout: arena.py / hypad_param_info), not 54 tensor copies per model
-            if host.shape != eng.params[net].shape:
-                raise _C.HypadError(f"arena layout mismatch for {net}: {tuple(host.shape)} vs {tuple(eng.params[net].shape)}")
-            eng.params[net].copy_(host)
+        with _one_host_thread():
+            for slot, i in enumerate(members):
+                torch.manual_seed(init_seed + i)                 # train.py:415-426 construction order
+                mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
+                templates.append(mods)                           # (the signal's module objects: checkpoints and the result are written through them)
+                x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
+            for net in ("enc", "dec", "cx", "cz"):               # the group's initial weights: ONE upload per network (a module's host arena IS the
+                host = torch.stack([t[net]._arena for t in templates])      # engine's row layout: arena.py / hypad_param_info), not 54 tensor copies per model
+                if host.shape != eng.params[net].shape:
+                    raise _C.HypadError(f"arena layout mismatch for {net}: {tuple(host.shape)} vs {tuple(eng.params[net].shape)}")
+                eng.params[net].copy_(host)
         in_graph = nmax <= eng.SHUFFLE_MAX_WINDOWS
         ri = torch.empty(k, n_critics + 1, nb * B, dtype=torch.int32, device=dev)
         gens = None if in_graph else [_host_shuffle_generator(dev, eng.seed, first + s) for s in range(k)]

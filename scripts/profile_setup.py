@@ -21,7 +21,12 @@ torch.cuda.init(); torch.zeros(1, device="cuda")
 data = [bench.synth_windows(bench.N_WINDOWS, bench.S, s) for s in range(n)]
 P = lambda: SimpleNamespace(batch_size=64, signal_shape=100, latent_space_dim=20, lr=5e-4, hyperbolic=True, epochs=2, dataset="bench", signal="s", resume=False, resume_epoch=0)
 os.chdir(tempfile.mkdtemp())
-for rep in range(2):
+for rep in range(3):
+    t0 = time.perf_counter()
+    ht.train_signals_resident(data, P(), seed=1, log=None, save=False)
+    torch.cuda.synchronize()
+    print("train_signals_resident(%d signals, 2 epochs) plain call %d: %.1f ms" % (n, rep, 1e3 * (time.perf_counter() - t0)))
+for rep in range(1):
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()

@@ -57,33 +57,44 @@ def states():
 @pytest.mark.parametrize("S,B,hyper,n,stage", [(100, 64, True, 1916, False), (100, 64, True, 3 * 64 + 5, True), (100, 64, False, 4 * 64, False),
                                                (150, 256, True, 2 * 256 + 9, False)])
 def test_epoch_form_equals_the_call_by_call_loop(tmp_path, capsys, S, B, hyper, n, stage):
-    """Same seeds, eval mode (dropout is the one stream the two forms draw differently: device Philox keyed per engine): two epochs.
-    First-epoch losses agree to 1e-4 (the hoisted critic phase and the stand-alone launches differ in summation order only); the
-    second epoch and the weights stay within what Adam's conditioning allows (a critic bias gradient of ~1e-8
-    moves its weight by lr * g / (|g| + eps))."""
+    """Same seeds, eval mode (dropout is the one stream the forms draw differently: device Philox keyed per engine): two epochs, three
+    forms -- the captured epoch with the resident critic launch, the captured epoch with one launch per critic iteration
+    (EPOCH_PER_ITERATION) and the call-by-call loop.  What pins the epoch form: its first-epoch losses (1e-4 against both other forms:
+    they differ in summation order only), the oracle-driven loop below (test_epoch_form_against_the_oracle_loop) and BOTH global
+    generators ending where the call-by-call loop leaves them.  The three forms are NOT bit-equal to each other (measured, r5: the
+    per-iteration epoch form and the call-by-call loop, which share the iteration kernels, still end 2.9e-3 apart in max |dw| after 580
+    steps at configs[1]'s shape: chunk shares, slabs and finalising launches sum in different orders, and Adam turns a last-bit
+    difference in a ~1e-8 bias gradient into lr-sized steps -- DESIGN.md section 2), so the weights are held to a TRAJECTORY bound with a
+    5-7x margin over what was measured (max |dw| 2.9e-3, relative L2 per tensor 1.5e-2), not to the vacuous lr x steps of round 4."""
     from hypad_amd import train as ht
     ds = Windows(n, S)
     loader = DataLoader(ds, batch_size=B, drop_last=True, shuffle=True, num_workers=0)
     runs = {}
-    for form in ("epoch", "call"):
+    from hypad_amd import _C
+    for form in ("epoch", "epoch_pi", "call"):
         mods = build(S, hyper, 5)
         np.random.seed(21); torch.manual_seed(21)
         P = P_(B, S, hyper, per_iteration=(form == "call"), stage_samples=stage)
+        if form == "epoch_pi":
+            P.epoch_flags = _C.EPOCH_PER_ITERATION
         hist = ht.train_tadgan(loader, *mods, n_epochs=2, params=P, path=str(tmp_path))
         torch.cuda.synchronize()
         runs[form] = (hist, weights(mods), states())
     out = capsys.readouterr().out
-    assert out.count("Encoder decoder training done in epoch") == 4 and ("Hyperbolic loss" in out) == hyper
-    he, hc = runs["epoch"][0], runs["call"][0]
-    for name in ("cx", "cz", "dec", "hyper" if hyper else "mse"):
-        a, b = getattr(he, name), getattr(hc, name)
-        assert len(a) == len(b) == 2
-        assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(b[0])), (name, a, b)
-        assert abs(a[1] - b[1]) < 5e-3 * max(1.0, abs(b[1])), (name, a, b)
-    steps = 2 * 5 * (n // B)
-    for wa, wb in zip(runs["epoch"][1], runs["call"][1]):
-        for k in wa:
-            assert float((wa[k] - wb[k]).abs().max()) <= 2.2 * 5e-4 * steps, k      # two trajectories, each within lr per step of the other
+    assert out.count("Encoder decoder training done in epoch") == 6 and ("Hyperbolic loss" in out) == hyper
+    for fa, fb in (("epoch", "call"), ("epoch", "epoch_pi"), ("epoch_pi", "call")):
+        ha, hb = runs[fa][0], runs[fb][0]
+        for name in ("cx", "cz", "dec", "hyper" if hyper else "mse"):
+            a, b = getattr(ha, name), getattr(hb, name)
+            assert len(a) == len(b) == 2
+            assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(b[0])), (fa, fb, name, a, b)
+            assert abs(a[1] - b[1]) < 2e-3 * max(1.0, abs(b[1])), (fa, fb, name, a, b)
+        for wa, wb in zip(runs[fa][1], runs[fb][1]):
+            for k in wa:
+                d = wa[k] - wb[k]
+                assert float(d.abs().max()) <= 2e-2, (fa, fb, k, float(d.abs().max()))
+                assert float(d.norm()) <= 0.08 * max(float(wb[k].norm()), 1e-3), (fa, fb, k, float(d.norm()), float(wb[k].norm()))
+        assert ha.repairs == 0 and hb.repairs == 0
     # both global generators end where the call-by-call loop leaves them
     (na, ta), (nb_, tb) = runs["epoch"][2], runs["call"][2]
     assert np.array_equal(na[0], nb_[0]) and na[1:] == nb_[1:] and torch.equal(ta, tb)
