@@ -92,5 +92,42 @@ def _build_locked(verbose, dev):
     return lib
 
 
+def kernel_metadata(obj):
+    """[{name, vgpr_count, vgpr_spill_count, sgpr_count, sgpr_spill_count, private_segment_fixed_size, group_segment_fixed_size, ...}]
+    of the gfx950 code object inside a host object file built above (the .hip_fatbin section, un-bundled with the ROCm LLVM tools;
+    names demangled): what tests/test_cabi_and_host.py holds the compile-time instantiations to."""
+    import re
+    import tempfile
+    llvm = os.environ.get("HYPAD_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return []
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+    out, cur = [], None
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2).strip().strip("'")
+        if key == "agpr_count" or key == "args":                     # (a kernel's first key in the note's order: agpr_count; args for argument lists)
+            pass
+        if key == "name" and val.startswith("_Z") or (key == "name" and cur is not None and "symbol" in cur and False):
+            cur = {"name": val}
+            out.append(cur)
+        elif cur is not None and key in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
+                                         "group_segment_fixed_size", "agpr_count", "max_flat_workgroup_size", "wavefront_size"):
+            cur[key] = int(val)
+    names = [k["name"] for k in out]
+    if names:
+        dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+        for k, n in zip(out, dem):
+            k["mangled"], k["name"] = k["name"], n
+    return [k for k in out if "vgpr_count" in k]
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

@@ -451,7 +451,6 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
   float4 sx[NITEM][4], sy[NITEM][4];
   float pv[NITEM][4], mv[NITEM][4], vv[NITEM][4];
   int off[NITEM][4], i_li[NITEM], i_n[NITEM], i_k[NITEM], i_so[NITEM];
-  const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
   // the weight tiles' padding columns (beyond the bias column) are read by the products: zero them once, here
   for (int i = threadIdx.x; i < L * (ldin - C0); i += FT) { const int n = i / (ldin - C0), c = i - n * (ldin - C0); w0[n * ldin + C0 + c] = 0.f; }
   for (int i = threadIdx.x; i < (nh - 1) * Lp * LQ; i += FT) {          // everything outside the L x L blocks
@@ -495,9 +494,9 @@ __device__ __forceinline__ void critic_iteration_body(const IterArgs& a, const P
     const int so = t * 512 + ((qq & 3) * 16 + jj) * 4;
     const int N = last ? 1 : L, K = first ? in_dim : L;                   // K = index of the bias column
     const int n = 4 * qq;
-    int wof = cw_[0], bof = cb_[0];
-#pragma unroll
-    for (int x = 1; x <= nh; ++x) { wof = li == x ? cw_[x] : wof; bof = li == x ? cb_[x] : bof; }
+    // critic_layout (layout.h) in closed form (a table indexed by li becomes a scratch array)
+    const int wof = li == 0 ? 0 : pad4(L * in_dim) + pad4(L) + (li - 1) * (pad4(L * L) + pad4(L));
+    const int bof = li == 0 ? pad4(L * in_dim) : (li == nh ? wof + pad4(L) : wof + pad4(L * L));
     i_li[u] = live ? li : -1; i_n[u] = n; i_k[u] = k; i_so[u] = so;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -960,7 +959,21 @@ constexpr unsigned SPIN_LIMIT = 1u << 21;    // bounded waits: ~1 s of polling
 // __builtin_amdgcn_raw_buffer_load_b128 element by element (v[1], v[2] ...) is narrowed to ONE buffer_load_dword whose value
 // stands for all four elements; bit-cast the whole vector to f32x4 first (and build stores the same way round).
 
-HD bool persist_geom_supported(const CritGeom& g, int nchunks) {
+// Adam-state quads ("slots") a thread of the resident kernel owns: layer 0's I0 quads take NA rounds of all 512 threads (phase A);
+// at the compile-time shapes the last round's free threads take other-layer quads from the END of the list (`tail` of them) where
+// that saves a slot; what is left of the other layers takes rounds of the five helper waves (phase B).  Window 150: 755 + 336 quads
+// = 2 rounds + (336 - 269 = 67 quads ->) 1 round = 3 slots (4 before the tail rode along: 12 more state registers per thread, part of
+// the 89 that instantiation spilled); window 100: 3 slots without a tail; critic_z: 2, never the kernel's register bound.
+constexpr int persist_tail(int in_dim, int L, int nh) {
+  const int Q = (L + 3) / 4, I0 = Q * (in_dim + 1), other = (nh - 1) * Q * (L + 1) + L + 1, NA = (I0 + FT - 1) / FT, BT = (NW - 3) * 64;
+  const int tail = NA * FT - I0 < other ? NA * FT - I0 : other;
+  return (nh == 4 && (other - tail + BT - 1) / BT < (other + BT - 1) / BT) ? tail : 0;
+}
+constexpr int persist_slots(int in_dim, int L, int nh) {
+  const int Q = (L + 3) / 4, I0 = Q * (in_dim + 1), other = (nh - 1) * Q * (L + 1) + L + 1, NA = (I0 + FT - 1) / FT, BT = (NW - 3) * 64;
+  return NA + (other - persist_tail(in_dim, L, nh) + BT - 1) / BT;
+}
+HD bool persist_geom_supported(const CritGeom& g, int nchunks) {      // (run-time shapes: no tail, PSLOT slots)
   const int Q = (g.L + 3) >> 2;
   const int I0 = Q * (g.in_dim + 1), nitems = I0 + (g.nh - 1) * Q * (g.L + 1) + g.L + 1;
   const int NA = (I0 + FT - 1) / FT, BT = (NW - 3) * 64;
@@ -983,7 +996,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   // weight-gradient tiles per wave (seven waves share them): exact at the compile-time shapes, MAXT otherwise
   constexpr int TPW = (SC && LC) ? (persist_tiles(IS_X ? SC : LC, LC, nh) + NW - 2) / (NW - 1) : MAXT;
   // state quads per thread: window 100 needs 1 (layer 0) + 2 (the other layers over waves 3-7); critic_z fewer still
-  constexpr int PS = !IS_X ? 2 : (SC == 100 && LC == 20 ? 3 : PSLOT);
+  constexpr int PS = (SC && LC) ? persist_slots(IS_X ? SC : LC, LC, nh) : (IS_X ? PSLOT : 2);
   const CriticLayout cl = IS_X ? cx_layout(S, L) : cz_layout(L);
   const CritGeom g = IS_X ? cx_geom(S, L) : cz_geom(L);
   const IterLds fl = iter_lds(g);
@@ -1010,6 +1023,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   const int I0 = Q * C0, Ih = Q * Ch, nitems = I0 + (nh - 1) * Ih + Ch;
   constexpr int BW0 = 3, BT = (NW - BW0) * 64;
   const int NA = (I0 + FT - 1) / FT;
+  constexpr int TAILI = (SC && LC) ? persist_tail(IS_X ? SC : LC, LC, nh) : 0;      // other-layer quads (the list's last ones) in phase A's free threads
   const bool bthread = wave >= BW0;
   const int btid = threadIdx.x - BW0 * 64;
   const int slabf = nitems * 4;
@@ -1045,7 +1059,6 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     const int n = i / (LQ - Ch), c = i - n * (LQ - Ch);
     wh[n * LQ + Ch + c] = 0.f;
   }
-  const int cw_[5] = {cl.w[0], cl.w[1], cl.w[2], cl.w[3], cl.w[4]}, cb_[5] = {cl.b[0], cl.b[1], cl.b[2], cl.b[3], cl.b[4]};
   int i_li[PS], i_n[PS], i_k[PS], i_e[PS];
   float pv[PS][4], mv[PS][4], vv[PS][4];
   // arena offset of row r of slot u (or -1); recomputed where needed (setup, final write) instead of held in registers
@@ -1054,16 +1067,23 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     if (li < 0) return -1;
     const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
     if (i_n[u] + r >= N) return -1;
-    int wof = cw_[0], bof = cb_[0];
-#pragma unroll
-    for (int x = 1; x <= nh; ++x) { wof = li == x ? cw_[x] : wof; bof = li == x ? cb_[x] : bof; }
+    // critic_layout (layout.h) in closed form -- a table indexed by li became a scratch array (64 bytes of private segment per lane)
+    const int wof = li == 0 ? 0 : pad4(L * in_dim) + pad4(L) + (li - 1) * (pad4(L * L) + pad4(L));
+    const int bof = li == 0 ? pad4(L * in_dim) : (li == nh ? wof + pad4(L) : wof + pad4(L * L));
     return i_k[u] < K ? wof + (i_n[u] + r) * K + i_k[u] : bof + i_n[u] + r;
   };
 #pragma unroll
   for (int u = 0; u < PS; ++u) {
     int e = -1;
-    if (u < NA) { const int e0 = threadIdx.x + u * FT; e = e0 < I0 ? e0 : -1; }
-    else if (bthread) { const int e0 = I0 + (u - NA) * BT + btid; e = e0 < nitems ? e0 : -1; }
+    if (u < NA) {
+      const int e0 = threadIdx.x + u * FT;
+      if constexpr (TAILI == 0) e = e0 < I0 ? e0 : -1;
+      else e = e0 < I0 ? e0 : (e0 - I0 < TAILI ? nitems - TAILI + (e0 - I0) : -1);
+    } else if (bthread) {
+      const int e0 = I0 + (u - NA) * BT + btid;
+      if constexpr (TAILI == 0) e = e0 < nitems ? e0 : -1;
+      else e = e0 < nitems - TAILI ? e0 : -1;
+    }
     i_e[u] = e;
     const int ee = e < 0 ? 0 : e;
     const bool first = ee < I0;
@@ -1155,7 +1175,11 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     PSTAMP(0);
     const bool fin = it == n_iters;
     const int ppar = (it - 1) & 1;
-    u32x4_t x0[PS][4];
+    // layer-0 slots whose first four shares are requested at the loop top: all of them, except at window 150 (two slots: the second
+    // one's sixteen registers were spilled; it loads inside finish() like the other layers' quads)
+    constexpr int NPRE_C = (SC == 150) ? 1 : PS;
+    const int NPRE = NA < NPRE_C ? NA : NPRE_C;
+    u32x4_t x0[NPRE_C][4];
     int obase = 0;
     if (it > 0) {
       // ---- every chunk's share of iteration it - 1
@@ -1194,7 +1218,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         for (int w = 0; w < 4; ++w) {
           // (measured and dropped in round 3: the helper waves requesting their other-layer quads here too, so that phase B starts
           // with its shares in registers -- the chains wait 1.8 k cycles for phase B: +28 spilled registers, epoch +0.015 ms)
-          if (u >= NA) continue;                                         // (compile-time for the reference shapes: NA is)
+          if (u >= NPRE) continue;                                       // (compile-time for the reference shapes: NA is)
           x0[u][w] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (obase + (w < nchunks ? w : 0) * slabf + (i_e[u] < 0 ? 0 : i_e[u]) * 4) * 4, 0, 16);
         }
       // Adam's bias corrections of this step: the tail of the previous iteration's record (whose flag this workgroup has seen:
@@ -1209,7 +1233,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     auto finish = [&](int u) __attribute__((always_inline)) {
       const int li = i_li[u];
       f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
-      const bool pre = u < NA;                                                       // the first four chunks' shares are in x0 already
+      const bool pre = u < NPRE;                                                     // the first four chunks' shares are in x0 already
       if (it > 0) {
         if (pre) {
 #pragma unroll
@@ -1220,6 +1244,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
             for (int r = 0; r < 4; ++r) gsum[r] += on * xf[r];
           }
         }
+#pragma unroll 1                                                                    // (batch 256 compiled in: unrolled, its loads were hoisted and spilled)
         for (int w0c = pre ? 4 : 0; w0c < nchunks; w0c += 4) {                        // batches above 64 rows: four more chunks at a time
           u32x4_t x[4];
 #pragma unroll
@@ -1723,7 +1748,7 @@ using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
 // compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
 static IterKernel phase_kernel(int S, int L, int B, bool persistent) {
   const bool s100 = S == 100 && L == 20 && B == 64, s150 = S == 150 && L == 20 && B == 256;
-  return persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 0> : critic_persistent_kernel<0, 0, 0>)
+  return persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 256> : critic_persistent_kernel<0, 0, 0>)
                     : (s100 ? critic_iteration_kernel<100, 20, 64> : s150 ? critic_iteration_kernel<150, 20, 0> : critic_iteration_kernel<0, 0, 0>);
 }
 // Does the runtime place at least one workgroup of the resident kernel on a CU (registers + the full LDS plan)?  Asked once
