@@ -108,19 +108,22 @@ def kernel_metadata(obj):
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
     out, cur = [], None
-    for line in notes.splitlines():
-        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+    for line in notes.splitlines():                          # (kernel entries: "  - .agpr_count: 0" then "    .key: value" lines; nested lists sit deeper)
+        m = re.match(r"^  ([- ]) \.(\w+):\s*(.*)$", line)
         if not m:
             continue
-        key, val = m.group(1), m.group(2).strip().strip("'")
-        if key == "agpr_count" or key == "args":                     # (a kernel's first key in the note's order: agpr_count; args for argument lists)
-            pass
-        if key == "name" and val.startswith("_Z") or (key == "name" and cur is not None and "symbol" in cur and False):
-            cur = {"name": val}
+        if m.group(1) == "-":
+            cur = {}
             out.append(cur)
-        elif cur is not None and key in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size",
-                                         "group_segment_fixed_size", "agpr_count", "max_flat_workgroup_size", "wavefront_size"):
+        if cur is None:
+            continue
+        key, val = m.group(2), m.group(3).strip().strip("'")
+        if key == "name":
+            cur["name"] = val
+        elif key in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size",
+                     "agpr_count", "max_flat_workgroup_size", "wavefront_size"):
             cur[key] = int(val)
+    out = [k for k in out if "name" in k]
     names = [k["name"] for k in out]
     if names:
         dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()

@@ -157,13 +157,13 @@ __device__ __forceinline__ void stage_critic_padded(float* dst, const float* __r
   const int in_dim = cl.in_dim, nh = cl.nh;
   for (int i = threadIdx.x; i < L * cp.ldin; i += blockDim.x) {
     const int n = i / cp.ldin, k = i - n * cp.ldin;
-    dst[cp.w0 + i] = k < in_dim ? P[cl.w[0] + n * in_dim + k] : (k == in_dim ? P[cl.b[0] + n] : 0.f);
+    dst[cp.w0 + i] = k < in_dim ? P[cl.wof(0) + n * in_dim + k] : (k == in_dim ? P[cl.bof(0) + n] : 0.f);
   }
   for (int i = threadIdx.x; i < (nh - 1) * L * cp.LQ; i += blockDim.x) {
     const int li = 1 + i / (L * cp.LQ), rem = i - (li - 1) * L * cp.LQ, n = rem / cp.LQ, k = rem - n * cp.LQ;
-    dst[cp.wh + i] = k < L ? P[cl.w[li] + n * L + k] : (k == L ? P[cl.b[li] + n] : 0.f);
+    dst[cp.wh + i] = k < L ? P[cl.wof(li) + n * L + k] : (k == L ? P[cl.bof(li) + n] : 0.f);
   }
-  for (int k = threadIdx.x; k < cp.LQ; k += blockDim.x) dst[cp.wl + k] = k < L ? P[cl.w[nh] + k] : (k == L ? P[cl.b[nh]] : 0.f);
+  for (int k = threadIdx.x; k < cp.LQ; k += blockDim.x) dst[cp.wl + k] = k < L ? P[cl.wof(nh) + k] : (k == L ? P[cl.bof(nh)] : 0.f);
 }
 // scratch of one tile pass: in [16][ldin] | act [nh][16][LQ] | dm [nh][16][LQ] | dl [2][16][LQ]
 HD int critic_tile_floats(const CriticPad& cp, int nh) { return 16 * cp.ldin + (2 * nh + 2) * 16 * cp.LQ; }

@@ -81,8 +81,8 @@ __device__ __forceinline__ void critic_batch_fwd(InRow in_row, const float* P, c
     float* a = s.act + li * R * LQ;
     float* dmk = s.dm + li * R * LQ;
     const int K = li == 0 ? cl.in_dim : L;
-    const float* W = P + cl.w[li];
-    const float* b = P + cl.b[li];
+    const float* W = P + cl.wof(li);
+    const float* b = P + cl.bof(li);
     const int total = R * L;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
       const int r = idx / L, c = idx - r * L;
@@ -96,8 +96,8 @@ __device__ __forceinline__ void critic_batch_fwd(InRow in_row, const float* P, c
   }
   if ((int)threadIdx.x < R) {
     const float* x = s.act + (cl.nh - 1) * R * LQ + threadIdx.x * LQ;
-    const float* w = P + cl.w[cl.nh];
-    float acc = P[cl.b[cl.nh]];
+    const float* w = P + cl.wof(cl.nh);
+    float acc = P[cl.bof(cl.nh)];
     for (int c = 0; c < L; ++c) acc += x[c] * w[c];
     s.out[threadIdx.x] = acc;
   }
@@ -113,7 +113,7 @@ __device__ __forceinline__ const float* critic_batch_bwd(DoutFn dout, const floa
   float* cur = s.dl;
   float* nxt = s.dl + R * LQ;
   {
-    const float* wl = P + cl.w[cl.nh];
+    const float* wl = P + cl.wof(cl.nh);
     const float* d = s.dm + (cl.nh - 1) * R * LQ;
     for (int idx = threadIdx.x; idx < R * L; idx += blockDim.x) {
       const int r = idx / L, c = idx - r * L;
@@ -124,7 +124,7 @@ __device__ __forceinline__ const float* critic_batch_bwd(DoutFn dout, const floa
   sink(cl.nh - 1, cur);
   for (int li = cl.nh - 2; li >= 0; --li) {
     const float* dd = s.dm + li * R * LQ;
-    dense_rows_valu_t(cur, LQ, L, P + cl.w[li + 1], L, R, [&](int r, int c, float v) { nxt[r * LQ + c] = v * dd[r * LQ + c]; });
+    dense_rows_valu_t(cur, LQ, L, P + cl.wof(li + 1), L, R, [&](int r, int c, float v) { nxt[r * LQ + c] = v * dd[r * LQ + c]; });
     __syncthreads();
     sink(li, nxt);
     float* t = cur; cur = nxt; nxt = t;

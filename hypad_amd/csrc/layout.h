@@ -126,9 +126,14 @@ struct CriticLayout {
   int w[5], b[5];      // layer li: weight (L, in_dim | L) ... last (1, L)
   float p_drop;
   int total;
+  int L;               // hidden width
+  // w[li] / b[li] in closed form, for device code that indexes with a run-time layer number: indexing the arrays there puts the
+  // whole struct into scratch memory (60 bytes of private segment per lane in every kernel that did)
+  HD int wof(int li) const { return li == 0 ? 0 : pad4(L * in_dim) + pad4(L) + (li - 1) * (pad4(L * L) + pad4(L)); }
+  HD int bof(int li) const { return li == 0 ? pad4(L * in_dim) : wof(li) + (li == nh ? pad4(L) : pad4(L * L)); }
 };
 HD CriticLayout critic_layout(int in_dim, int L, int nh, float p_drop) {
-  CriticLayout c; c.nh = nh; c.in_dim = in_dim; c.p_drop = p_drop; int o = 0;
+  CriticLayout c; c.nh = nh; c.in_dim = in_dim; c.p_drop = p_drop; c.L = L; int o = 0;
   for (int i = 0; i <= nh; ++i) {
     int k = i == 0 ? in_dim : L;
     int n = i == nh ? 1 : L;

@@ -238,7 +238,7 @@ __device__ __forceinline__ void critic_fwd_tile(const float* Xs, int ldx, const 
   for (int li = 0; li < cl.nh; ++li) {
     float* a = s.act + li * 16 * LP;
     float* d = s.dm + li * 16 * LP;
-    gemm_nt<1>(in, ldin, P + cl.w[li], kin, kin, L, identity_map(), P + cl.b[li], nullptr, a, LP, 0, wst);
+    gemm_nt<1>(in, ldin, P + cl.wof(li), kin, kin, L, identity_map(), P + cl.bof(li), nullptr, a, LP, 0, wst);
     __syncthreads();
     tile_for(16, L, [&](int r, int c) {
       const float pre = a[r * LP + c];
@@ -251,8 +251,8 @@ __device__ __forceinline__ void critic_fwd_tile(const float* Xs, int ldx, const 
   }
   // last layer (1, L): one thread per row
   if (threadIdx.x < 16) {
-    const float* w = P + cl.w[cl.nh];
-    float acc = P[cl.b[cl.nh]];
+    const float* w = P + cl.wof(cl.nh);
+    float acc = P[cl.bof(cl.nh)];
     for (int c = 0; c < L; ++c) acc += in[threadIdx.x * LP + c] * w[c];
     s.out[threadIdx.x] = acc;
   }
@@ -267,13 +267,13 @@ __device__ __forceinline__ const float* critic_bwd_chain_tile(const float* dout,
                                                               int L, const CriticLds& s, Sink sink) {
   float* cur = s.dl;
   float* nxt = s.dl + 16 * LP;
-  const float* wl = P + cl.w[cl.nh];
+  const float* wl = P + cl.wof(cl.nh);
   const float* d = s.dm + (cl.nh - 1) * 16 * LP;
   tile_for(16, L, [&](int r, int c) { cur[r * LP + c] = dout[r] * wl[c] * d[r * LP + c]; });
   __syncthreads();
   sink(cl.nh - 1, cur);
   for (int li = cl.nh - 2; li >= 0; --li) {
-    gemm_nn<1>(cur, LP, 0, P + cl.w[li + 1], L, L, identity_map(), L, nxt, LP, false);
+    gemm_nn<1>(cur, LP, 0, P + cl.wof(li + 1), L, L, identity_map(), L, nxt, LP, false);
     __syncthreads();
     const float* dd = s.dm + li * 16 * LP;
     tile_for(16, L, [&](int r, int c) { nxt[r * LP + c] *= dd[r * LP + c]; });

@@ -529,8 +529,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
   double* v = vals[wave];
   float* vf = vals32[wave];
   float* nf = nsq32[wave];
-  const double scottW = pow((double)W, -0.4);
-  const double rW1 = W > 1 ? 1.0 / (double)(W - 1) : 0.0;
+  // per-thread constants of the timestep loop, held in SCALAR registers (they are wave-uniform; as vector values the compiler kept them
+  // in scratch memory across the loop: 20 bytes of private segment per lane and two scratch loads per timestep)
+  auto uniform = [](double x) __attribute__((always_inline)) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+  };
+  // Scott's factor n^(-2/5) for every sample count 1 .. W, one power per thread, once (the 2 (W - 1) edge timesteps have fewer than W
+  // samples; a double-precision pow inside the loop -- ~200 instructions, its 40 polynomial constants hoisted into vector registers
+  // across the loop -- was what this kernel spilled around)
+  __shared__ double scott[WMAX];
+  for (int c = threadIdx.x; c < W && c < WMAX; c += THREADS) scott[c] = pow((double)(c + 1), -0.4);
+  __syncthreads();
+  const double rW1 = uniform(W > 1 ? 1.0 / (double)(W - 1) : 0.0);
   for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
     const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
     const int j1 = (int)(t + 1 < W ? t + 1 : W);
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
     const double var = cnt > 1 ? wave_sum(q) * (cnt == W ? rW1 : 1.0 / (double)(cnt - 1)) : 0.0;      // np.cov: ddof = 1, `c *= 1 / fact`
     // Scott: factor = n^(-1/5), squared.  (All but the 2 (W - 1) edge timesteps have cnt == W: that power is taken once per
     // thread, not once per timestep -- a double-precision pow is ~200 instructions.)
-    const double cov = var * (cnt == W ? scottW : pow((double)cnt, -0.4));
+    const double cov = var * uniform(scott[cnt - 1]);
     double out;
     if (cnt > 1 && cov > 0.0 && cov == cov) {
       // pass 1: fp32 densities of this lane's samples.  exp(-d^2 inv) = exp2(-(c d)^2) with c = sqrt(inv log2 e): the samples are

@@ -90,7 +90,7 @@ __device__ __forceinline__ void critic_three_passes(const IterArgs& a, int sig, 
   const float* d0 = critic_batch_bwd([&](int r) { return r < 16 ? -invB : r < 32 ? invB : 1.f; }, P, cl, L, cb,
                                      [&](int li, const float* delta) { tile_store_p(ws + cw.left[li] + (int64_t)g0 * L, L, B, delta, LQ, 48, L, 48); });
   // g = delta_0 W_0 for the interpolated rows (train.py:75-81)
-  dense_rows_valu_t(d0 + 32 * LQ, LQ, L, P + cl.w[0], in_dim, 16, [&](int r, int c, float v) { gbuf[r * ldgb + c] = v; });
+  dense_rows_valu_t(d0 + 32 * LQ, LQ, L, P + cl.wof(0), in_dim, 16, [&](int r, int c, float v) { gbuf[r * ldgb + c] = v; });
   __syncthreads();
   tile_store(ws + cw.in_right + ((int64_t)2 * B + g0) * in_dim, in_dim, gbuf, ldgb, 16, in_dim, 16);
   float sq = 0.f;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void gp_body(const IterArgs& a, float* smem) {
     us[r * ldu + c] = u;
   });
   __syncthreads();
-  dense_rows_valu(us, ldu, in_dim, PC + cl.w[0], nullptr, 16, L, [&](int r, int c, float v) { e0[r * LP + c] = v; });
+  dense_rows_valu(us, ldu, in_dim, PC + cl.wof(0), nullptr, 16, L, [&](int r, int c, float v) { e0[r * LP + c] = v; });
   __syncthreads();
   float* cur = e0; float* nxt = e1;
   for (int li = 1; li <= nh; ++li) {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void gp_body(const IterArgs& a, float* smem) {
     });
     __syncthreads();
     if (li < nh) {
-      dense_rows_valu(cur, LP, L, PC + cl.w[li], nullptr, 16, L, [&](int r, int c, float v) { nxt[r * LP + c] = v; });
+      dense_rows_valu(cur, LP, L, PC + cl.wof(li), nullptr, 16, L, [&](int r, int c, float v) { nxt[r * LP + c] = v; });
       __syncthreads();
       float* t = cur; cur = nxt; nxt = t;
     }
@@ -1130,6 +1130,11 @@ int check_dims(const hypad_dims* d) {
   if (d->batch % 16 != 0) return HYPAD_EINVAL;
   if (d->signal_shape > MAX_S || d->latent_dim > MAX_L) return HYPAD_EUNSUPPORTED;
   if (gen_table(*d).n < 0) return HYPAD_EUNSUPPORTED;      // cannot happen within MAX_S / MAX_L; the critic tables are far smaller
+  // the closed forms device code uses for a critic's tensor offsets (layout.h CriticLayout::wof / bof) ARE the layout's table
+  const CriticLayout cls[2] = {cx_layout(d->signal_shape, d->latent_dim), cz_layout(d->latent_dim)};
+  for (const CriticLayout& cl : cls)
+    for (int li = 0; li <= cl.nh; ++li)
+      if (cl.wof(li) != cl.w[li] || cl.bof(li) != cl.b[li]) return HYPAD_EUNSUPPORTED;
   return HYPAD_OK;
 }
 
@@ -1192,11 +1197,11 @@ __global__ __launch_bounds__(256) void pack_generator_kernel(IterArgs a, PackTab
       const float* C = a.P.cx + (int64_t)sig * a.pcx;
       const int L = a.L, in_dim = cl.in_dim;
       float v;
-      if (u < cp.wh) { const int n = u / cp.ldin, k = u - n * cp.ldin; v = k < in_dim ? C[cl.w[0] + n * in_dim + k] : (k == in_dim ? C[cl.b[0] + n] : 0.f); }
+      if (u < cp.wh) { const int n = u / cp.ldin, k = u - n * cp.ldin; v = k < in_dim ? C[cl.wof(0) + n * in_dim + k] : (k == in_dim ? C[cl.bof(0) + n] : 0.f); }
       else if (u < cp.wl) {
         const int i = u - cp.wh, li = 1 + i / (L * cp.LQ), rem = i - (li - 1) * L * cp.LQ, n = rem / cp.LQ, k = rem - n * cp.LQ;
-        v = k < L ? C[cl.w[li] + n * L + k] : (k == L ? C[cl.b[li] + n] : 0.f);
-      } else { const int k = u - cp.wl; v = k < L ? C[cl.w[cl.nh] + k] : (k == L ? C[cl.b[cl.nh]] : 0.f); }
+        v = k < L ? C[cl.wof(li) + n * L + k] : (k == L ? C[cl.bof(li) + n] : 0.f);
+      } else { const int k = u - cp.wl; v = k < L ? C[cl.wof(cl.nh) + k] : (k == L ? C[cl.bof(cl.nh)] : 0.f); }
       pk[u] = v;
     }
     return;

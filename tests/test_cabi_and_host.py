@@ -193,3 +193,33 @@ def test_product_library_reads_no_environment_variable():
     from hypad_amd import build
     und = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in und
+
+
+def test_no_scratch_in_the_kernels_the_baseline_configs_run():
+    """Code-object metadata of the built gfx950 objects (hypad_amd.build.kernel_metadata: the notes hipcc wrote): the kernels the BASELINE
+    configs launch -- every compile-time instantiation of configs[0..2]'s shape (window 100, latent 20, batch 64), the generator / dW / scoring
+    kernels of configs[3] and [4] -- spill no vector register and use no scratch memory.  Known gap, held to its current size so that it
+    can only shrink: critic_persistent_kernel<150, 20, 256> (configs[3]'s resident critic launch; 89 spilled registers and 384 bytes in
+    round 4).  Run-time-shape fallbacks (<0, 0, 0>) are not held to anything here."""
+    from hypad_amd import build
+    build.build()
+    ks = []
+    for f in sorted(os.listdir(build.LIB_DIR)):
+        if f.endswith(".o"):
+            ks += build.kernel_metadata(os.path.join(build.LIB_DIR, f))
+    assert len(ks) > 100
+    by_name = {k["name"]: k for k in ks}
+    clean = [n for n in by_name if any(t in n for t in ("<100, 20, 64>", "<true, 100, 20, 64", "<false, 100, 20, 64", "<100, 20>", "<150, 20, 256, ", "<true, 150, 20, 256>",
+                                                        "<100, 20, 64, ", "kde_mode_kernel", "score_forward_packed", "lstm_fwd_lds2_kernel", "lstm_fwd_lds3_kernel",
+                                                        "dtw_error_kernel", "rolling_mean_kernel", "qs_level_kernel", "unary_rows", "rowdist_rows", "mobius_add_rows",
+                                                        "pack_generator_kernel", "epoch_shuffle_kernel", "decay_steps_kernel"))]
+    clean += [n for n in by_name if "unroll_median_kernel" in n and ", 128>" in n]           # (the tile size every launch uses)
+    assert len(clean) >= 25, sorted(clean)
+    for must in ("critic_persistent_kernel<100, 20, 64>", "critic_iteration_kernel<100, 20, 64>", "gen_kernel<true, 100, 20, 64>", "gen_kernel<true, 150, 20, 256>",
+                 "dw_adam_kernel<100, 20, 64, 48", "critic_phase_precompute_kernel<100, 20>", "kde_mode_kernel<2>"):
+        assert any(must in n for n in clean), must
+    bad = {n: (by_name[n]["vgpr_spill_count"], by_name[n]["private_segment_fixed_size"]) for n in clean
+           if by_name[n]["vgpr_spill_count"] or by_name[n]["private_segment_fixed_size"]}
+    assert not bad, bad
+    gap = [k for n, k in by_name.items() if "critic_persistent_kernel<150, 20, 256>" in n]
+    assert len(gap) == 1 and gap[0]["vgpr_spill_count"] <= 22 and gap[0]["private_segment_fixed_size"] <= 96, gap
