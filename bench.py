@@ -1110,7 +1110,7 @@ def main():
     traffic, traffic_note = None, "no committed PMC profile matches these kernel sources"
     try:
         from hypad_amd.build import source_digest
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -1126,7 +1126,7 @@ def main():
     # committed rocprofv3 --pmc pass, under the same source-digest rule as `traffic`
     roofline_mfma = None
     try:
-        mfname = "r04_mfma_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04_mfma_util.json")) else "r03_mfma_util.json"
+        mfname = next(n for n in ("r05_mfma_util.json", "r04_mfma_util.json", "r03_mfma_util.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         path = os.path.join(ROOT, "profiles", mfname)
         mf = json.load(open(path))
         same = mf.get("source_sha256") == source_digest()
@@ -1135,7 +1135,7 @@ def main():
                          "formula": mf.get("formula"),
                          "kernels": {k: {"mfma_util": v.get("mfma_util"), "algorithmic_util": v.get("algorithmic_util"),
                                          "issued_over_algorithmic": v.get("issued_over_algorithmic")} for k, v in mf["kernels"].items()}}
-    except (OSError, KeyError, ValueError, NameError):
+    except (OSError, KeyError, ValueError, NameError, StopIteration):
         pass
 
     # algorithmic memory-side bytes of ONE resident critic launch (the kernel table): every record written once by
@@ -1179,7 +1179,7 @@ def main():
         traffic_alg_all["error"] = f"{type(e).__name__}: {e}"[:200]
     traffic_all = {}
     try:
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 pmc = json.load(open(path))

@@ -70,8 +70,14 @@ inline int64_t ws_pack_offset(const hypad_dims& d) {
   int64_t c = gen_ws(d.batch, d.signal_shape, d.latent_dim).total;
   return ((a > c ? a : c) + 63) & ~(int64_t)63;
 }
+// ... and the generator's dW + Adam work-item records follow the packed copies (train_iters.hip DwItem: 32 words per item, room for
+// DW_ITEM_CAP items; the launches read signal 0's copy): what a wave of that launch needs to know, prepared once per pack launch
+constexpr int DW_ITEM_WORDS = 32, DW_ITEM_CAP = 2048;
+inline int64_t ws_items_offset(const hypad_dims& d) {
+  return (ws_pack_offset(d) + gen_pack(d.signal_shape, d.latent_dim, d.hyperbolic).total + 63) & ~(int64_t)63;
+}
 inline int64_t ws_floats_per_signal(const hypad_dims& d) {
-  return ws_pack_offset(d) + gen_pack(d.signal_shape, d.latent_dim, d.hyperbolic).total;
+  return ws_items_offset(d) + (int64_t)DW_ITEM_WORDS * DW_ITEM_CAP;
 }
 
 // ------------------------------------------------------------------------------------------------ kernel arguments

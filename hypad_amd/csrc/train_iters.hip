@@ -956,17 +956,238 @@ __device__ __forceinline__ void dw_adam_body(const IterArgs& a, const Table& tab
     if (blockIdx.y == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
+// ---- the generator's dW + Adam launch from prepared work-item records.  A wave of that launch used to spend 2.2 of its 5.5 us before its
+// first operand load left: the workgroup's descriptor byte and the 52-byte descriptor out of a 3 KB kernel-argument table (whose
+// scalar registers the compiler spilled), the tile's (n0, k0) by integer division, clamps, and shadow_ref()'s search for the packed
+// positions of the updated weights.  All of that depends on the dimensions only: dw_items_kernel writes it once per pack launch, 128
+// bytes per item, and a wave fetches its record with two scalar loads.
+struct DwItem {                                // 32 words (train_common.h DW_ITEM_WORDS)
+  int32_t kind;                                // DwKind, or -1: nothing to do (padding behind a descriptor's last item)
+  int32_t net;
+  int32_t n0, k0;                              // weight tile origin; bias: n0 = first column; decay: n0 = first element
+  int32_t nrows, ncols, p_off, p_ld, p_off2;
+  int32_t left_off, left_ld, right_off, right_ld, red_rows;
+  int32_t fwd, fwd_kg, nbase, bwd, bwd_ng, mbase, bsum, gate_H;      // ShadowRef
+  int32_t pad[10];
+};
+static_assert(sizeof(DwItem) == 4 * DW_ITEM_WORDS, "DwItem is DW_ITEM_WORDS words");
+__global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __restrict__ out, int S, int L, int hyper) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= DW_ITEM_CAP) return;
+  DwItem it{};
+  it.kind = -1;
+  if (item < tab.total_items) {
+    const int bx = item >> 2;
+    const int di = (tab.block_desc[bx >> 2] >> (8 * (bx & 3))) & 0xff;
+    const DwDesc d = tab.d[di];
+    const int local = item - d.begin;
+    bool live = false;
+    if (d.kind == DW_WEIGHT) {
+      const int tk = (d.ncols + 15) >> 4;
+      live = local < ((d.nrows + 15) >> 4) * tk;
+      it.n0 = (local / tk) * 16; it.k0 = (local % tk) * 16;
+    } else if (d.kind == DW_BIAS) { live = local * 16 < d.nrows; it.n0 = local * 16; }
+    else if (d.kind == DW_DECAY) { live = local * 256 < d.nrows; it.n0 = local * 256; }
+    else if (d.kind == DW_BALL) live = local == 0;
+    if (live) {
+      it.kind = d.kind; it.net = d.net; it.nrows = d.nrows; it.ncols = d.ncols; it.p_off = d.p_off; it.p_ld = d.p_ld; it.p_off2 = d.p_off2;
+      it.left_off = d.left_off; it.left_ld = d.left_ld; it.right_off = d.right_off; it.right_ld = d.right_ld; it.red_rows = d.red_rows;
+      const ShadowRef sh = shadow_ref(d.net, d.p_off, S, L, hyper);
+      it.fwd = sh.fwd; it.fwd_kg = sh.fwd_kg; it.nbase = sh.nbase; it.bwd = sh.bwd; it.bwd_ng = sh.bwd_ng; it.mbase = sh.mbase; it.bsum = sh.bsum; it.gate_H = sh.gate_H;
+    }
+  }
+  out[item] = it;
+}
+
+template <int SC, int LC, int BC, int KS>
+__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx) {
+  const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
+  const int sig = blockIdx.y + a.sig0;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int j = lane & 15, q = lane >> 4;
+  float* ws = a.ws + sig * a.ws_sig_stride;
+  const int item = bx * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
+  // the record (wave-uniform address: scalar loads from the constant address space -- nothing writes the table during this launch) ...
+  using CWord = const __attribute__((address_space(4))) int32_t;
+  DwItem d;
+  {
+    CWord* src = (CWord*)(items + (item < total_items ? item : 0));
+    int32_t* dst = reinterpret_cast<int32_t*>(&d);
+#pragma unroll
+    for (int i = 0; i < 22; ++i) dst[i] = src[i];          // (the 22 words in use)
+  }
+  // ... and, in the same batch of scalar fetches, the step counter and the bias corrections the generator launch left behind
+  const int step = a.counters[a.opt] + (a.step_add >= 0 ? a.step_add + 1 : 0);      // (step_add < 0: already incremented by the iteration's first kernel)
+  const float* ac = a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gen_ws(B_, S_, L_).adamc;
+  AdamCoef co;
+  co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize;
+  co.step = step; co.bc1 = ac[0]; co.bc2 = ac[1]; co.sqrt_bc2 = ac[2];
+  const int64_t arena = d.net == HYPAD_NET_ENCODER ? a.pe : a.pd;
+  float* P = (d.net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + sig * arena;
+  float* M = (d.net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + sig * arena;
+  float* V = (d.net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + sig * arena;
+  if (item < total_items && d.kind >= 0) {
+    if (d.kind == DW_WEIGHT) {
+      const int n0 = d.n0, k0 = d.k0;
+      // out-of-range columns are clamped (their results are dropped below); rows past red_rows contribute zeros
+      const int nj = n0 + j < d.nrows ? n0 + j : d.nrows - 1, kj = k0 + j < d.ncols ? k0 + j : d.ncols - 1;
+      const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.left_off), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.right_off), 0, 0x7fffffff, 0x00020000);
+      const int lvo = (q * d.left_ld + nj) * 4, rvo = (q * d.right_ld + kj) * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // the optimiser state of this lane's four elements travels with the operand loads (one round trip, not two)
+      int po[4]; float pp[4], pm[4], pvv[4];
+      float* Pb = P + d.p_off; float* Mb = M + d.p_off; float* Vb = V + d.p_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * q + r, k = k0 + j;
+        const bool ok = n < d.nrows && k < d.ncols;
+        po[r] = ok ? n * d.p_ld + k : -1;
+        const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
+        pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
+      }
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // up to KS k-steps in flight
+        float la[KS], rb[KS];
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c)
+          if (rc + 16 * c < d.red_rows) {                  // wave-uniform
+#pragma unroll
+            for (int u = 4 * c; u < 4 * c + 4; ++u) {
+              la[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, lvo, (rc + 4 * u) * d.left_ld * 4, 0));
+              rb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, (rc + 4 * u) * d.right_ld * 4, 0));
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c)
+          if (rc + 16 * c < d.red_rows) {
+#pragma unroll
+            for (int u = 4 * c; u < 4 * c + 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc, 0, 0, 0);
+          }
+      }
+      float* pk = ws + a.pk_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = pp[r], m = pm[r], v = pvv[r];
+        adam_update(p, m, v, acc[r], co);
+        if (po[r] >= 0) {
+          const uint32_t o = (uint32_t)po[r];
+          Pb[o] = p; Mb[o] = m; Vb[o] = v;
+          const int nc = d.nbase + n0 + 4 * q + r, k = k0 + j;             // compact row, column
+          if (d.fwd >= 0) {
+            int nf = nc;                                                     // forward copy row: gates padded to 16-row blocks
+            if (d.gate_H > 0) nf += ((nc >= d.gate_H) + (nc >= 2 * d.gate_H)) * (((d.gate_H + 15) & ~15) - d.gate_H);   // nc < 3H
+            pk[d.fwd + (((nf >> 4) * d.fwd_kg + (k >> 4)) * 64 + (nf & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
+          }
+          if (d.bwd >= 0) {
+            const int mm = d.mbase + nc;                                      // reduction index of the transposed copy
+            pk[d.bwd + (((k >> 4) * d.bwd_ng + (mm >> 4)) * 64 + (k & 15) + 16 * ((mm & 15) >> 2)) * 4 + (mm & 3)] = p;
+          }
+        }
+      }
+    } else if (d.kind == DW_BIAS) {
+      // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
+      const int n = d.n0 + j;
+      const bool nv = n < d.nrows;
+      const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
+      const int rlast = d.red_rows - 1;
+      float g = 0.f;
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // KS rows per lane in flight
+        float t[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+          const int r = rc + 4 * u + q;
+          t[u] = left[(int64_t)(r < rlast ? r : rlast) * d.left_ld];
+        }
+#pragma unroll
+        for (int u = 0; u < KS; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
+      }
+      g += __shfl_xor(g, 16, WAVE);
+      g += __shfl_xor(g, 32, WAVE);
+      if (nv && q == 0) {
+        int64_t o = d.p_off + n;
+        float p = P[o], m = M[o], v = V[o];
+        adam_update(p, m, v, g, co);
+        P[o] = p; M[o] = m; V[o] = v;
+        float bs = p;
+        if (d.p_off2 >= 0) {
+          o = d.p_off2 + n;
+          p = P[o]; m = M[o]; v = V[o];
+          adam_update(p, m, v, g, co);
+          P[o] = p; M[o] = m; V[o] = v;
+          bs += p;
+        }
+        if (d.bsum >= 0) {
+          int nf = d.nbase + n;
+          if (d.gate_H > 0) { const int x = nf / d.gate_H; nf = x * ((d.gate_H + 15) & ~15) + nf - x * d.gate_H; }
+          ws[a.pk_off + d.bsum + nf] = bs;
+        }
+      }
+    } else if (d.kind == DW_DECAY) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = d.n0 + e * 64 + lane;
+        if (n < d.nrows) {
+          const int64_t o = d.p_off + n;
+          float p = P[o], m = M[o], v = V[o];
+          adam_update(p, m, v, 0.f, co);
+          P[o] = p; M[o] = m; V[o] = v;
+        }
+      }
+    } else if (d.kind == DW_BALL) {                // hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
+      const float* left = ws + d.left_off;
+      RowVec g;
+#pragma unroll
+      for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
+      for (int r0 = 0; r0 < d.red_rows; r0 += 8) {           // eight partial rows in flight per round trip (fixed order)
+        float t[8][MAX_EPL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u < d.red_rows ? r0 + u : d.red_rows - 1;
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) {
+            const int c = lane + 64 * e;
+            t[u][e] = c < d.nrows ? left[(int64_t)r * d.left_ld + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
+      }
+      radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
+    }
+  }
+#if HYPAD_DIAG
+  if (a.stamps && blockIdx.y == 0 && lane == 0 && item < 1024) {      // (scripts/diag_dw_items.py)
+    a.stamps[3 * 48 * 8 + 64 + 2 * item] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.stamps[3 * 48 * 8 + 64 + 2 * item + 1] = item < total_items && d.kind >= 0 ? d.kind * 1000 + d.net * 100 + (d.red_rows >> 4) : -1;
+  }
+#endif
+  if (bx == 0 && threadIdx.x == 0) {               // generator losses (train.py:232-234, 243-244)
+    const GenWs gw = gen_ws(B_, S_, L_);
+    float aux = 0.f, fx = 0.f, fz = 0.f;
+    for (int t = 0; t < B_ / 16; ++t) {
+      const float* part = ws + gw.partial + t * 4;
+      aux += part[0]; fx += part[1]; fz += part[2];
+    }
+    aux = a.hyperbolic ? aux / a.B : aux / ((float)a.B * (float)a.S);
+    float* lo = a.losses + sig * a.loss_sig_stride;
+    lo[0] = 10.f * aux - fx / a.B - fz / a.B;
+    lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
+    if (blockIdx.y == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
+  }
+}
 // COLOC: blockIdx.x is stretched by 8 and only the blocks that land on XCD (signal mod 8) work (workgroups are dealt round-robin
 // over the 8 XCDs), so one model's weight tiles share an L2: its ~0.9 MB of operand rows are fetched from HBM once, not once per
 // XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
 template <int SC, int LC, int BC, int KS, bool COLOC = false>
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, DwTable tab) {
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items) {
   if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
     if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;
-    dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab, (int)(blockIdx.x >> 3));
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)(blockIdx.x >> 3));
   } else {
-    dw_adam_body<DwTable, SC, LC, BC, KS>(a, tab);
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x);
   }
 }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
@@ -1539,6 +1760,17 @@ int run_critic_pair(const hypad_dims* d, const hypad_train_state* st, const Iter
   return HYPAD_OK;
 }
 
+// the work-item records of the generator's dW + Adam launch (DwItem), into signal 0's workspace: behind every pack launch whose
+// workspace generator steps will run in (run_gen with pack = true; hypad_train_epoch once per epoch)
+int launch_dw_items(const IterArgs& a, const hypad_dims& d, bool with_decay, hipStream_t s) {
+  const DwTable tab = gen_table(d, with_decay);
+  if (tab.n < 0 || tab.total_items > DW_ITEM_CAP) return HYPAD_EUNSUPPORTED;
+  DwItem* items = reinterpret_cast<DwItem*>(a.ws + ws_items_offset(d));
+  hipLaunchKernelGGL(dw_items_kernel, dim3(DW_ITEM_CAP / 256), dim3(256), 0, s, tab, items, d.signal_shape, d.latent_dim, d.hyperbolic);
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
+
 // with_decay = false: the decay-only parameters are left alone (the caller advances them with run_decay_steps)
 // sig0 / nsig / step_add: the models [sig0, sig0 + nsig) only, as generator iteration `step_add` of an epoch (IterArgs.step_add);
 // defaults: all models, counters read and advanced by the launches themselves.
@@ -1557,6 +1789,7 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
   if (pack) {                             // the workspace is scratch between calls: rebuild the packed weights
     rc = launch_pack(a, *d, s);           // (inside an epoch the dW + Adam kernel keeps them current)
+    if (!rc) rc = launch_dw_items(a, *d, with_decay, s);
     if (rc) return rc;
   }
   HYPAD_MARK(ev, 0, s);
@@ -1573,17 +1806,19 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
 #undef HYPAD_LAUNCH_GEN
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 1, s);
-  const DwTable tab = gen_table(*d, with_decay);
+  const DwTable tab = gen_table(*d, with_decay);           // (its item count; the records themselves were written behind the pack launch)
+  const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + ws_items_offset(*d));
+  const int total_items = tab.total_items;
   const bool coloc = (io.flags & HYPAD_EPOCH_DW_COLOC) ? true : (io.flags & HYPAD_EPOCH_DW_SPREAD) ? false : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
-      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, tab);
-    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, tab);
+      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
   }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
@@ -1884,6 +2119,7 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
     c.row_index = io->row_index; c.losses = io->losses;
     rc = fill_args(ag, d, st, c, 2);
     if (!rc) rc = launch_pack(ag, *d, (hipStream_t)s, zero_ptr, zero_words, &zeroed, false, snap);
+    if (!rc) rc = launch_dw_items(ag, *d, false, (hipStream_t)s);      // (the epoch's generator steps leave the decay-only tensors to decay_steps_kernel)
     if (rc) return rc;
   }
   if (hoisted) {                                       // train.py:315-328, generator forwards hoisted (critic_fused.hip)
