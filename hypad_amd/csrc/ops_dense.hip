@@ -145,9 +145,6 @@ __global__ __launch_bounds__(THREADS) void lstm_fwd_kernel(const float* __restri
 // k-group use the components in turn, so A and B agree on a permuted k order), one 16-unit block at a time takes its three
 // accumulators through the whole K, and the cell runs on the accumulators (lane (unit, q), register r = row 4 q + r: the three
 // gates of a unit on one lane).  No barrier after the weights are staged.
-#ifndef HYPAD_LSTM_EXP
-#define HYPAD_LSTM_EXP 0        // development what-if: 1 folds the saved gates of all tiles onto 1 024 rows (same instructions, no HBM writes)
-#endif
 template <int KG, int NW>              // k-groups of 16: in_dim <= 16 KG; NW waves per workgroup (16 where the registers allow: more waves to put
                                        // under the layer's stores)
 __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __restrict__ x, const float* wf, const float* bif, const float* bhf,
@@ -219,36 +216,22 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
       }
       // stores through buffer addressing: the tile's base in the descriptor, the lane's (row 4 q, unit) once as a 32-bit offset,
       // row and gate as scalar offsets -- per-element 64-bit address arithmetic was a third of this epilogue's instructions
-      const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + (HYPAD_LSTM_EXP == 1 ? (r0 & 1023) : r0) * 8 * H : out);
+      const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + r0 * 8 * H : out);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int unit = (ub + half) * 16 + j;
         if (half == 1 && !two) break;
         if (unit >= H) continue;
         const f32x4 pi = half ? ci : ai, pg = half ? cg : ag, po = half ? co : ao;
-#if HYPAD_LSTM_EXP == 4
-        const float bsi = 0.f, bsg = 0.f, bso = 0.f;
-#else
         const float bsi = b1[unit] + b2[unit], bsg = b1[2 * H + unit] + b2[2 * H + unit], bso = b1[3 * H + unit] + b2[3 * H + unit];
-#endif
         const int vo_h = (4 * q * 2 * H + dir * H + unit) * 4, vo_g = (4 * q * 8 * H + dir * 4 * H + unit) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (r0 + 4 * q + r >= rows) continue;
-#if HYPAD_LSTM_EXP == 2
-          const float gi = pi[r] + bsi, gg = pg[r] + bsg, go = po[r] + bso;
-          const float tc = gi * gg;
-#else
           const float gi = sigmoidf_(pi[r] + bsi), gg = tanhf_(pg[r] + bsg), go = sigmoidf_(po[r] + bso);
           const float tc = tanhf_(gi * gg);
-#endif
-#if HYPAD_LSTM_EXP == 3
-          if (gi + gg + go + tc == 123456.f) ob.st(go * tc, vo_h, r * 2 * H * 4);
-          if (false) {
-#else
           ob.st(go * tc, vo_h, r * 2 * H * 4);
           if (gates_save) {
-#endif
             // whole, aligned 64-byte segments (hidden a multiple of 16): past the caches (non-temporal) -- 323 -> 288 us at 128 -> 2 x 64;
             // with 200-byte gate rows (hidden 50) the same hint makes partial lines and costs 100 us, so it is not given there
             if (nt_ok) {
@@ -384,15 +367,11 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds2_kernel(const float* __r
     asm volatile("" ::: "memory");
     const int64_t r0 = tile << 4;
     const int64_t next = tile + tstep < ntiles ? tile + tstep : tile;
-    const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + r0 * 8 * (HYPAD_LSTM_EXP == 5 ? 64 : H) : out);
+    const GBuf ob(out + r0 * 2 * H), gb(gates_save ? gates_save + r0 * 8 * H : out);
     // the cell on one lane's (i, g, o) of unit `unit`, rows 4 q + r
     auto cell = [&](const f32x4& pi, const f32x4& pg, const f32x4& po, int unit) __attribute__((always_inline)) {
       const float bsi = bias_s[unit], bsg = bias_s[H + unit], bso = bias_s[2 * H + unit];
-#if HYPAD_LSTM_EXP == 5      /* what-if: gate rows padded to 64 floats (whole 64-byte sectors), needs a (rows, 8 * 64) buffer */
-      constexpr int HS = 64;
-#else
       constexpr int HS = H;
-#endif
       const int vo_h = (4 * q * 2 * H + dir * H + unit) * 4, vo_g = (4 * q * 8 * HS + dir * 4 * HS + unit) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
