@@ -969,9 +969,19 @@ constexpr int persist_tail(int in_dim, int L, int nh) {
   const int tail = NA * FT - I0 < other ? NA * FT - I0 : other;
   return (nh == 4 && (other - tail + BT - 1) / BT < (other + BT - 1) / BT) ? tail : 0;
 }
+// A second way to shorten phase B: where its last round holds only a few quads (window 100: 336 = 320 + 16), the three CHAIN waves'
+// first threads own those as one more phase-A slot -- requested with their layer-0 shares at the loop top, updated before the chains
+// start (the chain body has 45 registers to spare; the quads are the last layer's, needed at the top of the forward chain only) --
+// and the helper waves' phase B is ONE round of shares instead of two (the chains waited 1.8 k cycles for it).
+constexpr int persist_ctail(int in_dim, int L, int nh) {
+  const int Q = (L + 3) / 4, other = (nh - 1) * Q * (L + 1) + L + 1, BT = (NW - 3) * 64;
+  const int left = other - persist_tail(in_dim, L, nh), rest = left % BT;
+  return (nh == 4 && left > BT && rest > 0 && rest <= 64) ? rest : 0;
+}
 constexpr int persist_slots(int in_dim, int L, int nh) {
   const int Q = (L + 3) / 4, I0 = Q * (in_dim + 1), other = (nh - 1) * Q * (L + 1) + L + 1, NA = (I0 + FT - 1) / FT, BT = (NW - 3) * 64;
-  return NA + (other - persist_tail(in_dim, L, nh) + BT - 1) / BT;
+  const int b = (other - persist_tail(in_dim, L, nh) - persist_ctail(in_dim, L, nh) + BT - 1) / BT;
+  return NA + (b > 0 ? b : (persist_ctail(in_dim, L, nh) > 0 ? 1 : 0));
 }
 HD bool persist_geom_supported(const CritGeom& g, int nchunks) {      // (run-time shapes: no tail, PSLOT slots)
   const int Q = (g.L + 3) >> 2;
@@ -1024,6 +1034,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
   constexpr int BW0 = 3, BT = (NW - BW0) * 64;
   const int NA = (I0 + FT - 1) / FT;
   constexpr int TAILI = (SC && LC) ? persist_tail(IS_X ? SC : LC, LC, nh) : 0;      // other-layer quads (the list's last ones) in phase A's free threads
+  constexpr int CTAIL = (SC && LC) ? persist_ctail(IS_X ? SC : LC, LC, nh) : 0;     // ... and in slot NA of the chain waves' first threads (persist_ctail)
   const bool bthread = wave >= BW0;
   const int btid = threadIdx.x - BW0 * 64;
   const int slabf = nitems * 4;
@@ -1081,8 +1092,10 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       else e = e0 < I0 ? e0 : (e0 - I0 < TAILI ? nitems - TAILI + (e0 - I0) : -1);
     } else if (bthread) {
       const int e0 = I0 + (u - NA) * BT + btid;
-      if constexpr (TAILI == 0) e = e0 < nitems ? e0 : -1;
-      else e = e0 < nitems - TAILI ? e0 : -1;
+      if constexpr (TAILI == 0 && CTAIL == 0) e = e0 < nitems ? e0 : -1;
+      else e = e0 < nitems - TAILI - CTAIL ? e0 : -1;
+    } else if (CTAIL > 0 && u == NA) {
+      e = (int)threadIdx.x < CTAIL ? nitems - TAILI - CTAIL + (int)threadIdx.x : -1;      // chain waves: the quads phase B's last round would hold
     }
     i_e[u] = e;
     const int ee = e < 0 ? 0 : e;
@@ -1178,7 +1191,8 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     // layer-0 slots whose first four shares are requested at the loop top: all of them, except at window 150 (two slots: the second
     // one's sixteen registers were spilled; it loads inside finish() like the other layers' quads)
     constexpr int NPRE_C = (SC == 150) ? 1 : PS;
-    const int NPRE = NA < NPRE_C ? NA : NPRE_C;
+    const int NA_BODY = NA + ((CHAIN && CTAIL > 0) ? 1 : 0);             // phase-A slots of this body (the chain waves' extra one: CTAIL)
+    const int NPRE = NA_BODY < NPRE_C ? NA_BODY : NPRE_C;
     u32x4_t x0[NPRE_C][4];
     int obase = 0;
     if (it > 0) {
@@ -1274,12 +1288,12 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     };
 #pragma unroll
     for (int u = 0; u < PS; ++u)
-      if (u < NA) finish(u);
+      if (u < NA_BODY) finish(u);
     PSTAMP(2);                                                           // phase A: shares loaded, Adam, layer-0 image
     auto phase_b = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < PS; ++u)
-        if (u >= NA) finish(u);
+        if (u >= NA_BODY) finish(u);
     };
     if (fin) {
       if (!CHAIN) phase_b();
@@ -1291,7 +1305,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         for (int u = 0; u < PS; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (CHAIN && u >= NA) continue;                           // (a chain wave owns layer-0 quads only: the other slots' registers are dead in this body)
+            if (CHAIN && u >= NA_BODY) continue;                      // (a chain wave owns its phase-A slots only: the other slots' registers are dead in this body)
             const int o = arena_off(u, r);
             if (o >= 0) { arena_p[o] = pv[u][r]; arena_m[o] = mv[u][r]; arena_v[o] = vv[u][r]; }
           }

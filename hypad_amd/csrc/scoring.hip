@@ -812,14 +812,27 @@ __global__ __launch_bounds__(256) void critic_apply_kernel(const double* __restr
 // numpy does.  Any NaN makes every quantile NaN (numpy).  Nothing returns to the host.
 constexpr int QS_BITS = 11, QS_BINS = 1 << QS_BITS, QS_LEVELS = 6, QS_SEL = 4;
 struct QsState { unsigned long long prefix; long long rank; };
+// Round 5: after TWO levels (22 bits) the elements that still match a rank's prefix are few -- ~100 of 125 000 normal values, ~1 000 of
+// 10^6 -- so the third launch COMPACTS them (their keys into a per-rank candidate list, with the list's minimum and maximum) and one
+// workgroup finishes: a wave per rank runs the four remaining radix levels over its list in LDS, then numpy's interpolation.  Four
+// launches instead of seven (each is a chain of dependent memory round trips: ~9 us of stream time apiece).  A list whose keys are all
+// equal (heavy ties, constant input) needs no list at all (minimum == maximum is the answer); a list longer than QS_CAND distinct keys
+// (all values inside one of the 2^22 bins: a band 2^-10 wide relative to its magnitude) falls back to the same four levels over the
+// input itself, one wave per rank -- slow (a millisecond per million values) and exact.
+constexpr int QS_CAND = 4096;
 struct QsWs {                       // layout of the workspace (hypad_quantile_workspace_bytes)
-  unsigned int* hist;               // [QS_LEVELS][QS_SEL][QS_BINS], zeroed by the call's memset
+  unsigned int* hist;               // [QS_LEVELS][QS_SEL][QS_BINS] (levels 0 and 1 in use), zeroed by the call's memset
   QsState* state;                   // [QS_LEVELS + 1][QS_SEL]
   unsigned int* nan_count;          // [1] (inside the zeroed region)
+  unsigned int* cand_count;         // [QS_SEL] (zeroed)
+  unsigned long long* kmax;         // [QS_SEL] largest candidate key (zeroed)
+  unsigned long long* kinv;         // [QS_SEL] largest ~key = ~(smallest candidate key) (zeroed)
+  unsigned long long* cand;         // [QS_SEL][QS_CAND]
 };
 constexpr size_t QS_HIST_BYTES = (size_t)QS_LEVELS * QS_SEL * QS_BINS * sizeof(unsigned int);
-constexpr size_t QS_ZERO_BYTES = QS_HIST_BYTES + 64;
-constexpr size_t QS_WS_BYTES = QS_ZERO_BYTES + (QS_LEVELS + 1) * QS_SEL * sizeof(QsState) + 64;
+constexpr size_t QS_ZERO_BYTES = QS_HIST_BYTES + 128;
+constexpr size_t QS_STATE_BYTES = (QS_LEVELS + 1) * QS_SEL * sizeof(QsState) + 64;
+constexpr size_t QS_WS_BYTES = QS_ZERO_BYTES + QS_STATE_BYTES + (size_t)QS_SEL * QS_CAND * sizeof(unsigned long long);
 __host__ __device__ inline int qs_shift(int level) { const int sh = 64 - QS_BITS * (level + 1); return sh < 0 ? 0 : sh; }
 __host__ __device__ inline int qs_bins(int level) { return level == QS_LEVELS - 1 ? 1 << (64 - QS_BITS * (QS_LEVELS - 1)) : QS_BINS; }
 __device__ __forceinline__ unsigned long long qs_key(double x) {
@@ -833,11 +846,17 @@ __device__ __forceinline__ double qs_value(unsigned long long k) {
 // Wave `sel` of the block: which bin of hist[level][sel] holds rank st.rank?  The histogram row is first copied to LDS (`stage`,
 // >= qs_bins(level) words, private to the wave) with lane-consecutive loads that leave together -- walking it in global memory
 // cost one dependent L2 round trip per bin.  Every lane returns the new state.
+__device__ __forceinline__ QsState qs_descend_staged(const unsigned int* stage, int level, const QsState st);
 __device__ __forceinline__ QsState qs_descend(const unsigned int* __restrict__ hist, int level, const QsState st, unsigned int* stage) {
-  const int lane = threadIdx.x & 63, bins = qs_bins(level), per = bins / 64;       // 32 (or 8) consecutive bins per lane
+  const int lane = threadIdx.x & 63, bins = qs_bins(level);
   for (int i = lane; i < bins; i += 64) stage[i] = hist[i];
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
+  return qs_descend_staged(stage, level, st);
+}
+// ... the same with the level's histogram already in `stage` (LDS)
+__device__ __forceinline__ QsState qs_descend_staged(const unsigned int* stage, int level, const QsState st) {
+  const int lane = threadIdx.x & 63, bins = qs_bins(level), per = bins / 64;       // 32 (or 8) consecutive bins per lane
   unsigned long long mine = 0;
   for (int i = 0; i < per; ++i) mine += stage[lane * per + i];
   unsigned long long incl = mine;                                                   // inclusive wave scan
@@ -905,6 +924,43 @@ __global__ __launch_bounds__(256) void qs_level_kernel(const double* __restrict_
     if (c) atomicAdd(g + i, c);
   }
 }
+// third launch: the keys that match a rank's 22-bit prefix -> that rank's candidate list (+ the list's extremes)
+__global__ __launch_bounds__(256) void qs_compact_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int nsel) {
+  __shared__ unsigned int h[QS_SEL][QS_BINS];
+  __shared__ QsState cur[QS_SEL];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int PER = 4;
+  double x[PER];
+  int64_t base = (int64_t)blockIdx.x * (256 * PER);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) { const int64_t i = base + u * 256 + threadIdx.x; x[u] = i < n ? in[i] : 0.0; }
+  if (wave < nsel) {
+    const QsState st = qs_descend(ws.hist + ((size_t)1 * QS_SEL + wave) * QS_BINS, 1, ws.state[1 * QS_SEL + wave], h[wave]);
+    if (lane == 0) { cur[wave] = st; if (blockIdx.x == 0) ws.state[2 * QS_SEL + wave] = st; }
+  }
+  __syncthreads();
+  const int hi_sh = qs_shift(1);                          // the 22 bits fixed so far sit above it
+  unsigned long long pre[QS_SEL];
+  for (int s2 = 0; s2 < QS_SEL; ++s2) pre[s2] = s2 < nsel ? cur[s2].prefix : 0;
+  for (; base < n; base += (int64_t)gridDim.x * (256 * PER)) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      if (base + u * 256 + threadIdx.x >= n) continue;
+      const unsigned long long k = qs_key(x[u]);
+#pragma unroll
+      for (int s2 = 0; s2 < QS_SEL; ++s2)
+        if (s2 < nsel && ((k ^ pre[s2]) >> hi_sh) == 0) {
+          const unsigned int pos = atomicAdd(ws.cand_count + s2, 1u);
+          if (pos < (unsigned int)QS_CAND) ws.cand[(size_t)s2 * QS_CAND + pos] = k;
+          atomicMax(ws.kmax + s2, k);
+          atomicMax(ws.kinv + s2, ~k);
+        }
+    }
+    const int64_t nb = base + (int64_t)gridDim.x * (256 * PER);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const int64_t i = nb + u * 256 + threadIdx.x; x[u] = i < n ? in[i] : 0.0; }
+  }
+}
 __device__ __forceinline__ double np_lerp64(double a, double b, double t) {     // numpy.lib._function_base_impl._lerp
 #pragma clang fp contract(off)                   // numpy rounds the product before the sum: no fused multiply-add here
   const double diff = b - a;
@@ -912,14 +968,41 @@ __device__ __forceinline__ double np_lerp64(double a, double b, double t) {     
   if (t >= 0.5) r = b - diff * (1.0 - t);
   return r;
 }
-// one workgroup: the last digits, then out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
-__global__ __launch_bounds__(256) void qs_final_kernel(QsWs ws, int nsel, double t0, double t1, double* __restrict__ out) {
+// one workgroup: wave s fixes the remaining 42 bits of rank s's key from its candidate list (see QS_CAND), then
+// out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
+__global__ __launch_bounds__(256) void qs_final_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int nsel, double t0, double t1,
+                                                         double* __restrict__ out) {
   __shared__ unsigned long long keys[QS_SEL];
   __shared__ unsigned int stage[QS_SEL][QS_BINS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wave < nsel) {
-    const QsState st = qs_descend(ws.hist + ((size_t)(QS_LEVELS - 1) * QS_SEL + wave) * QS_BINS, QS_LEVELS - 1, ws.state[(QS_LEVELS - 1) * QS_SEL + wave], stage[wave]);
-    if (lane == 0) keys[wave] = st.prefix;
+    QsState st = ws.state[2 * QS_SEL + wave];
+    const unsigned int c = ws.cand_count[wave];
+    const unsigned long long kmx = ws.kmax[wave], kmn = ~ws.kinv[wave];
+    unsigned long long key = kmx;
+    if (kmx != kmn) {
+      const bool listed = c <= (unsigned int)QS_CAND;
+      const unsigned long long* cand = ws.cand + (size_t)wave * QS_CAND;
+      const int64_t m = listed ? (int64_t)c : n;
+      unsigned int* hst = stage[wave];
+      for (int level = 2; level < QS_LEVELS; ++level) {
+        const int bins = qs_bins(level), sh = qs_shift(level);
+        const int hi_sh = sh + (level == QS_LEVELS - 1 ? 64 - QS_BITS * (QS_LEVELS - 1) : QS_BITS);     // bits above the digit (<= 42)
+        for (int i = lane; i < bins; i += 64) hst[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int64_t i = lane; i < m; i += 64) {
+          const unsigned long long k = listed ? cand[i] : qs_key(in[i]);
+          if (((k ^ st.prefix) >> hi_sh) == 0) atomicAdd(hst + ((unsigned int)(k >> sh) & (unsigned int)(bins - 1)), 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        st = qs_descend_staged(hst, level, st);
+        __builtin_amdgcn_wave_barrier();
+      }
+      key = st.prefix;
+    }
+    if (lane == 0) keys[wave] = key;
   }
   __syncthreads();
   if (threadIdx.x < nsel / 2) {
@@ -932,6 +1015,9 @@ __global__ __launch_bounds__(256) void qs_final_kernel(QsWs ws, int nsel, double
 QsWs qs_ws(void* workspace) {
   QsWs w; char* p = (char*)workspace;
   w.hist = (unsigned int*)p; w.nan_count = (unsigned int*)(p + QS_HIST_BYTES); w.state = (QsState*)(p + QS_ZERO_BYTES);
+  w.cand_count = (unsigned int*)(p + QS_HIST_BYTES + 16);
+  w.kmax = (unsigned long long*)(p + QS_HIST_BYTES + 32); w.kinv = (unsigned long long*)(p + QS_HIST_BYTES + 64);      // (all inside the zeroed region)
+  w.cand = (unsigned long long*)(p + QS_ZERO_BYTES + QS_STATE_BYTES);
   return w;
 }
 // numpy (_function_base_impl._quantile, method "linear"): virtual index (n - 1) q, neighbours floor and floor + 1 (both the last
@@ -955,11 +1041,13 @@ int launch_quantiles(const double* in, int64_t n, const double* q, int nq, doubl
   const int nsel = 2 * nq;
   int64_t g = (n + 1023) / 1024;
   g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-  for (int level = 0; level < QS_LEVELS; ++level) {
+  for (int level = 0; level < 2; ++level) {
     hipLaunchKernelGGL(qs_level_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, level, nsel, r[0], r[1], r[2], r[3]);
     HYPAD_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(256), 0, s, ws, nsel, t[0], t[1], out);
+  hipLaunchKernelGGL(qs_compact_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, nsel);
+  HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(256), 0, s, in, n, ws, nsel, t[0], t[1], out);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

@@ -96,7 +96,8 @@ def run_signals(params, names, config_path=None, data_dir="./data", log=print):
             continue                                   # another rank's signal
         p.latent_space_dim = 20
         out = _detect(p, test_ds, read_path, mods[0], mods[1], mods[2], trained[name]["path"], data_dir, hasattr(train_ds, "device_windows"), log)
-        local[name] = {"confusion": [None if v is None else int(v) for v in out.get("confusion", [])] or None,      # (tn is None in the overlap-segment count) "metrics": out.get("metrics"),
+        # (tn is None in the overlap-segment count)
+        local[name] = {"confusion": [None if v is None else int(v) for v in out.get("confusion", [])] or None, "metrics": out.get("metrics"),
                        "n_intervals": int(len(out["intervals"])), "final": trained[name]["final"], "path": trained[name]["path"],
                        "rank": trained[name]["rank"]}
     return par.gather_signal_metrics(local)
