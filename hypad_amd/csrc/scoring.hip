@@ -812,14 +812,16 @@ __global__ __launch_bounds__(256) void critic_apply_kernel(const double* __restr
 // numpy does.  Any NaN makes every quantile NaN (numpy).  Nothing returns to the host.
 constexpr int QS_BITS = 11, QS_BINS = 1 << QS_BITS, QS_LEVELS = 6, QS_SEL = 4;
 struct QsState { unsigned long long prefix; long long rank; };
-// Round 5: after TWO levels (22 bits) the elements that still match a rank's prefix are few -- ~100 of 125 000 normal values, ~1 000 of
-// 10^6 -- so the third launch COMPACTS them (their keys into a per-rank candidate list, with the list's minimum and maximum) and one
-// workgroup finishes: a wave per rank runs the four remaining radix levels over its list in LDS, then numpy's interpolation.  Four
-// launches instead of seven (each is a chain of dependent memory round trips: ~9 us of stream time apiece).  A list whose keys are all
-// equal (heavy ties, constant input) needs no list at all (minimum == maximum is the answer); a list longer than QS_CAND distinct keys
-// (all values inside one of the 2^22 bins: a band 2^-10 wide relative to its magnitude) falls back to the same four levels over the
-// input itself, one wave per rank -- slow (a millisecond per million values) and exact.
-constexpr int QS_CAND = 4096;
+// Round 5: after QS_PRE = THREE levels (33 bits: sign, exponent, 21 mantissa bits) the elements that still match a rank's prefix are a
+// handful -- so the fourth launch COMPACTS them (their keys into a per-rank candidate list, with the list's minimum and maximum) and
+// one workgroup of 1 024 threads finishes: 256 threads per rank run the three remaining radix levels over its list, then numpy's
+// interpolation.  Five launches instead of seven (each is a chain of dependent memory round trips: ~9 us of stream time apiece).
+// (Two levels were measured first: critic scores cluster around a non-zero mean -- bench.py's sit in a band 2 % wide -- and a 22-bit bin,
+// 2^-10 of the magnitude wide, then held 3 % of the values: 3 000 candidates per rank at 125 000 values, 30 000 at 10^6.)
+// A list whose keys are all equal (heavy ties, constant input) needs no list at all (minimum == maximum is the answer); a list longer
+// than QS_CAND (all values inside a band 2^-21 of their magnitude wide, not all equal) falls back to the same three levels over the
+// input itself, 256 threads per rank with four loads in flight each -- exact, ~0.1 ms per million values and level.
+constexpr int QS_CAND = 4096, QS_PRE = 3;
 struct QsWs {                       // layout of the workspace (hypad_quantile_workspace_bytes)
   unsigned int* hist;               // [QS_LEVELS][QS_SEL][QS_BINS] (levels 0 and 1 in use), zeroed by the call's memset
   QsState* state;                   // [QS_LEVELS + 1][QS_SEL]
@@ -924,7 +926,7 @@ __global__ __launch_bounds__(256) void qs_level_kernel(const double* __restrict_
     if (c) atomicAdd(g + i, c);
   }
 }
-// third launch: the keys that match a rank's 22-bit prefix -> that rank's candidate list (+ the list's extremes)
+// launch QS_PRE + 1: the keys that match a rank's 33-bit prefix -> that rank's candidate list (+ the list's extremes)
 __global__ __launch_bounds__(256) void qs_compact_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int nsel) {
   __shared__ unsigned int h[QS_SEL][QS_BINS];
   __shared__ QsState cur[QS_SEL];
@@ -935,11 +937,11 @@ __global__ __launch_bounds__(256) void qs_compact_kernel(const double* __restric
 #pragma unroll
   for (int u = 0; u < PER; ++u) { const int64_t i = base + u * 256 + threadIdx.x; x[u] = i < n ? in[i] : 0.0; }
   if (wave < nsel) {
-    const QsState st = qs_descend(ws.hist + ((size_t)1 * QS_SEL + wave) * QS_BINS, 1, ws.state[1 * QS_SEL + wave], h[wave]);
-    if (lane == 0) { cur[wave] = st; if (blockIdx.x == 0) ws.state[2 * QS_SEL + wave] = st; }
+    const QsState st = qs_descend(ws.hist + ((size_t)(QS_PRE - 1) * QS_SEL + wave) * QS_BINS, QS_PRE - 1, ws.state[(QS_PRE - 1) * QS_SEL + wave], h[wave]);
+    if (lane == 0) { cur[wave] = st; if (blockIdx.x == 0) ws.state[QS_PRE * QS_SEL + wave] = st; }
   }
   __syncthreads();
-  const int hi_sh = qs_shift(1);                          // the 22 bits fixed so far sit above it
+  const int hi_sh = qs_shift(QS_PRE - 1);                 // the 33 bits fixed so far sit above it
   unsigned long long pre[QS_SEL];
   for (int s2 = 0; s2 < QS_SEL; ++s2) pre[s2] = s2 < nsel ? cur[s2].prefix : 0;
   for (; base < n; base += (int64_t)gridDim.x * (256 * PER)) {
@@ -968,42 +970,48 @@ __device__ __forceinline__ double np_lerp64(double a, double b, double t) {     
   if (t >= 0.5) r = b - diff * (1.0 - t);
   return r;
 }
-// one workgroup: wave s fixes the remaining 42 bits of rank s's key from its candidate list (see QS_CAND), then
-// out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
-__global__ __launch_bounds__(256) void qs_final_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int nsel, double t0, double t1,
-                                                         double* __restrict__ out) {
+// one workgroup of 1 024 threads: threads [256 s, 256 s + 256) fix the remaining 31 bits of rank s's key from its candidate list (see
+// QS_CAND), the four groups in lock step; then out[j] = lerp(x[floor], x[floor + 1], frac) for the nq quantiles
+__global__ __launch_bounds__(1024) void qs_final_kernel(const double* __restrict__ in, int64_t n, QsWs ws, int nsel, double t0, double t1,
+                                                          double* __restrict__ out) {
   __shared__ unsigned long long keys[QS_SEL];
   __shared__ unsigned int stage[QS_SEL][QS_BINS];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave < nsel) {
-    QsState st = ws.state[2 * QS_SEL + wave];
-    const unsigned int c = ws.cand_count[wave];
-    const unsigned long long kmx = ws.kmax[wave], kmn = ~ws.kinv[wave];
-    unsigned long long key = kmx;
-    if (kmx != kmn) {
-      const bool listed = c <= (unsigned int)QS_CAND;
-      const unsigned long long* cand = ws.cand + (size_t)wave * QS_CAND;
-      const int64_t m = listed ? (int64_t)c : n;
-      unsigned int* hst = stage[wave];
-      for (int level = 2; level < QS_LEVELS; ++level) {
-        const int bins = qs_bins(level), sh = qs_shift(level);
-        const int hi_sh = sh + (level == QS_LEVELS - 1 ? 64 - QS_BITS * (QS_LEVELS - 1) : QS_BITS);     // bits above the digit (<= 42)
-        for (int i = lane; i < bins; i += 64) hst[i] = 0u;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        for (int64_t i = lane; i < m; i += 64) {
-          const unsigned long long k = listed ? cand[i] : qs_key(in[i]);
-          if (((k ^ st.prefix) >> hi_sh) == 0) atomicAdd(hst + ((unsigned int)(k >> sh) & (unsigned int)(bins - 1)), 1u);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        st = qs_descend_staged(hst, level, st);
-        __builtin_amdgcn_wave_barrier();
+  __shared__ QsState cur[QS_SEL];
+  const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255, lane = threadIdx.x & 63;
+  const bool live = grp < nsel;
+  QsState st = ws.state[QS_PRE * QS_SEL + (live ? grp : 0)];
+  const unsigned int c = live ? ws.cand_count[grp] : 0u;
+  const unsigned long long kmx = live ? ws.kmax[grp] : 0ull, kmn = live ? ~ws.kinv[grp] : 0ull;
+  const bool decided = !live || kmx == kmn;                // (group-uniform) every candidate is the same key
+  const bool listed = c <= (unsigned int)QS_CAND;
+  const unsigned long long* cand = ws.cand + (size_t)(live ? grp : 0) * QS_CAND;
+  const int64_t m = decided ? 0 : (listed ? (int64_t)c : n);
+  unsigned int* hst = stage[live ? grp : 0];
+  for (int level = QS_PRE; level < QS_LEVELS; ++level) {   // (block-uniform trip count; a decided group only keeps the barriers)
+    const int bins = qs_bins(level), sh = qs_shift(level);
+    const int hi_sh = sh + (level == QS_LEVELS - 1 ? 64 - QS_BITS * (QS_LEVELS - 1) : QS_BITS);     // bits above the digit (<= 31)
+    for (int i = tg; i < bins; i += 256) hst[i] = 0u;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < m; i0 += 4 * 256) {          // four loads in flight per thread
+      unsigned long long k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t i = i0 + u * 256 + tg;
+        k[u] = i < m ? (listed ? cand[i] : qs_key(in[i])) : ~st.prefix;      // (~prefix never matches)
       }
-      key = st.prefix;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (((k[u] ^ st.prefix) >> hi_sh) == 0) atomicAdd(hst + ((unsigned int)(k[u] >> sh) & (unsigned int)(bins - 1)), 1u);
     }
-    if (lane == 0) keys[wave] = key;
+    __syncthreads();
+    if (tg < 64 && !decided) {                             // the group's first wave scans its histogram
+      const QsState nx = qs_descend_staged(hst, level, st);
+      if (lane == 0) cur[grp] = nx;
+    }
+    __syncthreads();
+    if (!decided) st = cur[grp];
   }
+  if (live && tg == 0) keys[grp] = decided ? kmx : st.prefix;
   __syncthreads();
   if (threadIdx.x < nsel / 2) {
     const int j = threadIdx.x;
@@ -1041,13 +1049,13 @@ int launch_quantiles(const double* in, int64_t n, const double* q, int nq, doubl
   const int nsel = 2 * nq;
   int64_t g = (n + 1023) / 1024;
   g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-  for (int level = 0; level < 2; ++level) {
+  for (int level = 0; level < QS_PRE; ++level) {
     hipLaunchKernelGGL(qs_level_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, level, nsel, r[0], r[1], r[2], r[3]);
     HYPAD_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(qs_compact_kernel, dim3((unsigned)g), dim3(256), 0, s, in, n, ws, nsel);
   HYPAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(256), 0, s, in, n, ws, nsel, t[0], t[1], out);
+  hipLaunchKernelGGL(qs_final_kernel, dim3(1), dim3(1024), 0, s, in, n, ws, nsel, t[0], t[1], out);
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }
