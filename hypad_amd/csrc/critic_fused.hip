@@ -1192,7 +1192,11 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     // one's sixteen registers were spilled; it loads inside finish() like the other layers' quads)
     constexpr int NPRE_C = (SC == 150) ? 1 : PS;
     const int NA_BODY = NA + ((CHAIN && CTAIL > 0) ? 1 : 0);             // phase-A slots of this body (the chain waves' extra one: CTAIL)
-    const int NPRE = NA_BODY < NPRE_C ? NA_BODY : NPRE_C;
+#ifndef HYPAD_CRITIC_PREB
+#define HYPAD_CRITIC_PREB 0
+#endif
+    // HYPAD_CRITIC_PREB (A/B): the helper waves request their phase-B shares at the loop top too (window 100: one slot)
+    const int NPRE = (HYPAD_CRITIC_PREB && !CHAIN && SC == 100) ? PS : (NA_BODY < NPRE_C ? NA_BODY : NPRE_C);
     u32x4_t x0[NPRE_C][4];
     int obase = 0;
     if (it > 0) {

@@ -361,7 +361,7 @@ def test_run_signals_end_to_end_on_two_csv_signals(tmp_path, monkeypatch, capsys
         r = res[name]
         assert r["path"] == f"./trained_models/models_hyper_NAB_2_0.0005/NAB/{name}" and r["rank"] == 0
         assert len(r["confusion"]) == 4 and r["n_intervals"] >= 0 and np.isfinite(r["final"]["dec"])
-        assert sorted(os.listdir(r["path"]))[:4] == ["critic_x.pt", "critic_z.pt", "decoder.pt", "encoder.pt"]
+        assert {"critic_x.pt", "critic_z.pt", "decoder.pt", "encoder.pt"} <= set(os.listdir(r["path"]))
         assert os.path.exists(os.path.join(r["path"], "recons_signal.pt"))          # the test loop's artefacts (anomaly_detection.py:116-131)
         json.dumps(r)                                                                # plain data: what all_gather_object carries
     # the function form with the same seed trains the same models, and each equals its single-signal run
