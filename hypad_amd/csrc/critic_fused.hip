@@ -1192,11 +1192,9 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     // one's sixteen registers were spilled; it loads inside finish() like the other layers' quads)
     constexpr int NPRE_C = (SC == 150) ? 1 : PS;
     const int NA_BODY = NA + ((CHAIN && CTAIL > 0) ? 1 : 0);             // phase-A slots of this body (the chain waves' extra one: CTAIL)
-#ifndef HYPAD_CRITIC_PREB
-#define HYPAD_CRITIC_PREB 0
-#endif
-    // HYPAD_CRITIC_PREB (A/B): the helper waves request their phase-B shares at the loop top too (window 100: one slot)
-    const int NPRE = (HYPAD_CRITIC_PREB && !CHAIN && SC == 100) ? PS : (NA_BODY < NPRE_C ? NA_BODY : NPRE_C);
+    // (measured and dropped in round 5, again: with phase B down to one round the helper waves requesting its shares at the loop top as
+    // well -- 251 registers, none spilled this time -- 2.796-2.805 vs 2.799-2.818 ms per epoch in four alternations: nothing)
+    const int NPRE = NA_BODY < NPRE_C ? NA_BODY : NPRE_C;
     u32x4_t x0[NPRE_C][4];
     int obase = 0;
     if (it > 0) {
@@ -1588,6 +1586,11 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
           else if (cc == in_dim) in0[(32 + row) * ldin + cc] = 0.f;
         }
       }
+      // (measured and dropped in round 5: at window 100 a wave's first two tiles are the layer-0 tiles whose k-tile is ITS g tile
+      // (t = slot + 7 i, t mod 7 = slot), so their penalty-row products need nothing another wave writes and can run here, beside wave
+      // 2's second-order chain, instead of behind the barrier.  Bit-equal, and SLOWER: 2.820-2.823 vs 2.810-2.817 ms per epoch in four
+      // alternations -- the tile waves, not wave 2, are this stage's long pole, and the stage behind the barrier is as long as the
+      // siblings' scalars take to arrive, not as its tiles.)
 #pragma unroll
       for (int i = 0; i < TPW; ++i) dw_tile(i, true, false);
     }
