@@ -176,7 +176,7 @@ __device__ __forceinline__ float4 rng_uniform4(uint64_t seed, uint32_t tick, uin
 struct PreLds { int xs, zs, bufA, bufB, total, ldS; };
 HD PreLds pre_lds(int S) {
   PreLds p; int o = 0;
-  p.ldS = pad4(S) + 4;
+  p.ldS = lds_stride(S);
   const int a = 16 * (2 * DEC_H + 4), b = 16 * p.ldS;      // h tiles (the gate tiles never reach LDS: fused LSTM layers)
   const int buf = a > b ? a : b;
   p.xs = o; o += 16 * p.ldS;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void precompute_body(const IterArgs& ax, const IterAr
       tile_for(16, L, [&](int r, int c) { zenc[r * LP + c] = tab[(int64_t)(ridx ? ridx[g0 + r] : g0 + r) * L + c]; });
     } else {
       const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
-      encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16);
+      encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, ENC_LDG, bufB, ENC_LDH, zenc, nullptr, nullptr, 16);
     }
     __syncthreads();
     const CritGeom g = cz_geom(L);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WP
   tile_load(xs, lp.ldS, az.x + sig * az.x_sig_stride + r0 * az.x_ld, az.x_ld, 16, S, valid);
   __syncthreads();
   const float* pk = az.ws + sig * az.ws_sig_stride + az.pk_off;
-  encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, 16);
+  encoder_fwd_tile_packed(xs, lp.ldS, S, L, pk, gen_pack(S, L, az.hyperbolic), bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, 16);
   __syncthreads();
   float* out = table + ((int64_t)sig * rows + r0) * L;
   tile_for(16, L, [&](int r, int c) { if (r < valid) out[r * L + c] = zs[r * LP + c]; });
@@ -1515,17 +1515,22 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         const float* left = dl + li * 48 * LQ + nj;
         const float* right = li == 0 ? in0 + k0 + j : act + (li - 1) * 48 * LQ + k0 + j;
         const int ldr = li == 0 ? ldin : LQ;
+        // (measured and dropped in round 5: which four rows make a k-step is free, and rows r, r + 4, r + 8, r + 12 instead of four
+        // consecutive ones make these ds_read_b32 -- the kernel's only conflicting LDS accesses by counter: the lane groups q and q + 1 of
+        // a 32-lane half sit 36 / 116 dwords = 4 / 20 banks apart -- conflict-free (144 / 464 dwords = 16 banks).  Same time, 2.802-2.813
+        // vs 2.807-2.814 ms per epoch: the stage waits on dependent latencies, not on LDS cycles.)
+        auto krow = [&](int base, int u) __attribute__((always_inline)) { return base + 4 * u + q; };
         if (rf) {
           float la[8], rb[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { la[u] = left[(4 * u + q) * LQ]; rb[u] = right[(4 * u + q) * ldr]; }
+          for (int u = 0; u < 8; ++u) { la[u] = left[krow(0, u) * LQ]; rb[u] = right[krow(0, u) * ldr]; }
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc_rf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_rf[i], 0, 0, 0);
         }
         if (gpp) {
           float la[4], rb[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { la[u] = left[(32 + 4 * u + q) * LQ]; rb[u] = right[(32 + 4 * u + q) * ldr]; }
+          for (int u = 0; u < 4; ++u) { la[u] = left[krow(32, u) * LQ]; rb[u] = right[krow(32, u) * ldr]; }
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc_gp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_gp[i], 0, 0, 0);
         }

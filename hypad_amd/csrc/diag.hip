@@ -23,7 +23,7 @@ __global__ void diag_decoder_kernel(const float* __restrict__ P, const float* __
                                     int64_t rows, int S, int L, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = MT * 16;
-  const int ldS = pad4(S) + 4;
+  const int ldS = lds_stride(S);
   const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
   float* zs = smem;
   float* bufA = zs + R * LP;
@@ -70,7 +70,7 @@ __global__ void diag_decoder_packed_kernel(const float* __restrict__ pk, PackedO
                                            long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int R = 16;
-  const int ldS = pad4(S) + 4;
+  const int ldS = lds_stride(S);
   const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
   float* zs = smem;
   float* bufA = zs + R * LP;
@@ -115,7 +115,7 @@ extern "C" __attribute__((visibility("default"))) int hypad_diag_decoder_packed(
                                          int S, int L, long long* stamps, void* stream) {
   PackedOffs po;
   for (int i = 0; i < 13; ++i) po.o[i] = offs[i];
-  const int ldS = pad4(S) + 4;
+  const int ldS = lds_stride(S);
   const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
   const size_t lds = (size_t)(16 * LP + 2 * 16 * per_row) * sizeof(float);
   const int nblk = (int)((rows + 15) / 16);
@@ -126,7 +126,7 @@ extern "C" __attribute__((visibility("default"))) int hypad_diag_decoder_packed(
 extern "C" __attribute__((visibility("default"))) int hypad_diag_decoder_timeline(const float* P, const float* z, float* hyper, int64_t rows, int S, int L, int mt,
                                            int threads, long long* stamps, hypad_stream_t s) {
   const int R = mt * 16;
-  const int ldS = pad4(S) + 4;
+  const int ldS = lds_stride(S);
   const int per_row = ldS > 6 * DEC_H + 4 ? ldS : 6 * DEC_H + 4;
   size_t lds = (size_t)(R * LP + 2 * R * per_row + 16 * WSTAGE_FLOATS) * sizeof(float);
   int blocks = (int)((rows + R - 1) / R);

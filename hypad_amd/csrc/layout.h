@@ -15,10 +15,19 @@ namespace hypad {
 constexpr int ENC_H = 50;      // Encoder LSTM hidden size      models/tadgan.py:17
 constexpr int DEC_H = 64;      // Decoder LSTM hidden size      models/tadgan.py:36
 constexpr int DEC_D1 = 50;     // Decoder dense1 out_features   models/tadgan.py:34
+constexpr int ENC_LDG = 6 * ENC_H + 8;   // LDS row stride of the encoder's gate tile [16][3 x 2 x 50]: 308 = 4 x 77 (lds_stride)
+constexpr int ENC_LDH = 2 * ENC_H + 8;   // ... of its hidden tile [16][2 x 50]: 108 = 4 x 27
 constexpr int MAX_S = 256;     // fused kernels: signal_shape limit (LDS budget)
 constexpr int MAX_L = 32;      // latent / critic width limit
 
 HD int pad4(int n) { return (n + 3) & ~3; }
+// LDS row stride (floats) of a 16-row tile: a multiple of four floats that is 4 x ODD.  Both ways a tile is touched are then free of
+// bank conflicts (MI355X_MICROARCH.md, LDS: banks = dword address mod 64 for ds_read_b128 within a 16-lane group, mod 32 for 4-byte
+// accesses within a 32-lane half): the MFMA A-operand reads (lane (row j, group q) takes 16 bytes of row j: sixteen rows at stride
+// 4 (2 m + 1) dwords fall on sixteen different 16-byte slots of the 256-byte bank row) and the epilogues' accumulator writes (lane
+// (j, q) writes rows 4 q + r: lane groups q and q + 1 are 16 (2 m + 1) dwords = 16 banks apart).  pad4(100) + 4 = 104 = 4 x 26 -- the
+// reference window of all things -- cost two LDS cycles for every such access: a third of the generator kernel's LDS cycles by counter.
+HD int lds_stride(int cols) { const int n = pad4(cols) + 4; return ((n >> 2) & 1) ? n : n + 4; }
 
 struct LstmDir { int w_ih, w_hh, b_ih, b_hh; };
 

@@ -683,7 +683,7 @@ struct NetLds {          // float offsets into dynamic LDS for the network kerne
 };
 __host__ __device__ inline NetLds net_lds(int S, int MT) {
   NetLds n;
-  n.ldS = pad4(S) + 4;
+  n.ldS = lds_stride(S);
   int rows = MT * 16;
   int per_row = n.ldS > 6 * DEC_H + 4 ? n.ldS : 6 * DEC_H + 4;
   n.bufFloats = rows * per_row;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(THREADS) void encoder_fwd_kernel(const float* __res
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(smem + nl.xs, nl.ldS, x + r0 * S, S, 16, S, valid);
   __syncthreads();
-  encoder_fwd_tile(smem + nl.xs, nl.ldS, S, L, P, el, smem + nl.bufA, 6 * ENC_H + 4, smem + nl.bufB, 2 * ENC_H + 4,
+  encoder_fwd_tile(smem + nl.xs, nl.ldS, S, L, P, el, smem + nl.bufA, ENC_LDG, smem + nl.bufB, ENC_LDH,
                    smem + nl.zs, nullptr, nullptr, valid, smem + nl.wst);
   tile_store(out + r0 * L, L, smem + nl.zs, LP, 16, L, valid);
 }
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(THREADS) void score_forward_kernel(const float* __r
     critic_fwd_tile(xs, nl.ldS, PC, cl, L, cs, no_drop(), 0, smem + nl.wst);
     if (threadIdx.x < valid) critic[r0 + threadIdx.x] = cs.out[threadIdx.x];
   }
-  encoder_fwd_tile(xs, nl.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid, smem + nl.wst);
+  encoder_fwd_tile(xs, nl.ldS, S, L, PE, el, bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, valid, smem + nl.wst);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   decoder_trunk_fwd_tile<1>(zs, L, S, PD, dl, bufA, bufB, nl.ldS, no_drop(), [](int r) { return r; }, none, valid, smem + nl.wst);
   if (eucl) tile_store(eucl + r0 * S, S, bufA, nl.ldS, 16, S, valid);

@@ -121,7 +121,7 @@ struct LdsPlan {
 constexpr int LDS_LIMIT_FLOATS = 160 * 1024 / 4;
 HD LdsPlan lds_plan(int S, int rows_lstm, int rows_head, int critic_floats, int crit_scratch = CRITIC_LDS_FLOATS) {
   LdsPlan p;
-  p.ldS = pad4(S) + 4;
+  p.ldS = lds_stride(S);
   int a = rows_lstm * (6 * DEC_H + 4), b = rows_head * p.ldS;
   p.bufFloats = a > b ? a : b;
   int o = 0;

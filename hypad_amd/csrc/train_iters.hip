@@ -182,7 +182,7 @@ __device__ __forceinline__ void cz_pass_body(const IterArgs& a, float* smem) {
   load_z(a, sig, tile, tick, zs);                       // real = z ~ N(0,1)
   __syncthreads();
   float* zenc = zs + 16 * LP;                           // fake = encoder(x)
-  encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zenc, nullptr, nullptr, 16, smem + lp.wst);
+  encoder_fwd_tile(xs, lp.ldS, S, L, PE, el, bufA, ENC_LDG, bufB, ENC_LDH, zenc, nullptr, nullptr, 16, smem + lp.wst);
   // injected mask order (hypad.h): fake | valid | interpolated
   critic_three_passes(a, sig, tile, tick, zs, LP, zenc, LP, small, LP, small + 16 * LP, LP, PC, cl, cs, ws, cw, 1, 0, 2, red);
 }
@@ -266,7 +266,7 @@ struct GenLds {
 };
 HD GenLds gen_lds(int S, int L, int hyper, int role) {
   GenLds p;
-  p.ldS = pad4(S) + 4;
+  p.ldS = lds_stride(S);
   const CriticPad cp = role == 0 ? critic_pad(S, L, 4) : critic_pad(L, L, 2);      // (chain R stages no critic; same plan as Z)
   const int rows_head = (role == 1 && hyper) ? 32 : 16;
   const int a = 16 * (6 * DEC_H + 4), b = rows_head * p.ldS;
@@ -313,7 +313,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   tile_store(ws + gw.xg + (int64_t)(B + g0) * S, S, xs, ldS, 16, S, 16);
   float* zin = zs + 16 * LP;
   float* gates = ws + gw.enc_g2 + (int64_t)g0 * 8 * ENC_H;
-  encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin, gates,
+  encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zin, gates,
                                 ws + gw.enc_h + (int64_t)(B + g0) * 2 * ENC_H, 16, pre_enc);
   const PackedPre pre_edt = gemm_nt_prefetch<WSC1>(pk + gp.enc_d_t, L, 2 * ENC_H);
   // critic_z(encoder(x)) and its input gradient (frozen critic; -mean(fake_z), train.py:215-217)
@@ -324,7 +324,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   // encoder backward of that gradient
   float* dP = bufA;
   {
-    LstmCellBwdEpi epi{gates, ENC_H, dP, 6 * ENC_H + 4, 16, 16, nullptr, 0, ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, {}, {}, {}, {}, {}};
+    LstmCellBwdEpi epi{gates, ENC_H, dP, ENC_LDG, 16, 16, nullptr, 0, ws + gw.dgenc + (int64_t)(B + g0) * 6 * ENC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dzc, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);      // dH, cell backward in the epilogue
   }
   float* part_out = ws + gw.partial + tile * 4;
@@ -412,7 +412,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     tile_store(ws + gw.xg + (int64_t)g0 * S, S, xs, ldS, 16, S, 16);
     if (HYPER) tile_store(ws + gw.ecat + (int64_t)(2 * B + g0) * S, S, xs, ldS, 16, S, 16);      // the head's second row block (pass 2)
     zin = zs + 16 * LP;
-    encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zin,
+    encoder_fwd_tile_packed<true, WSC1>(xs, ldS, S, L, pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zin,
                                   ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ws + gw.enc_h + (int64_t)g0 * 2 * ENC_H, 16, pre_enc);
     GEN_STAMP(1);
     pre_d1 = gemm_nt_prefetch<WSC1>(pk + gp.d1, L, DEC_D1);
@@ -624,7 +624,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   GEN_STAMP(10);
   // ---- encoder backward: dH = dZ W_dense, cell backward -> dG in Y
   {
-    LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, 6 * ENC_H + 4, 16, 16, nullptr, 0,
+    LstmCellBwdEpi epi{ws + gw.enc_g + (int64_t)g0 * 8 * ENC_H, ENC_H, Y, ENC_LDG, 16, 16, nullptr, 0,
                        ws + gw.dgenc + (int64_t)g0 * 6 * ENC_H, {}, {}, {}, {}, {}};
     gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
   }
@@ -1546,7 +1546,7 @@ struct ScoreLds { int xs, zs, bufA, bufB, cw, small, total, ldS; };
 #endif
 HD ScoreLds score_lds(int S, int L) {
   ScoreLds p; int o = 0;
-  p.ldS = pad4(S) + 4;
+  p.ldS = lds_stride(S);
   const CriticPad cp = critic_pad(S, L, 4);
   int buf = 16 * (2 * DEC_H + 4) > 32 * p.ldS ? 16 * (2 * DEC_H + 4) : 32 * p.ldS;       // h tiles / the 32-row head tile
   const int crit = 16 * cp.ldin + 2 * 16 * cp.LQ;                                        // critic_tile_fwd scratch, over bufA | bufB
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_SCORE_
   } else {
     __syncthreads();
   }
-  encoder_fwd_tile_packed(xs, ldS, S, L, a.pk, gp, bufA, 6 * ENC_H + 4, bufB, 2 * ENC_H + 4, zs, nullptr, nullptr, valid);
+  encoder_fwd_tile_packed(xs, ldS, S, L, a.pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, valid);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   decoder_trunk_fwd_tile_packed<1>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
   if (a.eucl) tile_store(a.eucl + r0 * S, S, bufA, ldS, 16, S, valid);
