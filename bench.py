@@ -770,9 +770,10 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0, smooth=200, kernels=T
         "rolling_mean(1250) of |true - pred|": (lambda: C.hypad_rolling_mean(_C.ptr(true64), _C.ptr(pred32), _C.ptr(sm64), T, n // 100, 0, roll_ws.data_ptr(), roll_bytes, st()), "hbm", None, 20 * T),
         "zscore_clip": (lambda: C.hypad_zscore_clip(_C.ptr(sm64), _C.ptr(z64), T, stats.data_ptr(), _C.STATS_WORKSPACE_BYTES, st()), "hbm", None, 24 * T),
         "kde_mode_kernel": (lambda: C.hypad_kde_mode(_C.ptr(critic), _C.ptr(modes64), n, S, st()), "valu", float(S) * S * T, 4 * n + 8 * T),
-        # np.quantile 25 / 75 % by radix selection (6 passes over the keys) + quantile-trimmed z-score, nothing through the host
+        # np.quantile 25 / 75 % by radix selection (3 histogram passes + 1 compaction pass over the keys, then one workgroup) + quantile-trimmed
+        # z-score, nothing through the host
         "critic_score (device quantiles + trimmed z-score)": (lambda: C.hypad_critic_score(_C.ptr(modes64), _C.ptr(z64), T, cs_ws.data_ptr(), cs_bytes, st()),
-                                                               "hbm", None, (6 * 8 + 24) * T),
+                                                               "hbm", None, (4 * 8 + 24) * T),
     }
     cs_bytes = C.hypad_critic_score_workspace_bytes()
     cs_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=device)

@@ -490,3 +490,74 @@ extern "C" __attribute__((visibility("default"))) int hypad_diag_store16(int for
   hipLaunchKernelGGL(diag_store16_check_kernel, dim3(1024), dim3(256), 0, (hipStream_t)s, buf, (unsigned)(blocks * 256 * iters), bad);
   return (int)hipGetLastError();
 }
+
+// ---- two concurrent kernels on one XCD handing data to each other (round 5: could the dW + Adam launch run BESIDE the generator
+// launch, fed through flags?).  Kernel `role` 0 writes `words` dwords of payload with PLAIN stores, drains, raises a flag word; role 1
+// polls the flag with sc1 (L1-bypassing) loads, reads the payload with sc1 loads, checks it, and answers with its own payload + flag --
+// `rounds` times.  Only the workgroup that finds itself on XCD `xcd` takes part (grid = 8 workgroups, dealt round-robin).
+// out[0..1]: shader-clock cycles of the whole exchange per role; out[2..3]: payload words that arrived wrong; out[4..5]: 1 = a bounded
+// wait gave up (the partner never showed: the two launches did not run beside each other).
+namespace {
+__global__ __launch_bounds__(256) void diag_pair_kernel(int role, int xcd, int rounds, int words, unsigned* flags, unsigned* payload, long long* out) {
+  const unsigned my_xcc = __builtin_amdgcn_s_getreg(6164) & 0xfu;
+  if ((int)my_xcc != xcd) return;
+  __shared__ int give_up;
+  if (threadIdx.x == 0) give_up = 0;
+  __syncthreads();
+  unsigned* mine = payload + role * words;
+  unsigned* theirs = payload + (1 - role) * words;
+  long long bad = 0;
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  for (int r = 1; r <= rounds; ++r) {
+    if (role == 0 || r > 0) {
+      if (role == 1) {                                                   // wait for the partner's round r
+        if (threadIdx.x == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(flags + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r) {
+            if (++spins > (1u << 22)) { give_up = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        __syncthreads();
+        if (give_up) break;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(theirs, 0, 0x7fffffff, 0x00020000);
+        for (int i = threadIdx.x; i < words; i += 256) {
+          const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, i * 4, 0, 16);      // sc1
+          if (v != (unsigned)(r * 131071 + i)) ++bad;
+        }
+      }
+      for (int i = threadIdx.x; i < words; i += 256) mine[i] = (unsigned)(r * 131071 + i) + (role ? 7u : 0u);      // plain stores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(flags + role, (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (role == 0) {                                                   // wait for the answer of round r
+        if (threadIdx.x == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)r) {
+            if (++spins > (1u << 22)) { give_up = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        __syncthreads();
+        if (give_up) break;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(theirs, 0, 0x7fffffff, 0x00020000);
+        for (int i = threadIdx.x; i < words; i += 256) {
+          const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, i * 4, 0, 16);
+          if (v != (unsigned)(r * 131071 + i) + 7u) ++bad;
+        }
+      }
+    }
+  }
+  const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+  if (bad) atomicAdd((unsigned long long*)(out + 2 + role), (unsigned long long)bad);
+  if (threadIdx.x == 0) { out[role] = t1 - t0; out[4 + role] = give_up; }
+}
+}  // namespace
+// flags: 2 words, payload: 2 * words dwords, out: 6 int64 -- all zeroed by the caller.  The two launches go to two streams.
+extern "C" __attribute__((visibility("default"))) int hypad_diag_pair(int xcd, int rounds, int words, unsigned* flags, unsigned* payload, long long* out,
+                                                                      hypad_stream_t s0, hypad_stream_t s1) {
+  if (xcd < 0 || xcd > 7 || rounds < 1 || words < 1) return HYPAD_EINVAL;
+  hipLaunchKernelGGL(diag_pair_kernel, dim3(8), dim3(256), 0, (hipStream_t)s0, 0, xcd, rounds, words, flags, payload, out);
+  hipLaunchKernelGGL(diag_pair_kernel, dim3(8), dim3(256), 0, (hipStream_t)s1, 1, xcd, rounds, words, flags, payload, out);
+  return (int)hipGetLastError();
+}
