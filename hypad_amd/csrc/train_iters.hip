@@ -584,7 +584,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
       ws[gw.ballpart + ((int64_t)role * (B / 16) + tile) * S + c] = s;
     }
     __syncthreads();
-    if (RES) gp_publish(sync, GG_H);        // du rows, the head's input rows (forward) and the bias partials are stored
     GEN_STAMP(25);
     // dE = dU W_h for the decoder pass, and d(pre-tanh) = dE * (1 - E^2) in its epilogue (E re-read from the workspace,
     // requested before the reduction)
@@ -605,7 +604,9 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
       gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
     }
     __syncthreads();
-    if (RES) gp_publish(sync, GG_D2);       // d(pre-tanh) rows (h1: forward)
+    // (resident: a group's rows are reported only behind this chain's LAST read of the group's weights -- the backward-data product
+    // through W^T comes after the layer's deltas are complete, and the dW side rewrites W the moment every chain has reported)
+    if (RES) gp_publish(sync, GG_H);        // du rows, the head's input rows, the bias partials; W_h^T has been read
     GEN_STAMP(26);
   } else {
     if (role == 1) {
@@ -640,7 +641,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   GEN_STAMP(32);
   __syncthreads();
-  if (RES) { if (HYPER) gp_publish(sync, GG_L1); else gp_publish(sync, GG_D2, GG_L1); }      // layer-1 gate deltas (Euclidean: + the d(pre-tanh) rows stored above)
+  if (RES) gp_publish(sync, GG_D2);         // d(pre-tanh) rows (h1: forward); W_2^T has been read
   GEN_STAMP(7);
   GEN_STAMP(33);
   const PackedPre pre_l0t = gemm_nt_prefetch<WSC1>(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
@@ -653,7 +654,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   GEN_STAMP(35);
   __syncthreads();
-  if (RES) gp_publish(sync, GG_L0);         // layer-0 gate deltas
+  if (RES) gp_publish(sync, GG_L1);         // layer-1 gate deltas; layer 1's W^T has been read
   GEN_STAMP(36);
   GEN_STAMP(8);
   GEN_STAMP(37);
@@ -669,17 +670,17 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   if (role == 0) {
     if (threadIdx.x == 0) part_out[1] = sum_crit;
     if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;      // keeps the warm-up loads alive
-    if (RES) gp_publish(sync, GG_D1);       // dA0 rows (+ this chain's loss partial)
+    if (RES) gp_publish(sync, GG_L0, GG_D1);      // layer-0 gate deltas, dA0 rows (+ this chain's loss partial): chain G reads no W_1^T
     GEN_STAMP(11);
     return;
   }
-  if (RES) gp_publish(sync, GG_D1);
+  if (RES) gp_publish(sync, GG_L0);
   // dZ = dA0 W1: the gradient reaching the encoder's output
   const PackedPre pre_edt = gemm_nt_prefetch<WSC1>(pk + gp.enc_d_t, L, 2 * ENC_H);
   gemm_nt_packed<1, true, ActIdentity, WSC1>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t, ActIdentity{}, nullptr, 0,
                           ws + gw.dzenc + (int64_t)g0 * L, L);                     // (the critic_z part of dZ: chain Z)
   __syncthreads();
-  if (RES) gp_publish(sync, GG_ED);         // dZ rows (the encoder's hidden rows: forward)
+  if (RES) gp_publish(sync, GG_D1);         // dA0 rows; W_1^T has been read
   GEN_STAMP(10);
   // ---- encoder backward: dH = dZ W_dense, cell backward -> dG in Y
   {
@@ -689,7 +690,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
-  if (RES) gp_publish(sync, GG_E);          // the encoder's gate deltas (+ this chain's loss partial)
+  if (RES) gp_publish(sync, GG_ED, GG_E);   // dZ rows, the encoder's gate deltas (+ this chain's loss partial); the dense layer's W^T has been read
   GEN_STAMP(11);
 }
 
@@ -1311,6 +1312,10 @@ __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPh
           float* lo = a.losses + sig * a.loss_sig_stride + (int64_t)b * 4;
           lo[0] = 10.f * aux - fx / a.B - fz / a.B;
           lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
+          // the partials have been read: the chains may overwrite them (counted as one more item of dense1's and of the encoder's group:
+          // between them every chain waits for one of the two)
+          __hip_atomic_fetch_add(sync + GP_DONE + GG_D1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(sync + GP_DONE + GG_E, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         continue;
       }
@@ -1339,9 +1344,33 @@ __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPh
 
 // One step of the resident chains as a real FUNCTION: inlined into the step loop, the compiler hoisted the body's loop-invariant
 // address arithmetic out of the 29-step loop and kept it in registers across it (256 VGPRs + 63 spilled; the per-step kernel needs 165).
+// The function takes the step number only and reads the launch's arguments where the kernel got them -- the kernel-argument segment
+// (constant address space: scalar loads, uniform values) -- because a pointer to a copy of them in private memory made every use a
+// flat load of a value the compiler must treat as lane-varying (6.6 ms per epoch instead of 2.8).
+template <class T>
+__device__ __forceinline__ T gp_kernarg(int byte_offset) {
+  using CWord = const __attribute__((address_space(4))) int32_t;
+  static_assert(sizeof(T) % 4 == 0, "whole words");
+  T out;
+  CWord* src = (CWord*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset);
+  int32_t* dst = reinterpret_cast<int32_t*>(&out);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = src[i];
+  return out;
+}
+constexpr int GP_KERNARG_OFFSET = (int)((sizeof(IterArgs) + 7) & ~(size_t)7);      // (IterArgs a, GenPhase gp): gp follows a, 8-byte aligned
 template <bool HYPER, int SC, int LC, int BC>
-__device__ __attribute__((noinline)) void gen_phase_step(const IterArgs* as, float* smem, unsigned* sync, int b) {
-  gen_body<HYPER, SC, LC, BC, true, true>(*as, smem, sync, b);
+__device__ __attribute__((noinline)) void gen_phase_step(float* smem, int b) {
+  IterArgs as = gp_kernarg<IterArgs>(0);
+  const GenPhase gp = gp_kernarg<GenPhase>(GP_KERNARG_OFFSET);
+  const int B = BC ? BC : as.B;
+  const int sig = blockIdx.y + as.sig0;
+  unsigned* sync = reinterpret_cast<unsigned*>(as.ws + sig * as.ws_sig_stride + gp.sync_off);
+  as.step_add = b;
+  as.row_index = as.row_index + (int64_t)b * B;
+  as.z = as.z ? as.z + (int64_t)b * gp.z_step : nullptr;
+  as.masks = as.masks ? as.masks + (int64_t)b * gp.mask_step : nullptr;
+  gen_body<HYPER, SC, LC, BC, true, true>(as, smem, sync, b);
 }
 // The chains of every step of the phase: gen_body per step on per-step arguments; at the top of a step the workgroup waits for the
 // updates of the weights it reads (the groups' done[] counters of the previous step).
@@ -1350,7 +1379,6 @@ __global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (a.guard && a.counters[4] != 0) return;
   if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;           // ALL three chains on the model's XCD: their rows meet the dW workgroups in its L2
-  const int B = BC ? BC : a.B;
   const int sig = blockIdx.y + a.sig0, role = blockIdx.z;
   unsigned* sync = reinterpret_cast<unsigned*>(a.ws + sig * a.ws_sig_stride + gp.sync_off);
   __shared__ int gave_up;
@@ -1370,12 +1398,7 @@ __global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) 
       __syncthreads();
       if (gave_up) return;
     }
-    IterArgs as = a;
-    as.step_add = b;
-    as.row_index = a.row_index + (int64_t)b * B;
-    as.z = a.z ? a.z + (int64_t)b * gp.z_step : nullptr;
-    as.masks = a.masks ? a.masks + (int64_t)b * gp.mask_step : nullptr;
-    gen_phase_step<HYPER, SC, LC, BC>(&as, smem, sync, b);
+    gen_phase_step<HYPER, SC, LC, BC>(smem, b);
     __syncthreads();                                 // (the step's LDS tiles are dead; the next step rewrites them)
   }
 }
@@ -2089,6 +2112,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
                       : x.kind == DW_DECAY ? (x.nrows + 255) / 256 : 1;
     gp.group_items[x.group] += items;
   }
+  gp.group_items[GG_D1] += 1; gp.group_items[GG_E] += 1;      // (the step's loss row: dw_phase_kernel counts it in both groups)
   gp.arrivals = 2 * (a.B / 16);
   gp.dw_waves = DWP_WGS * (DWP_THREADS / 64);
   gp.fault_step = fault_step;
