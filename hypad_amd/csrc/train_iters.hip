@@ -1347,12 +1347,16 @@ __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPh
 // The function takes the step number only and reads the launch's arguments where the kernel got them -- the kernel-argument segment
 // (constant address space: scalar loads, uniform values) -- because a pointer to a copy of them in private memory made every use a
 // flat load of a value the compiler must treat as lane-varying (6.6 ms per epoch instead of 2.8).
+// (the segment's address is handed down as an integer -- inside a callee __builtin_amdgcn_kernarg_segment_ptr() is null on this stack -- and
+// made wave-uniform again with readfirstlane: function arguments travel in vector registers)
 template <class T>
-__device__ __forceinline__ T gp_kernarg(int byte_offset) {
+__device__ __forceinline__ T gp_kernarg(unsigned long long segment, int byte_offset) {
   using CWord = const __attribute__((address_space(4))) int32_t;
   static_assert(sizeof(T) % 4 == 0, "whole words");
   T out;
-  CWord* src = (CWord*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset);
+  const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(segment >> 32)) << 32) |
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)segment);
+  CWord* src = (CWord*)(base + (unsigned long long)byte_offset);
   int32_t* dst = reinterpret_cast<int32_t*>(&out);
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = src[i];
@@ -1360,11 +1364,21 @@ __device__ __forceinline__ T gp_kernarg(int byte_offset) {
 }
 constexpr int GP_KERNARG_OFFSET = (int)((sizeof(IterArgs) + 7) & ~(size_t)7);      // (IterArgs a, GenPhase gp): gp follows a, 8-byte aligned
 template <bool HYPER, int SC, int LC, int BC>
-__device__ __attribute__((noinline)) void gen_phase_step(float* smem, int b) {
-  IterArgs as = gp_kernarg<IterArgs>(0);
-  const GenPhase gp = gp_kernarg<GenPhase>(GP_KERNARG_OFFSET);
+__device__ __attribute__((noinline)) void gen_phase_step(unsigned long long segment, unsigned lds_offset, int b_) {
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  // (the tiles' base as an LDS-address-space pointer again: handed down as a generic pointer every tile access became a flat instruction)
+  using LdsF = __attribute__((address_space(3))) float;
+  float* smem = (float*)(LdsF*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset);
+  IterArgs as = gp_kernarg<IterArgs>(segment, 0);
+  const GenPhase gp = gp_kernarg<GenPhase>(segment, GP_KERNARG_OFFSET);
   const int B = BC ? BC : as.B;
   const int sig = blockIdx.y + as.sig0;
+  // (and the arguments' pointers as GLOBAL-address-space pointers again: as kernel arguments they are known to be; read back from memory
+  // they are generic, and every access through them a flat instruction that counts on the LDS wait counter too)
+#define HYPAD_AS_GLOBAL(p) p = (decltype(p))(__attribute__((address_space(1))) void*)(unsigned long long)(p)
+  HYPAD_AS_GLOBAL(as.ws); HYPAD_AS_GLOBAL(as.x); HYPAD_AS_GLOBAL(as.row_index); HYPAD_AS_GLOBAL(as.z); HYPAD_AS_GLOBAL(as.masks); HYPAD_AS_GLOBAL(as.counters);
+  HYPAD_AS_GLOBAL(as.P.enc); HYPAD_AS_GLOBAL(as.P.dec); HYPAD_AS_GLOBAL(as.P.cx); HYPAD_AS_GLOBAL(as.P.cz); HYPAD_AS_GLOBAL(as.losses);
+#undef HYPAD_AS_GLOBAL
   unsigned* sync = reinterpret_cast<unsigned*>(as.ws + sig * as.ws_sig_stride + gp.sync_off);
   as.step_add = b;
   as.row_index = as.row_index + (int64_t)b * B;
@@ -1398,7 +1412,8 @@ __global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) 
       __syncthreads();
       if (gave_up) return;
     }
-    gen_phase_step<HYPER, SC, LC, BC>(smem, b);
+    gen_phase_step<HYPER, SC, LC, BC>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(),
+                                      (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem, b);
     __syncthreads();                                 // (the step's LDS tiles are dead; the next step rewrites them)
   }
 }
