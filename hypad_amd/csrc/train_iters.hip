@@ -272,7 +272,7 @@ HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) 
 // the head's ball bias are read with L1-bypassing (sc1) loads on the other side.  Same arithmetic in the same order as the launches:
 // same bits.  Every wait is bounded (status word, as the resident critic launch).
 enum GenGroup : int { GG_H = 0, GG_D2 = 1, GG_L1 = 2, GG_L0 = 3, GG_D1 = 4, GG_ED = 5, GG_E = 6 };      // in the order their operand rows become complete
-enum : int { GP_READY = 0, GP_DONE = 8, GP_ERR = 16 };                                                   // word offsets in a model's sync block
+enum : int { GP_READY = 0, GP_DONE = 8, GP_ERR = 16, GP_CLAIM_CHAIN = 17, GP_CLAIM_DW = 18 };            // word offsets in a model's sync block
 struct GenPhase {
   int nb;                       // steps (minibatches) of the phase
   int64_t z_step, mask_step;    // floats between two steps' injected planes (unused when the planes are null)
@@ -284,6 +284,7 @@ struct GenPhase {
   int arrivals;                 // chain workgroups that complete a group's operand rows per step: 2 * batch / 16
   int dw_waves;                 // resident dW waves per model: wave w takes items w, w + dw_waves, ...
   int fault_step;               // tests: > 0 = the dW side never raises done[] for that step (a bounded wait gives up)
+  int n_signals;
 };
 constexpr unsigned GP_SPIN_LIMIT = 1u << 21;
 // one lane (or a uniform wave) waits until *word >= target; false = gave up (bounded) or somebody else did (err word)
@@ -338,9 +339,9 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 // Chain Z of the generator step (see above): encoder forward of the tile's windows, critic_z forward / backward, encoder
 // backward of that gradient; operand rows into the second halves of xg / enc_h / dzenc / dgenc.
 template <int SC, int LC, int BC, bool WSC1 = false, bool RES = false>
-__device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0) {
+__device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0, int sig_ = -1, int tile_ = -1) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3;
+  const int sig = RES ? sig_ : (int)blockIdx.y + a.sig0, tile = RES ? tile_ : (int)(blockIdx.x >> 3);      // (resident: claimed, see gen_phase_kernel)
   const GenLds lp = gen_lds(S, L, a.hyperbolic, 2);
   const int ldS = lp.ldS;
   const GenWs gw = gen_ws(B, S, L);
@@ -396,11 +397,12 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsig
 // critic_fused.hip: every layer of the chain runs once per launch, so index arithmetic is never amortised.
 static_assert(TB == 512, "gen_body deals rows over 8 waves");
 template <bool HYPER, int SC, int LC, int BC, bool WSC1 = false, bool RES = false>
-__device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0) {
+__device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0, int sig_ = -1, int tile_ = -1,
+                                         int role_ = -1) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3, role = blockIdx.z;
+  const int sig = RES ? sig_ : (int)blockIdx.y + a.sig0, tile = RES ? tile_ : (int)(blockIdx.x >> 3), role = RES ? role_ : (int)blockIdx.z;
   __builtin_amdgcn_s_setprio(2);            // (tile_gemm.h mfma_prio_*: the MFMA loops run below everything else)
-  if (role == 2) { gen_role_z<SC, LC, BC, WSC1, RES>(a, smem, sync, step); return; }
+  if (role == 2) { gen_role_z<SC, LC, BC, WSC1, RES>(a, smem, sync, step, sig_, tile_); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
@@ -481,7 +483,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
   sv.e = ws + gw.ecat + prow0 * S;
-  sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
+  sv.stamps = (!RES && a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
@@ -1276,16 +1278,25 @@ template <int SC, int LC, int BC, int KS>
 __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPhase gp) {
   extern __shared__ __attribute__((aligned(16))) float unused_lds[];      // (requested, never touched)
   if (a.guard && a.counters[4] != 0) return;
-  if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;           // this model's XCD (workgroups are dealt round-robin over the XCDs)
-  const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
-  const int sig = blockIdx.y + a.sig0;
-  const int lane = threadIdx.x & 63, wave = wave_id();
-  const int j = lane & 15, q = lane >> 4;
+  // Model `sig` lives on the XCD whose hardware id is sig (both resident launches read HW_REG_XCC_ID: the dispatcher deals workgroups
+  // round-robin over the XCDs, but where a launch's first workgroup lands depends on the launches before it -- the first trial had the
+  // chains on XCD 7 and these workgroups on XCD 0, reading rows that were still in the other L2).  A workgroup on that XCD claims one of
+  // the model's DWP_WGS slots; whoever finds none left (the grid is twice the need) leaves.
+  const int sig = (int)(__builtin_amdgcn_s_getreg(6164) & 0xfu);          // hwreg(HW_REG_XCC_ID, 0, 4)
+  if (sig >= gp.n_signals) return;
+  __shared__ int claimed;
   float* ws = a.ws + sig * a.ws_sig_stride;
   unsigned* sync = reinterpret_cast<unsigned*>(ws + gp.sync_off);
+  if (threadIdx.x == 0) claimed = (int)__hip_atomic_fetch_add(sync + GP_CLAIM_DW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int slot = claimed;
+  if (slot >= DWP_WGS) return;
+  const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int j = lane & 15, q = lane >> 4;
   const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.items_off);
   const float* adamc = a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.adamc_off;
-  const int w_global = (int)(blockIdx.x >> 3) * (DWP_THREADS / 64) + wave;
+  const int w_global = slot * (DWP_THREADS / 64) + wave;
   const int step0 = a.counters[a.opt];
   using CWord = const __attribute__((address_space(4))) int32_t;
   bool alive = true;
@@ -1364,15 +1375,15 @@ __device__ __forceinline__ T gp_kernarg(unsigned long long segment, int byte_off
 }
 constexpr int GP_KERNARG_OFFSET = (int)((sizeof(IterArgs) + 7) & ~(size_t)7);      // (IterArgs a, GenPhase gp): gp follows a, 8-byte aligned
 template <bool HYPER, int SC, int LC, int BC>
-__device__ __attribute__((noinline)) void gen_phase_step(unsigned long long segment, unsigned lds_offset, int b_) {
-  const int b = __builtin_amdgcn_readfirstlane(b_);
+__device__ __attribute__((noinline)) void gen_phase_step(unsigned long long segment, unsigned lds_offset, int b_, int place_) {
+  const int b = __builtin_amdgcn_readfirstlane(b_), place = __builtin_amdgcn_readfirstlane(place_);
+  const int sig = place >> 16, role = (place >> 8) & 0xff, tile = place & 0xff;
   // (the tiles' base as an LDS-address-space pointer again: handed down as a generic pointer every tile access became a flat instruction)
   using LdsF = __attribute__((address_space(3))) float;
   float* smem = (float*)(LdsF*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset);
   IterArgs as = gp_kernarg<IterArgs>(segment, 0);
   const GenPhase gp = gp_kernarg<GenPhase>(segment, GP_KERNARG_OFFSET);
   const int B = BC ? BC : as.B;
-  const int sig = blockIdx.y + as.sig0;
   // (and the arguments' pointers as GLOBAL-address-space pointers again: as kernel arguments they are known to be; read back from memory
   // they are generic, and every access through them a flat instruction that counts on the LDS wait counter too)
 #define HYPAD_AS_GLOBAL(p) p = (decltype(p))(__attribute__((address_space(1))) void*)(unsigned long long)(p)
@@ -1384,7 +1395,7 @@ __device__ __attribute__((noinline)) void gen_phase_step(unsigned long long segm
   as.row_index = as.row_index + (int64_t)b * B;
   as.z = as.z ? as.z + (int64_t)b * gp.z_step : nullptr;
   as.masks = as.masks ? as.masks + (int64_t)b * gp.mask_step : nullptr;
-  gen_body<HYPER, SC, LC, BC, true, true>(as, smem, sync, b);
+  gen_body<HYPER, SC, LC, BC, true, true>(as, smem, sync, b, sig, tile, role);
 }
 // The chains of every step of the phase: gen_body per step on per-step arguments; at the top of a step the workgroup waits for the
 // updates of the weights it reads (the groups' done[] counters of the previous step).
@@ -1392,12 +1403,18 @@ template <bool HYPER, int SC, int LC, int BC>
 __global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (a.guard && a.counters[4] != 0) return;
-  if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;           // ALL three chains on the model's XCD: their rows meet the dW workgroups in its L2
-  const int sig = blockIdx.y + a.sig0, role = blockIdx.z;
+  // ALL three chains of model `sig` on the XCD whose hardware id is sig: their rows meet the dW workgroups in its L2 (dw_phase_kernel has
+  // the reason for the hardware id); a workgroup there claims one of the model's 3 * B/16 (chain, tile) slots
+  const int sig = (int)(__builtin_amdgcn_s_getreg(6164) & 0xfu);
+  if (sig >= gp.n_signals) return;
+  const int nt = (BC ? BC : a.B) / 16;
   unsigned* sync = reinterpret_cast<unsigned*>(a.ws + sig * a.ws_sig_stride + gp.sync_off);
-  __shared__ int gave_up;
-  if (threadIdx.x == 0) gave_up = 0;
+  __shared__ int gave_up, claimed;
+  if (threadIdx.x == 0) { gave_up = 0; claimed = (int)__hip_atomic_fetch_add(sync + GP_CLAIM_CHAIN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   __syncthreads();
+  const int slot = claimed;
+  if (slot >= 3 * nt) return;
+  const int role = slot / nt, tile = slot - role * nt;
   // the groups whose weights this role reads: G decoder + head; R everything; Z the encoder
   const unsigned need = role == 0 ? ((1u << GG_H) | (1u << GG_D2) | (1u << GG_L1) | (1u << GG_L0) | (1u << GG_D1))
                         : role == 1 ? 0x7fu : ((1u << GG_ED) | (1u << GG_E));
@@ -1413,7 +1430,7 @@ __global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) 
       if (gave_up) return;
     }
     gen_phase_step<HYPER, SC, LC, BC>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(),
-                                      (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem, b);
+                                      (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem, b, (sig << 16) | (role << 8) | tile);
     __syncthreads();                                 // (the step's LDS tiles are dead; the next step rewrites them)
   }
 }
@@ -2131,6 +2148,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
   gp.arrivals = 2 * (a.B / 16);
   gp.dw_waves = DWP_WGS * (DWP_THREADS / 64);
   gp.fault_step = fault_step;
+  gp.n_signals = d->n_signals;
   // the records in the phase's item order, the sync blocks zeroed, the bias corrections of its steps
   DwItem* items = reinterpret_cast<DwItem*>(a.ws + ws_items_offset(*d));
   hipLaunchKernelGGL(dw_items_kernel, dim3(DW_ITEM_CAP / 256), dim3(256), 0, s, tab, items, d->signal_shape, d->latent_dim, d->hyperbolic);
@@ -2140,7 +2158,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
   hipError_t e = hipEventRecord(forked, s);
   if (e == hipSuccess) e = hipStreamWaitEvent(s2, forked, 0);
   if (e != hipSuccess) return (int)e;
-  const dim3 grid(8 * (a.B / 16), d->n_signals, 3);
+  const dim3 grid(2 * 8 * 3 * (a.B / 16));                 // twice the slots of every XCD: the workgroups claim (chain, tile) slots on the XCD they land on
   const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
   const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
   if (lds > 160 * 1024 || lds + DWP_LDS_BYTES <= 160 * 1024) return HYPAD_EUNSUPPORTED;      // (a dW workgroup must not fit beside a chain workgroup)
@@ -2155,7 +2173,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
   else { if (ref_cfg) HYPAD_LAUNCH_PHASE(false, 100, 20, 64); else HYPAD_LAUNCH_PHASE(false, 0, 0, 0); }
 #undef HYPAD_LAUNCH_PHASE
   HYPAD_CHECK_LAUNCH();
-  const dim3 dgrid(8 * DWP_WGS, d->n_signals);
+  const dim3 dgrid(2 * 8 * DWP_WGS);
   if (ref_cfg) {
     e = allow_lds((const void*)dw_phase_kernel<100, 20, 64, 32>, DWP_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
