@@ -272,7 +272,7 @@ HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) 
 // the head's ball bias are read with L1-bypassing (sc1) loads on the other side.  Same arithmetic in the same order as the launches:
 // same bits.  Every wait is bounded (status word, as the resident critic launch).
 enum GenGroup : int { GG_H = 0, GG_D2 = 1, GG_L1 = 2, GG_L0 = 3, GG_D1 = 4, GG_ED = 5, GG_E = 6 };      // in the order their operand rows become complete
-enum : int { GP_READY = 0, GP_DONE = 8, GP_ERR = 16, GP_CLAIM_CHAIN = 17, GP_CLAIM_DW = 18 };            // word offsets in a model's sync block
+enum : int { GP_READY = 0, GP_DONE = 8, GP_ERR = 16, GP_CLAIM_CHAIN = 17, GP_CLAIM_DW = 18, GP_TICKET = 19 };      // word offsets in a model's sync block
 struct GenPhase {
   int nb;                       // steps (minibatches) of the phase
   int64_t z_step, mask_step;    // floats between two steps' injected planes (unused when the planes are null)
@@ -295,6 +295,27 @@ __device__ __forceinline__ bool gp_wait(const unsigned* word, unsigned target, c
     __builtin_amdgcn_s_sleep(1);
   }
   return false;
+}
+// a whole wave waits on one word: the value goes through an SGPR, so that the loop -- and the caller's -- stays wave-uniform for the compiler
+__device__ __forceinline__ bool gp_wait_wave(const unsigned* word, unsigned target, const unsigned* err) {
+  for (unsigned spins = 0; spins < GP_SPIN_LIMIT; ++spins) {
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= target) return true;
+    if ((spins & 255) == 255 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+// The dW side's counter updates, written as instructions: with the builtin atomics under `if (lane == 0)` in a loop whose other branches
+// are wave-uniform, the compiler's atomic optimiser and its tail merging folded the loss row's add and the item's add into one
+// instruction behind lane masks, and one build of it took the address from a register pair the record load had reused (memory aperture
+// violation on every run; an unrelated edit to a condition moved it away).  One lane, address in a register pair, nothing to fold.
+__device__ __forceinline__ void gp_add_one(unsigned* word, int lane) {
+  if (lane == 0) asm volatile("global_atomic_add %0, %1, off" :: "v"(word), "v"(1u) : "memory");
+}
+__device__ __forceinline__ unsigned gp_take_ticket(unsigned* word, int lane) {
+  unsigned t = 0;
+  if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(word), "v"(1u) : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
 }
 __device__ __forceinline__ void gp_give_up(const IterArgs& a, unsigned* sync, unsigned code) {      // one lane
   __hip_atomic_store(sync + GP_ERR, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1271,9 +1292,23 @@ __global__ __launch_bounds__(256) void gen_phase_prep_kernel(IterArgs a, GenPhas
   }
 }
 
+// The second stream's first launch: wait until every model's chain workgroups have claimed their slots -- i.e. are resident on their XCD --
+// before the dW launch may start.  The dispatcher deals workgroups round-robin over the XCDs only while each has room: when the dW launch
+// arrived first, its workgroups filled the model's XCD for a moment and the chain launch's workgroups were dealt to the other XCDs (where
+// they leave at once): 10 instead of 24 reached it, the chains were incomplete and every wait timed out.  Behind this gate the chains are
+// in place on 12 CUs and the dW workgroups find the other 20 free.
+__global__ __launch_bounds__(64) void gen_phase_gate_kernel(IterArgs a, GenPhase gp) {
+  if (a.guard && a.counters[4] != 0) return;
+  const int sig = threadIdx.x;
+  if (sig < gp.n_signals) {
+    unsigned* sync = reinterpret_cast<unsigned*>(a.ws + sig * a.ws_sig_stride + gp.sync_off);
+    if (!gp_wait(sync + GP_CLAIM_CHAIN, (unsigned)(3 * (a.B / 16)), sync + GP_ERR)) gp_give_up(a, sync, 0x700u);
+  }
+}
+
 constexpr int DWP_THREADS = 1024;            // one workgroup per CU (its LDS request keeps it off the chains' CUs and a second one off its own)
 constexpr int DWP_LDS_BYTES = 81 * 1024;
-constexpr int DWP_WGS = 20;                  // per model: the XCD's 32 CUs minus the 12 chain workgroups at batch 64
+constexpr int DWP_WGS = 16;                  // per model, at most: of the XCD's 32 CUs, 12 hold chain workgroups at batch 64; two stay free
 template <int SC, int LC, int BC, int KS>
 __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPhase gp) {
   extern __shared__ __attribute__((aligned(16))) float unused_lds[];      // (requested, never touched)
@@ -1289,67 +1324,81 @@ __global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPh
   unsigned* sync = reinterpret_cast<unsigned*>(ws + gp.sync_off);
   if (threadIdx.x == 0) claimed = (int)__hip_atomic_fetch_add(sync + GP_CLAIM_DW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  const int slot = claimed;
-  if (slot >= DWP_WGS) return;
+  if (__builtin_amdgcn_readfirstlane(claimed) >= DWP_WGS) return;
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.items_off);
   const float* adamc = a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.adamc_off;
-  const int w_global = slot * (DWP_THREADS / 64) + wave;
   const int step0 = a.counters[a.opt];
   using CWord = const __attribute__((address_space(4))) int32_t;
-  bool alive = true;
-  for (int b = 0; b < gp.nb && alive; ++b) {
+  // Work is handed out by TICKET: ticket t = (step t / (items + 1), item t mod (items + 1)), in the items' readiness order, the step's loss
+  // row last.  However many of the launch's workgroups reached this XCD (the dispatcher gives it its share only while the others are
+  // as full: 15 to 32 of the 32 dealt to it arrived in trials), every ticket is taken by a live wave; tickets are taken in order, so
+  // every item of step b is in some wave's hands before any of step b + 1 -- whose rows cannot exist before step b's updates do.
+  const unsigned per_step = (unsigned)gp.total_items + 1u;
+  // (every value that steers the loop goes through readfirstlane: with a single vector-typed condition in it the compiler masks the
+  // whole body per lane, keeps the record in vector registers and spills the row offsets it derives from it)
+  int alive = 1;
+  while (alive) {
+    const unsigned t = gp_take_ticket(sync + GP_TICKET, lane);
+    const int b = (int)(t / per_step), item = (int)(t - (unsigned)b * per_step);
+    if (b >= gp.nb) { alive = 0; continue; }
+    if (item == gp.total_items) {
+      // the step's losses (train.py:232-234, 243-244): every chain's partial is stored when the encoder's and dense1's rows are
+      const unsigned target = (unsigned)(gp.arrivals * (b + 1));
+      const int ok = gp_wait_wave(sync + GP_READY + GG_E, target, sync + GP_ERR) && gp_wait_wave(sync + GP_READY + GG_D1, target, sync + GP_ERR);
+      if (!ok) {
+        if (lane == 0) gp_give_up(a, sync, 0x500u + (unsigned)b);
+        alive = 0;
+        continue;
+      }
+      if (lane == 0) {
+        const GenWs gw = gen_ws(B_, S_, L_);
+        float aux = 0.f, fx = 0.f, fz = 0.f;
+        for (int tt = 0; tt < B_ / 16; ++tt) {
+          const unsigned* part = reinterpret_cast<const unsigned*>(ws + gw.partial + tt * 4);
+          aux += __uint_as_float(__hip_atomic_load(part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          fx += __uint_as_float(__hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          fz += __uint_as_float(__hip_atomic_load(part + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        aux = a.hyperbolic ? aux / a.B : aux / ((float)a.B * (float)a.S);
+        float* lo = a.losses + sig * a.loss_sig_stride + (int64_t)b * 4;
+        lo[0] = 10.f * aux - fx / a.B - fz / a.B;
+        lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
+        // the partials have been read: the chains may overwrite them (counted as one more item of dense1's and of the encoder's group:
+        // between them every chain waits for one of the two)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      gp_add_one(sync + GP_DONE + GG_D1, lane);
+      gp_add_one(sync + GP_DONE + GG_E, lane);
+      continue;
+    }
+    DwItem d;
+    {
+      CWord* src = (CWord*)(items + item);
+      int32_t* dst = reinterpret_cast<int32_t*>(&d);
+#pragma unroll
+      for (int i = 0; i < DW_ITEM_USED; ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    }
+    if (d.kind < 0) continue;
     AdamCoef co;
     co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize;
     co.step = step0 + b + 1; co.bc1 = adamc[4 * b]; co.bc2 = adamc[4 * b + 1]; co.sqrt_bc2 = adamc[4 * b + 2];
-    for (int item = w_global; item <= gp.total_items && alive; item += gp.dw_waves) {
-      if (item == gp.total_items) {
-        // the step's losses (train.py:232-234, 243-244): every chain's partial is stored when the encoder's and dense1's rows are
-        const unsigned target = (unsigned)(gp.arrivals * (b + 1));
-        alive = gp_wait(sync + GP_READY + GG_E, target, sync + GP_ERR) && gp_wait(sync + GP_READY + GG_D1, target, sync + GP_ERR);
-        if (!alive) { if (lane == 0) gp_give_up(a, sync, 0x500u + (unsigned)b); break; }
-        if (lane == 0) {
-          const GenWs gw = gen_ws(B_, S_, L_);
-          float aux = 0.f, fx = 0.f, fz = 0.f;
-          for (int t = 0; t < B_ / 16; ++t) {
-            const unsigned* part = reinterpret_cast<const unsigned*>(ws + gw.partial + t * 4);
-            aux += __uint_as_float(__hip_atomic_load(part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            fx += __uint_as_float(__hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            fz += __uint_as_float(__hip_atomic_load(part + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          }
-          aux = a.hyperbolic ? aux / a.B : aux / ((float)a.B * (float)a.S);
-          float* lo = a.losses + sig * a.loss_sig_stride + (int64_t)b * 4;
-          lo[0] = 10.f * aux - fx / a.B - fz / a.B;
-          lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
-          // the partials have been read: the chains may overwrite them (counted as one more item of dense1's and of the encoder's group:
-          // between them every chain waits for one of the two)
-          __hip_atomic_fetch_add(sync + GP_DONE + GG_D1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(sync + GP_DONE + GG_E, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        continue;
-      }
-      DwItem d;
-      {
-        CWord* src = (CWord*)(items + item);
-        int32_t* dst = reinterpret_cast<int32_t*>(&d);
-#pragma unroll
-        for (int i = 0; i < DW_ITEM_USED; ++i) dst[i] = src[i];
-      }
-      if (d.kind < 0) continue;
-      const int64_t arena = d.net == HYPAD_NET_ENCODER ? a.pe : a.pd;
-      float* P = (d.net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + sig * arena;
-      float* M = (d.net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + sig * arena;
-      float* V = (d.net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + sig * arena;
-      // this step's operand rows of the item's group: stored by every chain workgroup that feeds it
-      alive = gp_wait(sync + GP_READY + d.group, (unsigned)(gp.arrivals * (b + 1)), sync + GP_ERR);
-      if (!alive) { if (lane == 0) gp_give_up(a, sync, 0x400u + (unsigned)b); break; }
-      dw_item_update<SC, LC, BC, KS, true>(a, d, co, ws, P, M, V, lane, j, q);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the updated weights are in this XCD's L2 ...
-      if (lane == 0 && !(gp.fault_step > 0 && b + 1 == gp.fault_step))  // ... before the chains may read them
-        __hip_atomic_fetch_add(sync + GP_DONE + d.group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int64_t arena = d.net == HYPAD_NET_ENCODER ? a.pe : a.pd;
+    float* P = (d.net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + sig * arena;
+    float* M = (d.net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + sig * arena;
+    float* V = (d.net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + sig * arena;
+    // this step's operand rows of the item's group: stored by every chain workgroup that feeds it
+    if (!gp_wait_wave(sync + GP_READY + d.group, (unsigned)(gp.arrivals * (b + 1)), sync + GP_ERR)) {
+      if (lane == 0) gp_give_up(a, sync, 0x400u + (unsigned)b);
+      alive = 0;
+      continue;
     }
+    dw_item_update<SC, LC, BC, KS, true>(a, d, co, ws, P, M, V, lane, j, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the updated weights are in this XCD's L2 ...
+    if (!(gp.fault_step > 0 && b + 1 == gp.fault_step))                 // ... before the chains may read them
+      gp_add_one(sync + GP_DONE + d.group, lane);
   }
 }
 
@@ -2146,7 +2195,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
   }
   gp.group_items[GG_D1] += 1; gp.group_items[GG_E] += 1;      // (the step's loss row: dw_phase_kernel counts it in both groups)
   gp.arrivals = 2 * (a.B / 16);
-  gp.dw_waves = DWP_WGS * (DWP_THREADS / 64);
+  gp.dw_waves = 0;                                           // (unused: work items are handed out by ticket)
   gp.fault_step = fault_step;
   gp.n_signals = d->n_signals;
   // the records in the phase's item order, the sync blocks zeroed, the bias corrections of its steps
@@ -2173,6 +2222,7 @@ int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCa
   else { if (ref_cfg) HYPAD_LAUNCH_PHASE(false, 100, 20, 64); else HYPAD_LAUNCH_PHASE(false, 0, 0, 0); }
 #undef HYPAD_LAUNCH_PHASE
   HYPAD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gen_phase_gate_kernel, dim3(1), dim3(64), 0, s2, a, gp);
   const dim3 dgrid(2 * 8 * DWP_WGS);
   if (ref_cfg) {
     e = allow_lds((const void*)dw_phase_kernel<100, 20, 64, 32>, DWP_LDS_BYTES);

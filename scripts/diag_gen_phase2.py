@@ -23,7 +23,7 @@ for name, fl in (("stepwise", 0), ("resident", _C.EPOCH_GEN_RESIDENT)):
         items_off = (o_.value + c_.value + 63) & ~63
         sync_off = items_off + 32 * 2048
         words = eng.workspace[sync_off: sync_off + 32].view(torch.int32).cpu().tolist()
-        print("sync block: ready", words[0:7], "done", words[8:15], "err", words[16], "xcc chains", words[20:23], "xcc dW", words[24:28])
+        print("sync block: ready", words[0:7], "done", words[8:15], "err", hex(words[16]), "claims chain / dW", words[17], words[18])
 for net in ("enc", "dec"):
     for k, v in res["stepwise"][net].items():
         d = (v - res["resident"][net][k]).abs()
