@@ -90,9 +90,7 @@ class EpochIO(Structure):
 STATS_WORKSPACE_BYTES = 256 * 5 * 8  # HYPAD_STATS_WORKSPACE_BYTES
 EPOCH_PER_ITERATION = 1            # hypad_epoch_io.flags (include/hypad.h: HYPAD_EPOCH_*)
 EPOCH_NO_PRODUCERS, EPOCH_ID_ORDER, EPOCH_CLEAR_TILES, EPOCH_PER_MINIBATCH, EPOCH_DW_COLOC, EPOCH_DW_SPREAD = 2, 4, 8, 16, 32, 64
-EPOCH_GEN_RESIDENT = 128
 EPOCH_TEST_GIVE_UP_SHIFT = 8
-EPOCH_TEST_GEN_GIVE_UP_SHIFT = 16
 
 
 class RecordInfo(Structure):

@@ -32,18 +32,6 @@ __device__ __forceinline__ R row_load(const float* p, int dim, int lane) {
   }
   return r;
 }
-// ... through L1-bypassing (sc1) loads: a row another workgroup rewrites while this one stays resident (the generator phase as one
-// launch: the head's ball-valued bias is updated by the dW + Adam workgroups between two steps of the chains)
-template <class R = RowVec>
-__device__ __forceinline__ R row_load_sc1(const float* p, int dim, int lane) {
-  R r;
-#pragma unroll
-  for (int e = 0; e < R::EPL; ++e) {
-    int c = (lane & (R::G - 1)) + R::G * e;
-    r.v[e] = c < dim ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p) + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
-  }
-  return r;
-}
 template <class R>
 __device__ __forceinline__ void row_store(float* p, const R& r, int dim, int lane) {
 #pragma unroll

@@ -76,14 +76,8 @@ constexpr int DW_ITEM_WORDS = 32, DW_ITEM_CAP = 2048;
 inline int64_t ws_items_offset(const hypad_dims& d) {
   return (ws_pack_offset(d) + gen_pack(d.signal_shape, d.latent_dim, d.hyperbolic).total + 63) & ~(int64_t)63;
 }
-// ... then the synchronisation words of the generator phase as TWO resident launches (train_iters.hip gen_phase_kernel / dw_phase_kernel:
-// per model GP_SYNC_WORDS words, zeroed by the phase's preparation launch) and the optimiser's bias corrections of every step of the
-// phase (GP_MAX_STEPS x 4 floats; signal 0's copy)
-constexpr int GP_SYNC_WORDS = 32, GP_MAX_STEPS = 1024, GP_GROUPS = 7;
-inline int64_t ws_sync_offset(const hypad_dims& d) { return ws_items_offset(d) + (int64_t)DW_ITEM_WORDS * DW_ITEM_CAP; }
-inline int64_t ws_adamc_offset(const hypad_dims& d) { return ws_sync_offset(d) + GP_SYNC_WORDS; }
 inline int64_t ws_floats_per_signal(const hypad_dims& d) {
-  return ws_adamc_offset(d) + 4 * (int64_t)GP_MAX_STEPS;
+  return ws_items_offset(d) + (int64_t)DW_ITEM_WORDS * DW_ITEM_CAP;
 }
 
 // ------------------------------------------------------------------------------------------------ kernel arguments

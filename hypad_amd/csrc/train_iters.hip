@@ -261,79 +261,6 @@ HD int gp_lds_floats(int in_dim, int critic_floats) { return 16 * (pad4(in_dim) 
 //                chain R, the longest of the three.
 // One workgroup per (16-row tile, role): blockIdx.z = role.  Operand rows in the workspace are pass-major as before:
 // pass 0 = decoder(z), pass 1 = decoder(encoder(x)), pass 2 (hyperbolic only) = hyperbolic_linear(x).
-// ---- the generator phase of an epoch as TWO resident launches (round 5; hypad_epoch_io.flags & HYPAD_EPOCH_GEN_RESIDENT): the chains of all
-// n_batches steps in one launch (gen_phase_kernel: the three chains' workgroups of a model, all on the model's XCD, loop over the steps) and
-// the dW + Adam work items of all steps in another (dw_phase_kernel, on a second stream: its workgroups stay on the same XCD's other CUs).
-// What a kernel boundary did twice per step -- "the operand rows are complete", "the weights are updated" -- is a counter per matrix
-// GROUP in that XCD's L2: the chains raise ready[g] when the rows a group's weight gradients reduce over are stored (plain stores,
-// drained, one add per workgroup: MI355X_MICROARCH.md valid forms, first row, with the same-XCD store flavour the resident critic launch
-// uses), a dW wave waits for ready[g] of its item's group, updates, stores the weights (arena + packed copies, plain), drains and raises
-// done[g]; a chain workgroup waits for the done[] of the groups it reads at the top of the next step.  Operand rows, packed weights and
-// the head's ball bias are read with L1-bypassing (sc1) loads on the other side.  Same arithmetic in the same order as the launches:
-// same bits.  Every wait is bounded (status word, as the resident critic launch).
-enum GenGroup : int { GG_H = 0, GG_D2 = 1, GG_L1 = 2, GG_L0 = 3, GG_D1 = 4, GG_ED = 5, GG_E = 6 };      // in the order their operand rows become complete
-enum : int { GP_READY = 0, GP_DONE = 8, GP_ERR = 16, GP_CLAIM_CHAIN = 17, GP_CLAIM_DW = 18, GP_TICKET = 19 };      // word offsets in a model's sync block
-struct GenPhase {
-  int nb;                       // steps (minibatches) of the phase
-  int64_t z_step, mask_step;    // floats between two steps' injected planes (unused when the planes are null)
-  int64_t sync_off;             // a model's sync block: word offset from its workspace
-  int64_t adamc_off;            // float offset of the bias-correction table [nb][4] in the FIRST model's workspace
-  int64_t items_off;            // float offset of the work-item records (first model's workspace)
-  int total_items;
-  int group_items[GP_GROUPS];   // work items per group: done[g] reaches group_items[g] * (b + 1) when step b's updates are stored
-  int arrivals;                 // chain workgroups that complete a group's operand rows per step: 2 * batch / 16
-  int dw_waves;                 // resident dW waves per model: wave w takes items w, w + dw_waves, ...
-  int fault_step;               // tests: > 0 = the dW side never raises done[] for that step (a bounded wait gives up)
-  int n_signals;
-};
-constexpr unsigned GP_SPIN_LIMIT = 1u << 21;
-// one lane (or a uniform wave) waits until *word >= target; false = gave up (bounded) or somebody else did (err word)
-__device__ __forceinline__ bool gp_wait(const unsigned* word, unsigned target, const unsigned* err) {
-  for (unsigned spins = 0; spins < GP_SPIN_LIMIT; ++spins) {
-    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    if ((spins & 255) == 255 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return false;
-}
-// a whole wave waits on one word: the value goes through an SGPR, so that the loop -- and the caller's -- stays wave-uniform for the compiler
-__device__ __forceinline__ bool gp_wait_wave(const unsigned* word, unsigned target, const unsigned* err) {
-  for (unsigned spins = 0; spins < GP_SPIN_LIMIT; ++spins) {
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= target) return true;
-    if ((spins & 255) == 255 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return false;
-}
-// The dW side's counter updates, written as instructions: with the builtin atomics under `if (lane == 0)` in a loop whose other branches
-// are wave-uniform, the compiler's atomic optimiser and its tail merging folded the loss row's add and the item's add into one
-// instruction behind lane masks, and one build of it took the address from a register pair the record load had reused (memory aperture
-// violation on every run; an unrelated edit to a condition moved it away).  One lane, address in a register pair, nothing to fold.
-__device__ __forceinline__ void gp_add_one(unsigned* word, int lane) {
-  if (lane == 0) asm volatile("global_atomic_add %0, %1, off" :: "v"(word), "v"(1u) : "memory");
-}
-__device__ __forceinline__ unsigned gp_take_ticket(unsigned* word, int lane) {
-  unsigned t = 0;
-  if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(word), "v"(1u) : "memory");
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-}
-__device__ __forceinline__ void gp_give_up(const IterArgs& a, unsigned* sync, unsigned code) {      // one lane
-  __hip_atomic_store(sync + GP_ERR, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (a.guard) {
-    int expected = 0;
-    __hip_atomic_compare_exchange_strong(a.counters + 4, &expected, (int)code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// a chain workgroup: "this step's operand rows of group g are stored" (whole workgroup; ends with a barrier's worth of ordering)
-__device__ __forceinline__ void gp_publish(unsigned* sync, int g0, int g1 = -1) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains ...
-  __syncthreads();                                      // ... before ONE lane signals for all of them
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(sync + GP_READY + g0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (executes in this XCD's L2)
-    if (g1 >= 0) __hip_atomic_fetch_add(sync + GP_READY + g1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-}
-
 struct GenLds {
   int hb, xs, zs, bufA, bufB, small, cw, ct, total, ldS;
 };
@@ -359,10 +286,10 @@ HD GenLds gen_lds(int S, int L, int hyper, int role) {
 
 // Chain Z of the generator step (see above): encoder forward of the tile's windows, critic_z forward / backward, encoder
 // backward of that gradient; operand rows into the second halves of xg / enc_h / dzenc / dgenc.
-template <int SC, int LC, int BC, bool WSC1 = false, bool RES = false>
-__device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0, int sig_ = -1, int tile_ = -1) {
+template <int SC, int LC, int BC, bool WSC1 = false>
+__device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = RES ? sig_ : (int)blockIdx.y + a.sig0, tile = RES ? tile_ : (int)(blockIdx.x >> 3);      // (resident: claimed, see gen_phase_kernel)
+  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3;
   const GenLds lp = gen_lds(S, L, a.hyperbolic, 2);
   const int ldS = lp.ldS;
   const GenWs gw = gen_ws(B, S, L);
@@ -381,7 +308,7 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsig
   // hold its two dependent round trips back)
   tile_load_rows(xs, ldS, a.x + sig * a.x_sig_stride, a.x_ld, a.row_index ? a.row_index + (int64_t)sig * a.ri_sig_stride : nullptr, g0, 16, S, 16);
   const LstmPre pre_enc = lstm_layer_prefetch<WSC1>(pk + gp.enc_g[0], pk + gp.enc_g[1], ENC_H, S);
-  if (!RES || step == 0) stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);      // (frozen through the phase: staged once when resident)
+  stage_critic_padded(cw, a.P.cz + (int64_t)sig * a.pcz, clz, L, cpz);
   __syncthreads();
   tile_store(ws + gw.xg + (int64_t)(B + g0) * S, S, xs, ldS, 16, S, 16);
   float* zin = zs + 16 * LP;
@@ -402,7 +329,6 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsig
   }
   float* part_out = ws + gw.partial + tile * 4;
   if (threadIdx.x == 0) part_out[2] = sum_crit;
-  if (RES) { gp_publish(sync, GG_ED, GG_E); return; }      // (the bias corrections of every step come from the phase's table)
   if (tile == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     // optimizer step number and its bias corrections (double-precision powers): once per launch, for the dW + Adam launch --
     // here, on the chain with slack; they go to the workspace of the launch's first model (IterArgs.sig0)
@@ -417,13 +343,12 @@ __device__ __forceinline__ void gen_role_z(const IterArgs& a, float* smem, unsig
 // SC / LC / BC: window length, latent width, batch as compile-time constants (0 = from the arguments); see
 // critic_fused.hip: every layer of the chain runs once per launch, so index arithmetic is never amortised.
 static_assert(TB == 512, "gen_body deals rows over 8 waves");
-template <bool HYPER, int SC, int LC, int BC, bool WSC1 = false, bool RES = false>
-__device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigned* sync = nullptr, int step = 0, int sig_ = -1, int tile_ = -1,
-                                         int role_ = -1) {
+template <bool HYPER, int SC, int LC, int BC, bool WSC1 = false>
+__device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   const int S = SC ? SC : a.S, L = LC ? LC : a.L, B = BC ? BC : a.B;
-  const int sig = RES ? sig_ : (int)blockIdx.y + a.sig0, tile = RES ? tile_ : (int)(blockIdx.x >> 3), role = RES ? role_ : (int)blockIdx.z;
+  const int sig = blockIdx.y + a.sig0, tile = blockIdx.x >> 3, role = blockIdx.z;
   __builtin_amdgcn_s_setprio(2);            // (tile_gemm.h mfma_prio_*: the MFMA loops run below everything else)
-  if (role == 2) { gen_role_z<SC, LC, BC, WSC1, RES>(a, smem, sync, step, sig_, tile_); return; }
+  if (role == 2) { gen_role_z<SC, LC, BC, WSC1>(a, smem); return; }
   const GenLds lp = gen_lds(S, L, HYPER ? 1 : 0, role);
   const int ldS = lp.ldS;
   const EncLayout el = enc_layout(S, L);
@@ -455,7 +380,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   // first touch here misses this XCD's L2.  The working workgroups of a signal share one XCD (see gen_kernel): together
   // they touch every 128-byte line once, now, and the layers find the weights in L2 when they get there.
   float warm[3] = {0.f, 0.f, 0.f};
-  if (!RES) {                               // (resident: the weights come out of this XCD's L2, where the dW workgroups stored them)
+  {
     const int nwg = 2 * (B / 16), w = role * (B / 16) + tile;      // chains G and R (chain Z sits on another XCD)
     const int lines = gp.total / 32;
 #pragma unroll
@@ -470,7 +395,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   if (role == 0) {
     pre_d1 = gemm_nt_prefetch<WSC1>(pk + gp.d1, L, DEC_D1);
     const CriticLayout clx = cx_layout(S, L);
-    if (!RES || step == 0) stage_critic_padded(cw, a.P.cx + (int64_t)sig * a.pcx, clx, L, critic_pad(S, L, 4));      // (frozen: staged once when resident)
+    stage_critic_padded(cw, a.P.cx + (int64_t)sig * a.pcx, clx, L, critic_pad(S, L, 4));
     load_z(a, sig, tile, tick, zs);
     zin = zs;
     __syncthreads();
@@ -504,7 +429,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   sv.g1 = ws + gw.g1 + prow0 * 8 * DEC_H;
   sv.h1 = ws + gw.h1 + prow0 * 2 * DEC_H;
   sv.e = ws + gw.ecat + prow0 * S;
-  sv.stamps = (!RES && a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
+  sv.stamps = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0) ? a.stamps + (int64_t)blockIdx.z * 48 * 8 : nullptr;
   // injected layout: critic_z 2x(B,L) | critic_x 4x(B,L) | decoder(z) (B,128) | decoder(enc(x)) (B,128): as a
   // (layer, batch, 128) array with "layer" = pass, the two decoder masks are rows [0,B) and [B,2B) of one block.
   const DropSrc dd = drop_src(a, sig, mbase ? mbase + 6 * BL : nullptr, RS_DROP_DEC0, tick, 0.2f);
@@ -528,7 +453,7 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
     epl16_dispatch(S, [&](auto tag) {
       constexpr int EPL = decltype(tag)::value;
       using R16 = RowT<16, EPL>;
-      const R16 hb = RES ? row_load_sc1<R16>(PD + dl.head_b, S, lane) : row_load<R16>(PD + dl.head_b, S, lane);      // (rewritten between two resident steps)
+      const R16 hb = row_load<R16>(PD + dl.head_b, S, lane);
       const int r = wave * 4 + (lane >> 4);
       if (wave * 4 < hrows) {
         const R16 u = row_load<R16>(bufB + r * ldS, S, lane);
@@ -627,9 +552,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
       gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(dR, ldS, S, S, pk + gp.head_t, nullptr, 0, pre_ht, epi);
     }
     __syncthreads();
-    // (resident: a group's rows are reported only behind this chain's LAST read of the group's weights -- the backward-data product
-    // through W^T comes after the layer's deltas are complete, and the dW side rewrites W the moment every chain has reported)
-    if (RES) gp_publish(sync, GG_H);        // du rows, the head's input rows, the bias partials; W_h^T has been read
     GEN_STAMP(26);
   } else {
     if (role == 1) {
@@ -664,7 +586,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   GEN_STAMP(32);
   __syncthreads();
-  if (RES) gp_publish(sync, GG_D2);         // d(pre-tanh) rows (h1: forward); W_2^T has been read
   GEN_STAMP(7);
   GEN_STAMP(33);
   const PackedPre pre_l0t = gemm_nt_prefetch<WSC1>(pk + gp.l_t[0], 6 * DEC_H, DEC_D1);
@@ -677,7 +598,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   GEN_STAMP(35);
   __syncthreads();
-  if (RES) gp_publish(sync, GG_L1);         // layer-1 gate deltas; layer 1's W^T has been read
   GEN_STAMP(36);
   GEN_STAMP(8);
   GEN_STAMP(37);
@@ -693,17 +613,14 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   if (role == 0) {
     if (threadIdx.x == 0) part_out[1] = sum_crit;
     if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;      // keeps the warm-up loads alive
-    if (RES) gp_publish(sync, GG_L0, GG_D1);      // layer-0 gate deltas, dA0 rows (+ this chain's loss partial): chain G reads no W_1^T
     GEN_STAMP(11);
     return;
   }
-  if (RES) gp_publish(sync, GG_L0);
   // dZ = dA0 W1: the gradient reaching the encoder's output
   const PackedPre pre_edt = gemm_nt_prefetch<WSC1>(pk + gp.enc_d_t, L, 2 * ENC_H);
   gemm_nt_packed<1, true, ActIdentity, WSC1>(Y, ldA0, DEC_D1, L, pk + gp.d1_t, nullptr, X, LP, 0, 0, pre_d1t, ActIdentity{}, nullptr, 0,
                           ws + gw.dzenc + (int64_t)g0 * L, L);                     // (the critic_z part of dZ: chain Z)
   __syncthreads();
-  if (RES) gp_publish(sync, GG_D1);         // dA0 rows; W_1^T has been read
   GEN_STAMP(10);
   // ---- encoder backward: dH = dZ W_dense, cell backward -> dG in Y
   {
@@ -713,7 +630,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem, unsigne
   }
   if (threadIdx.x == 0) part_out[0] = sum_aux;
   if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
-  if (RES) gp_publish(sync, GG_ED, GG_E);   // dZ rows, the encoder's gate deltas (+ this chain's loss partial); the dense layer's W^T has been read
   GEN_STAMP(11);
 }
 
@@ -766,7 +682,6 @@ struct DwDesc {
   int32_t red_rows;
   int32_t p_off2;                             // second destination with the same gradient (b_hh), or -1
   int32_t begin;                              // first work item
-  int32_t group;                              // GenGroup of the generator's descriptors (whose operand rows / updated weights travel together)
 };
 template <int CAP, int BLK>
 struct DwTableT {
@@ -1053,10 +968,8 @@ struct DwItem {                                // 32 words (train_common.h DW_IT
   int32_t nrows, ncols, p_off, p_ld, p_off2;
   int32_t left_off, left_ld, right_off, right_ld, red_rows;
   int32_t fwd, fwd_kg, nbase, bwd, bwd_ng, mbase, bsum, gate_H;      // ShadowRef
-  int32_t group;                               // GenGroup (the resident launches' counters)
-  int32_t pad[9];
+  int32_t pad[10];
 };
-constexpr int DW_ITEM_USED = 23;               // words a wave fetches
 static_assert(sizeof(DwItem) == 4 * DW_ITEM_WORDS, "DwItem is DW_ITEM_WORDS words");
 __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __restrict__ out, int S, int L, int hyper) {
   const int item = blockIdx.x * 256 + threadIdx.x;
@@ -1081,150 +994,9 @@ __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __re
       it.left_off = d.left_off; it.left_ld = d.left_ld; it.right_off = d.right_off; it.right_ld = d.right_ld; it.red_rows = d.red_rows;
       const ShadowRef sh = shadow_ref(d.net, d.p_off, S, L, hyper);
       it.fwd = sh.fwd; it.fwd_kg = sh.fwd_kg; it.nbase = sh.nbase; it.bwd = sh.bwd; it.bwd_ng = sh.bwd_ng; it.mbase = sh.mbase; it.bsum = sh.bsum; it.gate_H = sh.gate_H;
-      it.group = d.group;
     }
   }
   out[item] = it;
-}
-
-// One work item's update (a wave): dW = left^T right on MFMA, Adam / Riemannian Adam in the accumulator registers, weights to the arena
-// and their packed positions.  RES: the operand rows were stored by workgroups of ANOTHER, concurrently resident launch on this XCD
-// (gen_phase_kernel): every load of them bypasses L1 (sc1).
-template <int SC, int LC, int BC, int KS, bool RES>
-__device__ __forceinline__ void dw_item_update(const IterArgs& a, const DwItem& d, const AdamCoef& co, float* ws, float* P, float* M, float* V,
-                                               const int lane, const int j, const int q) {
-  auto ldrow = [](const float* p) __attribute__((always_inline)) {
-    return RES ? __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : *p;
-  };
-  if (d.kind == DW_WEIGHT) {
-    const int n0 = d.n0, k0 = d.k0;
-    // out-of-range columns are clamped (their results are dropped below); rows past red_rows contribute zeros
-    const int nj = n0 + j < d.nrows ? n0 + j : d.nrows - 1, kj = k0 + j < d.ncols ? k0 + j : d.ncols - 1;
-    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.left_off), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.right_off), 0, 0x7fffffff, 0x00020000);
-    const int lvo = (q * d.left_ld + nj) * 4, rvo = (q * d.right_ld + kj) * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // the optimiser state of this lane's four elements travels with the operand loads (one round trip, not two)
-    int po[4]; float pp[4], pm[4], pvv[4];
-    float* Pb = P + d.p_off; float* Mb = M + d.p_off; float* Vb = V + d.p_off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + 4 * q + r, k = k0 + j;
-      const bool ok = n < d.nrows && k < d.ncols;
-      po[r] = ok ? n * d.p_ld + k : -1;
-      const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
-      pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
-    }
-    for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // up to KS k-steps in flight
-      float la[KS], rb[KS];
-#pragma unroll
-      for (int c = 0; c < KS / 4; ++c)
-        if (rc + 16 * c < d.red_rows) {                  // wave-uniform
-#pragma unroll
-          for (int u = 4 * c; u < 4 * c + 4; ++u) {
-            la[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, lvo, (rc + 4 * u) * d.left_ld * 4, RES ? 16 : 0));
-            rb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, (rc + 4 * u) * d.right_ld * 4, RES ? 16 : 0));
-          }
-        }
-#pragma unroll
-      for (int c = 0; c < KS / 4; ++c)
-        if (rc + 16 * c < d.red_rows) {
-#pragma unroll
-          for (int u = 4 * c; u < 4 * c + 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc, 0, 0, 0);
-        }
-    }
-    float* pk = ws + a.pk_off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float p = pp[r], m = pm[r], v = pvv[r];
-      adam_update(p, m, v, acc[r], co);
-      if (po[r] >= 0) {
-        const uint32_t o = (uint32_t)po[r];
-        Pb[o] = p; Mb[o] = m; Vb[o] = v;
-        const int nc = d.nbase + n0 + 4 * q + r, k = k0 + j;             // compact row, column
-        if (d.fwd >= 0) {
-          int nf = nc;                                                     // forward copy row: gates padded to 16-row blocks
-          if (d.gate_H > 0) nf += ((nc >= d.gate_H) + (nc >= 2 * d.gate_H)) * (((d.gate_H + 15) & ~15) - d.gate_H);   // nc < 3H
-          pk[d.fwd + (((nf >> 4) * d.fwd_kg + (k >> 4)) * 64 + (nf & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
-        }
-        if (d.bwd >= 0) {
-          const int mm = d.mbase + nc;                                      // reduction index of the transposed copy
-          pk[d.bwd + (((k >> 4) * d.bwd_ng + (mm >> 4)) * 64 + (k & 15) + 16 * ((mm & 15) >> 2)) * 4 + (mm & 3)] = p;
-        }
-      }
-    }
-  } else if (d.kind == DW_BIAS) {
-    // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
-    const int n = d.n0 + j;
-    const bool nv = n < d.nrows;
-    const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
-    const int rlast = d.red_rows - 1;
-    float g = 0.f;
-    for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // KS rows per lane in flight
-      float t[KS];
-#pragma unroll
-      for (int u = 0; u < KS; ++u) {
-        const int r = rc + 4 * u + q;
-        t[u] = ldrow(left + (int64_t)(r < rlast ? r : rlast) * d.left_ld);
-      }
-#pragma unroll
-      for (int u = 0; u < KS; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
-    }
-    g += __shfl_xor(g, 16, WAVE);
-    g += __shfl_xor(g, 32, WAVE);
-    if (nv && q == 0) {
-      int64_t o = d.p_off + n;
-      float p = P[o], m = M[o], v = V[o];
-      adam_update(p, m, v, g, co);
-      P[o] = p; M[o] = m; V[o] = v;
-      float bs = p;
-      if (d.p_off2 >= 0) {
-        o = d.p_off2 + n;
-        p = P[o]; m = M[o]; v = V[o];
-        adam_update(p, m, v, g, co);
-        P[o] = p; M[o] = m; V[o] = v;
-        bs += p;
-      }
-      if (d.bsum >= 0) {
-        int nf = d.nbase + n;
-        if (d.gate_H > 0) { const int x = nf / d.gate_H; nf = x * ((d.gate_H + 15) & ~15) + nf - x * d.gate_H; }
-        ws[a.pk_off + d.bsum + nf] = bs;
-      }
-    }
-  } else if (d.kind == DW_DECAY) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = d.n0 + e * 64 + lane;
-      if (n < d.nrows) {
-        const int64_t o = d.p_off + n;
-        float p = P[o], m = M[o], v = V[o];
-        adam_update(p, m, v, 0.f, co);
-        P[o] = p; M[o] = m; V[o] = v;
-      }
-    }
-  } else if (d.kind == DW_BALL) {                // hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
-    const float* left = ws + d.left_off;
-    RowVec g;
-#pragma unroll
-    for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
-    for (int r0 = 0; r0 < d.red_rows; r0 += 8) {           // eight partial rows in flight per round trip (fixed order)
-      float t[8][MAX_EPL];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + u < d.red_rows ? r0 + u : d.red_rows - 1;
-#pragma unroll
-        for (int e = 0; e < MAX_EPL; ++e) {
-          const int c = lane + 64 * e;
-          t[u][e] = c < d.nrows ? ldrow(left + (int64_t)r * d.left_ld + c) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
-    }
-    radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
-  }
 }
 
 template <int SC, int LC, int BC, int KS>
@@ -1242,7 +1014,7 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
     CWord* src = (CWord*)(items + (item < total_items ? item : 0));
     int32_t* dst = reinterpret_cast<int32_t*>(&d);
 #pragma unroll
-    for (int i = 0; i < DW_ITEM_USED; ++i) dst[i] = src[i];
+    for (int i = 0; i < 22; ++i) dst[i] = src[i];          // (the 22 words in use)
   }
   // ... and, in the same batch of scalar fetches, the step counter and the bias corrections the generator launch left behind
   const int step = a.counters[a.opt] + (a.step_add >= 0 ? a.step_add + 1 : 0);      // (step_add < 0: already incremented by the iteration's first kernel)
@@ -1254,7 +1026,137 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
   float* P = (d.net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + sig * arena;
   float* M = (d.net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + sig * arena;
   float* V = (d.net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + sig * arena;
-  if (item < total_items && d.kind >= 0) dw_item_update<SC, LC, BC, KS, false>(a, d, co, ws, P, M, V, lane, j, q);
+  if (item < total_items && d.kind >= 0) {
+    if (d.kind == DW_WEIGHT) {
+      const int n0 = d.n0, k0 = d.k0;
+      // out-of-range columns are clamped (their results are dropped below); rows past red_rows contribute zeros
+      const int nj = n0 + j < d.nrows ? n0 + j : d.nrows - 1, kj = k0 + j < d.ncols ? k0 + j : d.ncols - 1;
+      const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.left_off), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ws + d.right_off), 0, 0x7fffffff, 0x00020000);
+      const int lvo = (q * d.left_ld + nj) * 4, rvo = (q * d.right_ld + kj) * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // the optimiser state of this lane's four elements travels with the operand loads (one round trip, not two)
+      int po[4]; float pp[4], pm[4], pvv[4];
+      float* Pb = P + d.p_off; float* Mb = M + d.p_off; float* Vb = V + d.p_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * q + r, k = k0 + j;
+        const bool ok = n < d.nrows && k < d.ncols;
+        po[r] = ok ? n * d.p_ld + k : -1;
+        const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
+        pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
+      }
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // up to KS k-steps in flight
+        float la[KS], rb[KS];
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c)
+          if (rc + 16 * c < d.red_rows) {                  // wave-uniform
+#pragma unroll
+            for (int u = 4 * c; u < 4 * c + 4; ++u) {
+              la[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrs, lvo, (rc + 4 * u) * d.left_ld * 4, 0));
+              rb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, (rc + 4 * u) * d.right_ld * 4, 0));
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c)
+          if (rc + 16 * c < d.red_rows) {
+#pragma unroll
+            for (int u = 4 * c; u < 4 * c + 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc, 0, 0, 0);
+          }
+      }
+      float* pk = ws + a.pk_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = pp[r], m = pm[r], v = pvv[r];
+        adam_update(p, m, v, acc[r], co);
+        if (po[r] >= 0) {
+          const uint32_t o = (uint32_t)po[r];
+          Pb[o] = p; Mb[o] = m; Vb[o] = v;
+          const int nc = d.nbase + n0 + 4 * q + r, k = k0 + j;             // compact row, column
+          if (d.fwd >= 0) {
+            int nf = nc;                                                     // forward copy row: gates padded to 16-row blocks
+            if (d.gate_H > 0) nf += ((nc >= d.gate_H) + (nc >= 2 * d.gate_H)) * (((d.gate_H + 15) & ~15) - d.gate_H);   // nc < 3H
+            pk[d.fwd + (((nf >> 4) * d.fwd_kg + (k >> 4)) * 64 + (nf & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = p;
+          }
+          if (d.bwd >= 0) {
+            const int mm = d.mbase + nc;                                      // reduction index of the transposed copy
+            pk[d.bwd + (((k >> 4) * d.bwd_ng + (mm >> 4)) * 64 + (k & 15) + 16 * ((mm & 15) >> 2)) * 4 + (mm & 3)] = p;
+          }
+        }
+      }
+    } else if (d.kind == DW_BIAS) {
+      // 16 columns per item; lane (j, q) sums rows r = q (mod 4), then the four row classes are folded by shuffles
+      const int n = d.n0 + j;
+      const bool nv = n < d.nrows;
+      const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
+      const int rlast = d.red_rows - 1;
+      float g = 0.f;
+      for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // KS rows per lane in flight
+        float t[KS];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+          const int r = rc + 4 * u + q;
+          t[u] = left[(int64_t)(r < rlast ? r : rlast) * d.left_ld];
+        }
+#pragma unroll
+        for (int u = 0; u < KS; ++u) g += rc + 4 * u + q < d.red_rows ? t[u] : 0.f;
+      }
+      g += __shfl_xor(g, 16, WAVE);
+      g += __shfl_xor(g, 32, WAVE);
+      if (nv && q == 0) {
+        int64_t o = d.p_off + n;
+        float p = P[o], m = M[o], v = V[o];
+        adam_update(p, m, v, g, co);
+        P[o] = p; M[o] = m; V[o] = v;
+        float bs = p;
+        if (d.p_off2 >= 0) {
+          o = d.p_off2 + n;
+          p = P[o]; m = M[o]; v = V[o];
+          adam_update(p, m, v, g, co);
+          P[o] = p; M[o] = m; V[o] = v;
+          bs += p;
+        }
+        if (d.bsum >= 0) {
+          int nf = d.nbase + n;
+          if (d.gate_H > 0) { const int x = nf / d.gate_H; nf = x * ((d.gate_H + 15) & ~15) + nf - x * d.gate_H; }
+          ws[a.pk_off + d.bsum + nf] = bs;
+        }
+      }
+    } else if (d.kind == DW_DECAY) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = d.n0 + e * 64 + lane;
+        if (n < d.nrows) {
+          const int64_t o = d.p_off + n;
+          float p = P[o], m = M[o], v = V[o];
+          adam_update(p, m, v, 0.f, co);
+          P[o] = p; M[o] = m; V[o] = v;
+        }
+      }
+    } else if (d.kind == DW_BALL) {                // hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
+      const float* left = ws + d.left_off;
+      RowVec g;
+#pragma unroll
+      for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
+      for (int r0 = 0; r0 < d.red_rows; r0 += 8) {           // eight partial rows in flight per round trip (fixed order)
+        float t[8][MAX_EPL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u < d.red_rows ? r0 + u : d.red_rows - 1;
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) {
+            const int c = lane + 64 * e;
+            t[u][e] = c < d.nrows ? left[(int64_t)r * d.left_ld + c] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
+      }
+      radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
+    }
+  }
 #if HYPAD_DIAG
   if (a.stamps && blockIdx.y == 0 && lane == 0 && item < 1024) {      // (scripts/diag_dw_items.py)
     a.stamps[3 * 48 * 8 + 64 + 2 * item] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1275,215 +1177,6 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
     if (blockIdx.y == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
-// ---- the resident generator phase (GenPhase above): preparation, the dW + Adam side, the chains' side
-// one launch in front of the two resident ones: zero every model's sync block, and the optimiser's bias corrections of the phase's steps
-// (adam_coef: two double-precision powers per step -- what chain Z's first workgroup computes per launch in the stepwise form)
-__global__ __launch_bounds__(256) void gen_phase_prep_kernel(IterArgs a, GenPhase gp, int n_signals) {
-  if (a.guard && a.counters[4] != 0) return;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t < n_signals * GP_SYNC_WORDS) {
-    const int sig = t / GP_SYNC_WORDS, w = t - sig * GP_SYNC_WORDS;
-    reinterpret_cast<unsigned*>(a.ws + (int64_t)sig * a.ws_sig_stride + gp.sync_off)[w] = 0u;
-  }
-  if (t < gp.nb) {
-    const AdamCoef c = adam_coef(a.lr, a.b1, a.b2, a.eps, a.wd, a.riemannian, a.stabilize, a.counters[a.opt] + t + 1);
-    float* ac = a.ws + gp.adamc_off + 4 * t;
-    ac[0] = c.bc1; ac[1] = c.bc2; ac[2] = c.sqrt_bc2; ac[3] = 0.f;
-  }
-}
-
-// The second stream's first launch: wait until every model's chain workgroups have claimed their slots -- i.e. are resident on their XCD --
-// before the dW launch may start.  The dispatcher deals workgroups round-robin over the XCDs only while each has room: when the dW launch
-// arrived first, its workgroups filled the model's XCD for a moment and the chain launch's workgroups were dealt to the other XCDs (where
-// they leave at once): 10 instead of 24 reached it, the chains were incomplete and every wait timed out.  Behind this gate the chains are
-// in place on 12 CUs and the dW workgroups find the other 20 free.
-__global__ __launch_bounds__(64) void gen_phase_gate_kernel(IterArgs a, GenPhase gp) {
-  if (a.guard && a.counters[4] != 0) return;
-  const int sig = threadIdx.x;
-  if (sig < gp.n_signals) {
-    unsigned* sync = reinterpret_cast<unsigned*>(a.ws + sig * a.ws_sig_stride + gp.sync_off);
-    if (!gp_wait(sync + GP_CLAIM_CHAIN, (unsigned)(3 * (a.B / 16)), sync + GP_ERR)) gp_give_up(a, sync, 0x700u);
-  }
-}
-
-constexpr int DWP_THREADS = 1024;            // one workgroup per CU (its LDS request keeps it off the chains' CUs and a second one off its own)
-constexpr int DWP_LDS_BYTES = 81 * 1024;
-constexpr int DWP_WGS = 16;                  // per model, at most: of the XCD's 32 CUs, 12 hold chain workgroups at batch 64; two stay free
-template <int SC, int LC, int BC, int KS>
-__global__ __launch_bounds__(DWP_THREADS) void dw_phase_kernel(IterArgs a, GenPhase gp) {
-  extern __shared__ __attribute__((aligned(16))) float unused_lds[];      // (requested, never touched)
-  if (a.guard && a.counters[4] != 0) return;
-  // Model `sig` lives on the XCD whose hardware id is sig (both resident launches read HW_REG_XCC_ID: the dispatcher deals workgroups
-  // round-robin over the XCDs, but where a launch's first workgroup lands depends on the launches before it -- the first trial had the
-  // chains on XCD 7 and these workgroups on XCD 0, reading rows that were still in the other L2).  A workgroup on that XCD claims one of
-  // the model's DWP_WGS slots; whoever finds none left (the grid is twice the need) leaves.
-  const int sig = (int)(__builtin_amdgcn_s_getreg(6164) & 0xfu);          // hwreg(HW_REG_XCC_ID, 0, 4)
-  if (sig >= gp.n_signals) return;
-  __shared__ int claimed;
-  float* ws = a.ws + sig * a.ws_sig_stride;
-  unsigned* sync = reinterpret_cast<unsigned*>(ws + gp.sync_off);
-  if (threadIdx.x == 0) claimed = (int)__hip_atomic_fetch_add(sync + GP_CLAIM_DW, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (__builtin_amdgcn_readfirstlane(claimed) >= DWP_WGS) return;
-  const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
-  const int lane = threadIdx.x & 63, wave = wave_id();
-  const int j = lane & 15, q = lane >> 4;
-  const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.items_off);
-  const float* adamc = a.ws + (int64_t)a.sig0 * a.ws_sig_stride + gp.adamc_off;
-  const int step0 = a.counters[a.opt];
-  using CWord = const __attribute__((address_space(4))) int32_t;
-  // Work is handed out by TICKET: ticket t = (step t / (items + 1), item t mod (items + 1)), in the items' readiness order, the step's loss
-  // row last.  However many of the launch's workgroups reached this XCD (the dispatcher gives it its share only while the others are
-  // as full: 15 to 32 of the 32 dealt to it arrived in trials), every ticket is taken by a live wave; tickets are taken in order, so
-  // every item of step b is in some wave's hands before any of step b + 1 -- whose rows cannot exist before step b's updates do.
-  const unsigned per_step = (unsigned)gp.total_items + 1u;
-  // (every value that steers the loop goes through readfirstlane: with a single vector-typed condition in it the compiler masks the
-  // whole body per lane, keeps the record in vector registers and spills the row offsets it derives from it)
-  int alive = 1;
-  while (alive) {
-    const unsigned t = gp_take_ticket(sync + GP_TICKET, lane);
-    const int b = (int)(t / per_step), item = (int)(t - (unsigned)b * per_step);
-    if (b >= gp.nb) { alive = 0; continue; }
-    if (item == gp.total_items) {
-      // the step's losses (train.py:232-234, 243-244): every chain's partial is stored when the encoder's and dense1's rows are
-      const unsigned target = (unsigned)(gp.arrivals * (b + 1));
-      const int ok = gp_wait_wave(sync + GP_READY + GG_E, target, sync + GP_ERR) && gp_wait_wave(sync + GP_READY + GG_D1, target, sync + GP_ERR);
-      if (!ok) {
-        if (lane == 0) gp_give_up(a, sync, 0x500u + (unsigned)b);
-        alive = 0;
-        continue;
-      }
-      if (lane == 0) {
-        const GenWs gw = gen_ws(B_, S_, L_);
-        float aux = 0.f, fx = 0.f, fz = 0.f;
-        for (int tt = 0; tt < B_ / 16; ++tt) {
-          const unsigned* part = reinterpret_cast<const unsigned*>(ws + gw.partial + tt * 4);
-          aux += __uint_as_float(__hip_atomic_load(part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          fx += __uint_as_float(__hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          fz += __uint_as_float(__hip_atomic_load(part + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        aux = a.hyperbolic ? aux / a.B : aux / ((float)a.B * (float)a.S);
-        float* lo = a.losses + sig * a.loss_sig_stride + (int64_t)b * 4;
-        lo[0] = 10.f * aux - fx / a.B - fz / a.B;
-        lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
-        // the partials have been read: the chains may overwrite them (counted as one more item of dense1's and of the encoder's group:
-        // between them every chain waits for one of the two)
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      gp_add_one(sync + GP_DONE + GG_D1, lane);
-      gp_add_one(sync + GP_DONE + GG_E, lane);
-      continue;
-    }
-    DwItem d;
-    {
-      CWord* src = (CWord*)(items + item);
-      int32_t* dst = reinterpret_cast<int32_t*>(&d);
-#pragma unroll
-      for (int i = 0; i < DW_ITEM_USED; ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
-    }
-    if (d.kind < 0) continue;
-    AdamCoef co;
-    co.lr = a.lr; co.b1 = a.b1; co.b2 = a.b2; co.eps = a.eps; co.wd = a.wd; co.riemannian = a.riemannian; co.stabilize = a.stabilize;
-    co.step = step0 + b + 1; co.bc1 = adamc[4 * b]; co.bc2 = adamc[4 * b + 1]; co.sqrt_bc2 = adamc[4 * b + 2];
-    const int64_t arena = d.net == HYPAD_NET_ENCODER ? a.pe : a.pd;
-    float* P = (d.net == HYPAD_NET_ENCODER ? a.P.enc : a.P.dec) + sig * arena;
-    float* M = (d.net == HYPAD_NET_ENCODER ? a.M.enc : a.M.dec) + sig * arena;
-    float* V = (d.net == HYPAD_NET_ENCODER ? a.V.enc : a.V.dec) + sig * arena;
-    // this step's operand rows of the item's group: stored by every chain workgroup that feeds it
-    if (!gp_wait_wave(sync + GP_READY + d.group, (unsigned)(gp.arrivals * (b + 1)), sync + GP_ERR)) {
-      if (lane == 0) gp_give_up(a, sync, 0x400u + (unsigned)b);
-      alive = 0;
-      continue;
-    }
-    dw_item_update<SC, LC, BC, KS, true>(a, d, co, ws, P, M, V, lane, j, q);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the updated weights are in this XCD's L2 ...
-    if (!(gp.fault_step > 0 && b + 1 == gp.fault_step))                 // ... before the chains may read them
-      gp_add_one(sync + GP_DONE + d.group, lane);
-  }
-}
-
-// One step of the resident chains as a real FUNCTION: inlined into the step loop, the compiler hoisted the body's loop-invariant
-// address arithmetic out of the 29-step loop and kept it in registers across it (256 VGPRs + 63 spilled; the per-step kernel needs 165).
-// The function takes the step number only and reads the launch's arguments where the kernel got them -- the kernel-argument segment
-// (constant address space: scalar loads, uniform values) -- because a pointer to a copy of them in private memory made every use a
-// flat load of a value the compiler must treat as lane-varying (6.6 ms per epoch instead of 2.8).
-// (the segment's address is handed down as an integer -- inside a callee __builtin_amdgcn_kernarg_segment_ptr() is null on this stack -- and
-// made wave-uniform again with readfirstlane: function arguments travel in vector registers)
-template <class T>
-__device__ __forceinline__ T gp_kernarg(unsigned long long segment, int byte_offset) {
-  using CWord = const __attribute__((address_space(4))) int32_t;
-  static_assert(sizeof(T) % 4 == 0, "whole words");
-  T out;
-  const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(segment >> 32)) << 32) |
-                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)segment);
-  CWord* src = (CWord*)(base + (unsigned long long)byte_offset);
-  int32_t* dst = reinterpret_cast<int32_t*>(&out);
-#pragma unroll
-  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) dst[i] = src[i];
-  return out;
-}
-constexpr int GP_KERNARG_OFFSET = (int)((sizeof(IterArgs) + 7) & ~(size_t)7);      // (IterArgs a, GenPhase gp): gp follows a, 8-byte aligned
-template <bool HYPER, int SC, int LC, int BC>
-__device__ __attribute__((noinline)) void gen_phase_step(unsigned long long segment, unsigned lds_offset, int b_, int place_) {
-  const int b = __builtin_amdgcn_readfirstlane(b_), place = __builtin_amdgcn_readfirstlane(place_);
-  const int sig = place >> 16, role = (place >> 8) & 0xff, tile = place & 0xff;
-  // (the tiles' base as an LDS-address-space pointer again: handed down as a generic pointer every tile access became a flat instruction)
-  using LdsF = __attribute__((address_space(3))) float;
-  float* smem = (float*)(LdsF*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)lds_offset);
-  IterArgs as = gp_kernarg<IterArgs>(segment, 0);
-  const GenPhase gp = gp_kernarg<GenPhase>(segment, GP_KERNARG_OFFSET);
-  const int B = BC ? BC : as.B;
-  // (and the arguments' pointers as GLOBAL-address-space pointers again: as kernel arguments they are known to be; read back from memory
-  // they are generic, and every access through them a flat instruction that counts on the LDS wait counter too)
-#define HYPAD_AS_GLOBAL(p) p = (decltype(p))(__attribute__((address_space(1))) void*)(unsigned long long)(p)
-  HYPAD_AS_GLOBAL(as.ws); HYPAD_AS_GLOBAL(as.x); HYPAD_AS_GLOBAL(as.row_index); HYPAD_AS_GLOBAL(as.z); HYPAD_AS_GLOBAL(as.masks); HYPAD_AS_GLOBAL(as.counters);
-  HYPAD_AS_GLOBAL(as.P.enc); HYPAD_AS_GLOBAL(as.P.dec); HYPAD_AS_GLOBAL(as.P.cx); HYPAD_AS_GLOBAL(as.P.cz); HYPAD_AS_GLOBAL(as.losses);
-#undef HYPAD_AS_GLOBAL
-  unsigned* sync = reinterpret_cast<unsigned*>(as.ws + sig * as.ws_sig_stride + gp.sync_off);
-  as.step_add = b;
-  as.row_index = as.row_index + (int64_t)b * B;
-  as.z = as.z ? as.z + (int64_t)b * gp.z_step : nullptr;
-  as.masks = as.masks ? as.masks + (int64_t)b * gp.mask_step : nullptr;
-  gen_body<HYPER, SC, LC, BC, true, true>(as, smem, sync, b, sig, tile, role);
-}
-// The chains of every step of the phase: gen_body per step on per-step arguments; at the top of a step the workgroup waits for the
-// updates of the weights it reads (the groups' done[] counters of the previous step).
-template <bool HYPER, int SC, int LC, int BC>
-__global__ __launch_bounds__(TB) void gen_phase_kernel(IterArgs a, GenPhase gp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (a.guard && a.counters[4] != 0) return;
-  // ALL three chains of model `sig` on the XCD whose hardware id is sig: their rows meet the dW workgroups in its L2 (dw_phase_kernel has
-  // the reason for the hardware id); a workgroup there claims one of the model's 3 * B/16 (chain, tile) slots
-  const int sig = (int)(__builtin_amdgcn_s_getreg(6164) & 0xfu);
-  if (sig >= gp.n_signals) return;
-  const int nt = (BC ? BC : a.B) / 16;
-  unsigned* sync = reinterpret_cast<unsigned*>(a.ws + sig * a.ws_sig_stride + gp.sync_off);
-  __shared__ int gave_up, claimed;
-  if (threadIdx.x == 0) { gave_up = 0; claimed = (int)__hip_atomic_fetch_add(sync + GP_CLAIM_CHAIN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-  __syncthreads();
-  const int slot = claimed;
-  if (slot >= 3 * nt) return;
-  const int role = slot / nt, tile = slot - role * nt;
-  // the groups whose weights this role reads: G decoder + head; R everything; Z the encoder
-  const unsigned need = role == 0 ? ((1u << GG_H) | (1u << GG_D2) | (1u << GG_L1) | (1u << GG_L0) | (1u << GG_D1))
-                        : role == 1 ? 0x7fu : ((1u << GG_ED) | (1u << GG_E));
-  for (int b = 0; b < gp.nb; ++b) {
-    if (b > 0) {
-      if (threadIdx.x < GP_GROUPS && ((need >> threadIdx.x) & 1u) && gp.group_items[threadIdx.x] > 0) {
-        if (!gp_wait(sync + GP_DONE + threadIdx.x, (unsigned)(gp.group_items[threadIdx.x] * b), sync + GP_ERR)) {
-          gp_give_up(a, sync, 0x600u + (unsigned)b);
-          gave_up = 1;
-        }
-      }
-      __syncthreads();
-      if (gave_up) return;
-    }
-    gen_phase_step<HYPER, SC, LC, BC>((unsigned long long)__builtin_amdgcn_kernarg_segment_ptr(),
-                                      (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem, b, (sig << 16) | (role << 8) | tile);
-    __syncthreads();                                 // (the step's LDS tiles are dead; the next step rewrites them)
-  }
-}
-
 // COLOC: blockIdx.x is stretched by 8 and only the blocks that land on XCD (signal mod 8) work (workgroups are dealt round-robin
 // over the 8 XCDs), so one model's weight tiles share an L2: its ~0.9 MB of operand rows are fetched from HBM once, not once per
 // XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
@@ -1514,12 +1207,10 @@ struct TableBuilder {
     const int b0 = start / 4, b1 = (start + items + 3) / 4;
     if (t.n >= Table::cap || b1 > Table::blk) { overflow = true; return; }
     d.begin = start;
-    d.group = group;
     for (int b = b0; b < b1; ++b) t.block_desc[b >> 2] |= (uint32_t)t.n << (8 * (b & 3));
     t.d[t.n++] = d;
     t.total_items = start + items;
   }
-  int group = 0;                               // GenGroup stamped on the descriptors pushed next (generator table)
   Table done() { if (overflow) t.n = -1; return t; }
   void weight(int net, int p_off, int p_ld, int nrows, int ncols, int left_off, int left_ld, int right_off, int right_ld, int red) {
     DwDesc d{};
@@ -1626,9 +1317,7 @@ __global__ __launch_bounds__(256) void decay_steps_kernel(IterArgs a, DecayTable
   if (live) { *P = p; *M = m; *V = v; }
 }
 
-// backward_order: the descriptors in the order their operand rows become complete inside a generator step (head first, encoder last) --
-// the order the resident dW launch (dw_phase_kernel) deals its work items in; the per-step launches keep the forward order.
-DwTable gen_table(const hypad_dims& dm, bool with_decay = true, bool backward_order = false) {
+DwTable gen_table(const hypad_dims& dm, bool with_decay = true) {
   const int B = dm.batch, S = dm.signal_shape, L = dm.latent_dim;
   const bool hyp = dm.hyperbolic != 0;
   const EncLayout el = enc_layout(S, L);
@@ -1637,50 +1326,21 @@ DwTable gen_table(const hypad_dims& dm, bool with_decay = true, bool backward_or
   TableBuilder<DwTable> tb;
   tb.t.finalize = 1;
   tb.skip_decay = !with_decay;
-  auto enc_lstm = [&]() {
-    tb.group = GG_E;
-    for (int d = 0; d < 2; ++d)
-      tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, 2 * B, hyp);     // chains R and Z
-  };
-  auto enc_dense = [&]() {
-    tb.group = GG_ED;
-    tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, 2 * B);
-    tb.bias(HYPAD_NET_ENCODER, el.dense_b, -1, L, gw.dzenc, L, 2 * B);
-  };
-  auto d1 = [&]() {
-    tb.group = GG_D1;
-    tb.weight(HYPAD_NET_DECODER, dl.d1_w, L, DEC_D1, L, gw.da0, DEC_D1, gw.zcat, L, 2 * B);
-    tb.bias(HYPAD_NET_DECODER, dl.d1_b, -1, DEC_D1, gw.da0, DEC_D1, 2 * B);
-  };
-  auto l0 = [&]() {
-    tb.group = GG_L0;
-    for (int d = 0; d < 2; ++d) tb.lstm_dir(HYPAD_NET_DECODER, dl.l[0][d], DEC_H, DEC_D1, gw.dg0, 6 * DEC_H, d * 3 * DEC_H, gw.a0, DEC_D1, 2 * B, hyp);
-  };
-  auto l1 = [&]() {
-    tb.group = GG_L1;
-    for (int d = 0; d < 2; ++d) tb.lstm_dir(HYPAD_NET_DECODER, dl.l[1][d], DEC_H, 2 * DEC_H, gw.dg1, 6 * DEC_H, d * 3 * DEC_H, gw.h0d, 2 * DEC_H, 2 * B, hyp);
-  };
-  auto d2 = [&]() {
-    tb.group = GG_D2;
-    tb.weight(HYPAD_NET_DECODER, dl.d2_w, 2 * DEC_H, S, 2 * DEC_H, gw.dpre2, S, gw.h1, 2 * DEC_H, 2 * B);
-    tb.bias(HYPAD_NET_DECODER, dl.d2_b, -1, S, gw.dpre2, S, 2 * B);
-  };
-  auto head = [&]() {
-    tb.group = GG_H;
-    if (hyp) {
-      tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
-      tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, 2 * (B / 16));      // per (role, tile) partial column sums
-    }
-  };
-  if (!backward_order) {                     // (the order of rounds 1-4: the per-step launches' item numbering)
-    enc_lstm(); enc_dense(); d1();
-    for (int d = 0; d < 2; ++d) {
-      tb.group = GG_L0; tb.lstm_dir(HYPAD_NET_DECODER, dl.l[0][d], DEC_H, DEC_D1, gw.dg0, 6 * DEC_H, d * 3 * DEC_H, gw.a0, DEC_D1, 2 * B, hyp);
-      tb.group = GG_L1; tb.lstm_dir(HYPAD_NET_DECODER, dl.l[1][d], DEC_H, 2 * DEC_H, gw.dg1, 6 * DEC_H, d * 3 * DEC_H, gw.h0d, 2 * DEC_H, 2 * B, hyp);
-    }
-    d2(); head();
-  } else {
-    head(); d2(); l1(); l0(); d1(); enc_dense(); enc_lstm();
+  for (int d = 0; d < 2; ++d)
+    tb.lstm_dir(HYPAD_NET_ENCODER, el.dir[d], ENC_H, S, gw.dgenc, 6 * ENC_H, d * 3 * ENC_H, gw.xg, S, 2 * B, hyp);     // chains R and Z
+  tb.weight(HYPAD_NET_ENCODER, el.dense_w, 2 * ENC_H, L, 2 * ENC_H, gw.dzenc, L, gw.enc_h, 2 * ENC_H, 2 * B);
+  tb.bias(HYPAD_NET_ENCODER, el.dense_b, -1, L, gw.dzenc, L, 2 * B);
+  tb.weight(HYPAD_NET_DECODER, dl.d1_w, L, DEC_D1, L, gw.da0, DEC_D1, gw.zcat, L, 2 * B);
+  tb.bias(HYPAD_NET_DECODER, dl.d1_b, -1, DEC_D1, gw.da0, DEC_D1, 2 * B);
+  for (int d = 0; d < 2; ++d) {
+    tb.lstm_dir(HYPAD_NET_DECODER, dl.l[0][d], DEC_H, DEC_D1, gw.dg0, 6 * DEC_H, d * 3 * DEC_H, gw.a0, DEC_D1, 2 * B, hyp);
+    tb.lstm_dir(HYPAD_NET_DECODER, dl.l[1][d], DEC_H, 2 * DEC_H, gw.dg1, 6 * DEC_H, d * 3 * DEC_H, gw.h0d, 2 * DEC_H, 2 * B, hyp);
+  }
+  tb.weight(HYPAD_NET_DECODER, dl.d2_w, 2 * DEC_H, S, 2 * DEC_H, gw.dpre2, S, gw.h1, 2 * DEC_H, 2 * B);
+  tb.bias(HYPAD_NET_DECODER, dl.d2_b, -1, S, gw.dpre2, S, 2 * B);
+  if (hyp) {
+    tb.weight(HYPAD_NET_DECODER, dl.head_w, S, S, S, gw.du, S, gw.ecat, S, 3 * B);
+    tb.ball(HYPAD_NET_DECODER, dl.head_b, S, gw.ballpart, S, 2 * (B / 16));      // per (role, tile) partial column sums
   }
   return tb.done();
 }
@@ -2165,81 +1825,6 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   return HYPAD_OK;
 }
 
-// The generator phase of an epoch as two resident launches (GenPhase): possible where every model's 3 * B/16 chain workgroups and
-// DWP_WGS dW workgroups find their own CU on the model's XCD.
-bool gen_phase_resident_ok(const hypad_dims& d, int nb) {
-  if (nb < 1 || nb > GP_MAX_STEPS) return false;
-  if (d.n_signals > 8) return false;                                        // one model per XCD
-  if (3 * (d.batch / 16) + DWP_WGS > 32) return false;                      // CUs of an XCD
-  return true;
-}
-// io: the FIRST step's arguments (row_index, z, masks, losses of step 0); s2: the second stream (the caller forks / joins around the call)
-int run_gen_phase(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, int nb, int64_t z_step, int64_t mask_step, hipStream_t s,
-                  hipStream_t s2, hipEvent_t forked, hipEvent_t joined, int fault_step = 0) {
-  IterArgs a;
-  int rc = fill_args(a, d, st, io, 2);
-  if (rc) return rc;
-  a.sig0 = 0; a.step_add = 0;
-  const DwTable tab = gen_table(*d, false, true);          // backward order, no decay-only tensors
-  if (tab.n < 0 || tab.total_items > DW_ITEM_CAP) return HYPAD_EUNSUPPORTED;
-  GenPhase gp{};
-  gp.nb = nb; gp.z_step = z_step; gp.mask_step = mask_step;
-  gp.sync_off = ws_sync_offset(*d); gp.adamc_off = ws_adamc_offset(*d); gp.items_off = ws_items_offset(*d);
-  gp.total_items = tab.total_items;
-  for (int g = 0; g < GP_GROUPS; ++g) gp.group_items[g] = 0;
-  for (int i = 0; i < tab.n; ++i) {                         // live items per group (what dw_items_kernel marks kind >= 0)
-    const DwDesc& x = tab.d[i];
-    const int items = x.kind == DW_WEIGHT ? ((x.nrows + 15) / 16) * ((x.ncols + 15) / 16) : x.kind == DW_BIAS ? (x.nrows + 15) / 16
-                      : x.kind == DW_DECAY ? (x.nrows + 255) / 256 : 1;
-    gp.group_items[x.group] += items;
-  }
-  gp.group_items[GG_D1] += 1; gp.group_items[GG_E] += 1;      // (the step's loss row: dw_phase_kernel counts it in both groups)
-  gp.arrivals = 2 * (a.B / 16);
-  gp.dw_waves = 0;                                           // (unused: work items are handed out by ticket)
-  gp.fault_step = fault_step;
-  gp.n_signals = d->n_signals;
-  // the records in the phase's item order, the sync blocks zeroed, the bias corrections of its steps
-  DwItem* items = reinterpret_cast<DwItem*>(a.ws + ws_items_offset(*d));
-  hipLaunchKernelGGL(dw_items_kernel, dim3(DW_ITEM_CAP / 256), dim3(256), 0, s, tab, items, d->signal_shape, d->latent_dim, d->hyperbolic);
-  const int prep_threads = d->n_signals * GP_SYNC_WORDS > nb ? d->n_signals * GP_SYNC_WORDS : nb;
-  hipLaunchKernelGGL(gen_phase_prep_kernel, dim3((prep_threads + 255) / 256), dim3(256), 0, s, a, gp, d->n_signals);
-  HYPAD_CHECK_LAUNCH();
-  hipError_t e = hipEventRecord(forked, s);
-  if (e == hipSuccess) e = hipStreamWaitEvent(s2, forked, 0);
-  if (e != hipSuccess) return (int)e;
-  const dim3 grid(2 * 8 * 3 * (a.B / 16));                 // twice the slots of every XCD: the workgroups claim (chain, tile) slots on the XCD they land on
-  const int l0 = gen_lds(a.S, a.L, a.hyperbolic, 0).total, l1 = gen_lds(a.S, a.L, a.hyperbolic, 1).total;
-  const size_t lds = (size_t)(l0 > l1 ? l0 : l1) * sizeof(float);
-  if (lds > 160 * 1024 || lds + DWP_LDS_BYTES <= 160 * 1024) return HYPAD_EUNSUPPORTED;      // (a dW workgroup must not fit beside a chain workgroup)
-  const bool ref_cfg = a.S == 100 && a.L == 20 && a.B == 64;
-#define HYPAD_LAUNCH_PHASE(...)                                                    \
-  do {                                                                            \
-    e = allow_lds((const void*)gen_phase_kernel<__VA_ARGS__>, lds);               \
-    if (e != hipSuccess) return (int)e;                                           \
-    hipLaunchKernelGGL((gen_phase_kernel<__VA_ARGS__>), grid, dim3(TB), lds, s, a, gp);    \
-  } while (0)
-  if (a.hyperbolic) { if (ref_cfg) HYPAD_LAUNCH_PHASE(true, 100, 20, 64); else HYPAD_LAUNCH_PHASE(true, 0, 0, 0); }
-  else { if (ref_cfg) HYPAD_LAUNCH_PHASE(false, 100, 20, 64); else HYPAD_LAUNCH_PHASE(false, 0, 0, 0); }
-#undef HYPAD_LAUNCH_PHASE
-  HYPAD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gen_phase_gate_kernel, dim3(1), dim3(64), 0, s2, a, gp);
-  const dim3 dgrid(2 * 8 * DWP_WGS);
-  if (ref_cfg) {
-    e = allow_lds((const void*)dw_phase_kernel<100, 20, 64, 32>, DWP_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((dw_phase_kernel<100, 20, 64, 32>), dgrid, dim3(DWP_THREADS), DWP_LDS_BYTES, s2, a, gp);
-  } else {
-    e = allow_lds((const void*)dw_phase_kernel<0, 0, 0, 32>, DWP_LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((dw_phase_kernel<0, 0, 0, 32>), dgrid, dim3(DWP_THREADS), DWP_LDS_BYTES, s2, a, gp);
-  }
-  HYPAD_CHECK_LAUNCH();
-  e = hipEventRecord(joined, s2);
-  if (e == hipSuccess) e = hipStreamWaitEvent(s, joined, 0);
-  if (e != hipSuccess) return (int)e;
-  return HYPAD_OK;
-}
-
 int run_decay_steps(const hypad_dims* d, const hypad_train_state* st, const IterCall& io, int nsteps, hipStream_t s) {
   if (!d->hyperbolic || nsteps <= 0) return HYPAD_OK;          // torch.optim.Adam (Euclidean generator) has no weight decay: nothing moves
   IterArgs a;
@@ -2576,26 +2161,6 @@ int hypad_train_epoch(const hypad_dims* d, const hypad_train_state* st, const hy
   // generator launch (a generator launch keeps 12 workgroups per model busy for ~37 us, the optimizer launch that follows is
   // latency- or bandwidth-bound: in lock step the chip idles through both).  Every launch then carries its own step number and
   // rng tick (IterArgs.step_add) and nobody advances the counters until the groups have joined.
-  // (round 5) HYPAD_EPOCH_GEN_RESIDENT: the whole phase as two resident launches -- the chains on the caller's stream, the dW + Adam work
-  // items on the first auxiliary stream -- talking through counters in the model's XCD (GenPhase)
-  if ((io->flags & HYPAD_EPOCH_GEN_RESIDENT) && io->aux_streams && io->n_aux_streams >= 1 && io->n_batches >= 1 && gen_phase_resident_ok(*d, io->n_batches)) {
-    GenFork* fk = gen_fork_events();
-    if (fk) {
-      c.row_index = io->row_index + io->n_critics * pass_rows;
-      c.losses = io->losses + (int64_t)it * 4;
-      if (nz) {
-        c.z = nz->z_gen;
-        c.masks = inj_masks ? nz->masks_gen : nullptr;
-      }
-      rc = run_gen_phase(d, st, c, io->n_batches, ns * B * L, ns * mk_gen, (hipStream_t)s, (hipStream_t)io->aux_streams[0], fk->forked, fk->joined[0],
-                         (io->flags >> HYPAD_EPOCH_TEST_GEN_GIVE_UP_SHIFT) & 0xff);
-      if (rc) return rc;
-      hipLaunchKernelGGL(advance_counters_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, st->counters, 2, io->n_batches);      // generator steps (counters[2]) and rng ticks
-      HYPAD_CHECK_LAUNCH();
-      c.losses = io->losses;
-      return run_decay_steps(d, st, c, io->n_batches, (hipStream_t)s);
-    }
-  }
   int groups = 1 + (io->aux_streams ? (io->n_aux_streams < 0 ? 0 : io->n_aux_streams > 7 ? 7 : io->n_aux_streams) : 0);
   if (groups > d->n_signals) groups = d->n_signals;
   if (io->n_batches < 1) groups = 1;

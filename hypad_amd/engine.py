@@ -74,8 +74,6 @@ class Engine:
         them in groups on side streams, a group's optimizer launch overlapping another group's generator launch (include/hypad.h,
         ABI 4).  0 (or one signal) keeps everything on the caller's stream; same bits either way."""
         want = min(self.MAX_AUX_STREAMS, self.n - 1, self._aux_streams_wanted())
-        if self.epoch_flags & _C.EPOCH_GEN_RESIDENT:          # the resident generator phase runs its dW + Adam launch on the first auxiliary stream
-            want = max(want, 1)
         if want <= 0:
             return None, 0
         pool = self.__dict__.setdefault("_aux_pool", [])

@@ -312,14 +312,8 @@ enum {
   HYPAD_EPOCH_PER_MINIBATCH = 16,            /* no hoisting at all: one launch group per minibatch (critic_x || critic_z pass, penalty, dW) */
   HYPAD_EPOCH_DW_COLOC = 32,                 /* dW + Adam workgroups co-located per model and XCD (the default from 8 models per call on) */
   HYPAD_EPOCH_DW_SPREAD = 64,                /* ... spread over the chip (the default below 8 models) */
-  HYPAD_EPOCH_GEN_RESIDENT = 128,            /* the generator phase (train.py:347-352) as TWO resident launches -- the chains of all minibatches on the
-                                              * caller's stream, the dW + Adam work items on aux_streams[0] -- that hand operand rows and updated weights
-                                              * to each other through counters in the model's XCD instead of 2 n_batches kernel boundaries; needs
-                                              * n_aux_streams >= 1, n_signals <= 8, 3 batch / 16 + 20 <= 32 CUs per XCD; same bits as the launches */
   HYPAD_EPOCH_TEST_GIVE_UP_SHIFT = 8         /* tests only: bits 8..15 = k > 0 makes the resident launch behave as if its wait for the
                                                 siblings' shares had timed out at critic iteration k (signal 0, critic_x) */
-  , HYPAD_EPOCH_TEST_GEN_GIVE_UP_SHIFT = 16  /* tests only: bits 16..23 = k > 0: the resident generator phase's dW side never reports the updates
-                                                of step k (the chains' bounded wait at step k + 1 gives up) */
 };
 /* The DataLoader's shuffles of one epoch (main.py:38: shuffle=True, drop_last=True; train.py:315-351 iterates the loader once per
  * pass) drawn on the device: row_index (n_passes, take) int32 <- for every pass the first `take` = n_batches * batch entries of an
