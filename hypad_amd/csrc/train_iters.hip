@@ -1534,30 +1534,120 @@ int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned
 // ------------------------------------------------------------------------------------------------ scoring forward, packed
 // The test-loop body (anomaly_detection.py:67-113, eval mode) on the training kernels' machinery: 512 threads per 16 rows,
 // packed weights (no LDS re-shape), LSTM cells in the gate products' epilogues, the critic as LDS-resident MFMA layers, the
-// row-wise ball math four rows per wave.  79 KB of LDS: two workgroups per CU.
+// row-wise ball math four rows per wave.  The critic value of the windows (anomaly_detection.py:96-101) comes from its own launch,
+// critic_rows_kernel: inside this kernel it was six workgroup barriers and an 18 KB weight image per 16 windows for 1 % of the FLOPs
+// (0.526 -> 0.479 ms per 125 000 windows without it; the launch below takes 0.02).
+//
+// critic_x over rows, eval mode: the padded weight image (critic_mfma.h CriticPad) goes into LDS once per workgroup, then every WAVE walks
+// its own 16-row tiles -- rows into a wave-private LDS tile (the next tile's rows are requested into registers before the layers of
+// the current one), four layers on wave_gemm_nt with nothing but wave-local fences between them, the last layer as 16 dot products.
+// Same products in the same order as critic_tile_fwd: same bits.
+constexpr int CR_WAVES = 8;
+HD int critic_rows_lds_floats(int S, int L) {
+  const CriticPad cp = critic_pad(S, L, 4);
+  return cp.total + CR_WAVES * (16 * cp.ldin + 2 * 16 * cp.LQ);
+}
+template <int SC, int LC>
+__global__ __launch_bounds__(64 * CR_WAVES) void critic_rows_kernel(const float* __restrict__ cxpad, const float* __restrict__ x, int64_t x_ld,
+                                                                    float* __restrict__ out, int64_t rows, int S_, int L_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = SC ? SC : S_, L = LC ? LC : L_;
+  const CriticPad cp = critic_pad(S, L, 4);
+  const int ldin = cp.ldin, LQ = cp.LQ, nh = 4;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  float* in = smem + cp.total + wave * (16 * ldin + 2 * 16 * LQ);
+  float* act = in + 16 * ldin;
+  stage_params(smem, cxpad, cp.total);
+  // the tile's constant part: the ones column behind the window (the layer's bias sits in that column of the image), zero padding
+  for (int i = lane; i < 16 * ldin; i += 64) { const int c = i % ldin; in[i] = c == S ? 1.f : 0.f; }
+  for (int i = lane; i < 2 * 16 * LQ; i += 64) act[i] = 0.f;
+  __syncthreads();
+  const float* w0 = smem + cp.w0; const float* wh = smem + cp.wh; const float* wl = smem + cp.wl;
+  const int64_t tiles = (rows + 15) >> 4, stride = (int64_t)gridDim.x * CR_WAVES;
+  constexpr int NV = SC ? (16 * SC + 63) / 64 : 1;     // floats of a tile per lane (compiled-in window; any other streams its rows)
+  float xr[NV];
+  auto fetch = [&](int64_t t) __attribute__((always_inline)) {
+    const int64_t r0 = t * 16;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = lane + 64 * u, r = i / S, c = i - r * S;
+      const int64_t row = r0 + r < rows ? r0 + r : rows - 1;
+      xr[u] = i < 16 * S ? x[row * x_ld + c] : 0.f;
+    }
+  };
+  int64_t t = (int64_t)blockIdx.x * CR_WAVES + wave;
+  if constexpr (SC != 0) { if (t < tiles) fetch(t); }
+  for (; t < tiles; t += stride) {
+    if constexpr (SC != 0) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int i = lane + 64 * u, r = i / S, c = i - r * S;
+        if (i < 16 * S) in[r * ldin + c] = xr[u];
+      }
+    } else {
+      for (int i = lane; i < 16 * S; i += 64) {
+        const int r = i / S, c = i - r * S;
+        const int64_t row = t * 16 + r < rows ? t * 16 + r : rows - 1;
+        in[r * ldin + c] = x[row * x_ld + c];
+      }
+    }
+    wave_lds_fence();
+    if constexpr (SC != 0) { if (t + stride < tiles) fetch(t + stride); }          // the next tile's rows arrive under this tile's layers
+    for (int li = 0; li < nh; ++li) {
+      const float* A = li == 0 ? in : act + ((li - 1) & 1) * 16 * LQ;
+      const float* Wl = li == 0 ? w0 : wh + (li - 1) * L * LQ;
+      float* ao = act + (li & 1) * 16 * LQ;
+      wave_gemm_nt(A, li == 0 ? ldin : LQ, Wl, li == 0 ? ldin : LQ, L, L + 1, li == 0 ? cp.Kin : cp.Lp, lane, [&](int r, int c, float pre) {
+        if (c < L) ao[r * LQ + c] = pre * leaky_slope(pre);
+        else if (c == L) ao[r * LQ + c] = 1.f;
+      });
+      wave_lds_fence();
+    }
+    if (lane < 16) {
+      const float* xa = act + ((nh - 1) & 1) * 16 * LQ + lane * LQ;
+      float o = 0.f;
+      for (int c = 0; c <= L; ++c) o += xa[c] * wl[c];
+      if (t * 16 + lane < rows) out[t * 16 + lane] = o;
+    }
+    wave_lds_fence();
+  }
+}
+int launch_critic_rows(const float* cxpad, const float* x, int64_t x_ld, float* out, int64_t rows, int S, int L, hipStream_t s) {
+  const size_t lds = (size_t)critic_rows_lds_floats(S, L) * sizeof(float);
+  if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
+  const int64_t tiles = (rows + 15) / 16;
+  // (its LDS plan puts one workgroup on a CU: 256 of them cover an MI355X, the tiles go round)
+  const unsigned grid = (unsigned)std::min<int64_t>((tiles + CR_WAVES - 1) / CR_WAVES, 256);
+  if (S == 100 && L == 20) {
+    hipError_t e = allow_lds((const void*)critic_rows_kernel<100, 20>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((critic_rows_kernel<100, 20>), dim3(grid), dim3(64 * CR_WAVES), lds, s, cxpad, x, x_ld, out, rows, S, L);
+  } else {
+    hipError_t e = allow_lds((const void*)critic_rows_kernel<0, 0>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((critic_rows_kernel<0, 0>), dim3(grid), dim3(64 * CR_WAVES), lds, s, cxpad, x, x_ld, out, rows, S, L);
+  }
+  HYPAD_CHECK_LAUNCH();
+  return HYPAD_OK;
+}
 struct ScoreArgs {
-  const float* pk; const float* cx; const float* cxpad; const float* head_b; const float* x; int64_t x_ld;      // cxpad: critic_x, padded image
-  float* hyper; float* eucl; float* hyper_real; float* critic; float* rowdist;
+  const float* pk; const float* head_b; const float* x; int64_t x_ld;
+  float* hyper; float* eucl; float* hyper_real; float* rowdist;
   int64_t rows; int S, L, hyperbolic;
 };
-struct ScoreLds { int xs, zs, bufA, bufB, cw, small, total, ldS; };
+struct ScoreLds { int xs, zs, bufA, bufB, total, ldS; };
 #ifndef HYPAD_SCORE_WPE
 #define HYPAD_SCORE_WPE 4
 #endif
 HD ScoreLds score_lds(int S, int L) {
   ScoreLds p; int o = 0;
   p.ldS = lds_stride(S);
-  const CriticPad cp = critic_pad(S, L, 4);
   int buf = 16 * (2 * DEC_H + 4) > 32 * p.ldS ? 16 * (2 * DEC_H + 4) : 32 * p.ldS;       // h tiles / the 32-row head tile
-  const int crit = 16 * cp.ldin + 2 * 16 * cp.LQ;                                        // critic_tile_fwd scratch, over bufA | bufB
-  if (2 * buf < crit) buf = (crit + 1) / 2;
   buf = (buf + 3) & ~3;
   p.xs = o; o += 16 * p.ldS;
   p.zs = o; o += 16 * LP;
   p.bufA = o; o += buf;
   p.bufB = o; o += buf;
-  p.cw = o; o += cp.total;
-  p.small = o; o += 16;
   p.total = o;
   return p;
 }
@@ -1569,20 +1659,11 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_SCORE_
   const int ldS = lp.ldS;
   const GenPack gp = gen_pack(S, L, a.hyperbolic);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
-  float* cw = smem + lp.cw; float* outv = smem + lp.small;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)(a.rows - r0 < 16 ? a.rows - r0 : 16);
   const int lane = threadIdx.x & 63, wave = wave_id();
   tile_load(xs, ldS, a.x + r0 * a.x_ld, a.x_ld, 16, S, valid);
-  if (a.critic) {
-    const CriticLayout clx = cx_layout(S, L);
-    const CriticPad cpx = critic_pad(S, L, 4);
-    stage_params(cw, a.cxpad, cpx.total);      // the padded image hypad_score_forward_packed's pack launch wrote (critic_mfma.h CriticPad)
-    critic_tile_fwd(xs, ldS, cw, clx, L, cpx, bufA, outv);
-    if (threadIdx.x < valid) a.critic[r0 + threadIdx.x] = outv[threadIdx.x];
-  } else {
-    __syncthreads();
-  }
+  __syncthreads();
   encoder_fwd_tile_packed(xs, ldS, S, L, a.pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, valid);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   decoder_trunk_fwd_tile_packed<1>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
@@ -1919,10 +2000,14 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   pa.P.cx = const_cast<float*>(cx); pa.pcx = cx_layout(S, L).total;
   int rc = launch_pack(pa, d, (hipStream_t)s, nullptr, 0, nullptr, cx != nullptr);
   if (rc) return rc;
+  if (critic) {          // (the image the pack launch wrote: critic_mfma.h CriticPad)
+    rc = launch_critic_rows((const float*)workspace + score_critic_offset(S, L, hyperbolic), x, x_row_stride > 0 ? x_row_stride : S, critic, rows, S, L, (hipStream_t)s);
+    if (rc) return rc;
+  }
   ScoreArgs a;
-  a.pk = (const float*)workspace; a.cx = cx; a.cxpad = (const float*)workspace + score_critic_offset(S, L, hyperbolic); a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
+  a.pk = (const float*)workspace; a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
   a.x = x; a.x_ld = x_row_stride > 0 ? x_row_stride : S;
-  a.hyper = hyper; a.eucl = eucl; a.hyper_real = hyper_real; a.critic = critic; a.rowdist = rowdist;
+  a.hyper = hyper; a.eucl = eucl; a.hyper_real = hyper_real; a.rowdist = rowdist;
   a.rows = rows; a.S = S; a.L = L; a.hyperbolic = hyperbolic;
   const size_t lds = (size_t)score_lds(S, L).total * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
