@@ -81,6 +81,25 @@ __device__ __forceinline__ void tile_store(float* __restrict__ dst, int64_t gld,
   }
   tile_for(rows, cols, [&](int r, int c) { if (r < valid) dst[(int64_t)r * gld + c] = src[r * ld + c]; });
 }
+// The same two through a buffer descriptor on the tile's first row (src / dst: wave-uniform): 32-bit lane offsets instead of 64-bit
+// vector address arithmetic (the scoring kernel kept a 64-bit lane offset alive from its first load to its last store -- in scratch).
+__device__ __forceinline__ void tile_load_b(float* __restrict__ dst, int ld, const float* __restrict__ src, int gld, int rows, int cols, int valid) {
+  const GBuf b(src);
+  tile_for(rows, cols, [&](int r, int c) { dst[r * ld + c] = r < valid ? b.ld((r * gld + c) * 4, 0) : 0.f; });
+}
+// (the lane number comes from mbcnt here, two instructions: derived from threadIdx.x the compiler recognises the kernel's first lane
+// offset in it and keeps that one register alive -- spilled -- until the stores at the kernel's end)
+__device__ __forceinline__ void tile_store_b(float* __restrict__ dst, int gld, const float* __restrict__ src, int ld, int rows, int cols, int valid) {
+  const GBuf b(dst);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), wave = wave_id(), nw = blockDim.x >> 6;
+  if (tile_vec4_ok(dst, gld, ld, cols)) {
+    for (int r = wave; r < rows && r < valid; r += nw)
+      for (int c4 = lane; c4 < (cols >> 2); c4 += 64) b.st4(*reinterpret_cast<const float4*>(src + r * ld + 4 * c4), (r * gld + 4 * c4) * 4);
+    return;
+  }
+  for (int r = wave; r < rows && r < valid; r += nw)
+    for (int c = lane; c < cols; c += 64) b.st(src[r * ld + c], (r * gld + c) * 4, 0);
+}
 __device__ __forceinline__ void tile_store_p(float* __restrict__ dst, int64_t gld, int ps, const float* __restrict__ src, int ld,
                                              int rows, int cols, int valid) {
   if (tile_vec4_ok(dst, gld, ld, cols)) {
@@ -413,9 +432,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
     f32x4 ai[MT], ag[MT], ao[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { ai[m] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[m] = ai[m]; ao[m] = ai[m]; }
-    auto consume = [&](const float4 (&bi)[4], const float4 (&bg)[4], const float4 (&bo)[4], int g0) __attribute__((always_inline)) {
+    auto consume = [&](auto nb_, const float4* bi, const float4* bg, const float4* bo, int g0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < decltype(nb_)::value; ++u) {
         if (g0 + u < kg) {                             // wave-uniform
           const int k0 = 16 * (g0 + u) + 4 * q;
           const int ka = k0 < lda - 4 ? k0 : lda - 4;
@@ -439,9 +458,9 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
         }
       }
     };
-    auto fetch = [&](float4 (&bi)[4], float4 (&bg)[4], float4 (&bo)[4], int g0) __attribute__((always_inline)) {
+    auto fetch = [&](auto nb_, float4* bi, float4* bg, float4* bo, int g0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < decltype(nb_)::value; ++u) {
         const int o = g0 + u < kg ? g0 + u : kg - 1;
         bi[u] = wb(bi0 + o); bg[u] = wb(bg0 + o); bo[u] = wb(bo0 + o);
       }
@@ -453,21 +472,25 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
       float4 xi[4], xg[4], xo[4], yi[4], yg[4], yo[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { xi[u] = pre.bi[u]; xg[u] = pre.bg[u]; xo[u] = pre.bo[u]; }
+      constexpr std::integral_constant<int, 4> four{};
       for (int g0 = 0; g0 < kg; g0 += 8) {
-        if (g0 + 4 < kg) fetch(yi, yg, yo, g0 + 4);
+        if (g0 + 4 < kg) fetch(four, yi, yg, yo, g0 + 4);
         __builtin_amdgcn_sched_barrier(0);
-        consume(xi, xg, xo, g0);
-        if (g0 + 8 < kg) fetch(xi, xg, xo, g0 + 8);
+        consume(four, xi, xg, xo, g0);
+        if (g0 + 8 < kg) fetch(four, xi, xg, xo, g0 + 8);
         __builtin_amdgcn_sched_barrier(0);
-        if (g0 + 4 < kg) consume(yi, yg, yo, g0 + 4);
+        if (g0 + 4 < kg) consume(four, yi, yg, yo, g0 + 4);
       }
     } else {
-      // throughput callers (many workgroups per CU hide the latency): one batch in flight, half the registers
-      for (int g0 = 0; g0 < kg; g0 += 4) {
-        float4 bi[4], bg[4], bo[4];
-        fetch(bi, bg, bo, g0);
+      // throughput callers (many workgroups per CU hide the latency): one batch in flight, half the registers; with two row tiles a
+      // weight block feeds 24 MFMAs and two k-groups per batch are enough (the accumulators of the second tile take the registers)
+      constexpr int NB = MT >= 2 ? 2 : 4;
+      constexpr std::integral_constant<int, NB> nb_c{};
+      for (int g0 = 0; g0 < kg; g0 += NB) {
+        float4 bi[NB], bg[NB], bo[NB];
+        fetch(nb_c, bi, bg, bo, g0);
         __builtin_amdgcn_sched_barrier(0);
-        consume(bi, bg, bo, g0);
+        consume(nb_c, bi, bg, bo, g0);
       }
     }
     mfma_prio_end<PRE>();
@@ -502,17 +525,17 @@ __device__ __forceinline__ void lstm_layer_fwd_packed(const float* __restrict__ 
 }
 
 // PRE: the caller requested the layer's first weights earlier (lstm_layer_prefetch on gp.enc_g) and passes them in.
-template <bool PRE = false, bool SC1 = false>
+template <bool PRE = false, bool SC1 = false, int MT = 1>
 __device__ __forceinline__ void encoder_fwd_tile_packed(const float* Xs, int ldx, int S, int L, const float* pk, const GenPack& gp,
                                                         float* bufG, int ldg, float* bufH, int ldh, float* Zs,
                                                         float* gates_save, float* h_save, int valid, const LstmPre& pre = LstmPre{}) {
   (void)bufG; (void)ldg;
   PackedPre pred{};
   if constexpr (PRE) pred = gemm_nt_prefetch<SC1>(pk + gp.enc_d, 2 * ENC_H, L);   // the dense layer's weights, one stage ahead
-  lstm_layer_fwd_packed<1, PRE, SC1>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
+  lstm_layer_fwd_packed<MT, PRE, SC1>(Xs, ldx, S, pk + gp.enc_g[0], pk + gp.enc_gb[0], pk + gp.enc_g[1], pk + gp.enc_gb[1], ENC_H, bufH, ldh,
                                 gates_save, valid, 16, pre, h_save);          // (h_save written from the epilogue)
   __syncthreads();
-  gemm_nt_packed<1, PRE, ActIdentity, SC1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
+  gemm_nt_packed<MT, PRE, ActIdentity, SC1>(bufH, ldh, 2 * ENC_H, L, pk + gp.enc_d, pk + gp.enc_db, Zs, LP, 0, 0, pred);
   __syncthreads();
 }
 // PRE: the caller requested d1's first weights earlier (gemm_nt_prefetch on gp.d1) and passes them in.  next_W (may be

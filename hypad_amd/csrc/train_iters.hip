@@ -1639,50 +1639,68 @@ struct ScoreLds { int xs, zs, bufA, bufB, total, ldS; };
 #ifndef HYPAD_SCORE_WPE
 #define HYPAD_SCORE_WPE 4
 #endif
-HD ScoreLds score_lds(int S, int L) {
+HD ScoreLds score_lds(int S, int L, int MT) {
   ScoreLds p; int o = 0;
   p.ldS = lds_stride(S);
-  int buf = 16 * (2 * DEC_H + 4) > 32 * p.ldS ? 16 * (2 * DEC_H + 4) : 32 * p.ldS;       // h tiles / the 32-row head tile
+  const int rows = 16 * MT;
+  int buf = rows * (2 * DEC_H + 4) > rows * p.ldS ? rows * (2 * DEC_H + 4) : rows * p.ldS;       // h tiles / e and head tiles
+  if (MT == 1 && buf < 32 * p.ldS) buf = 32 * p.ldS;                                             // (the 32-row head tile of the 16-window form)
   buf = (buf + 3) & ~3;
-  p.xs = o; o += 16 * p.ldS;
-  p.zs = o; o += 16 * LP;
+  p.xs = o; o += rows * p.ldS;
+  p.zs = o; o += rows * LP;
   p.bufA = o; o += buf;
   p.bufB = o; o += buf;
   p.total = o;
   return p;
 }
-template <int SC, int LC>
+// MT = 1: 16 windows per workgroup (small calls: more workgroups).  MT = 2: 32 windows -- every weight block a wave fetches feeds two
+// row tiles, the stages' barriers and per-tile set-up are paid once per 32 windows.  Same products in the same order per row: same bits.
+template <int SC, int LC, int MT>
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_SCORE_WPE, HYPAD_SCORE_WPE))) void score_forward_packed_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ROWS = 16 * MT;
   const int S = SC ? SC : a.S, L = LC ? LC : a.L;
-  const ScoreLds lp = score_lds(S, L);
+  const ScoreLds lp = score_lds(S, L, MT);
   const int ldS = lp.ldS;
   const GenPack gp = gen_pack(S, L, a.hyperbolic);
   float* xs = smem + lp.xs; float* zs = smem + lp.zs; float* bufA = smem + lp.bufA; float* bufB = smem + lp.bufB;
-  const int64_t r0 = (int64_t)blockIdx.x * 16;
-  const int valid = (int)(a.rows - r0 < 16 ? a.rows - r0 : 16);
+  const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+  const int valid = (int)(a.rows - r0 < ROWS ? a.rows - r0 : ROWS);
   const int lane = threadIdx.x & 63, wave = wave_id();
-  tile_load(xs, ldS, a.x + r0 * a.x_ld, a.x_ld, 16, S, valid);
+  tile_load_b(xs, ldS, a.x + r0 * a.x_ld, (int)a.x_ld, ROWS, S, valid);
   __syncthreads();
-  encoder_fwd_tile_packed(xs, ldS, S, L, a.pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, valid);
+  encoder_fwd_tile_packed<false, false, MT>(xs, ldS, S, L, a.pk, gp, bufA, ENC_LDG, bufB, ENC_LDH, zs, nullptr, nullptr, valid);
   DecSave none{16, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  decoder_trunk_fwd_tile_packed<1>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
-  if (a.eucl) tile_store(a.eucl + r0 * S, S, bufA, ldS, 16, S, valid);
+  decoder_trunk_fwd_tile_packed<MT>(zs, L, S, a.pk, gp, bufA, bufB, ldS, no_drop(), [](int r) { return r; }, none, valid);
+  if (a.eucl) tile_store_b(a.eucl + r0 * S, S, bufA, ldS, ROWS, S, valid);
   if (a.hyperbolic) {
-    for (int i = threadIdx.x; i < 16 * ldS; i += blockDim.x) bufA[16 * ldS + i] = xs[i];      // rows 16-31: the real windows
+    // the head on the reconstruction AND on the real windows (anomaly_detection.py:84-90): u rows of both, then the ball rows
+    float* urec; float* ureal;
+    if constexpr (MT == 1) {
+      for (int i = threadIdx.x; i < 16 * ldS; i += blockDim.x) bufA[16 * ldS + i] = xs[i];      // rows 16-31: the real windows
+      __syncthreads();
+      gemm_nt_packed<2>(bufA, ldS, S, S, a.pk + gp.head, nullptr, bufB, ldS, 0);
+      __syncthreads();
+      head_rows_tile(bufB, ldS, 32, S, a.head_b);
+      urec = bufB; ureal = bufB + 16 * ldS;
+    } else {
+      gemm_nt_packed<MT>(bufA, ldS, S, S, a.pk + gp.head, nullptr, bufB, ldS, 0);
+      __syncthreads();                                       // (e has been read -- by the product and by the store above)
+      gemm_nt_packed<MT>(xs, ldS, S, S, a.pk + gp.head, nullptr, bufA, ldS, 0);
+      __syncthreads();
+      head_rows_tile(bufB, ldS, ROWS, S, a.head_b);
+      head_rows_tile(bufA, ldS, ROWS, S, a.head_b);
+      urec = bufB; ureal = bufA;
+    }
     __syncthreads();
-    gemm_nt_packed<2>(bufA, ldS, S, S, a.pk + gp.head, nullptr, bufB, ldS, 0);
-    __syncthreads();
-    head_rows_tile(bufB, ldS, 32, S, a.head_b);
-    __syncthreads();
-    if (a.hyper) tile_store(a.hyper + r0 * S, S, bufB, ldS, 16, S, valid);
-    if (a.hyper_real) tile_store(a.hyper_real + r0 * S, S, bufB + 16 * ldS, ldS, 16, S, valid);
-    if (a.rowdist && wave < 4) {
+    if (a.hyper) tile_store_b(a.hyper + r0 * S, S, urec, ldS, ROWS, S, valid);
+    if (a.hyper_real) tile_store_b(a.hyper_real + r0 * S, S, ureal, ldS, ROWS, S, valid);
+    if (a.rowdist && wave < 4 * MT) {
       // (pred = real window on the ball, true = reconstruction): anomaly_detection_utils.py:58-65; four rows per wave
       epl16_dispatch(S, [&](auto tag) {
         using R16 = RowT<16, decltype(tag)::value>;
         const int r = wave * 4 + (lane >> 4);
-        const float d = rowdist_row(row_load<R16>(bufB + (16 + r) * ldS, S, lane), row_load<R16>(bufB + r * ldS, S, lane));
+        const float d = rowdist_row(row_load<R16>(ureal + r * ldS, S, lane), row_load<R16>(urec + r * ldS, S, lane));
         if ((lane & 15) == 0 && r < valid) a.rowdist[r0 + r] = d;
       });
     }
@@ -1989,6 +2007,7 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
                                int hyperbolic, void* workspace, size_t workspace_bytes, hypad_stream_t s) {
   if (S < 1 || S > MAX_S || L < 1 || L > MAX_L) return HYPAD_EUNSUPPORTED;
   if (!enc || !dec || !x || rows < 0 || (critic && !cx)) return HYPAD_EINVAL;
+  if (x_row_stride > (1 << 24)) return HYPAD_EUNSUPPORTED;       // (a tile's rows are addressed with 32-bit byte offsets)
   if (!workspace || workspace_bytes < hypad_score_workspace_bytes(S, L, hyperbolic)) return HYPAD_EWORKSPACE;
   if (rows == 0) return HYPAD_OK;
   hypad_dims d; d.signal_shape = S; d.latent_dim = L; d.batch = 16; d.hyperbolic = hyperbolic; d.n_signals = 1; d.first_signal = 0;
@@ -2009,20 +2028,21 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
   a.x = x; a.x_ld = x_row_stride > 0 ? x_row_stride : S;
   a.hyper = hyper; a.eucl = eucl; a.hyper_real = hyper_real; a.rowdist = rowdist;
   a.rows = rows; a.S = S; a.L = L; a.hyperbolic = hyperbolic;
-  const size_t lds = (size_t)score_lds(S, L).total * sizeof(float);
+  // 32 windows per workgroup once that still leaves every CU several workgroups (two are resident on a CU at a time)
+  // (the reference window only: the run-time-shape build of the 32-window form and the one for window 150 do not fit 128 registers)
+  const bool ref_shape = S == 100 && L == 20;
+  const int mt = ref_shape && rows >= (int64_t)32 * 2048 ? 2 : 1;
+  const size_t lds = (size_t)score_lds(S, L, mt).total * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
-  const int64_t tiles = (rows + 15) / 16;
+  const int64_t tiles = (rows + 16 * mt - 1) / (16 * mt);
   if (tiles > 0x7fffffff) return HYPAD_EINVAL;
-  if (S == 100 && L == 20) {
-    hipError_t e = allow_lds((const void*)score_forward_packed_kernel<100, 20>, lds);
-    if (e != hipSuccess) return (int)e;
-    static const int score_threads = HYPAD_TUNE_INT("HYPAD_SCORE_THREADS", TB);      // (development switch)
-    hipLaunchKernelGGL((score_forward_packed_kernel<100, 20>), dim3((unsigned)tiles), dim3(score_threads), lds, (hipStream_t)s, a);
-  } else {
-    hipError_t e = allow_lds((const void*)score_forward_packed_kernel<0, 0>, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((score_forward_packed_kernel<0, 0>), dim3((unsigned)tiles), dim3(TB), lds, (hipStream_t)s, a);
-  }
+  const void* fn = ref_shape ? (mt == 2 ? (const void*)score_forward_packed_kernel<100, 20, 2> : (const void*)score_forward_packed_kernel<100, 20, 1>)
+                   : (const void*)score_forward_packed_kernel<0, 0, 1>;
+  hipError_t e = allow_lds(fn, lds);
+  if (e != hipSuccess) return (int)e;
+  void* kargs[] = {&a};
+  e = hipLaunchKernel(fn, dim3((unsigned)tiles), dim3(TB), kargs, lds, (hipStream_t)s);
+  if (e != hipSuccess) return (int)e;
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
 }

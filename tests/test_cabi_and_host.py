@@ -210,13 +210,14 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_run():
     assert len(ks) > 100
     by_name = {k["name"]: k for k in ks}
     clean = [n for n in by_name if any(t in n for t in ("<100, 20, 64>", "<true, 100, 20, 64", "<false, 100, 20, 64", "<100, 20>", "<150, 20, 256, ", "<true, 150, 20, 256>",
-                                                        "<100, 20, 64, ", "kde_mode_kernel", "score_forward_packed", "lstm_fwd_lds2_kernel", "lstm_fwd_lds3_kernel",
+                                                        "<100, 20, 64, ", "kde_mode_kernel", "score_forward_packed", "critic_rows_kernel", "lstm_fwd_lds2_kernel", "lstm_fwd_lds3_kernel",
                                                         "dtw_error_kernel", "rolling_mean_kernel", "qs_level_kernel", "unary_rows", "rowdist_rows", "mobius_add_rows",
                                                         "pack_generator_kernel", "epoch_shuffle_kernel", "decay_steps_kernel"))]
     clean += [n for n in by_name if "unroll_median_kernel" in n and ", 128>" in n]           # (the tile size every launch uses)
     assert len(clean) >= 25, sorted(clean)
     for must in ("critic_persistent_kernel<100, 20, 64>", "critic_iteration_kernel<100, 20, 64>", "gen_kernel<true, 100, 20, 64>", "gen_kernel<true, 150, 20, 256>",
-                 "dw_adam_kernel<100, 20, 64, 48", "critic_phase_precompute_kernel<100, 20>", "kde_mode_kernel<2>"):
+                 "dw_adam_kernel<100, 20, 64, 48", "critic_phase_precompute_kernel<100, 20>", "kde_mode_kernel<2>", "score_forward_packed_kernel<100, 20, 2>",
+                 "critic_rows_kernel<100, 20>"):
         assert any(must in n for n in clean), must
     # (dw_adam_kernel<150, 20, 256, 48, false>: no spilled vector register and not one scratch instruction in its code, but the register
     # allocator reserves a 20-byte emergency slot for its 68 spilled scalars -- allowed, as a reservation of at most 32 bytes)

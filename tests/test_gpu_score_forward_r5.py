@@ -1,0 +1,66 @@
+"""Round 5: the fused scoring forward's two tile forms and the critic launch beside it (anomaly_detection.py:67-113).
+
+hypad_score_forward_packed runs 32 windows per workgroup from 65 536 windows on (16 below) and takes the critic value of the windows from
+critic_rows_kernel.  The reference-pinned checks are on the 16-window form (tests/test_gpu_parity.py: fixtures and the streamed kernel);
+here: the 32-window form gives the same bits as the 16-window form, row for row, ragged tail and series view included, and the critic
+launch agrees with hypad_critic_x_fwd (the fixture-checked entry point)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from hypad_amd.models import tadgan
+    torch.manual_seed(5)
+    S, L = 100, 20
+    enc, dec, cx = tadgan.Encoder(S, L).cuda().eval(), tadgan.Decoder(S, L, True).cuda().eval(), tadgan.CriticX(S, L).cuda().eval()
+    with torch.no_grad():
+        dec.hyperbolic_linear.weight.mul_(30)
+    return S, L, enc, dec, cx
+
+
+def _forward(nets, src, stride, n, outs):
+    from hypad_amd import _C
+    S, L, enc, dec, cx = nets
+    ws_bytes = _C.lib.hypad_score_workspace_bytes(S, L, 1)
+    ws = torch.empty(ws_bytes // 4, device="cuda")
+    _C.check(_C.lib.hypad_score_forward_packed(_C.ptr(enc.arena()), _C.ptr(dec.arena()), _C.ptr(cx.arena()), _C.ptr(src), stride, *[_C.ptr(o) for o in outs],
+                                               n, S, L, 1, ws.data_ptr(), ws_bytes, _C.stream()), "score_forward_packed")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("view", ["rows", "series"])
+def test_32_window_form_equals_16_window_form(nets, view):
+    S = nets[0]
+    n = 65_536 + 16 + 5                 # the 32-window form, last workgroup: 21 valid rows of 32
+    series = (torch.rand(n + S - 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1).contiguous()
+    x = series.unfold(0, S, 1).contiguous()
+    new = lambda *s: torch.full(s, float("nan"), device="cuda")
+    big = [new(n, S), new(n, S), new(n, S), new(n), new(n)]
+    _forward(nets, series if view == "series" else x, 1 if view == "series" else 0, n, big)
+    small = [new(n, S), new(n, S), new(n, S), new(n), new(n)]
+    for lo in range(0, n, 30_000):      # every piece below the switch: the 16-window form
+        m = min(30_000, n - lo)
+        piece = [new(m, S), new(m, S), new(m, S), new(m), new(m)]
+        _forward(nets, x[lo:lo + m].contiguous(), 0, m, piece)
+        for dst, p in zip(small, piece):
+            dst[lo:lo + m] = p
+    for k, (a, b) in enumerate(zip(big, small)):
+        assert bool(torch.isfinite(a).all()), k
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
+
+
+def test_critic_launch_matches_the_entry_point(nets):
+    from hypad_amd import _C
+    S, L, enc, dec, cx = nets
+    for n in (1, 37, 128 * 16 + 3, 70_001):
+        x = (torch.rand(n, S, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n)) * 2 - 1).contiguous()
+        got, dist = torch.full((n,), float("nan"), device="cuda"), torch.empty(n, device="cuda")
+        _forward(nets, x, 0, n, [None, None, None, got, dist])
+        ref = torch.empty(n, device="cuda")
+        _C.check(_C.lib.hypad_critic_x_fwd(_C.ptr(cx.arena()), _C.ptr(x), _C.ptr(ref), n, S, L, None, _C.stream()), "critic_x_fwd")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(got).all()), n
+        assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (n, float((got - ref).abs().max()))
