@@ -638,19 +638,6 @@ def _event_ms_median(fn, rounds=21, per_round=3):
     return float(np.median(out))
 
 
-def _event_ms(fn, reps):
-    """Mean duration of fn's kernels, HIP events on the stream they are launched on (torch's current stream = _C.stream())."""
-    fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps
-
-
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec; 6 290 measured for a float4 copy
 
 
@@ -779,7 +766,7 @@ def bench_scoring(device, n=125_000, reps=5, cpu_sample=0, smooth=200, kernels=T
     cs_ws = torch.empty(cs_bytes, dtype=torch.uint8, device=device)
     roofline_scoring = {}
     for name, (fn, bound, work, nbytes) in kern.items():
-        ms = _event_ms(fn, reps)
+        ms = _event_ms_median(fn)           # (median of 21 rounds of 3 launches, as roofline_hbm / roofline_lstm: a mean of five calls moved by 10 % run to run)
         ent = {"bound": bound, "ms": ms, "windows_per_s": n / (ms * 1e-3)}
         if bound == "mfma":
             ent.update(achieved=work / (ms * 1e-3) / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s")

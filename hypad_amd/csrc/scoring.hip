@@ -524,7 +524,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
   __shared__ __attribute__((aligned(16))) float vals32[THREADS / 64][WMAX + 4];      // + the padding the fp32 pass reads past the end
   __shared__ __attribute__((aligned(16))) float nsq32[THREADS / 64][WMAX + 4];       // -(value^2) for the factored form of the fp32 pass
   __shared__ double terms[THREADS / 64][KDE_CB * WMAX];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t T = n + W - 1;
   double* v = vals[wave];
   float* vf = vals32[wave];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
   for (int64_t t = (int64_t)blockIdx.x * (THREADS / 64) + wave; t < T; t += (int64_t)gridDim.x * (THREADS / 64)) {
     const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
     const int j1 = (int)(t + 1 < W ? t + 1 : W);
-    const int cnt = j1 - j0;
+    const int cnt = __builtin_amdgcn_readfirstlane(j1 - j0);      // (wave-uniform: the pair loops below run on scalar counters)
     double s = 0.0;
     for (int k = lane; k < cnt; k += 64) {
       const float xf = critic[t - (j0 + k)];
@@ -622,8 +622,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(HYPAD_K
 #pragma unroll
           for (int u = 0; u < KPL; ++u) {
             if (u >= nu) continue;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[u][c] += __builtin_amdgcn_exp2f(__builtin_fmaf(x2[u], vm[c], nm[c]));
+            // (two fused multiply-adds per instruction: v_pk_fma_f32 -- the same roundings)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f xx = {x2[u], x2[u]};
+            const v2f a01 = __builtin_elementwise_fma(xx, v2f{vm[0], vm[1]}, v2f{nm[0], nm[1]});
+            const v2f a23 = __builtin_elementwise_fma(xx, v2f{vm[2], vm[3]}, v2f{nm[2], nm[3]});
+            acc[u][0] += __builtin_amdgcn_exp2f(a01.x); acc[u][1] += __builtin_amdgcn_exp2f(a01.y);
+            acc[u][2] += __builtin_amdgcn_exp2f(a23.x); acc[u][3] += __builtin_amdgcn_exp2f(a23.y);
           }
         }
 #pragma unroll

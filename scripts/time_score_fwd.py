@@ -23,3 +23,14 @@ for name, f in (("all outputs (bench)", fwd(hyper, eucl, hreal, critic, dist)), 
 out = new(n)
 ms = bench._event_ms_median(lambda: _C.check(_C.lib.hypad_critic_x_fwd(_C.ptr(cx.arena()), _C.ptr(xx), _C.ptr(out), n, S, L, None, _C.stream()), "cx"))
 print("hypad_critic_x_fwd alone                   %.4f ms" % ms)
+# the numerics kernels behind the forward (bench.py roofline_scoring times the same calls)
+crit = torch.randn(n, device=dev)
+modes = torch.empty(n + S - 1, dtype=torch.float64, device=dev)
+ms = bench._event_ms_median(lambda: _C.check(_C.lib.hypad_kde_mode(_C.ptr(crit), _C.ptr(modes), n, S, _C.stream()), "kde"))
+print("kde_mode (random-normal critic values)     %.4f ms" % ms)
+_forward_all = fwd(hyper, eucl, hreal, critic, dist); _forward_all()
+ms = bench._event_ms_median(lambda: _C.check(_C.lib.hypad_kde_mode(_C.ptr(critic), _C.ptr(modes), n, S, _C.stream()), "kde"))
+print("kde_mode (this model's critic values)      %.4f ms" % ms)
+pred32 = torch.empty(n + S - 1, device=dev)
+ms = bench._event_ms_median(lambda: _C.check(_C.lib.hypad_unroll_median(_C.ptr(eucl), _C.ptr(pred32), None, n, S, _C.stream()), "unroll"))
+print("unroll_median                              %.4f ms" % ms)
