@@ -2023,6 +2023,7 @@ int hypad_score_forward_packed(const float* enc, const float* dec, const float* 
     rc = launch_critic_rows((const float*)workspace + score_critic_offset(S, L, hyperbolic), x, x_row_stride > 0 ? x_row_stride : S, critic, rows, S, L, (hipStream_t)s);
     if (rc) return rc;
   }
+  if (!hyper && !eucl && !hyper_real && !rowdist) return HYPAD_OK;      // (only the critic value was asked for)
   ScoreArgs a;
   a.pk = (const float*)workspace; a.head_b = hyperbolic ? dec + dec_layout(S, L, 1).head_b : nullptr;
   a.x = x; a.x_ld = x_row_stride > 0 ? x_row_stride : S;
