@@ -322,6 +322,120 @@ extern "C" __attribute__((visibility("default"))) int hypad_diag_gemm(const floa
   return (int)hipGetLastError();
 }
 
+// ---- four-row tiles on v_mfma_f32_4x4x1 against sixteen-row tiles on 16x16x4 over the same packed weights (scripts/diag_gemm4.py):
+// cycles of one product call of a 512-thread workgroup, and both results (rows 0..3 must agree)
+namespace {
+// The same product for a FOUR-row tile, on v_mfma_f32_4x4x1_16B_f32 (sixteen independent 4 x 4 outer products per instruction, 8 cycles:
+// the same 64 FLOP / clock / SIMD as 16x16x4) over the SAME packed blocks: lane (j, q) of block (tn, g) holds W[16 tn + j][16 g + 4 q .. + 3].
+// MFMA block b = lane >> 2 = 4 q + (j >> 2) multiplies A[row = lane & 3][k] (taken from the lanes 4 b .. 4 b + 3: every lane loads its
+// own row lane & 3 at ITS k = 16 g + 4 q + s) with W[16 tn + j][k]: the four lane groups q accumulate the k classes 4 q .. 4 q + 3 (mod 16)
+// of the same 16 columns, and two swap-and-add steps (v_permlane16_swap / v_permlane32_swap) fold them: afterwards every lane (q, j)
+// holds column 16 tn + j of all four rows, and takes row q into the epilogue -- one element per lane and tile.
+// A latency-chain workgroup with 4 rows instead of 16 has a quarter of the MFMA cycles and a quarter of the epilogue elements -- but the
+// same weight bytes to pull through its CU, and that is what the probe found to bound it: K = 128, N = 384 (196 KB of weights) takes
+// 9.4 k cycles with four rows against 14.9 k with sixteen in this un-prefetched form = 21 bytes per clock; the generator kernel's
+// prefetched form of that product already runs at 32 bytes per clock (6.1 k cycles), the rate the guide measures for L2-served rows
+// per CU.  Rows are the only split of a chain that needs no exchange between workgroups, and it does not shrink a CU's weight bytes:
+// a chain's ~1 MB of packed weights is ~33 k cycles of streaming whatever its tile height.  Kept here as the measurement, not used.
+__device__ __forceinline__ float fold_q(float x) {            // sum over the four lane groups q (lanes l, l ^ 16, l ^ 32, l ^ 48)
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  u2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(a.x) + __uint_as_float(a.y);
+  u2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+// epi.prefetch4(n, row, ok) before the reduction, epi.emit4(row, n, value) after it: row = q in 0..3, n = output column.
+template <bool PRE, class Epi, bool SC1 = false>
+__device__ __forceinline__ void gemm4_nt_packed_epi(const float* __restrict__ Xs, int ldx, int K, int N, const float* __restrict__ Wp,
+                                                    const float* __restrict__ bsum, int wave_rot, const PackedPre& pre, Epi& epi) {
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, wave = (wave_id() + nwaves - wave_rot % nwaves) % nwaves;
+  const int j = lane & 15, q = lane >> 4, arow = lane & 3;
+  const int ntiles = (N + 15) >> 4, kg = (K + 15) >> 4;
+  auto run = [&](int t, auto first_from_pre) __attribute__((always_inline)) {
+    const WeightBlocks<SC1> wb(Wp, lane);
+    const int b0 = t * kg;
+    const int n = t * 16 + j;
+    const float bs = (bsum && n < N) ? weight_scalar<SC1>(bsum + n) : 0.f;
+    epi.prefetch4(n, q, n < N);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](const float4 (&w)[8], int g0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (g0 + u < kg) {                             // wave-uniform
+          const int k0 = 16 * (g0 + u) + 4 * q;
+          const int ka = k0 < ldx - 4 ? k0 : ldx - 4;
+          const float4 a = *reinterpret_cast<const float4*>(Xs + arow * ldx + ka);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(k0 < K ? a.x : 0.f, w[u].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(k0 + 1 < K ? a.y : 0.f, w[u].y, acc2, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(k0 + 2 < K ? a.z : 0.f, w[u].z, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(k0 + 3 < K ? a.w : 0.f, w[u].w, acc2, 0, 0, 0);
+        }
+      }
+    };
+    int gbeg = 0;
+    mfma_prio_begin<PRE>();
+    if constexpr (decltype(first_from_pre)::value) {
+      consume(pre.w, 0);
+      gbeg = 8;
+    }
+    for (int g0 = gbeg; g0 < kg; g0 += 8) {
+      float4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = wb(b0 + (g0 + u < kg ? g0 + u : kg - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      consume(w, g0);
+    }
+    mfma_prio_end<PRE>();
+    // this lane's row: q (fold the four k classes, then pick)
+    const float v0 = fold_q(acc[0] + acc2[0]), v1 = fold_q(acc[1] + acc2[1]), v2 = fold_q(acc[2] + acc2[2]), v3 = fold_q(acc[3] + acc2[3]);
+    const float v = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;
+    if (n < N) epi.emit4(q, n, v + bs);
+  };
+  if (wave < ntiles) run(wave, std::integral_constant<bool, PRE>{});
+  for (int t = wave + nwaves; t < ntiles; t += nwaves) run(t, std::false_type{});
+}
+template <class Act>
+struct PlainEpi4 {
+  float* Ys; int ldy, ycol0; Act act;
+  __device__ __forceinline__ void prefetch4(int, int, bool) {}
+  __device__ __forceinline__ void emit4(int row, int n, float v) { Ys[row * ldy + ycol0 + n] = act(v); }
+};
+
+__global__ void diag_gemm4_kernel(const float* __restrict__ Wp, const float* __restrict__ X, int K, int N, float* __restrict__ Y16, float* __restrict__ Y4,
+                                  long long* out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldx = lds_stride(K), ldy = lds_stride(N);
+  float* xs = smem; float* ys = xs + 16 * ldx; float* y4 = ys + 16 * ldy;
+  for (int i = threadIdx.x; i < 16 * ldx; i += blockDim.x) { const int r = i / ldx, c = i - r * ldx; xs[i] = c < K ? X[r * K + c] : 0.f; }
+  __syncthreads();
+  long long t[9];
+  for (int rep = 0; rep < 4; ++rep) {
+    __syncthreads();
+    t[rep] = __builtin_amdgcn_s_memtime();
+    gemm_nt_packed<1>(xs, ldx, K, N, Wp, nullptr, ys, ldy, 0);
+    __syncthreads();
+  }
+  t[4] = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < 4; ++rep) {
+    __syncthreads();
+    t[5 + rep] = __builtin_amdgcn_s_memtime();
+    PlainEpi4<ActIdentity> epi{y4, ldy, 0, ActIdentity{}};
+    gemm4_nt_packed_epi<false, PlainEpi4<ActIdentity>, false>(xs, ldx, K, N, Wp, nullptr, 0, PackedPre{}, epi);
+    __syncthreads();
+  }
+  const long long t9 = __builtin_amdgcn_s_memtime();
+  for (int i = threadIdx.x; i < 16 * N; i += blockDim.x) Y16[i] = ys[(i / N) * ldy + i % N];
+  for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) Y4[i] = y4[(i / N) * ldy + i % N];
+  if (threadIdx.x == 0) { out[0] = t[1] - t[0]; out[1] = t[4] - t[3]; out[2] = t[6] - t[5]; out[3] = t9 - t[8]; }
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int hypad_diag_gemm4(const float* Wp, const float* X, int K, int N, float* Y16, float* Y4, long long* out, hypad_stream_t s) {
+  const size_t lds = (size_t)(16 * lds_stride(K) + 20 * lds_stride(N)) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)diag_gemm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(diag_gemm4_kernel, dim3(1), dim3(512), lds, (hipStream_t)s, Wp, X, K, N, Y16, Y4, out);
+  return (int)hipGetLastError();
+}
+
 // ---- ablation of one 16x128 weight tile (1 tile per wave): which part of the per-tile chain costs the time?
 namespace {
 template <int MODE>
