@@ -11,7 +11,8 @@ import csv, glob, json, re, sys
 import numpy as np
 
 sys.path.insert(0, ".")
-KERNELS = {"score_forward_packed_kernel": 340312.0 / 2 * 125_000,                  # MACs per launch (algorithmic)
+KERNELS = {"score_forward_packed_kernel": (340312.0 / 2 - 3220.0) * 125_000,       # MACs per launch (algorithmic; critic_x's 3 220 per window are the launch below)
+           "critic_rows_kernel": 3220.0 * 125_000,
            "lstm_fwd(_lds[0-9]?)?_kernel": None,
            "gen_kernel": 561824.0 * 64, "dw_adam_kernel": 281872.0 * 64,
            "critic_persistent_kernel": (40400.0 + 156936.0) * 64 * 145}

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 KERNELS = ["critic_persistent_kernel", "critic_iteration_kernel", "critic_phase_precompute_kernel", "dw_adam_kernel", "gen_kernel", "pack_generator_kernel",
-           "score_forward_packed_kernel", "unroll_median_kernel", "dtw_error_kernel", "unary_rows", "mobius_add_rows", "rowdist_rows"]
+           "score_forward_packed_kernel", "critic_rows_kernel", "kde_mode_kernel", "unroll_median_kernel", "dtw_error_kernel", "unary_rows", "mobius_add_rows", "rowdist_rows"]
 
 
 def medians(d, counter):
