@@ -1542,10 +1542,10 @@ int launch_pack(const IterArgs& a, const hypad_dims& dm, hipStream_t s, unsigned
 // its own 16-row tiles -- rows into a wave-private LDS tile (the next tile's rows are requested into registers before the layers of
 // the current one), four layers on wave_gemm_nt with nothing but wave-local fences between them, the last layer as 16 dot products.
 // Same products in the same order as critic_tile_fwd: same bits.
-constexpr int CR_WAVES = 8;
-HD int critic_rows_lds_floats(int S, int L) {
+constexpr int CR_WAVES = 8;                  // waves per workgroup (fewer where the wave-private tiles of a wide window would not fit the LDS)
+HD int critic_rows_lds_floats(int S, int L, int waves) {
   const CriticPad cp = critic_pad(S, L, 4);
-  return cp.total + CR_WAVES * (16 * cp.ldin + 2 * 16 * cp.LQ);
+  return cp.total + waves * (16 * cp.ldin + 2 * 16 * cp.LQ);
 }
 template <int SC, int LC>
 __global__ __launch_bounds__(64 * CR_WAVES) void critic_rows_kernel(const float* __restrict__ cxpad, const float* __restrict__ x, int64_t x_ld,
@@ -1563,7 +1563,8 @@ __global__ __launch_bounds__(64 * CR_WAVES) void critic_rows_kernel(const float*
   for (int i = lane; i < 2 * 16 * LQ; i += 64) act[i] = 0.f;
   __syncthreads();
   const float* w0 = smem + cp.w0; const float* wh = smem + cp.wh; const float* wl = smem + cp.wl;
-  const int64_t tiles = (rows + 15) >> 4, stride = (int64_t)gridDim.x * CR_WAVES;
+  const int nwaves = blockDim.x >> 6;
+  const int64_t tiles = (rows + 15) >> 4, stride = (int64_t)gridDim.x * nwaves;
   constexpr int NV = SC ? (16 * SC + 63) / 64 : 1;     // floats of a tile per lane (compiled-in window; any other streams its rows)
   float xr[NV];
   auto fetch = [&](int64_t t) __attribute__((always_inline)) {
@@ -1575,7 +1576,7 @@ __global__ __launch_bounds__(64 * CR_WAVES) void critic_rows_kernel(const float*
       xr[u] = i < 16 * S ? x[row * x_ld + c] : 0.f;
     }
   };
-  int64_t t = (int64_t)blockIdx.x * CR_WAVES + wave;
+  int64_t t = (int64_t)blockIdx.x * nwaves + wave;
   if constexpr (SC != 0) { if (t < tiles) fetch(t); }
   for (; t < tiles; t += stride) {
     if constexpr (SC != 0) {
@@ -1613,19 +1614,21 @@ __global__ __launch_bounds__(64 * CR_WAVES) void critic_rows_kernel(const float*
   }
 }
 int launch_critic_rows(const float* cxpad, const float* x, int64_t x_ld, float* out, int64_t rows, int S, int L, hipStream_t s) {
-  const size_t lds = (size_t)critic_rows_lds_floats(S, L) * sizeof(float);
+  int waves = CR_WAVES;
+  while (waves > 1 && (size_t)critic_rows_lds_floats(S, L, waves) * sizeof(float) > 160 * 1024) waves >>= 1;
+  const size_t lds = (size_t)critic_rows_lds_floats(S, L, waves) * sizeof(float);
   if (lds > 160 * 1024) return HYPAD_EUNSUPPORTED;
   const int64_t tiles = (rows + 15) / 16;
   // (its LDS plan puts one workgroup on a CU: 256 of them cover an MI355X, the tiles go round)
-  const unsigned grid = (unsigned)std::min<int64_t>((tiles + CR_WAVES - 1) / CR_WAVES, 256);
+  const unsigned grid = (unsigned)std::min<int64_t>((tiles + waves - 1) / waves, 256);
   if (S == 100 && L == 20) {
     hipError_t e = allow_lds((const void*)critic_rows_kernel<100, 20>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((critic_rows_kernel<100, 20>), dim3(grid), dim3(64 * CR_WAVES), lds, s, cxpad, x, x_ld, out, rows, S, L);
+    hipLaunchKernelGGL((critic_rows_kernel<100, 20>), dim3(grid), dim3(64 * waves), lds, s, cxpad, x, x_ld, out, rows, S, L);
   } else {
     hipError_t e = allow_lds((const void*)critic_rows_kernel<0, 0>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((critic_rows_kernel<0, 0>), dim3(grid), dim3(64 * CR_WAVES), lds, s, cxpad, x, x_ld, out, rows, S, L);
+    hipLaunchKernelGGL((critic_rows_kernel<0, 0>), dim3(grid), dim3(64 * waves), lds, s, cxpad, x, x_ld, out, rows, S, L);
   }
   HYPAD_CHECK_LAUNCH();
   return HYPAD_OK;
