@@ -999,14 +999,21 @@ __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __re
   out[item] = it;
 }
 
+// chunk > 0 (the spread placement): the records are cut into eight contiguous chunks of `chunk` items and workgroup bx takes its four
+// from chunk bx mod 8 -- the workgroups of one chunk land on one XCD (round-robin dispatch), a matrix's tiles are neighbours in the
+// table, so its operand rows are fetched into one or two L2s instead of all eight.  Speed / traffic only: the items are independent.
 template <int SC, int LC, int BC, int KS>
-__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx) {
+__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx, const int chunk = 0) {
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = blockIdx.y + a.sig0;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
-  const int item = bx * (THREADS / 64) + wave;          // the launch covers total_items: one item per wave
+  int item = bx * (THREADS / 64) + wave;                // the launch covers total_items: one item per wave
+  if (chunk > 0) {
+    const int c = bx & 7, in_chunk = (bx >> 3) * (THREADS / 64) + wave;
+    item = in_chunk < chunk ? c * chunk + in_chunk : total_items;
+  }
   // the record (wave-uniform address: scalar loads from the constant address space -- nothing writes the table during this launch) ...
   using CWord = const __attribute__((address_space(4))) int32_t;
   DwItem d;
@@ -1187,7 +1194,9 @@ __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwIt
     if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;
     dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)(blockIdx.x >> 3));
   } else {
-    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x);
+    // (grid: 8 x ceil(chunk / 4) workgroups, chunk = ceil(total / 8) rounded up to a multiple of four)
+    const int chunk = ((total_items + 7) / 8 + 3) & ~3;
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, (int)gridDim.x == 8 * (chunk / 4) ? chunk : 0);
   }
 }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
@@ -1912,7 +1921,8 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + ws_items_offset(*d));
   const int total_items = tab.total_items;
   const bool coloc = (io.flags & HYPAD_EPOCH_DW_COLOC) ? true : (io.flags & HYPAD_EPOCH_DW_SPREAD) ? false : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
-  const dim3 dgrid((coloc ? 8 : 1) * dw_blocks(tab.total_items), nsig);
+  const int dw_chunk = ((tab.total_items + 7) / 8 + 3) & ~3;          // spread placement: eight chunks of the records, one per XCD (dw_adam_items_body)
+  const dim3 dgrid(coloc ? 8 * dw_blocks(tab.total_items) : 8 * (dw_chunk / 4), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
       if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
