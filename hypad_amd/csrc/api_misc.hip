@@ -115,11 +115,52 @@ __global__ __launch_bounds__(SHUF_THREADS) void epoch_shuffle_kernel(int32_t* __
     keys[i] = k;
   }
   __syncthreads();
-  // 66 compare-exchange stages at 2 048 keys.  Pair t sits in elements [128 (t / 64), 128 (t / 64) + 128) whenever stride < 64, and
-  // a stage with stride 64 reads what the stride-128 stage (other waves) wrote: so only the stages with stride >= 64 -- and the one
-  // right behind such a stage -- need the workgroup barrier (14 + 4 of the 66); in between, the 64 pairs of a wave touch 128 elements
-  // no other wave touches and a wave barrier is enough.  (Measured: 21.5 -> 20.6 us per launch -- the sort is bound by the 66 dependent
-  // LDS round trips themselves, not by the barriers; what would shorten it is keeping the strides below 64 in registers.)
+  // 66 compare-exchange stages at 2 048 keys.  As LDS round trips with a barrier each they were the kernel: 0.3 us per stage, 20.6 us per
+  // launch.  A stage with stride <= 64 stays inside a block of 128 keys, and a wave holds such a block in registers -- lane l the keys
+  // l and 64 + l of the block: stride 64 is the lane's own pair, strides 32 .. 1 exchange with lane l ^ stride (two 32-bit shuffles per
+  // key) -- so only the stages with stride >= 128 go through LDS (10 of the 66 at 2 048 keys): the first seven sizes (2 .. 128) are one
+  // register run, every later size is its wide stages in LDS and then one register run.  Any correct sort of these keys (all different:
+  // the index is their low word) gives the same permutation.
+  if (npow2 >= 128) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto xchg = [&](unsigned long long& k, int e, int stride, int size) __attribute__((always_inline)) {      // e: the key's index
+      const unsigned lo32 = (unsigned)__shfl_xor((int)(unsigned)k, stride, 64), hi32 = (unsigned)__shfl_xor((int)(unsigned)(k >> 32), stride, 64);
+      const unsigned long long other = ((unsigned long long)hi32 << 32) | lo32;
+      const bool up = ((e & ~stride) & size) == 0, is_lo = (e & stride) == 0;
+      const bool want_min = is_lo == up;
+      k = (k < other) == want_min ? k : other;
+    };
+    auto reg_run = [&](int base, int size_from, int size_to, bool first_strides_only) __attribute__((always_inline)) {
+      // sizes size_from .. size_to (each: its strides <= 64) on the block [base, base + 128); first_strides_only: one size, strides 64 .. 1
+      unsigned long long ka = keys[base + lane], kb = keys[base + 64 + lane];
+      for (int size = size_from; size <= size_to; size <<= 1) {
+        int stride = size >> 1;
+        if (stride > 64) stride = 64;
+        if (stride == 64) {                              // the lane's own pair (lo = base + lane)
+          const bool up = ((base + lane) & size) == 0;
+          if ((ka > kb) == up) { const unsigned long long t = ka; ka = kb; kb = t; }
+          stride = 32;
+        }
+        for (; stride > 0; stride >>= 1) { xchg(ka, base + lane, stride, size); xchg(kb, base + 64 + lane, stride, size); }
+      }
+      (void)first_strides_only;
+      keys[base + lane] = ka; keys[base + 64 + lane] = kb;
+    };
+    for (int base = wave * 128; base < npow2; base += (SHUF_THREADS / 64) * 128) reg_run(base, 2, 128, false);
+    for (int size = 256; size <= npow2; size <<= 1) {
+      for (int stride = size >> 1; stride >= 128; stride >>= 1) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < npow2 / 2; t += SHUF_THREADS) {
+          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const unsigned long long a = keys[lo], b = keys[hi];
+          if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+        }
+      }
+      __syncthreads();
+      for (int base = wave * 128; base < npow2; base += (SHUF_THREADS / 64) * 128) reg_run(base, size, size, true);
+    }
+  } else {
   bool wide = true;                                                       // the previous stage exchanged across waves (or the fill did)
   for (int size = 2; size <= npow2; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -133,6 +174,7 @@ __global__ __launch_bounds__(SHUF_THREADS) void epoch_shuffle_kernel(int32_t* __
         if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
       }
     }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < take; i += SHUF_THREADS) out[(int64_t)blockIdx.x * take + i] = (int32_t)(unsigned)keys[i];
 }
