@@ -1188,15 +1188,14 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
 // over the 8 XCDs), so one model's weight tiles share an L2: its ~0.9 MB of operand rows are fetched from HBM once, not once per
 // XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
 template <int SC, int LC, int BC, int KS, bool COLOC = false>
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items) {
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items, int chunk) {
   if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
     if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;
     dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)(blockIdx.x >> 3));
   } else {
-    // (grid: 8 x ceil(chunk / 4) workgroups, chunk = ceil(total / 8) rounded up to a multiple of four)
-    const int chunk = ((total_items + 7) / 8 + 3) & ~3;
-    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, (int)gridDim.x == 8 * (chunk / 4) ? chunk : 0);
+    // (chunk > 0: the grid is 8 x chunk / 4 workgroups, chunk = ceil(total / 8) rounded up to a multiple of four)
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, chunk);
   }
 }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
@@ -1925,12 +1924,12 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const dim3 dgrid(coloc ? 8 * dw_blocks(tab.total_items) : 8 * (dw_chunk / 4), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
-      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
-      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
-      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
-    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items);
+      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
   }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);

@@ -219,9 +219,9 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_run():
                  "dw_adam_kernel<100, 20, 64, 48", "critic_phase_precompute_kernel<100, 20>", "kde_mode_kernel<2>", "score_forward_packed_kernel<100, 20, 2>",
                  "critic_rows_kernel<100, 20>"):
         assert any(must in n for n in clean), must
-    # (dw_adam_kernel<150, 20, 256, 48, false>: no spilled vector register and not one scratch instruction in its code, but the register
-    # allocator reserves a 20-byte emergency slot for its 68 spilled scalars -- allowed, as a reservation of at most 32 bytes)
-    reserve = lambda n: 32 if "dw_adam_kernel<150, 20, 256, 48" in n else 0
+    # (dw_adam_kernel<.., 48, false>, the spread placement: no spilled vector register and not one scratch instruction in its code, but the
+    # register allocator reserves a 20-byte emergency slot for its 68 spilled scalars -- allowed, as a reservation of at most 32 bytes)
+    reserve = lambda n: 32 if ("dw_adam_kernel<150, 20, 256, 48" in n or "dw_adam_kernel<100, 20, 64, 48" in n) else 0
     bad = {n: (by_name[n]["vgpr_spill_count"], by_name[n]["private_segment_fixed_size"]) for n in clean
            if by_name[n]["vgpr_spill_count"] or by_name[n]["private_segment_fixed_size"] > reserve(n)}
     assert not bad, bad
