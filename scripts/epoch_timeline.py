@@ -21,3 +21,7 @@ for i, r in enumerate(pick):
         print(f"{(s - t0) / 1e3:9.2f} us  {name(r):32s} dur {(e - s) / 1e3:8.2f}  gap-before {g / 1e3:6.2f}")
     prev = e
 print(f"kernels {len(pick)}  span {(prev - t0) / 1e3:.2f} us  busy {busy / 1e3:.2f}  gaps {gaps / 1e3:.2f}")
+import statistics
+for k in ("gen_kernel", "dw_adam_kernel"):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in pick if name(r) == k]
+    print(f"{k}: first {d[0]:.2f} us, others mean {statistics.mean(d[1:]):.2f} median {statistics.median(d[1:]):.2f}")
