@@ -376,20 +376,10 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float sum_crit = 0.f, sum_aux = 0.f;
   constexpr int ldH = 2 * DEC_H + 4, ldG = 6 * DEC_H + 4, ldA0 = 52;
   GEN_STAMP(0);
-  // L2 warm-up: the packed generator weights were rewritten by the previous launch (dW + Adam, on any XCD), so their
-  // first touch here misses this XCD's L2.  The working workgroups of a signal share one XCD (see gen_kernel): together
-  // they touch every 128-byte line once, now, and the layers find the weights in L2 when they get there.
-  float warm[3] = {0.f, 0.f, 0.f};
-  {
-    const int nwg = 2 * (B / 16), w = role * (B / 16) + tile;      // chains G and R (chain Z sits on another XCD)
-    const int lines = gp.total / 32;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int line = (u * nwg + w) * TB + threadIdx.x;
-      if (line < lines) warm[u] = pk[line * 32];
-    }
-  }
-
+  // (Rounds 1-4 started with an "L2 warm-up": the workgroups of chains G and R together touched every 128-byte line of the packed
+  // weights once, so that the layers would find them in this XCD's L2.  Since the weights come through prefetched sc1 buffer loads a
+  // stage ahead it only stood in front of the chains' first loads -- loads return in order: the window gather and the first layer's
+  // weights waited behind ~0.4 MB of cold lines.  Without it: 2.749 against 2.766 ms per epoch, 36.0 against 36.15 us per launch.)
   float* zin;                               // decoder input rows [16][LP]
   PackedPre pre_d1;                         // first weights of the decoder's first layer, requested a stage ahead
   if (role == 0) {
@@ -612,7 +602,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
   float* part_out = ws + gw.partial + tile * 4;
   if (role == 0) {
     if (threadIdx.x == 0) part_out[1] = sum_crit;
-    if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;      // keeps the warm-up loads alive
     GEN_STAMP(11);
     return;
   }
@@ -629,7 +618,6 @@ __device__ __forceinline__ void gen_body(const IterArgs& a, float* smem) {
     gemm_nt_packed_epi<1, true, decltype(epi), WSC1>(X, LP, L, 2 * ENC_H, pk + gp.enc_d_t, nullptr, 0, pre_edt, epi);
   }
   if (threadIdx.x == 0) part_out[0] = sum_aux;
-  if (warm[0] + warm[1] + warm[2] == 1.2345e-30f) part_out[3] = 1.f;        // keeps the warm-up loads alive
   GEN_STAMP(11);
 }
 
