@@ -991,9 +991,10 @@ __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __re
 // from chunk bx mod 8 -- the workgroups of one chunk land on one XCD (round-robin dispatch), a matrix's tiles are neighbours in the
 // table, so its operand rows are fetched into one or two L2s instead of all eight.  Speed / traffic only: the items are independent.
 template <int SC, int LC, int BC, int KS>
-__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx, const int chunk = 0) {
+__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx, const int chunk = 0,
+                                                   const int model = (int)blockIdx.y) {      // model: index inside the launch (blockIdx.y, or the co-located form's own)
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
-  const int sig = blockIdx.y + a.sig0;
+  const int sig = model + a.sig0;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   float* ws = a.ws + sig * a.ws_sig_stride;
@@ -1153,7 +1154,7 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
     }
   }
 #if HYPAD_DIAG
-  if (a.stamps && blockIdx.y == 0 && lane == 0 && item < 1024) {      // (scripts/diag_dw_items.py)
+  if (a.stamps && model == 0 && lane == 0 && item < 1024) {      // (scripts/diag_dw_items.py)
     a.stamps[3 * 48 * 8 + 64 + 2 * item] = (long long)__builtin_amdgcn_s_memrealtime();
     a.stamps[3 * 48 * 8 + 64 + 2 * item + 1] = item < total_items && d.kind >= 0 ? d.kind * 1000 + d.net * 100 + (d.red_rows >> 4) : -1;
   }
@@ -1169,18 +1170,26 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
     float* lo = a.losses + sig * a.loss_sig_stride;
     lo[0] = 10.f * aux - fx / a.B - fz / a.B;
     lo[1] = aux; lo[2] = fx / a.B; lo[3] = fz / a.B;
-    if (blockIdx.y == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
+    if (model == 0 && a.tick_owner && a.step_add < 0) a.counters[3] += 1;     // rng tick: nobody reads it inside this kernel
   }
 }
-// COLOC: blockIdx.x is stretched by 8 and only the blocks that land on XCD (signal mod 8) work (workgroups are dealt round-robin
-// over the 8 XCDs), so one model's weight tiles share an L2: its ~0.9 MB of operand rows are fetched from HBM once, not once per
-// XCD.  Used from 8 signals per GPU on.  Speed only: no result depends on it.
+// COLOC: one model's weight tiles share an XCD's L2 -- its ~0.9 MB of operand rows are fetched from HBM once, not once per XCD.
+// Workgroups are dealt round-robin over the 8 XCDs, so in a ONE-dimensional grid workgroup id lands on XCD id mod 8: the launch's
+// models go in groups of eight, id mod 8 picks the model of the group and id / 8 its workgroup -- 8 x blocks x ceil(models / 8)
+// workgroups, none of them empty while the model count is a multiple of eight.  (Rounds 2-4 stretched blockIdx.x by 8 under a
+// (blocks, models) grid and let seven of eight workgroups leave at once: 10 500 workgroups at 8 models, 1.2 us of the launch's
+// 18.8 for the dispatcher to deal them -- 3.212 -> 3.178 ms per epoch at 8 models.  What the launch takes at 8 models and more
+// is its bytes: 6.4 MB per model in one burst of loads and one of stores through the model's XCD, ~3 TB/s over the chip.)  Used
+// from 8 signals per GPU on.  Speed only: no result depends on it.
 template <int SC, int LC, int BC, int KS, bool COLOC = false>
 __global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items, int chunk) {
   if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
-    if ((blockIdx.x & 7) != ((blockIdx.y + a.sig0) & 7)) return;
-    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)(blockIdx.x >> 3));
+    // chunk carries the launch's model count here
+    const int blocks = (total_items + THREADS / 64 - 1) / (THREADS / 64);
+    const int t = (int)(blockIdx.x >> 3), model = (t / blocks) * 8 + (int)(blockIdx.x & 7);
+    if (model >= chunk) return;
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, t % blocks, 0, model);
   } else {
     // (chunk > 0: the grid is 8 x chunk / 4 workgroups, chunk = ceil(total / 8) rounded up to a multiple of four)
     dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, chunk);
@@ -1909,15 +1918,15 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const int total_items = tab.total_items;
   const bool coloc = (io.flags & HYPAD_EPOCH_DW_COLOC) ? true : (io.flags & HYPAD_EPOCH_DW_SPREAD) ? false : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const int dw_chunk = ((tab.total_items + 7) / 8 + 3) & ~3;          // spread placement: eight chunks of the records, one per XCD (dw_adam_items_body)
-  const dim3 dgrid(coloc ? 8 * dw_blocks(tab.total_items) : 8 * (dw_chunk / 4), nsig);
+  const dim3 dgrid = coloc ? dim3(8 * dw_blocks(tab.total_items) * ((nsig + 7) / 8)) : dim3(8 * (dw_chunk / 4), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
-      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
-      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
-      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
-    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? 0 : dw_chunk);
+      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
   }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);
