@@ -188,8 +188,8 @@ __device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, floa
 }
 
 // Riemannian Adam on one ball-valued vector held by a wave (oracle/manual.py radam_ball_step)
-__device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, RowVec g, int dim, int lane, const AdamCoef& c) {
-  RowVec P = row_load(p, dim, lane), Mv = row_load(m, dim, lane), V = row_load(v, dim, lane);
+// (P, Mv, V: the rows at p, m, v -- loaded by the caller, so that they can be requested together with the gradient's parts)
+__device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, RowVec P, RowVec Mv, RowVec V, RowVec g, int dim, int lane, const AdamCoef& c) {
 #pragma unroll
   for (int e = 0; e < MAX_EPL; ++e) g.v[e] += c.wd * P.v[e];
   float lam = 2.f / fmaxf(1.f - row_dot(P, P), MIN_NORM);
@@ -224,6 +224,9 @@ __device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, Ro
   row_store(p, np, dim, lane);
   row_store(m, Mv, dim, lane);
   row_store(v, V, dim, lane);
+}
+__device__ __forceinline__ void radam_ball_wave(float* p, float* m, float* v, RowVec g, int dim, int lane, const AdamCoef& c) {
+  radam_ball_wave(p, m, v, row_load(p, dim, lane), row_load(m, dim, lane), row_load(v, dim, lane), g, dim, lane, c);
 }
 
 // critic_fused.hip: the critic phase of an epoch with the frozen generator's forwards hoisted out of the chain

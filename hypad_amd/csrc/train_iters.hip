@@ -1039,9 +1039,16 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
         const int n = n0 + 4 * q + r, k = k0 + j;
         const bool ok = n < d.nrows && k < d.ncols;
         po[r] = ok ? n * d.p_ld + k : -1;
-        const uint32_t oc = ok ? (uint32_t)po[r] : 0u;
-        pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
       }
+      // (requested BEHIND the first batch of operand rows -- loads return in order, and the products need only the rows)
+      auto load_state = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t oc = po[r] >= 0 ? (uint32_t)po[r] : 0u;
+          pp[r] = Pb[oc]; pm[r] = Mb[oc]; pvv[r] = Vb[oc];
+        }
+      };
+      if (d.red_rows <= 0) load_state();
       for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // up to KS k-steps in flight
         float la[KS], rb[KS];
 #pragma unroll
@@ -1053,6 +1060,7 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
               rb[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo, (rc + 4 * u) * d.right_ld * 4, 0));
             }
           }
+        if (rc == 0) load_state();
 #pragma unroll
         for (int c = 0; c < KS / 4; ++c)
           if (rc + 16 * c < d.red_rows) {
@@ -1086,6 +1094,10 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
       const bool nv = n < d.nrows;
       const float* left = ws + d.left_off + (nv ? n : d.nrows - 1);
       const int rlast = d.red_rows - 1;
+      // the optimiser state with the rows (one round trip: as a second one behind the sums it made the bias items the launch's long pole)
+      const bool own = nv && q == 0;
+      const int64_t o1 = d.p_off + (own ? n : 0), o2 = (d.p_off2 >= 0 ? d.p_off2 : d.p_off) + (own ? n : 0);
+      const float p1_ = P[o1], m1_ = M[o1], v1_ = V[o1], p2_ = P[o2], m2_ = M[o2], v2_ = V[o2];
       float g = 0.f;
       for (int rc = 0; rc < d.red_rows; rc += 4 * KS) {    // KS rows per lane in flight
         float t[KS];
@@ -1099,17 +1111,15 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
       }
       g += __shfl_xor(g, 16, WAVE);
       g += __shfl_xor(g, 32, WAVE);
-      if (nv && q == 0) {
-        int64_t o = d.p_off + n;
-        float p = P[o], m = M[o], v = V[o];
+      if (own) {
+        float p = p1_, m = m1_, v = v1_;
         adam_update(p, m, v, g, co);
-        P[o] = p; M[o] = m; V[o] = v;
+        P[o1] = p; M[o1] = m; V[o1] = v;
         float bs = p;
         if (d.p_off2 >= 0) {
-          o = d.p_off2 + n;
-          p = P[o]; m = M[o]; v = V[o];
+          p = p2_; m = m2_; v = v2_;
           adam_update(p, m, v, g, co);
-          P[o] = p; M[o] = m; V[o] = v;
+          P[o2] = p; M[o2] = m; V[o2] = v;
           bs += p;
         }
         if (d.bsum >= 0) {
@@ -1131,6 +1141,8 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
       }
     } else if (d.kind == DW_BALL) {                // hyperbolic_linear.bias; gradient = sum of the per-tile partial column sums
       const float* left = ws + d.left_off;
+      // (the ball rows with the gradient's parts: one round trip -- this item is the longest of the launch)
+      const RowVec Pr = row_load(P + d.p_off, d.nrows, lane), Mr = row_load(M + d.p_off, d.nrows, lane), Vr = row_load(V + d.p_off, d.nrows, lane);
       RowVec g;
 #pragma unroll
       for (int e = 0; e < MAX_EPL; ++e) g.v[e] = 0.f;
@@ -1150,7 +1162,7 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
 #pragma unroll
           for (int e = 0; e < MAX_EPL; ++e) g.v[e] += r0 + u < d.red_rows ? t[u][e] : 0.f;
       }
-      radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, g, d.nrows, lane, co);
+      radam_ball_wave(P + d.p_off, M + d.p_off, V + d.p_off, Pr, Mr, Vr, g, d.nrows, lane, co);
     }
   }
 #if HYPAD_DIAG
