@@ -276,7 +276,8 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
     const int b0 = t * kg;
     const int n = t * 16 + j;
     const float bs = (bsum && n < N) ? weight_scalar<SC1>(bsum + n) : 0.f;
-    epi.prefetch(n, q, n < N);
+    // (what the epilogue needs is requested behind the LAST batch of weights: loads return in order, and only the epilogue waits for it)
+    bool epi_asked = false;
     f32x4 acc[MT], acc2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -300,6 +301,7 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
     int gbeg = 0;
     mfma_prio_begin<PRE>();
     if constexpr (decltype(first_from_pre)::value) {
+      if (kg <= 8) { epi.prefetch(n, q, n < N); epi_asked = true; }
       consume(pre.w, 0);
       gbeg = 8;
     }
@@ -307,9 +309,11 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
       float4 w[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) w[u] = wb(b0 + (g0 + u < kg ? g0 + u : kg - 1));
+      if (g0 + 8 >= kg) { epi.prefetch(n, q, n < N); epi_asked = true; }
       __builtin_amdgcn_sched_barrier(0);
       consume(w, g0);
     }
+    if (!epi_asked) epi.prefetch(n, q, n < N);
     mfma_prio_end<PRE>();
     if (n < N) {
 #pragma unroll
