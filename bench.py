@@ -226,20 +226,65 @@ def bench_signals_product(n_signals, device, epochs=24):
     return out
 
 
-def _max_over_ranks(ms, dist, device):
-    """A per-rank duration -> the slowest rank's (the job's) under a process group; unchanged without one."""
-    if dist is None:
-        return ms
-    t = torch.tensor([ms], device=device, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t)
+class SectionAborted(Exception):
+    """Raised inside a detail section on the ranks that did NOT fail, at their next guarded collective."""
 
 
-def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True, dist=None, world=1):
+class RankGuard:
+    """The collectives a detail section may use under a process group, made unable to dead-lock the job when ONE rank fails in
+    the middle of a section (main.py:32-70's per-signal loop shards without a collective; these sections only agree on times).
+    Every guarded collective -- barrier(), max() and the agreement that closes a section -- is the SAME operation: one
+    all_reduce(MAX) of [value, failed].  A rank whose section raises posts exactly one more of them with failed = 1 (`run` does
+    it) and leaves the section; every other rank meets that message at ITS next guarded collective -- the sequence numbers
+    agree, because the failed rank's abort is the collective it would have performed next --, gets SectionAborted and leaves the
+    section too, without posting anything.  So all ranks leave at the same collective, the section is reported as skipped, and
+    the next section starts with the ranks in step.  Without a process group everything is the identity."""
+
+    def __init__(self, dist=None, device=None, world=1):
+        self.dist, self.device, self.world = dist, device, world
+
+    def _reduce(self, value, failed):
+        if self.dist is None:
+            return value
+        t = torch.tensor([value, 1.0 if failed else 0.0], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        v, f = t.tolist()
+        if f > 0 and not failed:
+            raise SectionAborted("another rank failed in this section")
+        return v
+
+    def max(self, ms):
+        """A per-rank duration -> the slowest rank's (the job's)."""
+        return self._reduce(float(ms), False)
+
+    def barrier(self):
+        self._reduce(0.0, False)
+
+    def run(self, fn, *a, **kw):
+        """fn(*a, **kw), or {"error": ...} in its place ON EVERY RANK when it raised on any rank: a detail section never costs
+        the run its headline, and never leaves a rank behind in a collective."""
+        import traceback
+        try:
+            res = fn(*a, **kw)
+            self._reduce(0.0, False)                  # the closing agreement (a rank that failed after the section's last collective is met here)
+            return res
+        except SectionAborted as e:
+            return {"error": "skipped on all ranks: %s" % e}
+        except Exception as e:
+            traceback.print_exc(file=sys.stderr)
+            try:
+                self._reduce(0.0, True)               # the abort message: this rank's next -- and last -- collective of the section
+            except Exception:                         # (the process group itself is gone: nothing more to agree on)
+                traceback.print_exc(file=sys.stderr)
+            return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=None, eager=True, guard=None, world=1):
     """`spg` signals (models) per GPU of workload `cfg`: the epoch replayed as a captured hipGraph (static shuffle buffer),
     `warmup` untimed + `steps` timed epochs; the same epochs launched eagerly (host-bound wherever ~61 launches of CPU enqueue
     exceed the GPU time); per-kernel launch times at this signal count and the chip-level rate: all algorithmic FLOPs of an
     epoch over the epoch's time, against the fp32-MFMA peak."""
+    guard = guard or RankGuard()
     eng, x = build_engine(spg, spg * rank, cfg.hyperbolic, device, cfg)
     out = {"workload": what or ("configs[2] per-GPU share: %d signals (%d models) per GPU, otherwise as configs[1]" % (spg, spg)),
            "signals_per_gpu": spg, "window": cfg.S, "batch": cfg.B, "windows_per_signal": cfg.n_windows, "hyperbolic": cfg.hyperbolic,
@@ -253,13 +298,12 @@ def bench_signals(spg, rank, device, gen, warmup=5, steps=20, cfg=CFG1, what=Non
             for _ in range(warmup):                   # eager launches of the same epoch next to it; it does not reproduce in isolation)
                 step()
             torch.cuda.synchronize()
-            if dist is not None:                      # every rank's timed region starts together; the job's time is the slowest rank's
-                dist.barrier()
+            guard.barrier()                           # every rank's timed region starts together; the job's time is the slowest rank's
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
             torch.cuda.synchronize()
-            runs[mode].append(_max_over_ranks(1e3 * (time.perf_counter() - t0) / steps, dist, device))
+            runs[mode].append(guard.max(1e3 * (time.perf_counter() - t0) / steps))
             eng.check_status()
             assert bool(torch.isfinite(losses).all())
     for mode, v in runs.items():
@@ -330,9 +374,10 @@ def bench_signals_sharded(device, world, rank, per_gpu=8, epochs=24, warm=3):
         assert sorted(res) == names and all(len(res[k]["history"]["dec"]) == epochs for k in names)      # every rank holds every signal's history
         assert all(np.isfinite(res[k]["history"]["dec"]).all() for k in names)
         w = np.diff(np.asarray(stamps))[warm - 1:] * 1e3
-        steady = _max_over_ranks(float(w.mean()), dist, device)
-        setup = _max_over_ranks(1e3 * (stamps[0] - t0), dist, device)
-        call_ms = _max_over_ranks(call_ms, dist, device)
+        guard = RankGuard(dist, device, dist.get_world_size())
+        steady = guard.max(float(w.mean()))
+        setup = guard.max(1e3 * (stamps[0] - t0))
+        call_ms = guard.max(call_ms)
         return {"what": "configs[2] through train_signals_resident under a process group: %d signals of %d windows (%d per GPU), hyperbolic, %d epochs; "
                         "value = all ranks' windows per epoch / the slowest rank's steady-state epoch time (epochs %d.. of one call)" % (n, N_WINDOWS, per_gpu, epochs, warm),
                 "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(), "signals": n, "signals_this_rank": mine,
@@ -947,8 +992,8 @@ def _claim_stdout():
 HEADLINE_MAX_BYTES = 4096           # the driver keeps a bounded tail of stdout: the LAST line must be small and whole
 
 _HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
-_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic", "traffic_ratio", "launch_ms", "launches_per_step",
-              "iterations_per_launch", "flop_per_launch")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_algorithmic", "traffic_ratio", "launch_ms",
+              "launches_per_step", "iterations_per_launch", "flop_per_launch")
 _CPU_KEYS = ("value", "unit", "cores", "host_cores", "kind", "sample")
 
 
@@ -965,9 +1010,10 @@ def _finite(o):
     return o
 
 
-def headline(full):
+def headline(full, provisional=False):
     """The compact strict-JSON object the driver parses: the contract's keys, `roofline` of the dominant kernel, `cpu_baseline`, and one
-    figure per detail section (each section whole: bench_detail.json next to this file, and one line per section on stderr)."""
+    figure per detail section (each section whole: bench_detail.json in the working directory, and one line per section on stderr).
+    Never raises over its size: what is optional is dropped step by step until the line fits, the contract's keys always stay."""
     full = _finite(full)
     head = {k: full[k] for k in _HEAD_KEYS if k in full}
     cfg = full.get("config", {})
@@ -976,36 +1022,56 @@ def headline(full):
         head["roofline"] = {k: full["roofline"][k] for k in _ROOF_KEYS if k in full["roofline"]}
     if isinstance(full.get("cpu_baseline"), dict):
         head["cpu_baseline"] = {k: full["cpu_baseline"][k] for k in _CPU_KEYS if k in full["cpu_baseline"]}
-        if head["cpu_baseline"].get("value"):
+        if head["cpu_baseline"].get("value") and full.get("value"):
             head["vs_cpu_baseline"] = full["value"] / head["cpu_baseline"]["value"]
-    also = {}
+    also, failed = {}, []
     for name, sec in full.items():                     # one number per section, so the line says what the detail file holds
-        if isinstance(sec, dict) and name not in ("config", "roofline", "cpu_baseline", "final_losses") and isinstance(sec.get("value"), (int, float)):
-            also[name] = round(sec["value"], 1)
+        if isinstance(sec, dict) and name not in ("config", "roofline", "cpu_baseline", "final_losses"):
+            if isinstance(sec.get("value"), (int, float)):
+                also[name] = round(sec["value"], 1)
+            elif "error" in sec:
+                failed.append(name)
     head["also_windows_per_s"] = also
+    if failed:
+        head["sections_failed"] = failed
+    if provisional:
+        head["provisional"] = True                     # (printed before the detail sections ran: the same run's final line follows)
     head["detail"] = "bench_detail.json"
-    line = json.dumps(head, allow_nan=False, separators=(",", ":"))
-    if len(line) >= HEADLINE_MAX_BYTES:                # never grow past what the driver keeps: drop the optional parts, keep the contract
-        head.pop("also_windows_per_s", None)
-        line = json.dumps(head, allow_nan=False, separators=(",", ":"))
-    assert len(line) < HEADLINE_MAX_BYTES, len(line)
+    dumps = lambda: json.dumps(head, allow_nan=False, separators=(",", ":"))
+    line = dumps()
+    # never grow past what the driver keeps: drop the optional parts in this order, keep the contract
+    _ROOF_CORE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")
+    steps = [lambda: head.pop("also_windows_per_s", None), lambda: head.pop("sections_failed", None),
+             lambda: head.__setitem__("roofline", {k: v for k, v in head.get("roofline", {}).items() if k in _ROOF_CORE}),
+             lambda: head.__setitem__("cpu_baseline", {k: (v[:120] if isinstance(v, str) else v) for k, v in head.get("cpu_baseline", {}).items()})
+             if "cpu_baseline" in head else None,
+             lambda: head["config"].__setitem__("workload", str(head["config"].get("workload", ""))[:160]),
+             lambda: head.__setitem__("config", {"workload": str(head["config"].get("workload", ""))[:80]}),
+             lambda: head.pop("roofline", None), lambda: head.pop("cpu_baseline", None)]
+    for shrink in steps:
+        if len(line) < HEADLINE_MAX_BYTES:
+            break
+        shrink()
+        line = dumps()
     return line
 
 
-def emit(full, json_out, detail_path=None):
-    """Every section whole -> bench_detail.json and stderr (one section per line); the compact headline -> the LAST line of stdout."""
+def emit(full, json_out, detail_path=None, final=True):
+    """Every section whole -> bench_detail.json (in the working directory unless a path is given) and, with the final line, stderr (one
+    section per line); the compact headline -> a new LAST line of stdout (`provisional` until the final one)."""
     full = _finite(full)
-    detail_path = detail_path or os.path.join(ROOT, "bench_detail.json")
+    detail_path = detail_path or os.path.join(os.getcwd(), "bench_detail.json")
     try:
         with open(detail_path, "w") as f:
             json.dump(full, f, allow_nan=False, indent=1)
     except OSError as e:                               # (a read-only checkout must not cost the run its line)
         print("bench_detail.json not written: %s" % e, file=sys.stderr)
-    for name, sec in full.items():
-        if isinstance(sec, (dict, list)):
-            print(json.dumps({name: sec}, allow_nan=False), file=sys.stderr)
-    sys.stderr.flush()
-    json_out.write(headline(full) + "\n")
+    if final:
+        for name, sec in full.items():
+            if isinstance(sec, (dict, list)):
+                print(json.dumps({name: sec}, allow_nan=False), file=sys.stderr)
+        sys.stderr.flush()
+    json_out.write(headline(full, provisional=not final) + "\n")
     json_out.flush()
 
 
@@ -1027,6 +1093,7 @@ def main():
     ap.add_argument("--no-sharded-scoring", action="store_true", help="skip configs[4]-style scoring sharded over all ranks (RCCL collectives; "
                                                                       "a one-rank nccl group at --gpus 1)")
     ap.add_argument("--sharded-scoring", action="store_true", help="run that section at --gpus > 1 too (it is on by default at one GPU)")
+    ap.add_argument("--detail", default=None, help="where every section goes whole (default: bench_detail.json in the working directory)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1182,61 +1249,11 @@ def main():
     except (OSError, KeyError, ValueError, NameError):
         pass
 
-    # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
-    # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
-    def section(fn, *a, **kw):
-        """A detail section must never cost the run its headline: an exception is reported in its place (under a process group it is
-        re-raised -- the other ranks would wait for this one in the section's collectives)."""
-        try:
-            return fn(*a, **kw)
-        except Exception as e:
-            if world > 1:
-                raise
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            return {"error": f"{type(e).__name__}: {e}"[:300]}
-
-    secondary = None
-    if spg == 1 and hyperbolic and not args.no_secondary:
-        secondary = section(bench_signals, 8, rank, device, gen, dist=dist, world=world)
-
-    # ---- the other BASELINE.json configs as sections of the same line, each the graph-replayed epoch of its shape with its own roofline:
-    # configs[0] on the GPU (hyperbolic=False), configs[3] (5 channels x 30 = window 150, batch 256, 20 480 windows: the compile-time
-    # <150, 20, 256> kernels), and 32 signals (models) per GPU -- every CU holds a critic workgroup
-    extra = {}
-    if spg == 1 and hyperbolic and not args.no_extra_configs:
-        extra["euclidean"] = section(bench_signals, 1, rank, device, gen, warmup=3, steps=20, cfg=Cfg("configs[0]", hyperbolic=False), eager=False, dist=dist, world=world,
-                                     what="configs[0] on the GPU: univariate, hyperbolic=False, batch 64, window 100, 1 916 windows, 1 signal")
-        extra["multivariate"] = section(bench_signals, 1, rank, device, gen, warmup=2, steps=8, cfg=Cfg("configs[3]", S=150, B=256, n_windows=20480, data="uniform"),
-                                        eager=False, dist=dist, world=world,
-                                        what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
-                                             "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations")
-        extra["signals32"] = section(bench_signals, 32, rank, device, gen, warmup=2, steps=8, eager=False, dist=dist, world=world,
-                                     what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share")
-        if world == 1 and "error" not in extra["signals32"]:      # (one process: the 32-model product loop with its set-up and checkpoint files)
-            extra["signals32"]["product_loop"] = section(bench_signals_product, 32, device)
-    # ---- configs[2] through the product path under a process group (train_signals_resident + plan_signal_groups): every rank, by default
-    if spg == 1 and hyperbolic and not args.no_secondary:
-        extra["signals_sharded"] = section(bench_signals_sharded, device, world, rank)
-    if spg == 1 and hyperbolic and rank == 0 and not args.no_drop_in:
-        extra["call_level"] = section(bench_call_level, device)
-
-    # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
-    # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
-    drop_in = None
-    if spg == 1 and rank == 0 and not args.no_drop_in:
-        drop_in = section(bench_drop_in, hyperbolic, device)
-
-    sharded = None
-    # (one GPU: on by default, through a one-rank RCCL group; several GPUs: only on request -- the multi-GPU collectives have never
-    # run on hardware in this pool, and the scaling run's headline line must not depend on them)
-    if not args.no_sharded_scoring and not args.no_scoring and (world == 1 or args.sharded_scoring):
-        try:
-            sharded = bench_scoring_sharded(device, world, rank)
-        except Exception as e:      # (an RCCL set-up problem on a box must not cost the run its headline line: reported, not hidden)
-            if world > 1:
-                raise
-            sharded = {"error": f"{type(e).__name__}: {e}"}
+    # ---- the headline object: everything the contract asks for is known here, so rank 0 prints it NOW (a provisional last line) and
+    # again after the detail sections with their figures filled in: nothing that happens later -- a detail section that raises, hangs
+    # in a collective or takes the process down -- can cost the run its line (main.py:32-70 is the loop these sections stand for)
+    guard = RankGuard(dist, device, world)
+    out = None
     if rank == 0:
         windows = world * spg * N_BATCHES * B * args.steps
         out = {
@@ -1280,30 +1297,85 @@ def main():
         if roofline_mfma is not None:
             out["roofline_mfma"] = roofline_mfma
         out["config"]["critics_on_one_xcd"] = int(eng.counters[5])          # placement census of the last resident critic launch (of 2 per signal)
-        if secondary is not None:
-            out["secondary"] = secondary
-        out.update(extra)
-        if drop_in is not None:
-            out["drop_in"] = drop_in
-        if not args.no_scoring:
-            out["scoring"], out["roofline_hbm"], out["roofline_scoring"] = bench_scoring(device, cpu_sample=0 if args.no_cpu_baseline else 40000)
+
+    def checkpoint(final=False):
+        if rank == 0:
+            emit(out, json_out, detail_path=args.detail, final=final)
+
+    def put(name, res):
+        if rank == 0 and res is not None:
+            out[name] = res
+        return res
+
+    checkpoint()
+    # the CPU leg: rank 0 at N = 1 only (task contract); ~25 s of host work, so the line is printed once more right behind it
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        put("cpu_baseline", RankGuard().run(cpu_baseline, hyperbolic))
+        checkpoint()
+
+    local = RankGuard().run                 # sections only rank 0 runs: guarded, no collective
+    # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
+    # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
+    if spg == 1 and hyperbolic and not args.no_secondary:
+        put("secondary", guard.run(bench_signals, 8, rank, device, gen, guard=guard, world=world))
+
+    # ---- the other BASELINE.json configs as sections of the same line, each the graph-replayed epoch of its shape with its own roofline:
+    # configs[0] on the GPU (hyperbolic=False), configs[3] (5 channels x 30 = window 150, batch 256, 20 480 windows: the compile-time
+    # <150, 20, 256> kernels), the reference's shipped multivariate.yaml shapes (WADI: window 123, SWAT: window 51; batch 64) and 32 signals
+    # (models) per GPU -- every CU holds a critic workgroup
+    if spg == 1 and hyperbolic and not args.no_extra_configs:
+        put("euclidean", guard.run(bench_signals, 1, rank, device, gen, warmup=3, steps=20, cfg=Cfg("configs[0]", hyperbolic=False), eager=False, guard=guard, world=world,
+                                   what="configs[0] on the GPU: univariate, hyperbolic=False, batch 64, window 100, 1 916 windows, 1 signal"))
+        put("multivariate", guard.run(bench_signals, 1, rank, device, gen, warmup=2, steps=8, cfg=Cfg("configs[3]", S=150, B=256, n_windows=20480, data="uniform"),
+                                      eager=False, guard=guard, world=world,
+                                      what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
+                                           "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations"))
+        s32 = put("signals32", guard.run(bench_signals, 32, rank, device, gen, warmup=2, steps=8, eager=False, guard=guard, world=world,
+                                         what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share"))
+        if rank == 0 and world == 1 and "error" not in s32:       # (one process: the 32-model product loop with its set-up and checkpoint files)
+            s32["product_loop"] = local(bench_signals_product, 32, device)
+    if spg == 1 and hyperbolic and rank == 0 and not args.no_drop_in:
+        put("call_level", local(bench_call_level, device))
+
+    # ---- the drop-in call surface (train.py:315-356 -> hypad_amd/train.py): the reference's own epoch loop over the same 29
+    # minibatches with the three iteration functions swapped for hypad_amd's (host NumPy / torch RNG, one H2D of noise per call)
+    if spg == 1 and rank == 0 and not args.no_drop_in:
+        drop_in = put("drop_in", local(bench_drop_in, hyperbolic, device))
+        if "value" in drop_in:                                    # the reference's call surface against the device-RNG path and the CPU
+            drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
+            if isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("value"):
+                drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
+    if rank == 0 and not args.no_scoring:
+        def scoring_sections():
+            sc, hbm, roof = bench_scoring(device, cpu_sample=0 if args.no_cpu_baseline or world > 1 else 40000)
+            put("scoring", sc); put("roofline_hbm", hbm); put("roofline_scoring", roof)
             # configs[4] whole on ONE GPU: 10^6 windows (400 MB of windows; the four (N, S) outputs 1.6 GB), errors smoothed over 10^4
             torch.cuda.empty_cache()
-            out["scoring_1e6"] = bench_scoring(device, n=1_000_000, reps=3, smooth=10_000, kernels=False)[0]
+            put("scoring_1e6", bench_scoring(device, n=1_000_000, reps=3, smooth=10_000, kernels=False)[0])
             torch.cuda.empty_cache()
-            out["roofline_lstm"] = bench_lstm_layers(device)
-        if sharded is not None:
-            out["scoring_sharded"] = sharded
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(hyperbolic)
-        if drop_in is not None and "value" in drop_in:          # the reference's call surface against the device-RNG path and the CPU
-            drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
-            if out.get("cpu_baseline", {}).get("value"):
-                drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
-        emit(out, json_out)
+            put("roofline_lstm", bench_lstm_layers(device))
+        err = local(scoring_sections)
+        if isinstance(err, dict):
+            put("scoring_error", err)
+
+    # ---- the sections whose collectives sit inside the PRODUCT path (train_signals_resident's gather of the metrics, the sharded
+    # scoring pass's all-reduce / all-gather): they run last, behind one more print of the line, because a rank that fails inside
+    # them leaves the others in a collective this script does not own
+    if world > 1:
+        checkpoint()
+    # configs[2] through the product path under a process group (train_signals_resident + plan_signal_groups): every rank, by default
+    if spg == 1 and hyperbolic and not args.no_secondary:
+        put("signals_sharded", guard.run(bench_signals_sharded, device, world, rank))
+    # (scoring_sharded -- one GPU: on by default, through a one-rank RCCL group; several GPUs: only on request)
+    if not args.no_sharded_scoring and not args.no_scoring and (world == 1 or args.sharded_scoring):
+        put("scoring_sharded", guard.run(bench_scoring_sharded, device, world, rank))
+    checkpoint(final=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                  # (the line is out: a failing tear-down is reported, not fatal)
+            print("process group tear-down: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
 
 if __name__ == "__main__":

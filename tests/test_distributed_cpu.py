@@ -211,7 +211,7 @@ def _bench_aggregate_worker(rank, world, port, ret):
         import bench
         from hypad_amd import train as ht
         mine_ms = 3.0 + 2.0 * rank                                      # rank 1 is the slow one
-        job_ms = bench._max_over_ranks(mine_ms, dist, torch.device("cpu"))
+        job_ms = bench.RankGuard(dist, torch.device("cpu"), world).max(mine_ms)
         n = 8 * world
         plan, stream = ht.plan_signal_groups([bench.N_WINDOWS] * n, bench.B, world, rank)
         members = [i for _, ms in plan for i in ms]
@@ -231,4 +231,4 @@ def test_bench_aggregate_is_all_ranks_windows_over_the_slowest_rank():
         job_ms, mine, union, value = ret[r]
         assert job_ms == 5.0 and mine == 8 and union == list(range(16))
         assert abs(value - 16 * 29 * 64 / 5.0e-3) < 1e-6
-    assert bench._max_over_ranks(1.25, None, torch.device("cpu")) == 1.25      # no group: unchanged
+    assert bench.RankGuard().max(1.25) == 1.25                                  # no group: unchanged
