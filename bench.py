@@ -1330,6 +1330,13 @@ def main():
                                       eager=False, guard=guard, world=world,
                                       what="configs[3]: multivariate stand-in (SURVEY.md 8d config 4): window 150 = 5 channels x 30, batch 256, "
                                            "20 480 windows U(-1, 1), hyperbolic=True; step = 1 epoch = 80 x (5 + 5 + 1) iterations"))
+        # the shapes the reference's own configs/multivariate.yaml:5-7 ships (batch_size 64; signal_shape 123 = WADI, 51 = SWAT,
+        # utils/dataloader_multivariate.py): compile-time <123, 20, 64> / <51, 20, 64> instantiations of the critic / generator / dW kernels
+        for tag, width in (("multivariate_wadi", 123), ("multivariate_swat", 51)):
+            put(tag, guard.run(bench_signals, 1, rank, device, gen, warmup=2, steps=6, cfg=Cfg(tag, S=width, B=64, n_windows=20480, data="uniform"),
+                               eager=False, guard=guard, world=world,
+                               what="the reference's configs/multivariate.yaml as shipped (%s): signal_shape %d, batch 64, 20 480 windows U(-1, 1), "
+                                    "hyperbolic=True; step = 1 epoch = 320 x (5 + 5 + 1) iterations" % ("WADI" if width == 123 else "SWAT", width)))
         s32 = put("signals32", guard.run(bench_signals, 32, rank, device, gen, warmup=2, steps=8, eager=False, guard=guard, world=world,
                                          what="32 signals (models) per GPU, otherwise as configs[1]: 4x configs[2]'s per-GPU share"))
         if rank == 0 and world == 1 and "error" not in s32:       # (one process: the 32-model product loop with its set-up and checkpoint files)

@@ -367,7 +367,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(HYPAD_PRE_WP
 }
 typedef void (*PreKernel)(IterArgs, IterArgs, PhaseArgs);
 inline PreKernel precompute_kernel(int S, int L) {
-  return S == 100 && L == 20 ? critic_phase_precompute_kernel<100, 20> : critic_phase_precompute_kernel<0, 0>;
+  if (L == 20 && S == 100) return critic_phase_precompute_kernel<100, 20>;
+  if (L == 20 && S == 123) return critic_phase_precompute_kernel<123, 20>;          // configs/multivariate.yaml: WADI
+  if (L == 20 && S == 51) return critic_phase_precompute_kernel<51, 20>;            // ... SWAT
+  return critic_phase_precompute_kernel<0, 0>;
 }
 
 // ---------------------------------------------------------------------------------------------- iteration kernel
@@ -1772,19 +1775,27 @@ static int device_cus() {
 }
 using IterKernel = void (*)(IterArgs, IterArgs, PhaseArgs);
 // compile-time shapes: BASELINE.json configs[0..2] (univariate) and configs[3] (5 channels x 30 = 150 wide, batch 256)
+// and the two shapes of the reference's shipped configs/multivariate.yaml:5-7 (WADI: 123 wide, SWAT: 51 wide; batch 64)
+static int shape_slot(int S, int L, int B) {
+  return (S == 100 && L == 20 && B == 64) ? 0 : (S == 150 && L == 20 && B == 256) ? 1 : (S == 123 && L == 20 && B == 64) ? 2 : (S == 51 && L == 20 && B == 64) ? 3 : 4;
+}
 static IterKernel phase_kernel(int S, int L, int B, bool persistent) {
-  const bool s100 = S == 100 && L == 20 && B == 64, s150 = S == 150 && L == 20 && B == 256;
-  return persistent ? (s100 ? critic_persistent_kernel<100, 20, 64> : s150 ? critic_persistent_kernel<150, 20, 256> : critic_persistent_kernel<0, 0, 0>)
-                    : (s100 ? critic_iteration_kernel<100, 20, 64> : s150 ? critic_iteration_kernel<150, 20, 0> : critic_iteration_kernel<0, 0, 0>);
+  switch (shape_slot(S, L, B)) {
+    case 0: return persistent ? critic_persistent_kernel<100, 20, 64> : critic_iteration_kernel<100, 20, 64>;
+    case 1: return persistent ? critic_persistent_kernel<150, 20, 256> : critic_iteration_kernel<150, 20, 0>;
+    case 2: return persistent ? critic_persistent_kernel<123, 20, 64> : critic_iteration_kernel<123, 20, 64>;
+    case 3: return persistent ? critic_persistent_kernel<51, 20, 64> : critic_iteration_kernel<51, 20, 64>;
+    default: return persistent ? critic_persistent_kernel<0, 0, 0> : critic_iteration_kernel<0, 0, 0>;
+  }
 }
 // Does the runtime place at least one workgroup of the resident kernel on a CU (registers + the full LDS plan)?  Asked once
 // per kernel instantiation and device.  (Residency itself comes from the grid: workgroups <= CUs, one per CU.)
 static bool persistent_kernel_fits(int S, int L, int B, size_t lds) {
-  static int cache[64][3] = {{0}};
+  static int cache[64][5] = {{0}};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  const int slot = (S == 100 && L == 20 && B == 64) ? 0 : (S == 150 && L == 20 && B == 256) ? 1 : 2;
-  if (cache[dev][slot] == 0 || slot == 2) {
+  const int slot = shape_slot(S, L, B);
+  if (cache[dev][slot] == 0 || slot == 4) {
     const void* kfn = (const void*)phase_kernel(S, L, B, true);
     int blocks = 0;
     bool ok = true;

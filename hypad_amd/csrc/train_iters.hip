@@ -1920,7 +1920,12 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
     if (e != hipSuccess) return (int)e;                                          \
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gen_kernel<__VA_ARGS__>), grid, dim3(TB), lds, s, a);    \
   } while (0)
-  if (a.hyperbolic) { if (ref_cfg) HYPAD_LAUNCH_GEN(true, 100, 20, 64); else if (mv_cfg) HYPAD_LAUNCH_GEN(true, 150, 20, 256); else HYPAD_LAUNCH_GEN(true, 0, 0, 0); }
+  const bool wadi_cfg = a.S == 123 && a.L == 20 && a.B == 64;         // the reference's configs/multivariate.yaml:5-7 as shipped (WADI)
+  const bool swat_cfg = a.S == 51 && a.L == 20 && a.B == 64;          // ... and its SWAT alternative
+  if (a.hyperbolic) {
+    if (ref_cfg) HYPAD_LAUNCH_GEN(true, 100, 20, 64); else if (mv_cfg) HYPAD_LAUNCH_GEN(true, 150, 20, 256);
+    else if (wadi_cfg) HYPAD_LAUNCH_GEN(true, 123, 20, 64); else if (swat_cfg) HYPAD_LAUNCH_GEN(true, 51, 20, 64); else HYPAD_LAUNCH_GEN(true, 0, 0, 0);
+  }
   else { if (ref_cfg) HYPAD_LAUNCH_GEN(false, 100, 20, 64); else HYPAD_LAUNCH_GEN(false, 0, 0, 0); }
 #undef HYPAD_LAUNCH_GEN
   HYPAD_CHECK_LAUNCH();
@@ -1938,6 +1943,8 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
       else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
     } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
     else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+    else if (wadi_cfg) hipLaunchKernelGGL((dw_adam_kernel<123, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+    else if (swat_cfg) hipLaunchKernelGGL((dw_adam_kernel<51, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
     else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
   }
   HYPAD_CHECK_LAUNCH();
