@@ -1308,11 +1308,6 @@ def main():
         return res
 
     checkpoint()
-    # the CPU leg: rank 0 at N = 1 only (task contract); ~25 s of host work, so the line is printed once more right behind it
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        put("cpu_baseline", RankGuard().run(cpu_baseline, hyperbolic))
-        checkpoint()
-
     local = RankGuard().run                 # sections only rank 0 runs: guarded, no collective
     # ---- BASELINE.json configs[2]'s per-GPU share as a secondary line: 8 signals (models) trained side by side on this GPU,
     # replayed as a captured hipGraph like the headline (and once more eagerly, so a host-bound launch path is visible)
@@ -1350,8 +1345,6 @@ def main():
         drop_in = put("drop_in", local(bench_drop_in, hyperbolic, device))
         if "value" in drop_in:                                    # the reference's call surface against the device-RNG path and the CPU
             drop_in["vs_resident_path"] = drop_in["value"] / out["value"] * world
-            if isinstance(out.get("cpu_baseline"), dict) and out["cpu_baseline"].get("value"):
-                drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
     if rank == 0 and not args.no_scoring:
         def scoring_sections():
             sc, hbm, roof = bench_scoring(device, cpu_sample=0 if args.no_cpu_baseline or world > 1 else 40000)
@@ -1365,11 +1358,18 @@ def main():
         if isinstance(err, dict):
             put("scoring_error", err)
 
+    # ---- the CPU leg: rank 0 at N = 1 only (task contract).  Behind every GPU section of this process: it leaves torch's host thread pool
+    # and allocator in another state (call_level's set-up, 20 pinned staging buffers, took 870 ms behind it against 10-16 ms in front)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        put("cpu_baseline", local(cpu_baseline, hyperbolic))
+        drop_in = out.get("drop_in")
+        if isinstance(drop_in, dict) and "value" in drop_in and out["cpu_baseline"].get("value"):
+            drop_in["vs_cpu_baseline"] = drop_in["value"] / out["cpu_baseline"]["value"]
+
     # ---- the sections whose collectives sit inside the PRODUCT path (train_signals_resident's gather of the metrics, the sharded
     # scoring pass's all-reduce / all-gather): they run last, behind one more print of the line, because a rank that fails inside
     # them leaves the others in a collective this script does not own
-    if world > 1:
-        checkpoint()
+    checkpoint()
     # configs[2] through the product path under a process group (train_signals_resident + plan_signal_groups): every rank, by default
     if spg == 1 and hyperbolic and not args.no_secondary:
         put("signals_sharded", guard.run(bench_signals_sharded, device, world, rank))

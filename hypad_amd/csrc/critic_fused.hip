@@ -1860,6 +1860,11 @@ void critic_phase_zero_block(const hypad_dims& d, float* extra, size_t extra_flo
   *words = (int)(sync_block_bytes(d, p) / 4);
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int words) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < words) p[i] = 0u;
+}
+
 int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_iters, float* losses, float* extra, size_t extra_floats,
                      int n_signals, hipStream_t s, hipEvent_t* ev, const hypad_epoch_noise* noise, int* persistent_used,
                      const unsigned* zeroed, int flags, int only, float* enc_table, int64_t enc_rows) {
@@ -1978,8 +1983,13 @@ int run_critic_phase(IterArgs ax, IterArgs az, const int32_t* row_index, int n_i
     if (ev) (void)hipEventRecord(ev[1], s);
     if (persistent) {
       if (!fold && !(it0 == 0 && zeroed == ph.flags)) {   // (the first slice's block may come zeroed from the caller's previous launch)
-        hipError_t e = hipMemsetAsync(ph.flags, 0, sync_bytes, s);
-        if (e != hipSuccess) return (int)e;
+        // a KERNEL, not hipMemsetAsync: inside a captured epoch a memset NODE between two resident launches (phases of more than
+        // 512 iterations: one per slice) was not reliably ordered against its neighbours on ROCm 7.2 -- queued replays of a sliced
+        // phase went non-finite (round 6: window 100 and 123 at 20 480 windows, 1 600 iterations; eager launches and
+        // one-replay-at-a-time never did) -- a kernel node is.
+        const int words = (int)(sync_bytes / 4);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((words + 255) / 256), dim3(256), 0, s, ph.flags, words);
+        HYPAD_CHECK_LAUNCH();
       }
       if (ev) (void)hipEventRecord(ev[2], s);
       // (one-dimensional grid: the critics' ids stretched by 8 for XCD placement, then the producers -- critic_persistent_kernel)

@@ -1044,10 +1044,17 @@ inline void qs_position(int64_t n, double q, long long* lo, long long* hi, doubl
   if (l < 0) l = 0;
   *lo = l; *hi = l + 1 > n - 1 ? n - 1 : l + 1;
 }
+__global__ __launch_bounds__(256) void qs_zero_kernel(unsigned* __restrict__ p, int words) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < words) p[i] = 0u;
+}
 int launch_quantiles(const double* in, int64_t n, const double* q, int nq, double* out, void* workspace, hipStream_t s) {
   const QsWs ws = qs_ws(workspace);
-  hipError_t e = hipMemsetAsync(workspace, 0, QS_ZERO_BYTES, s);
-  if (e != hipSuccess) return (int)e;
+  // (a kernel, not hipMemsetAsync: captured into a graph a memset node between kernels proved unreliably ordered on ROCm 7.2 --
+  // critic_fused.hip run_critic_phase, round 6; the scoring pass is replayed from a graph too)
+  static_assert(QS_ZERO_BYTES % 4 == 0, "whole words");
+  hipLaunchKernelGGL(qs_zero_kernel, dim3((unsigned)((QS_ZERO_BYTES / 4 + 255) / 256)), dim3(256), 0, s, (unsigned*)workspace, (int)(QS_ZERO_BYTES / 4));
+  HYPAD_CHECK_LAUNCH();
   long long r[QS_SEL] = {0, 0, 0, 0};
   double t[2] = {0.0, 0.0};
   for (int j = 0; j < nq; ++j) qs_position(n, q[j], &r[2 * j], &r[2 * j + 1], &t[j]);

@@ -956,14 +956,24 @@ struct DwItem {                                // 32 words (train_common.h DW_IT
   int32_t nrows, ncols, p_off, p_ld, p_off2;
   int32_t left_off, left_ld, right_off, right_ld, red_rows;
   int32_t fwd, fwd_kg, nbase, bwd, bwd_ng, mbase, bsum, gate_H;      // ShadowRef
-  int32_t pad[10];
+  int32_t table_sig;                           // dw_table_sig of the table the records were written from: a launch that expects another table refuses them
+  int32_t pad[9];
 };
+// what the records of a workspace depend on: the table (item count, with / without the decay-only ranges) and the dimensions.  The launch
+// that consumes them carries the signature it expects; records written for another table (a pack with other arguments, or a caller that
+// used the workspace as scratch in between) poison the step's loss instead of silently applying the wrong item set.
+__host__ __device__ inline int32_t dw_table_sig(int total_items, int S, int L, int hyper, int n_desc) {
+  uint32_t h = 0x9E3779B9u * (uint32_t)(total_items + 1);
+  h ^= (uint32_t)S << 20; h ^= (uint32_t)L << 10; h ^= (uint32_t)n_desc << 2; h ^= (uint32_t)(hyper ? 1 : 0);
+  return (int32_t)(h | 0x40000000u);          // never 0 (a zeroed workspace is not a table)
+}
 static_assert(sizeof(DwItem) == 4 * DW_ITEM_WORDS, "DwItem is DW_ITEM_WORDS words");
 __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __restrict__ out, int S, int L, int hyper) {
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= DW_ITEM_CAP) return;
   DwItem it{};
   it.kind = -1;
+  it.table_sig = dw_table_sig(tab.total_items, S, L, hyper, tab.n);
   if (item < tab.total_items) {
     const int bx = item >> 2;
     const int di = (tab.block_desc[bx >> 2] >> (8 * (bx & 3))) & 0xff;
@@ -991,8 +1001,8 @@ __global__ __launch_bounds__(256) void dw_items_kernel(DwTable tab, DwItem* __re
 // from chunk bx mod 8 -- the workgroups of one chunk land on one XCD (round-robin dispatch), a matrix's tiles are neighbours in the
 // table, so its operand rows are fetched into one or two L2s instead of all eight.  Speed / traffic only: the items are independent.
 template <int SC, int LC, int BC, int KS>
-__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx, const int chunk = 0,
-                                                   const int model = (int)blockIdx.y) {      // model: index inside the launch (blockIdx.y, or the co-located form's own)
+__device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwItem* __restrict__ items, int total_items, const int bx, const int32_t table_sig,
+                                                   const int chunk = 0, const int model = (int)blockIdx.y) {      // model: index inside the launch (blockIdx.y, or the co-located form's own)
   const int S_ = SC ? SC : a.S, L_ = LC ? LC : a.L, B_ = BC ? BC : a.B;
   const int sig = model + a.sig0;
   const int lane = threadIdx.x & 63, wave = wave_id();
@@ -1010,7 +1020,11 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
     CWord* src = (CWord*)(items + (item < total_items ? item : 0));
     int32_t* dst = reinterpret_cast<int32_t*>(&d);
 #pragma unroll
-    for (int i = 0; i < 22; ++i) dst[i] = src[i];          // (the 22 words in use)
+    for (int i = 0; i < 23; ++i) dst[i] = src[i];          // (the 23 words in use)
+  }
+  if (d.table_sig != table_sig) {                           // (wave-uniform) records of another table: refuse them loudly -- a NaN loss for this model
+    if (threadIdx.x == 0 && a.losses) { float* lo = a.losses + sig * a.loss_sig_stride; lo[0] = lo[1] = __builtin_nanf(""); }
+    return;
   }
   // ... and, in the same batch of scalar fetches, the step counter and the bias corrections the generator launch left behind
   const int step = a.counters[a.opt] + (a.step_add >= 0 ? a.step_add + 1 : 0);      // (step_add < 0: already incremented by the iteration's first kernel)
@@ -1194,17 +1208,17 @@ __device__ __forceinline__ void dw_adam_items_body(const IterArgs& a, const DwIt
 // is its bytes: 6.4 MB per model in one burst of loads and one of stores through the model's XCD, ~3 TB/s over the chip.)  Used
 // from 8 signals per GPU on.  Speed only: no result depends on it.
 template <int SC, int LC, int BC, int KS, bool COLOC = false>
-__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items, int chunk) {
+__global__ __launch_bounds__(THREADS) void dw_adam_kernel(IterArgs a, const DwItem* __restrict__ items, int total_items, int chunk, int32_t table_sig) {
   if (a.guard && a.counters[4] != 0) return;
   if constexpr (COLOC) {
     // chunk carries the launch's model count here
     const int blocks = (total_items + THREADS / 64 - 1) / (THREADS / 64);
     const int t = (int)(blockIdx.x >> 3), model = (t / blocks) * 8 + (int)(blockIdx.x & 7);
     if (model >= chunk) return;
-    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, t % blocks, 0, model);
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, t % blocks, table_sig, 0, model);
   } else {
     // (chunk > 0: the grid is 8 x chunk / 4 workgroups, chunk = ceil(total / 8) rounded up to a multiple of four)
-    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, chunk);
+    dw_adam_items_body<SC, LC, BC, KS>(a, items, total_items, (int)blockIdx.x, table_sig, chunk);
   }
 }
 __global__ __launch_bounds__(THREADS) void dw_adam_small_kernel(IterArgs a, DwTableS tab) { dw_adam_body(a, tab); }
@@ -1933,19 +1947,20 @@ int run_gen(const hypad_dims* d, const hypad_train_state* st, const IterCall& io
   const DwTable tab = gen_table(*d, with_decay);           // (its item count; the records themselves were written behind the pack launch)
   const DwItem* items = reinterpret_cast<const DwItem*>(a.ws + ws_items_offset(*d));
   const int total_items = tab.total_items;
+  const int32_t tsig = dw_table_sig(tab.total_items, d->signal_shape, d->latent_dim, d->hyperbolic, tab.n);      // (the records carry the signature of the table they were written from)
   const bool coloc = (io.flags & HYPAD_EPOCH_DW_COLOC) ? true : (io.flags & HYPAD_EPOCH_DW_SPREAD) ? false : d->n_signals >= 8;      // (measured: -2 % of the epoch at 8-32 signals, +8 % at 1-2: few signals' tiles want all of the chip's CUs)
   const int dw_chunk = ((tab.total_items + 7) / 8 + 3) & ~3;          // spread placement: eight chunks of the records, one per XCD (dw_adam_items_body)
   const dim3 dgrid = coloc ? dim3(8 * dw_blocks(tab.total_items) * ((nsig + 7) / 8)) : dim3(8 * (dw_chunk / 4), nsig);
   for (int r = 0; r < reps; ++r) {
     if (coloc) {
-      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-    else if (wadi_cfg) hipLaunchKernelGGL((dw_adam_kernel<123, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-    else if (swat_cfg) hipLaunchKernelGGL((dw_adam_kernel<51, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
-    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk);
+      if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+      else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+      else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, HYPAD_DW_KS_MANY, true>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+    } else if (ref_cfg) hipLaunchKernelGGL((dw_adam_kernel<100, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+    else if (mv_cfg) hipLaunchKernelGGL((dw_adam_kernel<150, 20, 256, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+    else if (wadi_cfg) hipLaunchKernelGGL((dw_adam_kernel<123, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+    else if (swat_cfg) hipLaunchKernelGGL((dw_adam_kernel<51, 20, 64, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
+    else hipLaunchKernelGGL((dw_adam_kernel<0, 0, 0, 48>), dgrid, dim3(THREADS), 0, s, a, items, total_items, coloc ? nsig : dw_chunk, tsig);
   }
   HYPAD_CHECK_LAUNCH();
   HYPAD_MARK(ev, 2, s);

@@ -410,12 +410,13 @@ class _CheckpointWriter:
                 (snap, ev), files, pick = job
                 torch.cuda.current_stream().wait_event(ev)
                 if pick is None:
-                    if self.templates is None:
-                        self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}
+                    if self.templates is None:               # the writer's OWN deep copies: the flags the reference's loop has set when it saves
+                        self.templates = {k: copy.deepcopy(m) for k, m in self.modules.items()}      # (train.py:333-340, 381-385: generator trainable,
+                        for k, t in self.templates.items():                                          # critics frozen) are pickled with the module
+                            _set_requires_grad((t,), k in ("enc", "dec"))
                     pick = [(self.templates[k], k, None, f) for k, f in files.items()]
-                for t, k, _, _ in pick:                      # the flags the reference's loop has set when it saves (train.py:333-340, 381-385):
-                    if id(t) not in self.layouts:            # generator trainable, critics frozen -- pickled with the module, so set before its first save
-                        _set_requires_grad((t,), k in ("enc", "dec"))
+                # (modules handed in through `pick` belong to the caller -- train_signals_resident sets those flags when it builds them, on its
+                # own thread: this thread never changes an object somebody else may hold)
                 host = {}                                    # the snapshot on the host: ONE copy per arena tensor, not one per file -- a small
                 for t, k, i, f in pick:                      # copy queues behind the kernels that hold the chip (128 of them: 40-130 ms)
                     src = snap[k] if i is None else snap[k][i]
@@ -679,24 +680,44 @@ def train(train_loader, params, config_path):
 import contextlib
 
 
+_ONE_THREAD_LOCK = __import__("threading").Lock()
+_ONE_THREAD_STATE = {"depth": 0, "saved": None}
+_ONE_THREAD_LOCAL = __import__("threading").local()
+
+
 @contextlib.contextmanager
 def _one_host_thread():
     """Module construction is thousands of tiny CPU tensor ops (fills and copies of <= 40 000 floats).  On a many-core host torch's
     intra-op pool wakes every core for the ones above its grain size -- torch.zeros of a 63 000-float arena took 1.7 ms on the GPU box's
-    256-core host, half of train_signals_resident's set-up -- so they run on the calling thread; the setting is restored on exit."""
-    n = torch.get_num_threads()
-    torch.set_num_threads(1)
+    256-core host, half of train_signals_resident's set-up -- so they run on the calling thread.  Overlapping uses (a nested call, two
+    calls on two threads) must not leave the process at one thread whatever the order they end in: the value to go back to is taken ONCE,
+    by the first use in flight (a later one would read the 1 the first has set wherever torch keeps the count per process; with OpenMP it
+    is kept per thread), and every thread restores it when ITS outermost use ends."""
+    tl = _ONE_THREAD_LOCAL
+    with _ONE_THREAD_LOCK:
+        if _ONE_THREAD_STATE["depth"] == 0:
+            _ONE_THREAD_STATE["saved"] = torch.get_num_threads()
+        _ONE_THREAD_STATE["depth"] += 1
+        tl.depth = getattr(tl, "depth", 0) + 1
+        if tl.depth == 1:
+            tl.saved = _ONE_THREAD_STATE["saved"]
+            torch.set_num_threads(1)
     try:
         yield
     finally:
-        torch.set_num_threads(n)
+        with _ONE_THREAD_LOCK:
+            _ONE_THREAD_STATE["depth"] -= 1
+            tl.depth -= 1
+            if tl.depth == 0:
+                torch.set_num_threads(tl.saved)
 
 
 def _host_shuffle_generator(dev, seed, stream):
     """The device generator that draws a signal's shuffles when they cannot be drawn inside the captured epoch (more than
     Engine.SHUFFLE_MAX_WINDOWS windows): keyed by (run seed, the signal's stream number = first_signal + slot) -- ONE rule for
     train_tadgan_resident and train_signals_resident, so that a long signal trains the same way alone and inside a group, and two
-    signals of a run never share their permutations."""
+    signals of a run never share their permutations.  (Round 5 changed this derivation -- train_tadgan_resident used ``seed & 0x7FFFFFFF`` before --,
+    so runs and resumes of signals longer than SHUFFLE_MAX_WINDOWS windows do not reproduce the shuffles of builds older than ABI 6.)"""
     return torch.Generator(device=dev).manual_seed((int(seed) ^ (0x9E3779B97F4A7C15 * int(stream))) & 0x7FFFFFFFFFFFFFFF)
 
 
@@ -924,6 +945,8 @@ def train_signals_resident(datasets, params, names=None, seed=None, init_seed=No
                 torch.manual_seed(init_seed + i)                 # train.py:415-426 construction order
                 mods = dict(enc=tadgan.Encoder(S, L), dec=tadgan.Decoder(S, L, hyp), cx=tadgan.CriticX(S, L), cz=tadgan.CriticZ(L))
                 templates.append(mods)                           # (the signal's module objects: checkpoints and the result are written through them)
+                _set_requires_grad((mods["enc"], mods["dec"]), True)     # what the reference's loop leaves behind (train.py:331-340): set here, once, so
+                _set_requires_grad((mods["cx"], mods["cz"]), False)      # that the returned modules and every checkpoint carry them with or without `save`
                 x[slot, : counts[i]] = torch.from_numpy(windows(i)).to(torch.float32)
             for net in ("enc", "dec", "cx", "cz"):               # the group's initial weights: ONE upload per network (a module's host arena IS the
                 host = torch.stack([t[net]._arena for t in templates])      # engine's row layout: arena.py / hypad_param_info), not 54 tensor copies per model

@@ -169,7 +169,11 @@ int hypad_critic_z_fwd(const float* params, const float* z, float* out, int64_t 
  * Any output pointer may be NULL (that output is then not written).  Euclidean mode: recon = eucl only. */
 /* The same on the training kernels' machinery (MFMA-native packed weights built into `workspace` by the call, LSTM cells in
  * the gate products' epilogues, 512 threads per 16 windows): ~4x the rate of hypad_score_forward at large `rows`.
- * x_row_stride: 0 / S = window matrix, 1 = x is the scaled series and window n is x[n .. n+S) (no matrix at all).
+ * x_row_stride: 0 / S = window matrix, 1 = x is the scaled series and window n is x[n .. n+S) (no matrix at all); any other
+ *   stride in floats up to 2^24 (a tile's rows are addressed with 32-bit byte offsets: 16 rows x 2^24 floats x 4 bytes): a larger
+ *   one returns HYPAD_EUNSUPPORTED (hypad_score_forward takes contiguous rows only; gather such rows first).
+ * Which tile form runs (16 or 32 windows per workgroup; the latter from 65 536 windows on, window 100 / latent 20 only) depends on
+ *   the arguments alone and changes no result bit.
  * workspace: hypad_score_workspace_bytes(S, L, hyperbolic). */
 size_t hypad_score_workspace_bytes(int signal_shape, int latent_dim, int hyperbolic);
 int hypad_score_forward_packed(const float* enc, const float* dec, const float* cx, const float* x, int64_t x_row_stride,

@@ -52,3 +52,38 @@ def test_networks_start_from_the_weights_the_reference_construction_draws(S, hyp
         assert list(sm) == list(sr)
         for k in sr:
             assert torch.equal(sm[k], sr[k]), k
+
+
+def test_one_host_thread_is_reentrant_and_restores_the_setting():
+    """overlapping uses (nested, or from two threads) must leave torch's intra-op thread count as they found it."""
+    import threading
+    import torch
+    from hypad_amd import train as ht
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(2, before))
+    want = torch.get_num_threads()
+    try:
+        with ht._one_host_thread():
+            assert torch.get_num_threads() == 1
+            with ht._one_host_thread():
+                assert torch.get_num_threads() == 1
+            assert torch.get_num_threads() == 1                   # the inner exit does not restore under the outer one
+        assert torch.get_num_threads() == want
+        gate_in, gate_out, seen = threading.Event(), threading.Event(), []
+
+        def other():
+            with ht._one_host_thread():                           # enters while the main thread's use is in flight, leaves after it
+                seen.append(torch.get_num_threads())
+                gate_in.set()
+                gate_out.wait(10)
+            seen.append(torch.get_num_threads())
+        t = threading.Thread(target=other)
+        with ht._one_host_thread():
+            t.start()
+            assert gate_in.wait(10)
+        assert torch.get_num_threads() == want                    # this thread's outermost use ended: restored, whatever the other thread does
+        gate_out.set()
+        t.join()
+        assert torch.get_num_threads() == want and seen == [1, want]      # the late one went back to the value taken by the FIRST use, not to 1
+    finally:
+        torch.set_num_threads(before)

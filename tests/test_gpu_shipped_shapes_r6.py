@@ -44,3 +44,29 @@ def test_shipped_multivariate_epoch_against_the_oracle(S, N, critic_its, gen_lau
     crit_rows, gen_rows, dpl, x = check_against_oracle(S, B, N, nb, xw, [w0], planes, full, ri, critic_its, None, (0,))
     final_critics = [{k: {n: v.cpu() for n, v in eng.state_dict(k, 0).items()} for k in ("cx", "cz")}]
     generator_against_oracle(S, B, nb, xw, [w0], planes, full, gen_rows, dpl, x, final_critics, gen_launches, (0,))
+
+
+@pytest.mark.parametrize("S", [100, 123])
+def test_queued_replays_of_a_sliced_phase_equal_eager_launches(S):
+    """Round 6 regression.  A critic phase of more than 512 iterations runs as several resident launches (slices), each behind the zeroing of its
+    exchange block.  Captured into the epoch's hipGraph that zeroing was a memset NODE, and graph replays queued back to back (bench.py's timed
+    loop) went non-finite from the ninth epoch on at 20 480 windows -- window 100 and 123 alike; eager launches, and replays with a host
+    synchronisation in front of each, never did.  The zeroing is a kernel node now: twelve queued replays == twelve eager epochs, bit for bit."""
+    import bench
+    N, B, nb = 20480, 64, 320
+    dev = torch.device("cuda", 0)
+    cfg = bench.Cfg("sliced", S=S, B=B, n_windows=N, data="uniform")
+    results = []
+    for graph in (True, False):
+        gen = torch.Generator(device=dev).manual_seed(100)
+        eng, x = bench.build_engine(1, 0, True, dev, cfg)
+        step, losses = bench.make_step(eng, x, 1, gen, dev, graph=graph, cfg=cfg)
+        for _ in range(12):
+            step()                                     # no host synchronisation between the epochs
+        torch.cuda.synchronize()
+        assert eng.status() == 0
+        assert bool(torch.isfinite(losses).all()), ("graph" if graph else "eager")
+        results.append((losses.clone(), {net: eng.params[net].clone() for net in ("enc", "dec", "cx", "cz")}))
+    assert torch.equal(results[0][0], results[1][0])
+    for net in ("enc", "dec", "cx", "cz"):
+        assert torch.equal(results[0][1][net], results[1][1][net]), net
