@@ -20,7 +20,7 @@ class HypadError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
+ABI_VERSION = 7            # include/hypad.h: HYPAD_ABI_VERSION -- the struct layouts below are this version's
 
 
 def _load():
@@ -131,6 +131,9 @@ _SIGS = {
     "hypad_lstm_bidir_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "hypad_lstm_seq_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
     "hypad_lstm_bidir_seq_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_int, c_void_p, c_size_t, P]),
+    "hypad_lstm_bidir_seq_fwd_train": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_int, c_void_p, c_size_t, P]),
+    "hypad_lstm_seq_bwd_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "hypad_lstm_bidir_seq_bwd": (c_int, [P] * 21 + [c_int, c_int64, c_int, c_int, c_void_p, c_size_t, P]),
     "hypad_encoder_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "hypad_decoder_fwd": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, POINTER(Dropout), P]),
     "hypad_critic_x_fwd": (c_int, [P, P, P, c_int64, c_int, c_int, POINTER(Dropout), P]),

@@ -137,14 +137,70 @@ def critic_forward(m, x, n_hidden, p_drop):                  # models/tadgan.py:
     return linear_act(h, d.weight, d.bias)
 
 
+class _LstmBidirSeq(torch.autograd.Function):
+    """One bidirectional LSTM layer over a whole sequence with back-propagation through time (csrc/lstm_seq.hip: hypad_lstm_bidir_seq_fwd_train /
+    hypad_lstm_bidir_seq_bwd) -- what autograd gives ``nn.LSTM(in, H, bidirectional=True)`` (models/tadgan.py:15-27, 35-38) at any T.
+    Inputs: x (T, rows, in), h0 / c0 (2, rows, H) or None, then the eight parameters in nn.LSTM's order
+    (weight_ih, weight_hh, bias_ih, bias_hh of the forward direction, then of the reverse one).  Returns out, h_n, c_n."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, wif, whf, bif, bhf, wir, whr, bir, bhr):
+        x = _f32c(x, "input")
+        ps = [_f32c(t, "lstm parameter") for t in (wif, whf, bif, bhf, wir, whr, bir, bhr)]
+        T, rows, k = x.shape
+        H = ps[1].shape[1]
+        h0c = None if h0 is None else _f32c(h0, "h0")
+        c0c = None if c0 is None else _f32c(c0, "c0")
+        new = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
+        out, hn, cn, saved = new(T, rows, 2 * H), new(2, rows, H), new(2, rows, H), new(T, rows, 2, 5, H)
+        nbytes = _C.lib.hypad_lstm_seq_workspace_bytes(T, rows, H)
+        ws = new(max(nbytes // 4, 1))
+        _C.check(_C.lib.hypad_lstm_bidir_seq_fwd_train(_C.ptr(x), *[_C.ptr(p) for p in ps], _C.ptr(h0c), _C.ptr(c0c), _C.ptr(out), _C.ptr(hn), _C.ptr(cn),
+                                                       _C.ptr(saved), T, rows, k, H, ws.data_ptr(), nbytes, _C.stream()), "lstm_bidir_seq_fwd_train")
+        ctx.save_for_backward(x, ps[0], ps[1], ps[4], ps[5], out, saved, *(t for t in (h0c, c0c) if t is not None))
+        ctx.has_h0, ctx.has_c0 = h0c is not None, c0c is not None
+        return out, hn, cn
+
+    @staticmethod
+    @_C.first_order_only
+    def backward(ctx, g_out, g_hn, g_cn):
+        x, wif, whf, wir, whr, out, saved, *rest = ctx.saved_tensors
+        h0 = rest.pop(0) if ctx.has_h0 else None
+        c0 = rest.pop(0) if ctx.has_c0 else None
+        T, rows, k = x.shape
+        H = whf.shape[1]
+        new = lambda *s: torch.empty(*s, device=x.device, dtype=torch.float32)
+        g_out, g_hn, g_cn = (None if g is None else _f32c(g, "grad") for g in (g_out, g_hn, g_cn))
+        if g_out is None and g_hn is None and g_cn is None:
+            return (None,) * 11
+        gx, gwif, gwhf, gbf, gwir, gwhr, gbr = new(T, rows, k), new(4 * H, k), new(4 * H, H), new(4 * H), new(4 * H, k), new(4 * H, H), new(4 * H)
+        gh0, gc0 = (new(2, rows, H) if ctx.has_h0 else None), (new(2, rows, H) if ctx.has_c0 else None)
+        nbytes = _C.lib.hypad_lstm_seq_bwd_workspace_bytes(T, rows, k, H)
+        ws = new(max(nbytes // 4, 1))
+        _C.check(_C.lib.hypad_lstm_bidir_seq_bwd(_C.ptr(x), _C.ptr(wif), _C.ptr(whf), _C.ptr(wir), _C.ptr(whr), _C.ptr(h0), _C.ptr(c0), _C.ptr(out), _C.ptr(saved),
+                                                 _C.ptr(g_out), _C.ptr(g_hn), _C.ptr(g_cn), _C.ptr(gx), _C.ptr(gwif), _C.ptr(gwhf), _C.ptr(gbf), _C.ptr(gwir),
+                                                 _C.ptr(gwhr), _C.ptr(gbr), _C.ptr(gh0), _C.ptr(gc0), T, rows, k, H, ws.data_ptr(), nbytes, _C.stream()),
+                 "lstm_bidir_seq_bwd")
+        return gx, gh0, gc0, gwif, gwhf, gbf, gbf.clone(), gwir, gwhr, gbr, gbr.clone()
+
+
+def lstm_seq(x, lstm, layer=0, hx=None):
+    """The differentiable form of lstm_seq_forward: ``(out, (h_n, c_n))`` of one bidirectional layer of a ``torch.nn.LSTM``-shaped parameter holder
+    over (T, rows, in), with gradients for the input, the initial states and all eight parameters (back-propagation through time on the device)."""
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    ps = [getattr(lstm, n + f"_l{layer}") for n in names] + [getattr(lstm, n + f"_l{layer}_reverse") for n in names]
+    h0, c0 = (None, None) if hx is None else hx
+    out, hn, cn = _LstmBidirSeq.apply(x, h0, c0, *ps)
+    return out, (hn, cn)
+
+
 def lstm_seq_forward(x, lstm, layer=0, hx=None):
     """One bidirectional layer of a ``torch.nn.LSTM``-shaped parameter holder over a whole sequence (inference): ``x`` (T, rows, in)
     -> ``(out (T, rows, 2H), (h_n, c_n) each (2, rows, H))`` as ``nn.LSTM(in, H, bidirectional=True)(x, hx)`` returns them.  The
     reference's modules (models/tadgan.py:15-20, :35-38) are such layers driven with T = 1; this is the general-T
     form: one MFMA GEMM for the input projections of all steps + a persistent recurrence kernel (csrc/lstm_seq.hip)."""
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in lstm.parameters())):
-        raise _C.HypadError("lstm_seq_forward is inference only (the reference never back-propagates through time: T = 1); "
-                            "wrap the call in torch.no_grad()")
+        raise _C.HypadError("lstm_seq_forward is the inference form: wrap the call in torch.no_grad(), or use lstm_seq (back-propagation through time)")
     x = _f32c(x, "input")
     T, rows, k = x.shape
     g = lambda n: _f32c(getattr(lstm, n + f"_l{layer}").detach(), n)

@@ -28,7 +28,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HYPAD_ABI_VERSION 6
+#define HYPAD_ABI_VERSION 7
 
 enum {
   HYPAD_OK = 0,
@@ -132,13 +132,34 @@ int hypad_lstm_bidir_bwd(const float* w_ih_f, const float* w_ih_r, const float* 
  * in_dim), w_hh_* (4*hidden, hidden), biases (4*hidden), PyTorch gate order [i,f,g,o]; h0 / c0 (2, rows, hidden) or NULL = zeros;
  * out (seq_len, rows, 2*hidden) = [h_fwd(t) | h_rev(t)]; hn / cn (2, rows, hidden) final states, may be NULL.  The input
  * projections of all steps run as one MFMA GEMM; the recurrence is a persistent kernel per (16-row tile, direction): W_hh in
- * LDS, h_t in LDS, c_t in registers, the four gates of a unit on one lane, one barrier per step.  hidden <= 64.  Forward only.
+ * LDS, h_t in LDS, c_t in registers, the four gates of a unit on one lane, one barrier per step.  hidden <= 64.
  * workspace: hypad_lstm_seq_workspace_bytes(seq_len, rows, hidden). */
 size_t hypad_lstm_seq_workspace_bytes(int seq_len, int64_t rows, int hidden);
 int hypad_lstm_bidir_seq_fwd(const float* x, const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
                              const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
                              const float* h0, const float* c0, float* out, float* hn, float* cn, int seq_len, int64_t rows,
                              int in_dim, int hidden, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
+/* The training form and its back-propagation through time (ABI 7) -- what autograd gives the nn.LSTM modules of
+ * models/tadgan.py:15-27, 35-38 at any seq_len.  fwd_train = the forward above that also fills
+ *   saved (seq_len, rows, 2, 5, hidden) = per (step, row, direction) [i | f | g | o | c]: gate activations and cell state.
+ * bwd: grad_out (seq_len, rows, 2*hidden), grad_hn / grad_cn (2, rows, hidden) -- any of the three may be NULL (= zeros), not all;
+ *   grad_x (seq_len, rows, in_dim); grad_w_ih_* (4*hidden, in_dim); grad_w_hh_* (4*hidden, hidden); grad_b_* (4*hidden) = the
+ *   gradient of b_ih_* AND of b_hh_* (they enter as a sum); grad_h0 / grad_c0 (2, rows, hidden) may be NULL.  h0 / c0 / out as
+ *   the forward took / returned them.  A persistent kernel per (16-row tile, direction) walks the steps in reverse (W_hh^T in
+ *   LDS, carried dh / dc in registers, one barrier per step) and writes the pre-activation gradients of every step; the
+ *   parameter / input gradients are dense contractions over seq_len * rows rows (hypad_linear_act_bwd).  hidden <= 64.
+ * workspace: hypad_lstm_seq_bwd_workspace_bytes(seq_len, rows, in_dim, hidden). */
+int hypad_lstm_bidir_seq_fwd_train(const float* x, const float* w_ih_f, const float* w_hh_f, const float* b_ih_f, const float* b_hh_f,
+                                   const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r,
+                                   const float* h0, const float* c0, float* out, float* hn, float* cn, float* saved, int seq_len,
+                                   int64_t rows, int in_dim, int hidden, void* workspace, size_t workspace_bytes, hypad_stream_t stream);
+size_t hypad_lstm_seq_bwd_workspace_bytes(int seq_len, int64_t rows, int in_dim, int hidden);
+int hypad_lstm_bidir_seq_bwd(const float* x, const float* w_ih_f, const float* w_hh_f, const float* w_ih_r, const float* w_hh_r,
+                             const float* h0, const float* c0, const float* out, const float* saved, const float* grad_out,
+                             const float* grad_hn, const float* grad_cn, float* grad_x, float* grad_w_ih_f, float* grad_w_hh_f,
+                             float* grad_b_f, float* grad_w_ih_r, float* grad_w_hh_r, float* grad_b_r, float* grad_h0, float* grad_c0,
+                             int seq_len, int64_t rows, int in_dim, int hidden, void* workspace, size_t workspace_bytes,
+                             hypad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Networks, forward (eval or train-mode dropout).  `params` = arena of that network.

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_limits_and_errors(lib):
-    assert lib.hypad_abi_version() == 6
+    assert lib.hypad_abi_version() == 7
     a, b = ctypes.c_int(), ctypes.c_int()
     lib.hypad_limits(ctypes.byref(a), ctypes.byref(b))
     assert a.value >= 150 and b.value >= 20

@@ -40,7 +40,7 @@ def test_one_step_equals_the_training_paths_lstm_kernel():
         one = hag.lstm_layer(x, lstm, 0)
     assert float((seq[0] - one).abs().max()) < 2e-6
     with pytest.raises(Exception):
-        hag.lstm_seq_forward(x.view(1, 64, 100).requires_grad_(True), lstm)      # inference only
+        hag.lstm_seq_forward(x.view(1, 64, 100).requires_grad_(True), lstm)      # the inference form (lstm_seq is the differentiable one)
 
 
 def test_lstm_sequence_entry_point_validates_arguments():
