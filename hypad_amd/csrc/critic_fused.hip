@@ -1396,6 +1396,11 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       }
       epilogue(0);
       PSTAMP(4);                                                         // layer 0 forward
+      // (measured and dropped in round 6: a "done" word per helper wave, phase B's quads dealt in the order 3, 7, 4, 5, 6 -- the second
+      // layer's quads on the two waves of SIMD 3, which finish 1.5 k cycles before the ones that share a SIMD with a chain -- and the chains
+      // waiting layer by layer only for the waves that hold that layer: by the shader-clock stamps the second layer would start 1 k cycles
+      // earlier; on one box 2.771 against 2.744 ms per epoch -- its MFMAs then run beside waves 4-6's phase B and slow THAT down, and the
+      // five-word poll alone costs 0.014 ms.  A SIMD's issue slots are what the stage is short of, not its order.)
       while (__hip_atomic_load(bdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NW - BW0) __builtin_amdgcn_s_sleep(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       PSTAMP(5);                                                         // phase B's weights seen
@@ -1639,22 +1644,28 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         __builtin_amdgcn_s_sleep(1);
       }
       if (!ok && lane == 0) give_up(0x200u + (unsigned)it);
+      // The whole-batch norm, the penalty's coefficient and this iteration's loss ONCE, on this wave (it has nothing else to do until the
+      // barrier).  Until round 6 all eight waves did it behind the barrier -- four dependent LDS round trips, a square root and a division
+      // at the head of the store stage: 2.747 -> 2.719 ms per epoch on one box (scripts/ab_variants.sh).  The same additions in the same
+      // fixed order as before, so every chunk of the critic still gets the same bits.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float gs = 0.f, sreal = 0.f, sfake = 0.f;
+      for (int w = 0; w < nchunks; ++w) { gs += xsc[w]; sreal += xsc[MAXCH + w]; sfake += xsc[2 * MAXCH + w]; }   // fixed order
+      const float nrm = sqrtf(gs + 1e-12f);               // train.py:90, whole batch
+      if (lane == 0) xsc[3 * MAXCH + 2] = 20.f * (nrm - 1.f) / nrm;      // d(10 gp) / d g = coef * g  (control word [2])
+      if (writer && lane == 0) {
+        const float gp = (nrm - 1.f) * (nrm - 1.f);
+        float* lo = lo_base + (int64_t)(2 * it) * 4;
+        lo[0] = sfake * invB - sreal * invB + 10.f * gp;  // train.py:98-99
+        lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
+      }
     }
     __syncthreads();
     if (ctl[0]) { if (writer && threadIdx.x == 0) lo_base[(int64_t)(2 * it) * 4] = __builtin_nanf(""); return; }
     PSTAMP(13);                                                          // siblings' scalars are there
     if (ph.clear_each) clear_tiles();                     // (every read of this iteration's tiles is behind the barrier above; one
                                                           // wave -- wave 2 has no share to store -- clearing alone took 5 k cycles)
-    float gs = 0.f, sreal = 0.f, sfake = 0.f;
-    for (int w = 0; w < nchunks; ++w) { gs += xsc[w]; sreal += xsc[MAXCH + w]; sfake += xsc[2 * MAXCH + w]; }   // fixed order
-    const float nrm = sqrtf(gs + 1e-12f);                 // train.py:90, whole batch
-    const float coef = 20.f * (nrm - 1.f) / nrm;          // d(10 gp) / d g = coef * g
-    if (writer && threadIdx.x == 0) {
-      const float gp = (nrm - 1.f) * (nrm - 1.f);
-      float* lo = lo_base + (int64_t)(2 * it) * 4;
-      lo[0] = sfake * invB - sreal * invB + 10.f * gp;    // train.py:98-99
-      lo[1] = gp; lo[2] = sreal * invB; lo[3] = sfake * invB;
-    }
+    const float coef = xsc[3 * MAXCH + 2];
     // ---- merged share -> compact valid quads, write-through; then the epoch word
     // (measured and dropped in round 3: publishing dW(real, fake) and dW(penalty rows) as two unscaled parts the moment each exists --
     // the consumers apply the coefficient -- so that the epoch word need not wait for the siblings' scalars: twice the share
