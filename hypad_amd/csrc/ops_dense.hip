@@ -748,7 +748,9 @@ __global__ __launch_bounds__(THREADS) void critic_fwd_kernel(const float* __rest
   float* xs = smem;
   CriticLds cs = critic_lds(smem + 16 * ldx);
   float* wst = smem + 16 * ldx + CRITIC_LDS_FLOATS;
-  const CriticLayout cl = critic_layout(in_dim, L, nh, p);
+  // (only the scalar fields: critic_fwd_tile takes its offsets from the closed forms wof / bof -- filling the w[] / b[] tables with a
+  // run-time layer count put the struct into 64 bytes of scratch per lane)
+  CriticLayout cl; cl.nh = nh; cl.in_dim = in_dim; cl.L = L; cl.p_drop = p; cl.total = 0;
   const int64_t r0 = (int64_t)blockIdx.x * 16;
   const int valid = (int)min((int64_t)16, rows - r0);
   tile_load(xs, ldx, x + r0 * in_dim, in_dim, 16, in_dim, valid);
@@ -916,18 +918,22 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
     const size_t lw = (size_t)3 * Hp * (KG * 16 + 4) * sizeof(float);
     const int64_t ntiles = (rows + 15) >> 4;
     static const int nw_env = HYPAD_TUNE_INT("HYPAD_LSTM_WAVES", 0);
-    const int nw = nw_env == 8 ? 8 : 16;            // (16 waves: 357 -> 349 us at 100 -> 2 x 50, 356 -> 321 at 128 -> 2 x 64, gates saved, 200 000 rows)
+    // (16 waves: 357 -> 349 us at 100 -> 2 x 50, 356 -> 321 at 128 -> 2 x 64, gates saved, 200 000 rows -- for inputs up to 96 wide: at seven and
+    // eight k-groups the 128-register budget of sixteen waves spills 2 / 10 registers, so those widths run eight waves, spill-free)
+    const int nw = (nw_env == 8 || KG >= 7) ? 8 : 16;
     int nslices = (int)((ntiles + nw - 1) / nw);
     if (nslices > 128) nslices = 128;
     const dim3 grid(2 * nslices);
 #define HYPAD_LSTM_LDS_LAUNCH(KGC)                                                                                               \
     do {                                                                                                                         \
-      if (nw == 16) {                                                                                                            \
+      if constexpr (KGC < 7) if (nw == 16) {                                                                                     \
         hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC, 16>, lw);                                                \
         if (e2 != hipSuccess) return (int)e2;                                                                                    \
         hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC, 16>), grid, dim3(1024), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
                            gates_save, rows, K, H);                                                                              \
-      } else {                                                                                                                   \
+        break;                                                                                                                   \
+      }                                                                                                                          \
+      {                                                                                                                          \
         hipError_t e2 = allow_lds((const void*)lstm_fwd_lds_kernel<KGC, 8>, lw);                                                 \
         if (e2 != hipSuccess) return (int)e2;                                                                                    \
         hipLaunchKernelGGL((lstm_fwd_lds_kernel<KGC, 8>), grid, dim3(512), lw, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \

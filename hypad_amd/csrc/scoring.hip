@@ -1127,8 +1127,8 @@ int hypad_unroll_median(const float* y_hat, float* median, double* summary, int6
   } while (0)
 #define HYPAD_UNROLL(EPL)                                                                                                      \
   do {                                                                                                                        \
-    if (ut == 64) { if (filter) HYPAD_UNROLL2(EPL, true, 64); else HYPAD_UNROLL2(EPL, false, 64); }                            \
-    else { if (filter) HYPAD_UNROLL2(EPL, true, 128); else HYPAD_UNROLL2(EPL, false, 128); }                                    \
+    if (HYPAD_DIAG && ut == 64) { if constexpr (HYPAD_DIAG != 0) { if (filter) HYPAD_UNROLL2(EPL, true, 64); else HYPAD_UNROLL2(EPL, false, 64); } }   \
+    else { if (filter) HYPAD_UNROLL2(EPL, true, 128); else if constexpr (HYPAD_DIAG != 0) HYPAD_UNROLL2(EPL, false, 128); }      \
   } while (0)
   if (window <= 64) HYPAD_UNROLL(1); else if (window <= 128) HYPAD_UNROLL(2); else HYPAD_UNROLL(4);
 #undef HYPAD_UNROLL

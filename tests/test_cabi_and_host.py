@@ -229,5 +229,10 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_run():
     bad = {n: (by_name[n]["vgpr_spill_count"], by_name[n]["private_segment_fixed_size"]) for n in clean
            if by_name[n]["vgpr_spill_count"] or by_name[n]["private_segment_fixed_size"] > reserve(n)}
     assert not bad, bad
+    # ... and NOTHING else in the product library spills a vector register or owns scratch, except the two run-time-shape fallbacks of the critic phase
+    # (<0, 0, 0>: any window / latent / batch the compile-time list does not name) and the gap below
+    others = {n: (k["vgpr_spill_count"], k["private_segment_fixed_size"]) for n, k in by_name.items()
+              if (k["vgpr_spill_count"] or k["private_segment_fixed_size"] > reserve(n)) and "<0, 0, 0>" not in n and "critic_persistent_kernel<150, 20, 256>" not in n}
+    assert not others, others
     gap = [k for n, k in by_name.items() if "critic_persistent_kernel<150, 20, 256>" in n]
     assert len(gap) == 1 and gap[0]["vgpr_spill_count"] <= 17 and gap[0]["private_segment_fixed_size"] <= 72, gap
