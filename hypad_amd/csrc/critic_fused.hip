@@ -955,6 +955,15 @@ __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterA
 #else
 #define PSTAMP(k) do { } while (0)
 #endif
+#ifndef HYPAD_R6_BATCH
+#define HYPAD_R6_BATCH 1
+#endif
+#ifndef HYPAD_R6_G
+#define HYPAD_R6_G 1
+#endif
+#ifndef HYPAD_R6_STAGE
+#define HYPAD_R6_STAGE 1
+#endif
 constexpr int PSLOT = 4;                     // Adam-state quads per thread
 constexpr int MAXCH = 21;                    // chunks whose granules one wave sweeps in one pass (3 x 21 <= 64 lanes)
 constexpr unsigned SPIN_LIMIT = 1u << 21;    // bounded waits: ~1 s of polling
@@ -1318,18 +1327,23 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       return;
     }
 
-    // ---- record -> LDS; constant d loss / d out  (act | dl were cleared at the end of the previous iteration)
+    // ---- record -> LDS; constant d loss / d out.  Round 6: the record of iteration it + 1 is staged at the END of iteration it, between
+    // the share stores and their drain (nothing reads in0 / dm behind the barrier in front of the stores; the LDS writes fill the wait
+    // for the write-through stores) instead of here, between the optimizer step and the chains; only iteration 0's is staged here.
+    auto stage_record = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < MAX_ROW4; ++u) {
-      const int i = threadIdx.x + u * FT;
-      if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<u32x4_t*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
-    }
+      for (int u = 0; u < MAX_ROW4; ++u) {
+        const int i = threadIdx.x + u * FT;
+        if (i < g.rec_rows4) { const int r = i / (Kin / 4), c4 = i - r * (Kin / 4); *reinterpret_cast<u32x4_t*>(in0 + r * ldin + 4 * c4) = rrow[u]; }
+      }
 #pragma unroll
-    for (int u = 0; u < MAX_MASK4; ++u) {
-      const int i = threadIdx.x + u * FT;
-      if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<u32x4_t*>(dm + r * LQ + 4 * c4) = rmask[u]; }
-    }
-    if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
+      for (int u = 0; u < MAX_MASK4; ++u) {
+        const int i = threadIdx.x + u * FT;
+        if (i < g.rec_mask4) { const int r = i / (g.L4 / 4), c4 = i - r * (g.L4 / 4); *reinterpret_cast<u32x4_t*>(dm + r * LQ + 4 * c4) = rmask[u]; }
+      }
+      if (threadIdx.x < 48) { const int p = threadIdx.x >> 4; dl[(nh * 48 + threadIdx.x) * LQ] = p == 0 ? -invB : p == 1 ? invB : 1.f; }
+    };
+    if (!HYPAD_R6_STAGE || it == 0) stage_record();
     int* bdone = reinterpret_cast<int*>(red + 40);
     if (threadIdx.x == 0) *bdone = 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1387,6 +1401,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         const float* ap = w0 + (m < L ? m : L - 1) * ldin + 4 * q;
         const float* bp = in0 + myrow * ldin + 4 * q;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        // (measured and dropped in round 6: each k-group's operands requested one group ahead behind scheduling barriers -- same time)
         for (int g16 = 0; g16 < Kin; g16 += 32) {
           acc = mfma4(*reinterpret_cast<const float4*>(ap + g16), *reinterpret_cast<const float4*>(bp + g16), acc);
           if (g16 + 16 < Kin) acc2 = mfma4(*reinterpret_cast<const float4*>(ap + g16 + 16), *reinterpret_cast<const float4*>(bp + g16 + 16), acc2);
@@ -1532,6 +1547,9 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
           float la[8], rb[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { la[u] = left[krow(0, u) * LQ]; rb[u] = right[krow(0, u) * ldr]; }
+#if HYPAD_R6_BATCH
+          __builtin_amdgcn_sched_barrier(0);               // all operands requested before the first product: ONE exposed LDS latency per tile
+#endif
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc_rf[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_rf[i], 0, 0, 0);
         }
@@ -1539,16 +1557,23 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
           float la[4], rb[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) { la[u] = left[krow(32, u) * LQ]; rb[u] = right[krow(32, u) * ldr]; }
+#if HYPAD_R6_BATCH
+          __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc_gp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(la[u], rb[u], acc_gp[i], 0, 0, 0);
         }
       }
     };
+    // (measured and dropped in round 6: the tiles ONE AHEAD -- tile i + 1's operands requested under tile i's products: 2.689 against
+    // 2.672 ms per epoch, 250 registers; the partner wave of the SIMD already fills the one round trip that is left)
     // (measured and dropped: requesting the operands of all of a wave's tiles first and running the k-steps tile-interleaved --
     // independent accumulators, no dependent-latency stalls -- left this stage at the same 6 k cycles and cost 54 spilled
     // registers: the stage is not bound by the MFMAs' dependent latency)
     if (CHAIN && wave == 2) {
       f32x4 E[MF];
+      // (measured and dropped in round 6: this chain's weight rows requested one layer ahead, as the forward / backward chains do: +0.007 ms
+      // per epoch -- wave 2 is not the stage's long pole, and the extra registers cost the other body)
       for (int li = 0; li < nh; ++li) {
         f32x4 N[MF];
 #pragma unroll
@@ -1581,6 +1606,23 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
       for (int ct = slot; ct < CT; ct += NW - 1) {
         int c = ct * 16 + j; c = c < in_dim ? c : in_dim - 1;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#if HYPAD_R6_G
+        if (Lp == 32) {                                     // (latent 17 .. 32: both k-groups' operands requested before the first product)
+          float4 bv[2], avv[2];
+#pragma unroll
+          for (int gi = 0; gi < 2; ++gi) {
+            const int o = 16 * gi + 4 * q;
+            bv[gi].x = w0[(o < L ? o : L - 1) * ldin + c];
+            bv[gi].y = w0[(o + 1 < L ? o + 1 : L - 1) * ldin + c];
+            bv[gi].z = w0[(o + 2 < L ? o + 2 : L - 1) * ldin + c];
+            bv[gi].w = w0[(o + 3 < L ? o + 3 : L - 1) * ldin + c];
+            avv[gi] = *reinterpret_cast<const float4*>(av + 16 * gi);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma4(avv[0], bv[0], acc);
+          acc = mfma4(avv[1], bv[1], acc);
+        } else
+#endif
 #pragma unroll 2
         for (int g16 = 0; g16 < Lp; g16 += 16) {
           const int o = g16 + 4 * q;
@@ -1692,6 +1734,7 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
         }
       }
     }
+    if (HYPAD_R6_STAGE && it + 1 < n_iters) stage_record();      // the next iteration's record (requested behind barrier 2), under the stores' drain
     PSTAMP(14);                                                          // share stored
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
     __syncthreads();                                      // ... before ONE lane signals for all of them
