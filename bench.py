@@ -1165,7 +1165,7 @@ def main():
     traffic, traffic_note = None, "no committed PMC profile matches these kernel sources"
     try:
         from hypad_amd.build import source_digest
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(path):
                 continue
@@ -1181,7 +1181,7 @@ def main():
     # committed rocprofv3 --pmc pass, under the same source-digest rule as `traffic`
     roofline_mfma = None
     try:
-        mfname = next(n for n in ("r05_mfma_util.json", "r04_mfma_util.json", "r03_mfma_util.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        mfname = next(n for n in ("r06_mfma_util.json", "r05_mfma_util.json", "r04_mfma_util.json", "r03_mfma_util.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         path = os.path.join(ROOT, "profiles", mfname)
         mf = json.load(open(path))
         same = mf.get("source_sha256") == source_digest()
@@ -1234,7 +1234,7 @@ def main():
         traffic_alg_all["error"] = f"{type(e).__name__}: {e}"[:200]
     traffic_all = {}
     try:
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 pmc = json.load(open(path))
