@@ -964,6 +964,12 @@ __global__ __launch_bounds__(FT) void critic_iteration_kernel(IterArgs ax, IterA
 #ifndef HYPAD_R6_STAGE
 #define HYPAD_R6_STAGE 1
 #endif
+#ifndef HYPAD_R6_EOFF
+#define HYPAD_R6_EOFF 1
+#endif
+#ifndef HYPAD_R6_TOFF
+#define HYPAD_R6_TOFF 1
+#endif
 constexpr int PSLOT = 4;                     // Adam-state quads per thread
 constexpr int MAXCH = 21;                    // chunks whose granules one wave sweeps in one pass (3 x 21 <= 64 lanes)
 constexpr unsigned SPIN_LIMIT = 1u << 21;    // bounded waits: ~1 s of polling
@@ -1185,6 +1191,37 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     request_record(0);
   }
 
+#if HYPAD_R6_EOFF
+  // Byte offset of this lane's quad of every tile it owns inside a merged share (or an offset past the descriptor's range: the hardware
+  // drops that store -- lanes outside the tile's valid quads, tiles past the list, wave 2).  Once per launch: inside the loop the tile
+  // arithmetic, its exec masks and the spilled scalars behind them cost ~400 cycles per tile and iteration (round 6, shader-clock stamps).
+  int eoff[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = (wave < 2 ? wave : wave - 1) + (NW - 1) * i;
+    int li, n0, k0;
+    tile_desc(t < g.ntiles ? t : 0, li, n0, k0);
+    const int N = li == nh ? 1 : L, K = li == 0 ? in_dim : L;
+    const int n = n0 + 4 * q, k = k0 + j, qq = n >> 2;
+    const int e = li == 0 ? qq * C0 + k : (li < nh ? I0 + (li - 1) * Ih + qq * Ch + k : I0 + (nh - 1) * Ih + k);
+    eoff[i] = (t < g.ntiles && wave != 2 && n < N && k <= K) ? e * 16 : (int)0x80000000u;      // (past the 2 GB range whatever is added)
+  }
+#endif
+  // ... and the LDS offsets (floats from `smem`) of its operand rows in every tile: left = the layer's deltas at column n0 + j, right = the
+  // layer's input rows at column k0 + j (row 0 of the tile; the k-steps add row strides).  Windows up to 100 only: eight more registers
+  // make the window-123 build spill 4 (it is 1.3 % faster with them all the same) and cost the window-150 build 5 % (41 spilled).
+  constexpr bool TOFF = HYPAD_R6_TOFF && SC != 0 && SC <= 100;
+  int lofs[TOFF ? TPW : 1], rofs[TOFF ? TPW : 1];
+#pragma unroll
+  for (int i = 0; i < (TOFF ? TPW : 0); ++i) {
+    const int t = (wave < 2 ? wave : wave - 1) + (NW - 1) * i;
+    int li, n0, k0;
+    tile_desc(t < g.ntiles ? t : 0, li, n0, k0);
+    const int N = li == nh ? 1 : L;
+    const int nj = n0 + j < N ? n0 + j : N - 1;
+    lofs[i] = fl.dl + li * 48 * LQ + nj;
+    rofs[i] = li == 0 ? fl.in0 + k0 + j : fl.act + (li - 1) * 48 * LQ + k0 + j;
+  }
   const int j_ = j, q_ = q, lane_ = lane;
   // Wave specialisation: the loop is instantiated twice -- for the three chain waves (which carry the register-resident
   // forward / backward chains and, of the optimiser state, only their layer-0 quads) and for the five helper waves (which carry
@@ -1531,13 +1568,18 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     auto dw_tile = [&](int i, bool rf, bool gpp) __attribute__((always_inline)) {
       const int t = tslot + (NW - 1) * i;
       if (t < g.ntiles) {
-        int li, n0, k0;
-        tile_desc(t, li, n0, k0);
-        const int N = li == nh ? 1 : L;
-        const int nj = n0 + j < N ? n0 + j : N - 1;
-        const float* left = dl + li * 48 * LQ + nj;
-        const float* right = li == 0 ? in0 + k0 + j : act + (li - 1) * 48 * LQ + k0 + j;
-        const int ldr = li == 0 ? ldin : LQ;
+        const float* left; const float* right; int ldr;
+        if constexpr (TOFF) {
+          left = smem + lofs[i]; right = smem + rofs[i]; ldr = t < g.tiles0 ? ldin : LQ;
+        } else {
+          int li, n0, k0;
+          tile_desc(t, li, n0, k0);
+          const int N = li == nh ? 1 : L;
+          const int nj = n0 + j < N ? n0 + j : N - 1;
+          left = dl + li * 48 * LQ + nj;
+          right = li == 0 ? in0 + k0 + j : act + (li - 1) * 48 * LQ + k0 + j;
+          ldr = li == 0 ? ldin : LQ;
+        }
         // (measured and dropped in round 5: which four rows make a k-step is free, and rows r, r + 4, r + 8, r + 12 instead of four
         // consecutive ones make these ds_read_b32 -- the kernel's only conflicting LDS accesses by counter: the lane groups q and q + 1 of
         // a 32-lane half sit 36 / 116 dwords = 4 / 20 banks apart -- conflict-free (144 / 464 dwords = 16 banks).  Same time, 2.802-2.813
@@ -1708,12 +1750,25 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
     if (ph.clear_each) clear_tiles();                     // (every read of this iteration's tiles is behind the barrier above; one
                                                           // wave -- wave 2 has no share to store -- clearing alone took 5 k cycles)
     const float coef = xsc[3 * MAXCH + 2];
+    PSTAMP(17);
     // ---- merged share -> compact valid quads, write-through; then the epoch word
     // (measured and dropped in round 3: publishing dW(real, fake) and dW(penalty rows) as two unscaled parts the moment each exists --
     // the consumers apply the coefficient -- so that the epoch word need not wait for the siblings' scalars: twice the share
     // stores and loads cost more than the shorter dependency saves, 2.86 -> 3.03 ms per epoch)
     {
       const int obase = ((it & 1) * nchunks + chunk) * slabf;
+#if HYPAD_R6_EOFF
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc_rf[i][r] + coef * acc_gp[i][r];
+        // (16-byte stores take no scalar offset: GBuf::st4's hazard note)
+        if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, eoff[i] + obase * 4, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, eoff[i] + obase * 4, 0, 16);
+        PSTAMP(18 + (i < 4 ? i : 3));
+      }
+#else
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         const int t = tslot + (NW - 1) * i;
@@ -1732,9 +1787,12 @@ __device__ __forceinline__ void critic_persistent_body(const IterArgs& a, const 
             else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), xrs, (obase + e * 4) * 4, 0, 16);
           }
         }
+        PSTAMP(18 + (i < 4 ? i : 3));
       }
+#endif
     }
-    if (HYPAD_R6_STAGE && it + 1 < n_iters) stage_record();      // the next iteration's record (requested behind barrier 2), under the stores' drain
+    if (HYPAD_R6_STAGE && it + 1 < n_iters) stage_record();
+    PSTAMP(22);      // the next iteration's record (requested behind barrier 2), under the stores' drain
     PSTAMP(14);                                                          // share stored
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores ...
     __syncthreads();                                      // ... before ONE lane signals for all of them
