@@ -84,7 +84,7 @@ __global__ __launch_bounds__(THREADS) void linear_bwd_data_kernel(const float* _
 __global__ __launch_bounds__(THREADS) void outer_sum_kernel(const float* __restrict__ left, int ldl, const float* __restrict__ right,
                                                              int ldr, float* __restrict__ gw, float* __restrict__ gb,
                                                              int64_t rows, int N, int K) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int j = lane & 15, q = lane >> 4;
   const int tk = (K + 15) >> 4, tn = (N + 15) >> 4;
   const int tile = blockIdx.x * 4 + wave;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds_kernel(const float* __re
     smem[idx] = (n < H && k < K) ? w[(int64_t)((g3 == 0 ? 0 : g3 + 1) * H + n) * K + k] : 0.f;      // PyTorch gate order i, f, g, o
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (rows + 15) >> 4;
   const bool vec = (K & 3) == 0 && ((uintptr_t)x & 15) == 0;
   const bool nt_ok = (H & 15) == 0 && gates_save && ((uintptr_t)gates_save & 63) == 0;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds2_kernel(const float* __r
     bias_s[idx] = b1[pg] + b2[pg];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (rows + 15) >> 4;
   constexpr int gfull = K >> 4;                               // full k-groups; the rest (K & 15) in `tq` quads
   constexpr int tq = ((K & 15) + 3) >> 2;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_fwd_lds3_kernel(const float* __r
     bias_s[idx] = b1[pg] + b2[pg];
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), j = lane & 15, q = lane >> 4;
   const int64_t ntiles = (rows + 15) >> 4;
   constexpr int gfull = K >> 4;                               // full k-groups; the rest (K & 15) in `tq` quads
   constexpr int tq = ((K & 15) + 3) >> 2;
