@@ -202,6 +202,9 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ Xs, int ldx, c
 // The first batch of a wave's first tile can be requested ahead of time (weights do not depend on activations): issue
 // gemm_nt_prefetch() before the previous stage's work and pass the result with PRE = true; the product then starts with its
 // B operands in registers instead of an L2 round trip (~2 k cycles on a chain that runs every product once).
+#ifndef HYPAD_R6_ABATCH
+#define HYPAD_R6_ABATCH 1
+#endif
 struct PackedPre { float4 w[8]; };
 // Packed weights through one of two doors.  SC1 = false: plain global loads (throughput callers).  SC1 = true: `sc1` buffer loads
 // on a descriptor built from the (wave-uniform) matrix pointer -- 1 KB blocks at scalar offsets, the lane's 16 bytes at a
@@ -282,6 +285,35 @@ __device__ __forceinline__ void gemm_nt_packed_epi(const float* __restrict__ Xs,
 #pragma unroll
     for (int m = 0; m < MT; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     auto consume = [&](const float4 (&w)[8], int g0) __attribute__((always_inline)) {
+#if HYPAD_R6_ABATCH
+      if constexpr (SC1 && MT <= HYPAD_R6_ABATCH) {    // (the latency-chain callers: all A fragments of the batch requested before its first product)
+        float4 av[8][MT];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k0 = 16 * (g0 + u) + 4 * q;
+          const int ka = k0 < ldx - 4 ? k0 : ldx - 4;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            av[u][m] = (g0 + u < kg) ? *reinterpret_cast<const float4*>(Xs + (m * 16 + j) * ldx + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (g0 + u < kg) {
+            const int k0 = 16 * (g0 + u) + 4 * q;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float4 a = av[u][m];
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 < K ? a.x : 0.f, w[u].x, acc[m], 0, 0, 0);
+              acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 1 < K ? a.y : 0.f, w[u].y, acc2[m], 0, 0, 0);
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 2 < K ? a.z : 0.f, w[u].z, acc[m], 0, 0, 0);
+              acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(k0 + 3 < K ? a.w : 0.f, w[u].w, acc2[m], 0, 0, 0);
+            }
+          }
+        }
+        return;
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (g0 + u < kg) {                             // wave-uniform
