@@ -64,6 +64,9 @@ long long* g_unroll_stamps = nullptr;        // development aid (dev library): [
 #endif
 // UT: timesteps per workgroup tile, one wave per 16 of them (UT = 64: 256 threads, 128: 512).  A longer tile reads longer runs
 // of every source row (fewer partly used 128-byte lines at the runs' ends: the tile's triangle rows) for twice the LDS.
+#ifndef HYPAD_R6_UWAVE
+#define HYPAD_R6_UWAVE 1
+#endif
 template <int EPL, bool FILTER, int UT>
 __global__ __launch_bounds__(UT * 4) __attribute__((amdgpu_waves_per_eu(HYPAD_UNROLL_WPE, HYPAD_UNROLL_WPE))) void unroll_median_kernel(const float* __restrict__ y_hat, float* __restrict__ median,
                                                                 double* __restrict__ summary, int64_t n, int W, long long* stamps) {
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(UT * 4) __attribute__((amdgpu_waves_per_eu(HYPAD_UN
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   constexpr int NWV = THREADS / 64;
   const int64_t T = n + W - 1;
-  float* s = sorted + wave * MAX_WINDOW;
+  float* s = sorted + (HYPAD_R6_UWAVE ? wave_s : wave) * MAX_WINDOW;
   const float INF = __int_as_float(0x7f800000);
 #if HYPAD_DIAG
   const bool ucount = stamps && stamps[14] != 0;             // (counting costs one contended atomic per timestep: a run of its own)
@@ -144,7 +147,9 @@ __global__ __launch_bounds__(UT * 4) __attribute__((amdgpu_waves_per_eu(HYPAD_UN
     USTAMP(1);
     __syncthreads();
     USTAMP(2);
-    for (int tt = wave; tt < UT; tt += NWV) {
+    // (round 6: the timestep a wave works on is a scalar -- as a vector value every count, address and "wave-uniform" branch below was
+    // vector arithmetic and exec-mask code)
+    for (int tt = HYPAD_R6_UWAVE ? wave_s : wave; tt < UT; tt += NWV) {
       const int64_t t = t0 + tt;
       if (t >= T) break;
       const int j0 = (int)(t - n + 1 > 0 ? t - n + 1 : 0);
