@@ -236,3 +236,16 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_run():
     assert not others, others
     gap = [k for n, k in by_name.items() if "critic_persistent_kernel<150, 20, 256>" in n]
     assert len(gap) == 1 and gap[0]["vgpr_spill_count"] <= 28 and gap[0]["private_segment_fixed_size"] <= 116, gap
+
+
+def test_design_document_stays_readable():
+    """DESIGN.md is the CURRENT design -- at most 40 KB, lines of at most 160 characters; the round-by-round record lives
+    under docs/history/."""
+    path = os.path.join(ROOT, "DESIGN.md")
+    text = open(path, encoding="utf-8").read()
+    assert len(text.encode("utf-8")) <= 40 * 1024
+    assert max(len(line) for line in text.splitlines()) <= 160
+    assert os.path.exists(os.path.join(ROOT, "docs", "history", "DESIGN_rounds1-5.md")) and os.path.exists(os.path.join(ROOT, "docs", "history", "round6.md"))
+    for section in ("## 0. Scope", "## 1. The path and its boundary", "## 2. Oracle and parity", "## 3. Data layout in HBM", "## 4. Kernels", "## 5. Measurement",
+                    "## 6. Multi-GPU", "## 7. Next components", "## 8. Status"):
+        assert section in text, section
