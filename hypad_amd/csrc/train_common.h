@@ -179,6 +179,15 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
     p -= (c.lr * __builtin_amdgcn_rcpf(c.bc1)) * (m * __builtin_amdgcn_rcpf(denom));
   }
 }
+// torch.optim.Adam's rule of adam_update with the two reciprocals that do not depend on the element -- 1 / sqrt(bc2) and lr / bc1 -- taken
+// once by the caller (isb2 = rcp(c.sqrt_bc2), lrb1 = c.lr * rcp(c.bc1)): the same operations on the same values, so the same bits; the
+// compiler did not hoist them out of the per-row branches itself (3 rcp + 1 sqrt per element, each a quarter-rate instruction).
+__device__ __forceinline__ void adam_update_hoisted(float& p, float& m, float& v, float g, const AdamCoef& c, float isb2, float lrb1) {
+  m = c.b1 * m + (1.f - c.b1) * g;
+  v = c.b2 * v + (1.f - c.b2) * g * g;
+  const float denom = __builtin_amdgcn_sqrtf(v) * isb2 + c.eps;
+  p -= lrb1 * (m * __builtin_amdgcn_rcpf(denom));
+}
 __device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, float wd, int riem, int stab, int step) {
   AdamCoef c;
   c.lr = lr; c.b1 = b1; c.b2 = b2; c.eps = eps; c.wd = wd; c.riemannian = riem; c.stabilize = stab; c.step = step;

@@ -235,7 +235,7 @@ def test_no_scratch_in_the_kernels_the_baseline_configs_run():
               if (k["vgpr_spill_count"] or k["private_segment_fixed_size"] > reserve(n)) and "<0, 0, 0>" not in n and "critic_persistent_kernel<150, 20, 256>" not in n}
     assert not others, others
     gap = [k for n, k in by_name.items() if "critic_persistent_kernel<150, 20, 256>" in n]
-    assert len(gap) == 1 and gap[0]["vgpr_spill_count"] <= 28 and gap[0]["private_segment_fixed_size"] <= 116, gap
+    assert len(gap) == 1 and gap[0]["vgpr_spill_count"] <= 29 and gap[0]["private_segment_fixed_size"] <= 120, gap   # (29: the hoisted reciprocals, 10.14 -> 10.09 ms per epoch with them)
 
 
 def test_design_document_stays_readable():
