@@ -19,10 +19,10 @@ torch.cuda.synchronize()
 s = st.cpu().numpy().reshape(2, 32, 8)
 names = {0: "loop top", 1: "shares there", 2: "phase A done", 3: "record staged", 4: "fwd0 / phase B", 5: "B seen", 6: "fwd done", 7: "bwd done",
          8: "pre-barrier 1", 9: "barrier 1", 10: "2nd-order | g+dWrf", 11: "barrier 2", 12: "dW gp", 13: "scalars there", 14: "share stored",
-         15: "drained+flag", 16: "cleared", 17: "  coef read", 18: "  share tile 0", 19: "  share tile 1", 20: "  share tile 2", 21: "  share tile 3", 22: "  record staged", 23: "  fwd0 products", 24: "  B: requested", 25: "  B: slot 1 applied", 26: "  B: slot 1 posted"}
+         15: "drained+flag", 16: "cleared", 17: "  coef read", 18: "  share tile 0", 19: "  share tile 1", 20: "  share tile 2", 21: "  share tile 3", 22: "  record staged"}
 for z, nm in ((0, "critic_x"), (1, "critic_z")):
     t0 = s[z, 0].min()
     print(nm, "iteration cycles (wave 0, top to cleared):", s[z, 16, 0] - s[z, 0, 0])
-    for k in (0, 1, 2, 3, 23, 24, 25, 26, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 21, 22, 14, 15, 16):
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 17, 18, 19, 20, 21, 22, 14, 15, 16):
         row = s[z, k]
         print("  %2d %-20s " % (k, names[k]) + " ".join("%6d" % (v - t0) if v else "     -" for v in row))
