@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void zscore_apply_kernel(const double* __restr
 #define HYPAD_KDE_FACTORED 1
 #endif
 #ifndef HYPAD_KDE_WPE
-#define HYPAD_KDE_WPE 5
+#define HYPAD_KDE_WPE 7        // (round 6, re-swept on the final kernel: 5 -> 0.233, 6 -> 0.229, 7 -> 0.224 ms per 125 000 windows at 70 registers, none spilled; 8 spills 4)
 #endif
 constexpr int KDE_CB = HYPAD_KDE_CB;         // candidates per pass-2 batch.  Its term buffer is the kernel's largest LDS array (4 KB per wave at 2): with 2
                                              // and five waves per SIMD (96 registers) the kernel takes 0.354 ms per 125 000 windows; 0.438 at 4 / three waves
