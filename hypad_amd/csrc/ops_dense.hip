@@ -887,28 +887,29 @@ int hypad_lstm_bidir_fwd(const float* x, const float* wf, const float* bif, cons
 #define HYPAD_LSTM_NW 16
 #endif
     constexpr int nw = HYPAD_LSTM_NW;
-    int nslices = (int)((ntiles + nw - 1) / nw);
-    if (nslices > 128) nslices = 128;
-    const dim3 grid(2 * nslices);
-#define HYPAD_LSTM_LDS2_LAUNCH(KC, HC)                                                                                           \
+    // one workgroup per CU and direction slice; NWC waves each (16, except 50 -> 2 x 64 with saved gates: eight waves, 132 -> 117 us per
+    // 200 000 rows -- round 6 sweep of waves x slices, scripts/time_lstm.py; every other shape is fastest at sixteen)
+    auto slices = [&](int nwc) { int n = (int)((ntiles + nwc - 1) / nwc); return n > 128 ? 128 : n; };
+#define HYPAD_LSTM_LDS2_LAUNCH(KC, HC, NWC)                                                                                      \
     do {                                                                                                                         \
       constexpr int NTC = 3 * (HC / 16) + ((HC % 16) ? 1 : 0);                                                                   \
       const size_t lw2 = (size_t)(NTC * 16 * (((KC + 15) / 16) * 16 + 4) + 3 * HC) * sizeof(float);                              \
-      hipError_t e2 = allow_lds((const void*)lstm_fwd_lds2_kernel<KC, HC, nw>, lw2);                                             \
+      hipError_t e2 = allow_lds((const void*)lstm_fwd_lds2_kernel<KC, HC, NWC>, lw2);                                            \
       if (e2 != hipSuccess) return (int)e2;                                                                                      \
-      hipLaunchKernelGGL((lstm_fwd_lds2_kernel<KC, HC, nw>), grid, dim3(64 * nw), lw2, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
+      hipLaunchKernelGGL((lstm_fwd_lds2_kernel<KC, HC, NWC>), dim3(2 * slices(NWC)), dim3(64 * NWC), lw2, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, \
                          gates_save, rows);                                                                                      \
     } while (0)
-    if (H == 50 && !gates_save) HYPAD_LSTM_LDS2_LAUNCH(100, 50);      // (forward only: 163 us per 200 000 rows, 171 through the slab)
+    if (H == 50 && !gates_save) HYPAD_LSTM_LDS2_LAUNCH(100, 50, nw);      // (forward only: 163 us per 200 000 rows, 171 through the slab)
     else if (H == 50) {
       constexpr int KC = 100, HC = 50, NTC = 3 * (HC / 16) + 1;
       const size_t lw3 = (size_t)(NTC * 16 * (((KC + 15) / 16) * 16 + 4) + 3 * HC + nw * 8 * (3 * HC + 2)) * sizeof(float);
       hipError_t e3 = allow_lds((const void*)lstm_fwd_lds3_kernel<KC, HC, nw>, lw3);
       if (e3 != hipSuccess) return (int)e3;
-      hipLaunchKernelGGL((lstm_fwd_lds3_kernel<KC, HC, nw>), grid, dim3(64 * nw), lw3, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, gates_save, rows);
+      hipLaunchKernelGGL((lstm_fwd_lds3_kernel<KC, HC, nw>), dim3(2 * slices(nw)), dim3(64 * nw), lw3, (hipStream_t)s, x, wf, bif, bhf, wr, bir, bhr, out, gates_save, rows);
     }
-    else if (K == 128) HYPAD_LSTM_LDS2_LAUNCH(128, 64);
-    else HYPAD_LSTM_LDS2_LAUNCH(50, 64);
+    else if (K == 128) HYPAD_LSTM_LDS2_LAUNCH(128, 64, nw);
+    else if (gates_save && nw == 16) HYPAD_LSTM_LDS2_LAUNCH(50, 64, 8);
+    else HYPAD_LSTM_LDS2_LAUNCH(50, 64, nw);
 #undef HYPAD_LSTM_LDS2_LAUNCH
     HYPAD_CHECK_LAUNCH();
     return HYPAD_OK;
